@@ -1,0 +1,84 @@
+"""ctypes binding of libcdpr_hip.so (include/cdpr.h).
+
+The library is built in-tree (`make -C cdpr-simulation_amd/csrc`, or
+`__graft_entry__.build()`); there is no fallback: if it is missing, importing
+the engine fails loudly.
+"""
+import ctypes as C
+import os
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcdpr_hip.so")
+
+# every symbol include/cdpr.h declares
+EXPORTS = [
+    "cdpr_abi_version", "cdpr_config_size", "cdpr_device_count", "cdpr_bytes_per_state_step", "cdpr_derivative_weights",
+    "cdpr_create", "cdpr_destroy", "cdpr_reset", "cdpr_last_error", "cdpr_set_platform_state",
+    "cdpr_set_velocity_command", "cdpr_set_position_command", "cdpr_set_velocity_command_device",
+    "cdpr_set_position_command_device", "cdpr_update", "cdpr_update_fused", "cdpr_synchronize", "cdpr_step_count",
+    "cdpr_get_joint_states", "cdpr_get_platform_state", "cdpr_get_pid_debug", "cdpr_get_fk_state", "cdpr_get_td_state",
+    "cdpr_get_raw_state", "cdpr_profile_begin", "cdpr_profile_end", "cdpr_solve_ik", "cdpr_solve_fk", "cdpr_solve_td",
+]  # fmt: skip
+
+_lib = None
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+def lib():
+    """Load libcdpr_hip.so once and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or __graft_entry__.build()). There is no CPU fallback for the CDPR step engine."
+        )
+    L = C.CDLL(LIB_PATH)
+    fp, dp, ip = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    cfgp = C.POINTER(_abi.ConfigStruct)
+    H = C.c_void_p
+    L.cdpr_abi_version.restype = C.c_uint32
+    L.cdpr_config_size.restype = C.c_size_t
+    L.cdpr_device_count.restype = C.c_int
+    L.cdpr_bytes_per_state_step.restype = C.c_size_t
+    L.cdpr_bytes_per_state_step.argtypes = [cfgp]
+    L.cdpr_derivative_weights.argtypes = [C.c_uint32, C.c_uint32, dp]
+    L.cdpr_create.argtypes = [cfgp, C.c_int, C.POINTER(H)]
+    L.cdpr_destroy.argtypes = [H]
+    L.cdpr_destroy.restype = None
+    L.cdpr_reset.argtypes = [H]
+    L.cdpr_last_error.argtypes = [H]
+    L.cdpr_last_error.restype = C.c_char_p
+    L.cdpr_set_platform_state.argtypes = [H, fp, fp]
+    for name in ("cdpr_set_velocity_command", "cdpr_set_position_command"):
+        getattr(L, name).argtypes = [H, fp, C.c_size_t]
+    for name in ("cdpr_set_velocity_command_device", "cdpr_set_position_command_device"):
+        getattr(L, name).argtypes = [H, C.c_void_p, C.c_size_t]
+    L.cdpr_update.argtypes = [H, C.c_int]
+    L.cdpr_update_fused.argtypes = [H, C.c_int, C.c_int]
+    L.cdpr_synchronize.argtypes = [H]
+    L.cdpr_step_count.argtypes = [H]
+    L.cdpr_step_count.restype = C.c_uint64
+    L.cdpr_get_joint_states.argtypes = [H, fp, fp, fp]
+    L.cdpr_get_platform_state.argtypes = [H, fp, fp]
+    L.cdpr_get_raw_state.argtypes = [H, fp, fp]
+    L.cdpr_get_pid_debug.argtypes = [H, fp]
+    L.cdpr_get_fk_state.argtypes = [H, fp, fp, ip]
+    L.cdpr_get_td_state.argtypes = [H, fp, ip]
+    L.cdpr_profile_begin.argtypes = [H]
+    L.cdpr_profile_end.argtypes = [H, fp, C.POINTER(C.c_uint64)]
+    L.cdpr_solve_ik.argtypes = [H, fp, fp, fp, fp, fp]
+    L.cdpr_solve_fk.argtypes = [H, fp, fp, fp, fp, ip]
+    L.cdpr_solve_td.argtypes = [H, fp, fp, fp, ip]
+    if L.cdpr_abi_version() != _abi.ABI_VERSION:
+        raise ImportError("libcdpr_hip.so ABI version mismatch")
+    if L.cdpr_config_size() != C.sizeof(_abi.ConfigStruct):
+        raise ImportError("cdpr_config_t layout mismatch between include/cdpr.h and _abi.py")
+    _lib = L
+    return L

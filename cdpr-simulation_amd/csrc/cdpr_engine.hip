@@ -1,0 +1,746 @@
+// cdpr_engine.hip — host side of libcdpr_hip.so: the C-ABI of include/cdpr.h over the
+// gfx950 step kernels.  No CPU compute path exists here: every entry point that
+// touches robot state needs a GPU and fails with CDPR_ERR_DEVICE without one.
+//
+// Reference paths (relative to src/cdpr_gazebo/ of balazs-bamer/cdpr-simulation):
+//   PLG.cpp = src/CdprGazeboPlugin.cpp, JFC.cpp = src/JointForceCalculator.cpp, Pid.cpp = src/Pid.cpp
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cdpr.h"
+#include "cdpr_kernels.hpp"
+
+using namespace cdpr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Mode { kModeForce = 0, kModePosition = 1, kModeVelocity = 2 };  // JFC.h:35-37
+
+#define HIP_TRY(h, expr)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
+      return CDPR_ERR_DEVICE;                                                                    \
+    }                                                                                            \
+  } while (0)
+
+}  // namespace
+
+struct cdpr_engine {
+  cdpr_config_t cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t n = 0, batch = 0, stride = 0;
+  bool fk = false, td = false, dbg = false;
+  int n_state = 0, n_obs = 0;
+  float4* d_state = nullptr;
+  float4* d_obs = nullptr;
+  float* d_dbg = nullptr;
+  float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
+  float* d_pos[2] = {nullptr, nullptr};
+  bool vel_pending = false, pos_pending = false;
+  bool have_vel = false, have_pos = false;  // a command of that kind has been latched since Load
+  int mode = kModePosition;
+  uint64_t step = 0;
+  double prev_publish = 0.0;
+  StepConsts consts{};
+  PidConsts pid_vel{}, pid_pos{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint64_t launches = 0, launches_mark = 0;
+  std::string err;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// Least-squares end-point derivative weights on a uniform grid: the closed form of
+// Pid::derive + fitPolynomial (Pid.cpp:193-247) when samples are one step apart.
+// ---------------------------------------------------------------------------------
+int derivative_weights(uint32_t n, uint32_t degree, double* w) {
+  if (n < 2 || n > CDPR_MAX_D_BUFFER || degree < 1 || degree > CDPR_MAX_D_DEGREE || degree >= n) return CDPR_ERR_INVALID;
+  const int m = (int)degree + 1;
+  long double a[5][10];  // [XtX | I], centred abscissae x_j = j - (n-1)/2
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < 2 * m; ++j) a[i][j] = 0.0L;
+  std::vector<long double> x(n);
+  for (uint32_t j = 0; j < n; ++j) x[j] = (long double)j - (long double)(n - 1) / 2.0L;
+  for (int i = 0; i < m; ++i) {
+    for (int k = 0; k < m; ++k) {
+      long double s = 0;
+      for (uint32_t j = 0; j < n; ++j) s += powl(x[j], i + k);
+      a[i][k] = s;
+    }
+    a[i][m + i] = 1.0L;
+  }
+  for (int col = 0; col < m; ++col) {  // Gauss-Jordan, partial pivoting
+    int piv = col;
+    for (int r = col + 1; r < m; ++r)
+      if (fabsl(a[r][col]) > fabsl(a[piv][col])) piv = r;
+    if (piv != col)
+      for (int k = 0; k < 2 * m; ++k) std::swap(a[piv][k], a[col][k]);
+    long double d = a[col][col];
+    for (int k = 0; k < 2 * m; ++k) a[col][k] /= d;
+    for (int r = 0; r < m; ++r) {
+      if (r == col) continue;
+      long double f = a[r][col];
+      for (int k = 0; k < 2 * m; ++k) a[r][k] -= f * a[col][k];
+    }
+  }
+  // derivative at the newest sample x_e: sum_k k x_e^(k-1) c_k, c = (XtX)^-1 Xt y
+  const long double xe = x[n - 1];
+  for (uint32_t j = 0; j < n; ++j) {
+    long double wj = 0;
+    for (int k = 1; k < m; ++k) {
+      long double ck = 0;  // row k of (XtX)^-1 Xt, column j
+      for (int i = 0; i < m; ++i) ck += a[k][m + i] * powl(x[j], i);
+      wj += (long double)k * powl(xe, k - 1) * ck;
+    }
+    w[j] = (double)wj;
+  }
+  return CDPR_OK;
+}
+
+bool mat3_inverse_sym(const double in[6], double out[6]) {
+  const double m[9] = {in[0], in[3], in[4], in[3], in[1], in[5], in[4], in[5], in[2]};
+  const double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+  const double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
+  if (!(std::fabs(det) > 0.0)) return false;
+  out[0] = c0 / det;
+  out[1] = (m[0] * m[8] - m[2] * m[6]) / det;
+  out[2] = (m[0] * m[4] - m[1] * m[3]) / det;
+  out[3] = c1 / det;
+  out[4] = c2 / det;
+  out[5] = (m[1] * m[6] - m[0] * m[7]) / det;
+  return true;
+}
+
+// Returns "" when the configuration is acceptable, else the reason.
+std::string validate(const cdpr_config_t& c) {
+  char buf[256];
+  if (c.abi_version != CDPR_ABI_VERSION) return "abi_version mismatch";
+  if (c.n_cables < 1 || c.n_cables > CDPR_MAX_CABLES) {
+    snprintf(buf, sizeof buf, "invalid joint count %u (PLG.cpp:167-168; engine takes 1..%u)", c.n_cables, CDPR_MAX_CABLES);
+    return buf;
+  }
+  if (c.batch < 1 || c.batch > (1ull << 31)) return "batch out of range";
+  if (!(c.dt > 0.0)) return "dt must be > 0";
+  if (!(c.mass > 0.0)) return "mass must be > 0";
+  double inv[6];
+  if (!mat3_inverse_sym(c.inertia, inv)) return "inertia is singular";
+  for (uint32_t i = 0; i < c.n_cables; ++i)
+    if (!(c.cable_ref_length[i] > 0.0)) return "cable_ref_length must be > 0";
+  const cdpr_pid_params_t* pids[2] = {&c.velocity_pid, &c.position_pid};
+  for (auto* p : pids) {
+    if (p->d_buffer_length < 2 || p->d_buffer_length > CDPR_MAX_D_BUFFER) return "d_buffer_length out of range";
+    if (p->d_degree < 1 || p->d_degree > CDPR_MAX_D_DEGREE || p->d_degree >= p->d_buffer_length) return "d_degree out of range";
+    if (p->p_filter.cascade > CDPR_MAX_CASCADE || p->d_filter.cascade > CDPR_MAX_CASCADE) return "filter cascade out of range";
+  }
+  if ((c.stages & (CDPR_STAGE_FK | CDPR_STAGE_TD)) && c.n_cables < 6) return "FK / tension distribution need >= 6 cables";
+  if ((c.stages & CDPR_STAGE_FK) && (c.fk_max_iterations < 1 || c.fk_max_iterations > 64)) return "fk_max_iterations out of range";
+  if ((c.stages & CDPR_STAGE_TD) && !(c.td_f_max > c.td_f_min)) return "td_f_max must exceed td_f_min";
+  if (c.mapping > CDPR_MAP_LANE_PER_CABLE) return "unknown mapping";
+  return "";
+}
+
+// What the register-resident fast path cannot represent (it keeps ONE Pid record per
+// cable: the active mode's): the position-hold branch (JFC.cpp:78-82) keeps both PIDs
+// alive in Velocity mode, filters add state, long windows do not fit the record.
+std::string fast_path_obstacle(const cdpr_config_t& c) {
+  if (!(c.velocity_epsilon < 0.0)) return "velocity_epsilon >= 0 (position-hold branch live)";
+  const cdpr_pid_params_t* pids[2] = {&c.velocity_pid, &c.position_pid};
+  for (auto* p : pids) {
+    if (p->p_filter.cascade || p->d_filter.cascade) return "biquad cascades enabled";
+    if (p->d_buffer_length > kWin + 1) return "derivative window longer than 11 samples";
+    if (!(std::fabs(p->cmd_limit) > 0.0)) return "cmd_limit == 0 (command clamp disabled, Pid.cpp:175)";
+  }
+  return "";
+}
+
+void fill_pid(const cdpr_pid_params_t& p, double dt, PidConsts& k) {
+  k.kf = (float)p.forward_gain;
+  k.kp = (float)p.p_gain;
+  k.ki = (float)p.i_gain;
+  k.kd = (float)p.d_gain;
+  k.imax = (float)std::fabs(p.i_limit);  // Pid.cpp:70-73 (abs -> fabs)
+  k.imin = -(float)std::fabs(p.i_limit);
+  k.cmax = (float)std::fabs(p.cmd_limit);
+  k.cmin = -(float)std::fabs(p.cmd_limit);
+  k.inv_dt = (float)(1.0 / dt);
+  k.nbuf = (int)p.d_buffer_length;
+  k.clamp_cmd = k.cmax > k.cmin;
+  double w[CDPR_MAX_D_BUFFER];
+  for (int j = 0; j <= kWin; ++j) k.w[j] = 0.f;
+  if (derivative_weights(p.d_buffer_length, p.d_degree, w) == CDPR_OK && p.d_buffer_length <= (uint32_t)kWin + 1)
+    for (uint32_t j = 0; j < p.d_buffer_length; ++j) k.w[kWin + 1 - p.d_buffer_length + j] = (float)w[j];
+}
+
+void fill_consts(const cdpr_config_t& c, StepConsts& k) {
+  memset(&k, 0, sizeof k);
+  for (uint32_t i = 0; i < c.n_cables; ++i) {
+    k.ax[i] = (float)c.frame_anchor[i][0];
+    k.ay[i] = (float)c.frame_anchor[i][1];
+    k.az[i] = (float)c.frame_anchor[i][2];
+    k.bx[i] = (float)c.platform_anchor[i][0];
+    k.by[i] = (float)c.platform_anchor[i][1];
+    k.bz[i] = (float)c.platform_anchor[i][2];
+    k.l0[i] = (float)c.cable_ref_length[i];
+  }
+  k.dt = (float)c.dt;
+  k.half_dt = (float)(0.5 * c.dt);
+  k.inv_mass = (float)(1.0 / c.mass);
+  k.fgx = (float)(c.mass * c.gravity[0]);
+  k.fgy = (float)(c.mass * c.gravity[1]);
+  k.fgz = (float)(c.mass * c.gravity[2]);
+  double inv[6];
+  mat3_inverse_sym(c.inertia, inv);
+  for (int i = 0; i < 6; ++i) {
+    k.ib[i] = (float)c.inertia[i];
+    k.ibinv[i] = (float)inv[i];
+  }
+  k.damping = (float)c.joint_damping;
+  k.effort = (float)c.effort_limit;
+  k.fk_lambda = (float)c.fk_lambda;
+  k.fk_tol = (float)c.fk_tolerance;
+  k.fk_iters = (int)c.fk_max_iterations;
+  k.td_min = (float)c.td_f_min;
+  k.td_max = (float)c.td_f_max;
+  k.td_mid = (float)(0.5 * (c.td_f_min + c.td_f_max));
+}
+
+using StepKernel = void (*)(const StepArgs);
+
+template <int N>
+StepKernel pick_stage(bool fk, bool td) {
+  if constexpr (N >= 6) {
+    if (fk && td) return step_lane_per_robot<N, true, true>;
+    if (fk) return step_lane_per_robot<N, true, false>;
+    if (td) return step_lane_per_robot<N, false, true>;
+  }
+  return step_lane_per_robot<N, false, false>;
+}
+
+StepKernel pick_kernel(uint32_t n, bool fk, bool td) {
+  switch (n) {
+    case 1: return pick_stage<1>(fk, td);
+    case 2: return pick_stage<2>(fk, td);
+    case 3: return pick_stage<3>(fk, td);
+    case 4: return pick_stage<4>(fk, td);
+    case 5: return pick_stage<5>(fk, td);
+    case 6: return pick_stage<6>(fk, td);
+    case 7: return pick_stage<7>(fk, td);
+    case 8: return pick_stage<8>(fk, td);
+  }
+  return nullptr;
+}
+
+double sim_time(uint64_t step, double dt) {
+  // gazebo::common::Time keeps integer sec + nsec; Double() = sec + nsec * 1e-9 [EXT]
+  const int64_t dt_ns = (int64_t)std::llround(dt * 1e9);
+  const int64_t now_ns = (int64_t)step * dt_ns;
+  return (double)(now_ns / 1000000000LL) + (double)(now_ns % 1000000000LL) * 1e-9;
+}
+
+int set_device(cdpr_engine* h) {
+  HIP_TRY(h, hipSetDevice(h->device));
+  return CDPR_OK;
+}
+
+// Host image of the state a fresh Load leaves: platform at home, zero twist, FK seed at
+// home, every controller record zero (count 0 => the first Pid call returns 0).
+std::vector<float4> home_state(const cdpr_engine* h) {
+  std::vector<float4> s((size_t)h->n_state * h->stride, make_float4(0.f, 0.f, 0.f, 0.f));
+  const double* hp = h->cfg.home_pose;
+  for (uint32_t r = 0; r < h->stride; ++r) {
+    s[0 * (size_t)h->stride + r] = make_float4((float)hp[0], (float)hp[1], (float)hp[2], (float)hp[3]);
+    s[1 * (size_t)h->stride + r] = make_float4((float)hp[4], (float)hp[5], (float)hp[6], 0.f);
+    s[3 * (size_t)h->stride + r] = make_float4(0.f, (float)hp[0], (float)hp[1], (float)hp[2]);
+    if (h->fk) s[4 * (size_t)h->stride + r] = make_float4((float)hp[3], (float)hp[4], (float)hp[5], (float)hp[6]);
+  }
+  return s;
+}
+
+int upload_home(cdpr_engine* h) {
+  std::vector<float4> s = home_state(h);
+  HIP_TRY(h, hipMemcpyAsync(h->d_state, s.data(), s.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  // observables before the first publish: the home pose, zeros elsewhere
+  std::vector<float4> o((size_t)h->n_obs * h->stride, make_float4(0.f, 0.f, 0.f, 0.f));
+  for (uint32_t r = 0; r < h->stride; ++r) {
+    o[0 * (size_t)h->stride + r] = s[0 * (size_t)h->stride + r];
+    o[1 * (size_t)h->stride + r] = s[1 * (size_t)h->stride + r];
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->d_obs, o.data(), o.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  if (h->d_dbg) HIP_TRY(h, hipMemsetAsync(h->d_dbg, 0, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float), h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CDPR_OK;
+}
+
+void free_all(cdpr_engine* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->d_state) (void)hipFree(h->d_state);
+  if (h->d_obs) (void)hipFree(h->d_obs);
+  if (h->d_dbg) (void)hipFree(h->d_dbg);
+  for (int i = 0; i < 2; ++i) {
+    if (h->d_vel[i]) (void)hipFree(h->d_vel[i]);
+    if (h->d_pos[i]) (void)hipFree(h->d_pos[i]);
+  }
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+void engine_reset_host(cdpr_engine* h) {
+  h->vel_pending = h->pos_pending = false;
+  h->have_vel = h->have_pos = false;
+  h->mode = kModePosition;  // PLG.cpp:153-157: Position mode, target 0 after operator= -> reset()
+  h->step = 0;
+  h->prev_publish = 0.0;  // PLG.cpp:59
+}
+
+int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bool from_device) {
+  const size_t n = h->n, B = h->batch;
+  if (!src) {
+    h->err = "null command buffer";
+    return CDPR_ERR_INVALID;
+  }
+  if (count != n * B && count != n) return CDPR_IGNORED;  // PLG.cpp:68-73,77-82: silently dropped
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (count == n * B) {
+    HIP_TRY(h, hipMemcpyAsync(dst, src, n * B * sizeof(float), from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                              h->stream));
+    if (!from_device) HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller may reuse its buffer on return
+  } else {
+    std::vector<float> one(n);
+    if (from_device)
+      HIP_TRY(h, hipMemcpy(one.data(), src, n * sizeof(float), hipMemcpyDeviceToHost));
+    else
+      memcpy(one.data(), src, n * sizeof(float));
+    std::vector<float> all(n * B);
+    for (size_t b = 0; b < B; ++b) memcpy(&all[b * n], one.data(), n * sizeof(float));
+    HIP_TRY(h, hipMemcpyAsync(dst, all.data(), n * B * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  return CDPR_OK;
+}
+
+int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (nsteps < 0 || per_launch < 1 || per_launch > 64) {
+    h->err = "nsteps must be >= 0 and steps_per_launch in 1..64";
+    return CDPR_ERR_INVALID;
+  }
+  if (nsteps == 0) return CDPR_OK;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+
+  // --- PLG.cpp:206-219: latch pending commands, velocity first, then position
+  bool reset_pid = false;
+  if (h->vel_pending) {
+    std::swap(h->d_vel[0], h->d_vel[1]);
+    h->vel_pending = false;
+    h->have_vel = true;
+    reset_pid = (h->mode != kModeVelocity);  // JFC.cpp:113-115
+    h->mode = kModeVelocity;
+  }
+  if (h->pos_pending) {
+    std::swap(h->d_pos[0], h->d_pos[1]);
+    h->pos_pending = false;
+    h->have_pos = true;
+    reset_pid = (h->mode != kModePosition);  // JFC.cpp:101-103 (single record: it now belongs to the position Pid)
+    h->mode = kModePosition;
+  }
+
+  StepKernel kern = pick_kernel(h->n, h->fk, h->td);
+  StepArgs a;
+  a.state = h->d_state;
+  a.obs = h->d_obs;
+  a.dbg = h->dbg ? h->d_dbg : nullptr;
+  a.batch = h->batch;
+  a.stride = h->stride;
+  a.c = h->consts;
+  if (h->mode == kModeVelocity) {
+    a.pid = h->pid_vel;
+    a.cmd = h->d_vel[0];
+  } else {
+    a.pid = h->pid_pos;
+    a.cmd = h->have_pos ? h->d_pos[0] : nullptr;  // target 0 until the first jointPositions message
+  }
+  const dim3 grid((h->batch + 63u) / 64u), block(64);
+
+  int done = 0;
+  while (done < nsteps) {
+    const int k = std::min(per_launch, nsteps - done);
+    a.nsteps = k;
+    a.flags = (h->mode == kModeVelocity ? kFlagActualIsVelocity : 0u);
+    if (h->step == 0) a.flags |= kFlagFirstWorldStep;
+    if (reset_pid) a.flags |= kFlagResetPid;
+    reset_pid = false;
+    a.publish_mask = 0;
+    for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
+      const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
+      if ((now - h->prev_publish) > h->cfg.publish_period) {
+        h->prev_publish = now;
+        a.publish_mask |= (1ull << j);
+      }
+    }
+    hipLaunchKernelGGL(kern, grid, block, 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    ++h->launches;
+    h->step += (uint64_t)k;
+    done += k;
+  }
+  return CDPR_OK;
+}
+
+int fetch_slots(cdpr_engine* h, const float4* dsrc, int nslots, std::vector<float4>& host) {
+  host.resize((size_t)nslots * h->stride);
+  HIP_TRY(h, hipMemcpyAsync(host.data(), dsrc, host.size() * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CDPR_OK;
+}
+
+inline float comp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+
+void unpack_platform(const cdpr_engine* h, const std::vector<float4>& s, float* pose7, float* twist6) {
+  const size_t st = h->stride;
+  for (uint32_t r = 0; r < h->batch; ++r) {
+    const float4 a = s[0 * st + r], b = s[1 * st + r], c = s[2 * st + r], d = s[3 * st + r];
+    if (pose7) {
+      float* p = pose7 + (size_t)r * 7;
+      p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z;
+    }
+    if (twist6) {
+      float* t = twist6 + (size_t)r * 6;
+      t[0] = b.w; t[1] = c.x; t[2] = c.y; t[3] = c.z; t[4] = c.w; t[5] = d.x;
+    }
+  }
+}
+
+}  // namespace
+
+// =================================================================================
+// C-ABI
+// =================================================================================
+extern "C" {
+
+uint32_t cdpr_abi_version(void) { return CDPR_ABI_VERSION; }
+size_t cdpr_config_size(void) { return sizeof(cdpr_config_t); }
+
+int cdpr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+size_t cdpr_bytes_per_state_step(const cdpr_config_t* cfg) {
+  // read command n; read+write platform 13 and controller 12 per cable;
+  // write observables 13 + 3n.  4 * (39 + 28 n).
+  if (!cfg) return 0;
+  return 4u * (39u + 28u * (size_t)cfg->n_cables);
+}
+
+int cdpr_derivative_weights(uint32_t n, uint32_t degree, double* w) {
+  if (!w) return CDPR_ERR_INVALID;
+  return derivative_weights(n, degree, w);
+}
+
+const char* cdpr_last_error(cdpr_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
+  if (out) *out = nullptr;
+  if (!cfg || !out) {
+    g_create_error = "null argument";
+    return CDPR_ERR_INVALID;
+  }
+  std::string why = validate(*cfg);
+  if (!why.empty()) {
+    g_create_error = why;
+    return CDPR_ERR_INVALID;
+  }
+  why = fast_path_obstacle(*cfg);
+  if (!why.empty()) {
+    g_create_error = "configuration needs the general controller path, not built yet: " + why;
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (cfg->mapping == CDPR_MAP_LANE_PER_CABLE) {
+    g_create_error = "lane-per-cable mapping not built yet";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = "no HIP device visible (this engine has no CPU path)";
+    return CDPR_ERR_DEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    g_create_error = "device index out of range";
+    return CDPR_ERR_INVALID;
+  }
+  cdpr_engine* h = new cdpr_engine();
+  h->cfg = *cfg;
+  h->device = device;
+  h->n = cfg->n_cables;
+  h->batch = (uint32_t)cfg->batch;
+  h->stride = (h->batch + 63u) & ~63u;
+  h->fk = (cfg->stages & CDPR_STAGE_FK) != 0;
+  h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
+  h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
+  h->n_state = state_slots((int)h->n, h->fk);
+  h->n_obs = obs_slots((int)h->n);
+  fill_consts(*cfg, h->consts);
+  fill_pid(cfg->velocity_pid, cfg->dt, h->pid_vel);
+  fill_pid(cfg->position_pid, cfg->dt, h->pid_pos);
+  engine_reset_host(h);
+
+  auto fail = [&](const char* what, hipError_t code) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(code);
+    free_all(h);
+    return code == hipErrorOutOfMemory ? CDPR_ERR_NOMEM : CDPR_ERR_DEVICE;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+  const size_t slot_bytes = (size_t)h->stride * sizeof(float4);
+  if ((e = hipMalloc(&h->d_state, slot_bytes * h->n_state)) != hipSuccess) return fail("hipMalloc(state)", e);
+  if ((e = hipMalloc(&h->d_obs, slot_bytes * h->n_obs)) != hipSuccess) return fail("hipMalloc(obs)", e);
+  const size_t cmd_bytes = (size_t)h->stride * h->n * sizeof(float);
+  for (int i = 0; i < 2; ++i) {
+    if ((e = hipMalloc(&h->d_vel[i], cmd_bytes)) != hipSuccess) return fail("hipMalloc(cmd)", e);
+    if ((e = hipMalloc(&h->d_pos[i], cmd_bytes)) != hipSuccess) return fail("hipMalloc(cmd)", e);
+    (void)hipMemset(h->d_vel[i], 0, cmd_bytes);
+    (void)hipMemset(h->d_pos[i], 0, cmd_bytes);
+  }
+  if (h->dbg)
+    if ((e = hipMalloc(&h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float))) != hipSuccess)
+      return fail("hipMalloc(dbg)", e);
+  if (upload_home(h) != CDPR_OK) {
+    g_create_error = h->err;
+    free_all(h);
+    return CDPR_ERR_DEVICE;
+  }
+  *out = h;
+  return CDPR_OK;
+}
+
+void cdpr_destroy(cdpr_handle_t h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  free_all(h);
+}
+
+int cdpr_reset(cdpr_handle_t h) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  engine_reset_host(h);
+  return upload_home(h);
+}
+
+int cdpr_set_platform_state(cdpr_handle_t h, const float* pose7, const float* twist6) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  const int P = plat_slots(h->fk);
+  std::vector<float4> s;
+  int rc = fetch_slots(h, h->d_state, P, s);
+  if (rc != CDPR_OK) return rc;
+  const size_t st = h->stride;
+  for (uint32_t r = 0; r < h->batch; ++r) {
+    float4 &a = s[0 * st + r], &b = s[1 * st + r], &c = s[2 * st + r], &d = s[3 * st + r];
+    if (pose7) {
+      const float* p = pose7 + (size_t)r * 7;
+      a = make_float4(p[0], p[1], p[2], p[3]);
+      b.x = p[4]; b.y = p[5]; b.z = p[6];
+      d.y = p[0]; d.z = p[1]; d.w = p[2];  // the FK seed follows the spawn pose
+      if (h->fk) s[4 * st + r] = make_float4(p[3], p[4], p[5], p[6]);
+    }
+    if (twist6) {
+      const float* t = twist6 + (size_t)r * 6;
+      b.w = t[0]; c.x = t[1]; c.y = t[2]; c.z = t[3]; c.w = t[4]; d.x = t[5];
+    }
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->d_state, s.data(), s.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CDPR_OK;
+}
+
+int cdpr_set_velocity_command(cdpr_handle_t h, const float* axes, size_t count) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = stage_command(h, h->d_vel[1], axes, count, false);
+  if (rc == CDPR_OK) h->vel_pending = true;
+  return rc;
+}
+
+int cdpr_set_position_command(cdpr_handle_t h, const float* axes, size_t count) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = stage_command(h, h->d_pos[1], axes, count, false);
+  if (rc == CDPR_OK) h->pos_pending = true;
+  return rc;
+}
+
+int cdpr_set_velocity_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = stage_command(h, h->d_vel[1], d_axes, count, true);
+  if (rc == CDPR_OK) h->vel_pending = true;
+  return rc;
+}
+
+int cdpr_set_position_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = stage_command(h, h->d_pos[1], d_axes, count, true);
+  if (rc == CDPR_OK) h->pos_pending = true;
+  return rc;
+}
+
+int cdpr_update(cdpr_handle_t h, int nsteps) { return run_steps(h, nsteps, 1); }
+
+int cdpr_update_fused(cdpr_handle_t h, int nsteps, int steps_per_launch) { return run_steps(h, nsteps, steps_per_launch); }
+
+int cdpr_synchronize(cdpr_handle_t h) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CDPR_OK;
+}
+
+uint64_t cdpr_step_count(cdpr_handle_t h) { return h ? h->step : 0; }
+
+int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, float* effort) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  std::vector<float4> o;
+  int rc = fetch_slots(h, h->d_obs, h->n_obs, o);
+  if (rc != CDPR_OK) return rc;
+  const size_t st = h->stride;
+  const int G = joint_groups((int)h->n);
+  float* dst[3] = {position, velocity, effort};
+  for (int f = 0; f < 3; ++f) {
+    if (!dst[f]) continue;
+    for (uint32_t r = 0; r < h->batch; ++r)
+      for (uint32_t i = 0; i < h->n; ++i) dst[f][(size_t)r * h->n + i] = comp(o[(size_t)(4 + f * G + i / 4) * st + r], i % 4);
+  }
+  return CDPR_OK;
+}
+
+int cdpr_get_platform_state(cdpr_handle_t h, float* pose7, float* twist6) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  std::vector<float4> o;
+  int rc = fetch_slots(h, h->d_obs, 4, o);
+  if (rc != CDPR_OK) return rc;
+  unpack_platform(h, o, pose7, twist6);
+  return CDPR_OK;
+}
+
+int cdpr_get_raw_state(cdpr_handle_t h, float* pose7, float* twist6) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  std::vector<float4> s;
+  int rc = fetch_slots(h, h->d_state, 4, s);
+  if (rc != CDPR_OK) return rc;
+  unpack_platform(h, s, pose7, twist6);
+  return CDPR_OK;
+}
+
+int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
+  if (!h || !axes9) return CDPR_ERR_INVALID;
+  if (!h->dbg) {
+    h->err = "CDPR_STAGE_PID_DEBUG not enabled";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipMemcpyAsync(axes9, h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float), hipMemcpyDeviceToHost,
+                            h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CDPR_OK;
+}
+
+int cdpr_get_fk_state(cdpr_handle_t h, float* pose7, float* residual, int32_t* iterations) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (!h->fk) {
+    h->err = "CDPR_STAGE_FK not enabled";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  std::vector<float4> s, o;
+  int rc = fetch_slots(h, h->d_state, 5, s);
+  if (rc != CDPR_OK) return rc;
+  rc = fetch_slots(h, h->d_obs, 4, o);
+  if (rc != CDPR_OK) return rc;
+  const size_t st = h->stride;
+  for (uint32_t r = 0; r < h->batch; ++r) {
+    if (pose7) {
+      float* p = pose7 + (size_t)r * 7;
+      const float4 d = s[3 * st + r], e = s[4 * st + r];
+      p[0] = d.y; p[1] = d.z; p[2] = d.w; p[3] = e.x; p[4] = e.y; p[5] = e.z; p[6] = e.w;
+    }
+    if (residual) residual[r] = o[3 * st + r].y;
+    if (iterations) iterations[r] = (int32_t)o[3 * st + r].z;
+  }
+  return CDPR_OK;
+}
+
+int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (!h->td) {
+    h->err = "CDPR_STAGE_TD not enabled";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  int rc = cdpr_get_joint_states(h, nullptr, nullptr, tension);  // applied force == distributed tension
+  if (rc != CDPR_OK) return rc;
+  if (infeasible) {
+    std::vector<float4> o;
+    rc = fetch_slots(h, h->d_obs, 4, o);
+    if (rc != CDPR_OK) return rc;
+    for (uint32_t r = 0; r < h->batch; ++r) infeasible[r] = (int32_t)o[3 * (size_t)h->stride + r].w;
+  }
+  return CDPR_OK;
+}
+
+int cdpr_profile_begin(cdpr_handle_t h) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  h->launches_mark = h->launches;
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  return CDPR_OK;
+}
+
+int cdpr_profile_end(cdpr_handle_t h, float* elapsed_ms, uint64_t* kernel_launches) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  if (elapsed_ms) *elapsed_ms = ms;
+  if (kernel_launches) *kernel_launches = h->launches - h->launches_mark;
+  return CDPR_OK;
+}
+
+int cdpr_solve_ik(cdpr_handle_t h, const float*, const float*, float*, float*, float*) {
+  if (!h) return CDPR_ERR_INVALID;
+  h->err = "cdpr_solve_ik: not built yet";
+  return CDPR_ERR_UNSUPPORTED;
+}
+int cdpr_solve_fk(cdpr_handle_t h, const float*, const float*, float*, float*, int32_t*) {
+  if (!h) return CDPR_ERR_INVALID;
+  h->err = "cdpr_solve_fk: not built yet";
+  return CDPR_ERR_UNSUPPORTED;
+}
+int cdpr_solve_td(cdpr_handle_t h, const float*, const float*, float*, int32_t*) {
+  if (!h) return CDPR_ERR_INVALID;
+  h->err = "cdpr_solve_td: not built yet";
+  return CDPR_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+"""Thin object wrapper over the C-ABI: one `Engine` = one `cdpr_handle_t` on one GPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _abi
+from ._native import lib
+from .config import Config
+
+
+class CdprError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"cdpr error {code}: {message}")
+        self.code = code
+
+
+def _fp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def derivative_weights(n: int, degree: int) -> np.ndarray:
+    """End-point least-squares derivative weights (closed form of Pid::derive, Pid.cpp:193-247)."""
+    w = np.empty(n, dtype=np.float64)
+    rc = lib().cdpr_derivative_weights(n, degree, w.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != _abi.OK:
+        raise CdprError(rc, "bad (n, degree)")
+    return w
+
+
+class Engine:
+    """B independent robots advanced in lock step on one GPU."""
+
+    def __init__(self, config: Config, device: int = 0):
+        self.config = config
+        self._cfg = config.to_struct()
+        self.n = config.n_cables
+        self.B = int(config.batch)
+        self._h = C.c_void_p()
+        rc = lib().cdpr_create(C.byref(self._cfg), int(device), C.byref(self._h))
+        if rc != _abi.OK:
+            msg = lib().cdpr_last_error(None).decode()
+            self._h = C.c_void_p()
+            if rc == _abi.ERR_INVALID:
+                raise ValueError(msg)  # PLG.cpp:167-168 throws on a bad joint count
+            raise CdprError(rc, msg)
+
+    # -- lifecycle
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().cdpr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise CdprError(rc, lib().cdpr_last_error(self._h).decode())
+        return rc
+
+    def reset(self) -> None:
+        self._check(lib().cdpr_reset(self._h))
+
+    # -- inputs
+    def set_platform_state(self, pose7=None, twist6=None) -> None:
+        p = None if pose7 is None else np.ascontiguousarray(pose7, dtype=np.float32).reshape(self.B, 7)
+        t = None if twist6 is None else np.ascontiguousarray(twist6, dtype=np.float32).reshape(self.B, 6)
+        self._check(lib().cdpr_set_platform_state(self._h, _fp(p), _fp(t)))
+
+    def set_velocity_command(self, axes) -> int:
+        a = np.ascontiguousarray(axes, dtype=np.float32).ravel()
+        return self._check(lib().cdpr_set_velocity_command(self._h, _fp(a), a.size))
+
+    def set_position_command(self, axes) -> int:
+        a = np.ascontiguousarray(axes, dtype=np.float32).ravel()
+        return self._check(lib().cdpr_set_position_command(self._h, _fp(a), a.size))
+
+    def set_velocity_command_device(self, dptr: int, count: int) -> int:
+        return self._check(lib().cdpr_set_velocity_command_device(self._h, C.c_void_p(dptr), count))
+
+    def set_position_command_device(self, dptr: int, count: int) -> int:
+        return self._check(lib().cdpr_set_position_command_device(self._h, C.c_void_p(dptr), count))
+
+    # -- stepping
+    def update(self, nsteps: int = 1, steps_per_launch: int = 1) -> None:
+        if steps_per_launch == 1:
+            self._check(lib().cdpr_update(self._h, int(nsteps)))
+        else:
+            self._check(lib().cdpr_update_fused(self._h, int(nsteps), int(steps_per_launch)))
+
+    def synchronize(self) -> None:
+        self._check(lib().cdpr_synchronize(self._h))
+
+    @property
+    def step_count(self) -> int:
+        return int(lib().cdpr_step_count(self._h))
+
+    @property
+    def sim_time(self) -> float:
+        return self.step_count * self.config.dt
+
+    # -- observables
+    def joint_states(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        q, qd, e = (np.empty((self.B, self.n), dtype=np.float32) for _ in range(3))
+        self._check(lib().cdpr_get_joint_states(self._h, _fp(q), _fp(qd), _fp(e)))
+        return q, qd, e
+
+    def platform_state(self) -> Tuple[np.ndarray, np.ndarray]:
+        p, t = np.empty((self.B, 7), dtype=np.float32), np.empty((self.B, 6), dtype=np.float32)
+        self._check(lib().cdpr_get_platform_state(self._h, _fp(p), _fp(t)))
+        return p, t
+
+    def raw_state(self) -> Tuple[np.ndarray, np.ndarray]:
+        p, t = np.empty((self.B, 7), dtype=np.float32), np.empty((self.B, 6), dtype=np.float32)
+        self._check(lib().cdpr_get_raw_state(self._h, _fp(p), _fp(t)))
+        return p, t
+
+    def pid_debug(self) -> np.ndarray:
+        d = np.empty((self.B, _abi.PID_DEBUG_AXES), dtype=np.float32)
+        self._check(lib().cdpr_get_pid_debug(self._h, _fp(d)))
+        return d
+
+    def fk_state(self):
+        p, r, it = np.empty((self.B, 7), dtype=np.float32), np.empty(self.B, dtype=np.float32), np.empty(self.B, dtype=np.int32)
+        self._check(lib().cdpr_get_fk_state(self._h, _fp(p), _fp(r), it.ctypes.data_as(C.POINTER(C.c_int32))))
+        return p, r, it
+
+    def td_state(self):
+        t, f = np.empty((self.B, self.n), dtype=np.float32), np.empty(self.B, dtype=np.int32)
+        self._check(lib().cdpr_get_td_state(self._h, _fp(t), f.ctypes.data_as(C.POINTER(C.c_int32))))
+        return t, f
+
+    # -- timing (HIP events on the engine's own stream)
+    def profile_begin(self) -> None:
+        self._check(lib().cdpr_profile_begin(self._h))
+
+    def profile_end(self) -> Tuple[float, int]:
+        ms, n = C.c_float(), C.c_uint64()
+        self._check(lib().cdpr_profile_end(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def bytes_per_state_step(self) -> int:
+        return int(lib().cdpr_bytes_per_state_step(C.byref(self._cfg)))

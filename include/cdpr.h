@@ -1,0 +1,219 @@
+/*
+ * cdpr.h — C-ABI of the MI355X-native batched CDPR step engine (libcdpr_hip.so).
+ *
+ * This is the drop-in boundary for the per-step hot path of the reference Gazebo
+ * plugin `cdpr_gazebo` (balazs-bamer/cdpr-simulation).  The reference has no C ABI
+ * of its own (it is a Gazebo ModelPlugin registered by GZ_REGISTER_MODEL_PLUGIN,
+ * CdprGazeboPlugin.h:105); every entry point below names the reference interface
+ * it replaces so a maintainer can bind it from the plugin shell (see
+ * INTEGRATION.md for the C++ stub).  Paths are relative to
+ * src/cdpr_gazebo/ in the reference tree:
+ *   PLG.h/.cpp = include/cdpr_gazebo/CdprGazeboPlugin.h, src/CdprGazeboPlugin.cpp
+ *   JFC.h/.cpp = .../JointForceCalculator.h/.cpp      Pid.h/.cpp, Filter.h likewise
+ *
+ * Conventions
+ *   - plain C, no C++ exceptions cross the boundary; every call returns an int:
+ *       0  = CDPR_OK, >0 = accepted-but-ignored (mirrors the reference's silent
+ *       drops), <0 = error (text via cdpr_last_error()).
+ *   - the caller owns every host buffer passed in or out; the library owns all
+ *     device state behind the opaque handle and never retains a caller pointer
+ *     after the call returns (PLG.cpp:69,78: messages are copied on receipt).
+ *   - batched payloads are robot-major ("leading B dimension"): a Joy.axes of
+ *     one robot is float[n]; the batch is float[B][n].
+ *   - a handle is bound to one GPU and is not thread-safe (the reference runs
+ *     update() and both callbacks on the one physics thread, PLG.cpp:203-204).
+ *   - quaternions are x,y,z,w on the wire (PLG.cpp:266-269).
+ *   - sign: positive joint position / velocity / force = cable shortening /
+ *     tension (prismatic axis = -u, gen_cdpr.py:181, cube.sdf:434).
+ */
+#ifndef CDPR_H_
+#define CDPR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDPR_ABI_VERSION 1u
+#define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
+#define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
+#define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
+#define CDPR_MAX_CASCADE 4u         /* Pid::CascadeFilter: mCascade             */
+#define CDPR_PID_DEBUG_AXES 9u      /* PLG.cpp:194  pidMsg.axes.resize(9)       */
+
+/* return codes */
+#define CDPR_OK 0
+#define CDPR_IGNORED 1              /* wrong-length command, dropped (PLG.cpp:68-73,77-82) */
+#define CDPR_ERR_INVALID (-1)       /* bad argument / bad configuration         */
+#define CDPR_ERR_DEVICE (-2)        /* HIP runtime failure                      */
+#define CDPR_ERR_UNSUPPORTED (-3)   /* valid request the engine cannot serve    */
+#define CDPR_ERR_NOMEM (-4)
+
+/* cdpr_config_t.stages: optional stages added to the always-on IK -> PID -> dynamics loop */
+#define CDPR_STAGE_FK 0x1u          /* Newton-Raphson forward kinematics (n >= 6) */
+#define CDPR_STAGE_TD 0x2u          /* closed-form tension distribution  (n >= 6) */
+#define CDPR_STAGE_PID_DEBUG 0x4u   /* record the `pid` debug topic for cable 0 (PLG.cpp:223-227,233-235) */
+
+/* cdpr_config_t.mapping: how robots are laid onto wavefronts */
+#define CDPR_MAP_AUTO 0u
+#define CDPR_MAP_LANE_PER_ROBOT 1u  /* one lane owns one robot, state in float4 SoA            */
+#define CDPR_MAP_LANE_PER_CABLE 2u  /* n lanes own one robot, J rows in LDS, DPP row reductions */
+
+/* Pid::FilterParameters (Pid.h:64-68) */
+typedef struct cdpr_filter_params {
+  double rel_cutoff;                /* relCutoff: fc relative to fs = 1 (Pid.cpp:34) */
+  double quality;                   /* Q                                               */
+  uint32_t cascade;                 /* number of identical biquads in series; 0 = bypass */
+  uint32_t reserved_;
+} cdpr_filter_params_t;
+
+/* Pid::PidParameters (Pid.h:70-81) */
+typedef struct cdpr_pid_params {
+  double forward_gain;
+  double p_gain;
+  double i_gain;
+  double d_gain;
+  uint32_t d_degree;                /* polynomial degree of the derivative fit */
+  uint32_t d_buffer_length;         /* samples in the derivative window        */
+  double i_limit;
+  double cmd_limit;
+  cdpr_filter_params_t p_filter;
+  cdpr_filter_params_t d_filter;
+} cdpr_pid_params_t;
+
+/*
+ * Everything CdprGazeboPlugin::Load reads from the ROS parameter server
+ * (PLG.h:32-54, PLG.cpp:57,102-138) plus the model constants Gazebo takes from
+ * cube.sdf / cube.yaml (anchors, mass, inertia, damping, effort limit) and the
+ * world constants that are Gazebo defaults (dt, gravity).
+ */
+typedef struct cdpr_config {
+  uint32_t abi_version;             /* CDPR_ABI_VERSION */
+  uint32_t n_cables;                /* PLG.h:20 cWireCount */
+  uint64_t batch;                   /* B independent robots on this handle */
+  double dt;                        /* world step, Gazebo default 1e-3 s */
+
+  double frame_anchor[CDPR_MAX_CABLES][3];     /* a_i, frame coords    (cube.yaml:21-29 `frame`)    */
+  double platform_anchor[CDPR_MAX_CABLES][3];  /* b_i, platform coords (cube.yaml:21-29 `platform`) */
+  double cable_ref_length[CDPR_MAX_CABLES];    /* L0_i = cable length at joint position 0           */
+  double home_pose[7];              /* x y z qx qy qz qw (cube.sdf:310); state after create/reset   */
+
+  double mass;                      /* cube.sdf:340 */
+  double inertia[6];                /* ixx iyy izz ixy ixz iyz, body frame (cube.sdf:332-339) */
+  double gravity[3];                /* frame coords; Gazebo default (0,0,-9.8) */
+  double joint_damping;             /* cube.sdf:442 actuated-joint damping */
+  double effort_limit;              /* cube.sdf:438; Joint::SetForce clamp; < 0 disables */
+
+  cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
+  cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */
+  double velocity_epsilon;          /* PLG.cpp:137-138, JFC.cpp:72 */
+  double publish_period;            /* PLG.cpp:57,237; observables are refreshed when now - prev > period */
+
+  uint32_t stages;                  /* CDPR_STAGE_* */
+  uint32_t mapping;                 /* CDPR_MAP_*   */
+  uint32_t fk_max_iterations;       /* Newton-Raphson iteration cap */
+  uint32_t reserved_;
+  double fk_lambda;                 /* Levenberg damping added to the diagonal of J^T J */
+  double fk_tolerance;              /* stop when max_i |L*_i - L_i| < tol; 0 = always run the cap */
+  double td_f_min;                  /* cube.yaml:9 `min: 5`   */
+  double td_f_max;                  /* cube.yaml:9 `effort`   */
+} cdpr_config_t;
+
+typedef struct cdpr_engine *cdpr_handle_t;
+
+/* Library-level queries (no GPU needed). */
+uint32_t cdpr_abi_version(void);
+size_t cdpr_config_size(void);                       /* sizeof(cdpr_config_t) as compiled */
+int cdpr_device_count(void);                         /* visible GPUs, 0 if none */
+/* Algorithmic HBM bytes one robot moves per state-step for this configuration
+ * (state round trip + command read + observables written); see DESIGN.md. */
+size_t cdpr_bytes_per_state_step(const cdpr_config_t *cfg);
+/* Least-squares end-point derivative weights for an N-sample, degree-d window
+ * on a uniform grid (the closed form of Pid::derive + fitPolynomial,
+ * Pid.cpp:193-247): derivative = (1/dt) * sum_j w[j] * e[j], oldest first. */
+int cdpr_derivative_weights(uint32_t n, uint32_t degree, double *w);
+
+/* Replaces CdprGazeboPlugin::Load (PLG.cpp:49-65): validates the configuration
+ * (invalid cable count -> error, PLG.cpp:167-168), allocates device state for
+ * `batch` robots on GPU `device`, puts every robot at home_pose with zero twist
+ * and every JointForceCalculator in Position mode with target 0
+ * (PLG.cpp:153-157, JFC.cpp:38-51). */
+int cdpr_create(const cdpr_config_t *cfg, int device, cdpr_handle_t *out);
+void cdpr_destroy(cdpr_handle_t h);
+/* World reset: back to the state cdpr_create leaves (JFC.h:69-73 reset()). */
+int cdpr_reset(cdpr_handle_t h);
+const char *cdpr_last_error(cdpr_handle_t h);       /* h may be NULL: last create error */
+
+/* Overwrite the platform state of every robot: pose7[B][7] (x y z qx qy qz qw),
+ * twist6[B][6] (world-frame linear, angular).  Either may be NULL (unchanged).
+ * Stands in for spawning the model at a pose (launch file `-x -y -z -R -P -Y`). */
+int cdpr_set_platform_state(cdpr_handle_t h, const float *pose7, const float *twist6);
+
+/* Replaces cableVelocityCommandCallback / cablePositionCommandCallback
+ * (PLG.cpp:67-83).  `count` = number of floats in `axes`: n*B (one Joy per
+ * robot) or n (one Joy broadcast to every robot).  Any other count returns
+ * CDPR_IGNORED and changes nothing.  The command is latched at the next
+ * cdpr_update and zero-order-held until replaced (PLG.cpp:206-219). */
+int cdpr_set_velocity_command(cdpr_handle_t h, const float *axes, size_t count);
+int cdpr_set_position_command(cdpr_handle_t h, const float *axes, size_t count);
+/* Same, from a device buffer already resident in HBM (float[B][n]). */
+int cdpr_set_velocity_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
+int cdpr_set_position_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
+
+/* Replaces nsteps x { CdprGazeboPlugin::update (PLG.cpp:202-246) followed by
+ * the Gazebo/ODE world step }.  Asynchronous: returns once the work is queued
+ * on the handle's stream. */
+int cdpr_update(cdpr_handle_t h, int nsteps);
+/* Same loop with `steps_per_launch` world steps fused into each kernel launch
+ * (state stays on chip between them; observables still written every step). */
+int cdpr_update_fused(cdpr_handle_t h, int nsteps, int steps_per_launch);
+int cdpr_synchronize(cdpr_handle_t h);
+uint64_t cdpr_step_count(cdpr_handle_t h);           /* world steps since create/reset; sim time = count * dt */
+
+/* Replaces publishJointStates (PLG.cpp:248-256): sensor_msgs/JointState
+ * position / velocity / effort, float[B][n] each, as of the last published
+ * step.  Any pointer may be NULL.  Synchronises the stream. */
+int cdpr_get_joint_states(cdpr_handle_t h, float *position, float *velocity, float *effort);
+/* Replaces publishPlatformState (PLG.cpp:258-280): cdpr_gazebo/PlatformState
+ * pose7[B][7] (x y z qx qy qz qw) and twist6[B][6] (linear, angular), relative
+ * to the frame link. */
+int cdpr_get_platform_state(cdpr_handle_t h, float *pose7, float *twist6);
+/* Replaces the `pid` debug topic (PLG.cpp:193-194,223-227,233-235;
+ * Pid.cpp:139-142,158-168): axes9[B][9] = P term, I term before clamp, D term,
+ * desired, applied force of cable 0, then four unused zeros.  Needs
+ * CDPR_STAGE_PID_DEBUG. */
+int cdpr_get_pid_debug(cdpr_handle_t h, float *axes9);
+/* Forward-kinematics estimate of the last step (CDPR_STAGE_FK): pose7[B][7],
+ * residual[B] = max_i |L*_i - L_i(estimate)|, iterations[B]. */
+int cdpr_get_fk_state(cdpr_handle_t h, float *pose7, float *residual, int32_t *iterations);
+/* Tension distribution of the last step (CDPR_STAGE_TD): tension[B][n] after
+ * bounds, infeasible[B] = 1 where a bound was active. */
+int cdpr_get_td_state(cdpr_handle_t h, float *tension, int32_t *infeasible);
+/* Current platform state (not decimated by publish_period), for checkpoints
+ * and tests: pose7[B][7], twist6[B][6]. */
+int cdpr_get_raw_state(cdpr_handle_t h, float *pose7, float *twist6);
+
+/* Timing of the step kernel on the handle's own stream with HIP events:
+ * begin records an event, end records another, synchronises, and returns the
+ * elapsed milliseconds and the number of step-kernel launches in between. */
+int cdpr_profile_begin(cdpr_handle_t h);
+int cdpr_profile_end(cdpr_handle_t h, float *elapsed_ms, uint64_t *kernel_launches);
+
+/* One-shot batched solvers on caller data (host buffers, float32), for
+ * callers that want the kinematics without the step loop.
+ * IK  (Joint::Position / GetVelocity restated, JFC.cpp:68,75-76): pose7[B][7],
+ *     twist6[B][6] -> q[B][n], qdot[B][n], jac[B][n][6]. Outputs may be NULL. */
+int cdpr_solve_ik(cdpr_handle_t h, const float *pose7, const float *twist6, float *q, float *qdot, float *jac);
+/* FK: lengths[B][n], seed7[B][7] -> pose7[B][7], residual[B], iterations[B]. */
+int cdpr_solve_fk(cdpr_handle_t h, const float *lengths, const float *seed7, float *pose7, float *residual,
+                  int32_t *iterations);
+/* TD: pose7[B][7], wrench6[B][6] (wrench the cables must apply to the
+ *     platform) -> tension[B][n], infeasible[B]. */
+int cdpr_solve_td(cdpr_handle_t h, const float *pose7, const float *wrench6, float *tension, int32_t *infeasible);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDPR_H_ */

@@ -1,0 +1,880 @@
+/*
+ * cdpr_oracle.c — CPU fp64 restatement of the cdpr_gazebo per-step path.
+ * TEST INFRASTRUCTURE ONLY (see cdpr_oracle.h for the rules and the parity status;
+ * parts of this file are "parity unpinned" and say so there).
+ *
+ * Reference paths are relative to /root/reference/src/cdpr_gazebo/:
+ *   PLG.cpp = src/CdprGazeboPlugin.cpp, JFC.cpp = src/JointForceCalculator.cpp,
+ *   Pid.cpp = src/Pid.cpp, Filter.h = include/cdpr_gazebo/Filter.h,
+ *   gen = sdf/gen_cdpr.py.
+ */
+#include "cdpr_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------ */
+/* BiQuad low-pass — Filter.h:102-172                                  */
+/* ------------------------------------------------------------------ */
+void orc_biquad_set_fc(orc_biquad *f, double fc, double fs, double q) {
+  /* Filter.h:130-140 */
+  double k = tan(M_PI * fc / fs);
+  double den = k * k + k / q + 1.0;
+  f->a0 = k * k / den;
+  f->a1 = 2 * f->a0;
+  f->a2 = f->a0;
+  f->b1 = 2 * (k * k - 1.0) / den;
+  f->b2 = (k * k - k / q + 1.0) / den;
+}
+
+void orc_biquad_set_value(orc_biquad *f, double v) {
+  /* Filter.h:144-147 (y0 is not state that survives a call) */
+  f->x1 = f->x2 = f->y1 = f->y2 = v;
+}
+
+double orc_biquad_process(orc_biquad *f, double x) {
+  /* Filter.h:152-165, direct form I */
+  double y0 = f->a0 * x + f->a1 * f->x1 + f->a2 * f->x2 - f->b1 * f->y1 - f->b2 * f->y2;
+  f->x2 = f->x1;
+  f->x1 = x;
+  f->y2 = f->y1;
+  f->y1 = y0;
+  return y0;
+}
+
+/* Pid::CascadeFilter::update — Pid.cpp:38-44 */
+static double cascade_update(orc_biquad *f, unsigned cascade, double x) {
+  double out = x;
+  for (unsigned i = 0; i < cascade; ++i) out = orc_biquad_process(&f[i], out);
+  return out;
+}
+
+/* ------------------------------------------------------------------ */
+/* Column-pivoted Householder QR solve — Eigen 3.3 ColPivHouseholderQR  */
+/* (third-party, not vendored; call site Pid.cpp:246).  Restated from   */
+/* the published algorithm: pivot on the largest remaining column norm, */
+/* reflect, rank-truncate on |R_kk| <= eps * n * max|R_kk|, back-solve. */
+/* ------------------------------------------------------------------ */
+void orc_colpiv_qr_solve(int n, double *a, double *b, double *x) {
+  int perm[16];
+  double y[16];
+  if (n > 16) n = 16;
+  for (int j = 0; j < n; ++j) perm[j] = j;
+  for (int i = 0; i < n; ++i) y[i] = b[i];
+  double maxpivot = 0.0;
+  int rank = n;
+  for (int k = 0; k < n; ++k) {
+    /* pick the column with the largest remaining squared norm */
+    int piv = k;
+    double best = -1.0;
+    for (int j = k; j < n; ++j) {
+      double s = 0;
+      for (int i = k; i < n; ++i) s += a[i * n + j] * a[i * n + j];
+      if (s > best) {
+        best = s;
+        piv = j;
+      }
+    }
+    if (piv != k) {
+      for (int i = 0; i < n; ++i) {
+        double t = a[i * n + k];
+        a[i * n + k] = a[i * n + piv];
+        a[i * n + piv] = t;
+      }
+      int t = perm[k];
+      perm[k] = perm[piv];
+      perm[piv] = t;
+    }
+    /* Householder reflector for column k, rows k..n-1 */
+    double alpha = a[k * n + k];
+    double tail = 0;
+    for (int i = k + 1; i < n; ++i) tail += a[i * n + k] * a[i * n + k];
+    double beta;
+    if (tail == 0.0) {
+      beta = alpha; /* nothing to annihilate */
+    } else {
+      double norm = sqrt(alpha * alpha + tail);
+      beta = (alpha >= 0) ? -norm : norm;
+      double v0 = alpha - beta;
+      /* v = [1, a[k+1..]/v0], tau = (beta - alpha)/beta */
+      double tau = (beta - alpha) / beta;
+      for (int i = k + 1; i < n; ++i) a[i * n + k] /= v0;
+      for (int j = k + 1; j < n; ++j) {
+        double s = a[k * n + j];
+        for (int i = k + 1; i < n; ++i) s += a[i * n + k] * a[i * n + j];
+        s *= tau;
+        a[k * n + j] -= s;
+        for (int i = k + 1; i < n; ++i) a[i * n + j] -= s * a[i * n + k];
+      }
+      double s = y[k];
+      for (int i = k + 1; i < n; ++i) s += a[i * n + k] * y[i];
+      s *= tau;
+      y[k] -= s;
+      for (int i = k + 1; i < n; ++i) y[i] -= s * a[i * n + k];
+    }
+    a[k * n + k] = beta;
+    if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
+  }
+  /* rank by Eigen's default threshold: eps * diagonal size */
+  double thr = 2.220446049250313e-16 * (double)n * maxpivot;
+  rank = 0;
+  for (int k = 0; k < n; ++k)
+    if (fabs(a[k * n + k]) > thr) ++rank;
+  double z[16];
+  for (int i = 0; i < n; ++i) z[i] = 0.0;
+  for (int i = rank - 1; i >= 0; --i) {
+    double s = y[i];
+    for (int j = i + 1; j < rank; ++j) s -= a[i * n + j] * z[j];
+    z[i] = s / a[i * n + i];
+  }
+  for (int i = 0; i < n; ++i) x[perm[i]] = z[i];
+}
+
+/* ------------------------------------------------------------------ */
+/* Pid — Pid.cpp                                                       */
+/* ------------------------------------------------------------------ */
+void orc_pid_reset(orc_pid *p) {
+  /* Pid.cpp:100-115 */
+  p->was_last_time = 0;
+  p->perr = p->ierr = p->derr = p->cmd = 0.0;
+  for (unsigned i = 0; i < p->prm.p_filter.cascade; ++i) orc_biquad_set_value(&p->pf[i], 0.0); /* Pid.h:48-52 */
+  for (unsigned i = 0; i < p->prm.d_filter.cascade; ++i) orc_biquad_set_value(&p->df[i], 0.0);
+  for (unsigned i = 0; i < p->prm.d_buffer_length; ++i) p->bx[i] = p->by[i] = 0.0;
+  p->missing = p->prm.d_buffer_length;
+}
+
+void orc_pid_init(orc_pid *p, const cdpr_pid_params_t *prm, int deriv_mode) {
+  /* Pid.cpp:63-77.  The reference writes abs(double) unqualified (Pid.cpp:70-73),
+   * which may bind to int abs(int); it is exact for the shipped 100.0 — fabs here. */
+  memset(p, 0, sizeof(*p));
+  p->prm = *prm;
+  if (p->prm.d_buffer_length > CDPR_MAX_D_BUFFER) p->prm.d_buffer_length = CDPR_MAX_D_BUFFER;
+  if (p->prm.d_degree > CDPR_MAX_D_DEGREE) p->prm.d_degree = CDPR_MAX_D_DEGREE;
+  if (p->prm.p_filter.cascade > CDPR_MAX_CASCADE) p->prm.p_filter.cascade = CDPR_MAX_CASCADE;
+  if (p->prm.d_filter.cascade > CDPR_MAX_CASCADE) p->prm.d_filter.cascade = CDPR_MAX_CASCADE;
+  p->i_max = fabs(prm->i_limit);
+  p->i_min = -fabs(prm->i_limit);
+  p->cmd_max = fabs(prm->cmd_limit);
+  p->cmd_min = -fabs(prm->cmd_limit);
+  p->deriv_mode = deriv_mode;
+  /* CascadeFilter ctor, Pid.cpp:27-36: SetValue(0), SetFc(relCutoff, 1.0, quality) */
+  for (unsigned i = 0; i < p->prm.p_filter.cascade; ++i) {
+    orc_biquad_set_value(&p->pf[i], 0.0);
+    orc_biquad_set_fc(&p->pf[i], prm->p_filter.rel_cutoff, 1.0, prm->p_filter.quality);
+  }
+  for (unsigned i = 0; i < p->prm.d_filter.cascade; ++i) {
+    orc_biquad_set_value(&p->df[i], 0.0);
+    orc_biquad_set_fc(&p->df[i], prm->d_filter.rel_cutoff, 1.0, prm->d_filter.quality);
+  }
+  orc_pid_reset(p);
+}
+
+/* Pid::fitPolynomial — Pid.cpp:219-247.  coef[0..d] of the fitted polynomial in
+ * the abscissa x[] handed in (absolute time for FAITHFUL, scaled time for EXACT). */
+static void fit_polynomial(const double *x, const double *yv, unsigned nbuf, unsigned degree, double *coef) {
+  double fx[2 * CDPR_MAX_D_DEGREE + 1];
+  double fa[(CDPR_MAX_D_DEGREE + 1) * (CDPR_MAX_D_DEGREE + 1)];
+  double fb[CDPR_MAX_D_DEGREE + 1];
+  unsigned dp1 = degree + 1u, d2p1 = 2u * degree + 1u;
+  for (unsigned i = 0; i < d2p1; ++i) { /* Pid.cpp:224-229 */
+    fx[i] = 0.0;
+    for (unsigned j = 0; j < nbuf; ++j) fx[i] += pow(x[j], (double)i);
+  }
+  for (unsigned i = 0; i < dp1; ++i) /* Pid.cpp:231-235 */
+    for (unsigned j = 0; j < dp1; ++j) fa[i * dp1 + j] = fx[i + j];
+  for (unsigned i = 0; i < dp1; ++i) { /* Pid.cpp:238-244 */
+    double tmp = 0.0;
+    for (unsigned j = 0; j < nbuf; ++j) tmp += pow(x[j], (double)i) * yv[j];
+    fb[i] = tmp;
+  }
+  orc_colpiv_qr_solve((int)dp1, fa, fb, coef); /* Pid.cpp:246 */
+}
+
+double orc_pid_derive(orc_pid *p, double value, double now) {
+  /* Pid.cpp:193-217 */
+  unsigned nbuf = p->prm.d_buffer_length, degree = p->prm.d_degree;
+  for (unsigned i = 1; i < nbuf; ++i) {
+    p->bx[i - 1] = p->bx[i];
+    p->by[i - 1] = p->by[i];
+  }
+  p->bx[nbuf - 1] = now;
+  p->by[nbuf - 1] = value;
+  p->missing -= (p->missing > 0u ? 1u : 0u);
+
+  double derived = 0;
+  if (p->missing == 0u) {
+    double coef[CDPR_MAX_D_DEGREE + 2];
+    if (p->deriv_mode == ORC_DERIV_FAITHFUL) {
+      fit_polynomial(p->bx, p->by, nbuf, degree, coef);
+      for (unsigned i = 1; i <= degree; ++i) coef[i - 1] = i * coef[i]; /* Pid.cpp:205-208 */
+      coef[degree] = 0.0;
+      for (unsigned i = degree; i > 0; --i) derived = now * (derived + coef[i]); /* Pid.cpp:209-212 */
+      derived += coef[0];
+    } else {
+      /* the same least-squares problem, posed in centred time scaled to the mean
+       * sample spacing so the normal equations stay well conditioned at any t */
+      double xs[CDPR_MAX_D_BUFFER];
+      double mean = 0;
+      for (unsigned j = 0; j < nbuf; ++j) mean += p->bx[j];
+      mean /= (double)nbuf;
+      double h = (nbuf > 1) ? (p->bx[nbuf - 1] - p->bx[0]) / (double)(nbuf - 1) : 1.0;
+      if (!(h > 0.0)) h = 1.0;
+      for (unsigned j = 0; j < nbuf; ++j) xs[j] = (p->bx[j] - mean) / h;
+      fit_polynomial(xs, p->by, nbuf, degree, coef);
+      double xn = (now - mean) / h;
+      for (unsigned i = 1; i <= degree; ++i) coef[i - 1] = i * coef[i];
+      coef[degree] = 0.0;
+      for (unsigned i = degree; i > 0; --i) derived = xn * (derived + coef[i]);
+      derived += coef[0];
+      derived /= h;
+    }
+  }
+  return derived;
+}
+
+static double clampd(double v, double lo, double hi) {
+  /* ignition::math::clamp = max(min(v, hi), lo) */
+  double m = v < hi ? v : hi;
+  return m > lo ? m : lo;
+}
+
+double orc_pid_update(orc_pid *p, double desired, double actual, double now) {
+  /* Pid.cpp:122-191 */
+  p->dbg_pi_written = p->dbg_d_written = p->dbg_desired_written = 0;
+  if (!p->was_last_time) {
+    p->was_last_time = 1;
+    p->cmd = 0.0;
+  } else {
+    double f_term = p->prm.forward_gain * desired;
+    double error = desired - actual;
+    double dt = now - p->last_time;
+    p->last_time = now;
+
+    p->perr = cascade_update(p->pf, p->prm.p_filter.cascade, error);
+    double p_term = p->prm.p_gain * p->perr;
+
+    double prev_ierr = p->ierr;
+    p->ierr += dt * error;
+    double i_term = p->prm.i_gain * p->ierr;
+    p->dbg_p = p_term; /* Pid.cpp:139-142 */
+    p->dbg_i = i_term;
+    p->dbg_pi_written = 1;
+    if (i_term > p->i_max) {
+      i_term = p->i_max;
+      p->ierr = i_term / p->prm.i_gain;
+    } else if (i_term < p->i_min) {
+      i_term = p->i_min;
+      p->ierr = i_term / p->prm.i_gain;
+    }
+
+    if (dt > 0.0) {
+      double derived = orc_pid_derive(p, error, now);
+      p->derr = cascade_update(p->df, p->prm.d_filter.cascade, derived);
+      p->dbg_desired = desired; /* Pid.cpp:159 */
+      p->dbg_desired_written = 1;
+    }
+    double d_term = p->prm.d_gain * p->derr;
+    p->dbg_d = d_term; /* Pid.cpp:166-168 */
+    p->dbg_d_written = 1;
+
+    double cmd = f_term + p_term + i_term + d_term;
+    if (p->cmd_max > p->cmd_min) p->cmd = clampd(cmd, p->cmd_min, p->cmd_max); /* Pid.cpp:175-177 */
+    if (p->cmd != cmd) { /* Pid.cpp:181-184: anti-windup, may leave cmd one increment past the clamp */
+      p->ierr = prev_ierr;
+      p->cmd += dt * error * p->prm.i_gain;
+    }
+  }
+  p->last_time = now;
+  return p->cmd;
+}
+
+/* ------------------------------------------------------------------ */
+/* JointForceCalculator — JFC.cpp                                      */
+/* ------------------------------------------------------------------ */
+enum { MODE_FORCE = 0, MODE_POSITION = 1, MODE_VELOCITY = 2 }; /* JFC.h:35-37 */
+
+typedef struct orc_jfc {
+  orc_pid pos, vel;
+  int mode;
+  double eps, last_pos, force, pos_target, vel_target;
+  int64_t last_update_ns; /* gazebo::common::Time is integer sec + nsec [EXT] */
+  int last_pid;           /* which PID ran in the last update: 0 none, 1 pos, 2 vel */
+} orc_jfc;
+
+static void jfc_set_position_target(orc_jfc *j, double target) {
+  /* JFC.cpp:99-107 */
+  j->pos_target = target;
+  if (j->mode != MODE_POSITION) orc_pid_reset(&j->pos);
+  j->mode = MODE_POSITION;
+}
+
+static void jfc_set_velocity_target(orc_jfc *j, double target) {
+  /* JFC.cpp:111-119 */
+  j->vel_target = target;
+  if (j->mode != MODE_VELOCITY) orc_pid_reset(&j->vel);
+  j->mode = MODE_VELOCITY;
+}
+
+static void jfc_init(orc_jfc *j, const cdpr_config_t *cfg, int deriv_mode, double joint_position) {
+  /* PLG.cpp:153-157: construct, setPositionTarget(joint->Position()), then copy-assign
+   * into the slot; operator= (JFC.cpp:38-51) copies the mode and calls reset()
+   * (JFC.h:69-73), which zeroes force and both targets and resets both PIDs.
+   * mLastPosition is not copied and keeps its default 0 (JFC.h:45). */
+  orc_pid_init(&j->pos, &cfg->position_pid, deriv_mode);
+  orc_pid_init(&j->vel, &cfg->velocity_pid, deriv_mode);
+  j->mode = MODE_FORCE; /* JFC.h:42 default */
+  j->eps = cfg->velocity_epsilon;
+  j->last_pos = 0.0;
+  j->force = j->pos_target = j->vel_target = 0.0;
+  jfc_set_position_target(j, joint_position);
+  j->force = j->pos_target = j->vel_target = 0.0; /* reset() */
+  orc_pid_reset(&j->vel);
+  orc_pid_reset(&j->pos);
+  j->last_update_ns = 0; /* World::SimTime() at Load */
+  j->last_pid = 0;
+}
+
+static double jfc_update(orc_jfc *j, int64_t now_ns, double now, double q, double qd) {
+  /* JFC.cpp:59-96 */
+  int64_t step_ns = now_ns - j->last_update_ns;
+  j->last_update_ns = now_ns;
+  double force = 0.0;
+  j->last_pid = 0;
+  if (step_ns > 0) {
+    if (j->mode == MODE_FORCE) {
+      j->last_pos = q;
+      force = j->force;
+    } else if (j->mode == MODE_VELOCITY) {
+      /* JFC.cpp:72 writes abs() unqualified (int-abs hazard); fabs here, the two agree
+       * for the shipped eps = -0.001 where the test is always true */
+      if (fabs(j->vel_target) > j->eps) {
+        j->last_pos = q;
+        force = orc_pid_update(&j->vel, j->vel_target, qd, now);
+        j->last_pid = 2;
+      } else {
+        force = orc_pid_update(&j->pos, j->last_pos, q, now);
+        j->last_pid = 1;
+      }
+    } else if (j->mode == MODE_POSITION) {
+      j->last_pos = q;
+      force = orc_pid_update(&j->pos, j->pos_target, q, now);
+      j->last_pid = 1;
+    }
+  }
+  return force;
+}
+
+/* ------------------------------------------------------------------ */
+/* small linear algebra                                                */
+/* ------------------------------------------------------------------ */
+static void quat_to_rot(const double q[4], double r[9]) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  r[0] = 1 - 2 * (y * y + z * z);
+  r[1] = 2 * (x * y - z * w);
+  r[2] = 2 * (x * z + y * w);
+  r[3] = 2 * (x * y + z * w);
+  r[4] = 1 - 2 * (x * x + z * z);
+  r[5] = 2 * (y * z - x * w);
+  r[6] = 2 * (x * z - y * w);
+  r[7] = 2 * (y * z + x * w);
+  r[8] = 1 - 2 * (x * x + y * y);
+}
+
+static void cross3(const double a[3], const double b[3], double c[3]) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* in-place Cholesky solve of the SPD 6x6 system m x = rhs */
+static void chol6_solve(double m[6][6], double rhs[6]) {
+  for (int j = 0; j < 6; ++j) {
+    double d = m[j][j];
+    for (int k = 0; k < j; ++k) d -= m[j][k] * m[j][k];
+    d = sqrt(d);
+    m[j][j] = d;
+    for (int i = j + 1; i < 6; ++i) {
+      double s = m[i][j];
+      for (int k = 0; k < j; ++k) s -= m[i][k] * m[j][k];
+      m[i][j] = s / d;
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    double s = rhs[i];
+    for (int k = 0; k < i; ++k) s -= m[i][k] * rhs[k];
+    rhs[i] = s / m[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = rhs[i];
+    for (int k = i + 1; k < 6; ++k) s -= m[k][i] * rhs[k];
+    rhs[i] = s / m[i][i];
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* IK — Joint::Position / GetVelocity restated;     */
+/* geometry statement gen:113-118: pp = pf_t + pf_R b, u = (pp-fp)/|..| */
+/* ------------------------------------------------------------------ */
+void orc_ik(const cdpr_config_t *cfg, const double pose[7], const double twist[6], double *q, double *qdot,
+            double *len, double *jac) {
+  double r[9];
+  quat_to_rot(pose + 3, r);
+  for (unsigned i = 0; i < cfg->n_cables; ++i) {
+    const double *b = cfg->platform_anchor[i], *a = cfg->frame_anchor[i];
+    double rb[3] = {r[0] * b[0] + r[1] * b[1] + r[2] * b[2], r[3] * b[0] + r[4] * b[1] + r[5] * b[2],
+                    r[6] * b[0] + r[7] * b[1] + r[8] * b[2]};
+    double l[3] = {pose[0] + rb[0] - a[0], pose[1] + rb[1] - a[1], pose[2] + rb[2] - a[2]};
+    double L = sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+    double u[3] = {l[0] / L, l[1] / L, l[2] / L};
+    double rbxu[3];
+    cross3(rb, u, rbxu);
+    double row[6] = {u[0], u[1], u[2], rbxu[0], rbxu[1], rbxu[2]};
+    if (len) len[i] = L;
+    if (q) q[i] = cfg->cable_ref_length[i] - L; /* prismatic axis = -u (gen:181) */
+    if (qdot && twist) {
+      double s = 0;
+      for (int k = 0; k < 6; ++k) s += row[k] * twist[k];
+      qdot[i] = -s;
+    }
+    if (jac)
+      for (int k = 0; k < 6; ++k) jac[i * 6 + k] = row[k];
+  }
+}
+
+/* world-frame rotation increment: q <- exp(theta/2) (x) q */
+static void quat_apply_rotvec(double q[4], const double th[3]) {
+  double a2 = th[0] * th[0] + th[1] * th[1] + th[2] * th[2];
+  double a = sqrt(a2);
+  double k = (a < 1e-8) ? 0.5 - a2 / 48.0 : sin(0.5 * a) / a;
+  double c = cos(0.5 * a);
+  double d[4] = {k * th[0], k * th[1], k * th[2], c};
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  double n[4];
+  n[3] = d[3] * w - d[0] * x - d[1] * y - d[2] * z;
+  n[0] = d[3] * x + w * d[0] + d[1] * z - d[2] * y;
+  n[1] = d[3] * y + w * d[1] + d[2] * x - d[0] * z;
+  n[2] = d[3] * z + w * d[2] + d[0] * y - d[1] * x;
+  double nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + n[3] * n[3]);
+  for (int i = 0; i < 4; ++i) q[i] = n[i] / nn;
+}
+
+/* J^T J (+ lambda I) and J^T r */
+static void normal_eq(unsigned n, const double *jac, const double *r, double lambda, double m[6][6], double g[6]) {
+  for (int a = 0; a < 6; ++a) {
+    for (int b = 0; b < 6; ++b) {
+      double s = 0;
+      for (unsigned i = 0; i < n; ++i) s += jac[i * 6 + a] * jac[i * 6 + b];
+      m[a][b] = s + (a == b ? lambda : 0.0);
+    }
+    double s = 0;
+    for (unsigned i = 0; i < n; ++i) s += jac[i * 6 + a] * r[i];
+    g[a] = s;
+  }
+}
+
+/* Newton-Raphson FK — [NEW], SURVEY 8(a) row 14 */
+int orc_fk(const cdpr_config_t *cfg, const double *lengths, const double seed[7], double pose_out[7],
+           double *residual) {
+  unsigned n = cfg->n_cables;
+  double pose[7], len[CDPR_MAX_CABLES], jac[CDPR_MAX_CABLES * 6], r[CDPR_MAX_CABLES];
+  memcpy(pose, seed, sizeof(pose));
+  int it = 0;
+  for (; it < (int)cfg->fk_max_iterations; ++it) {
+    orc_ik(cfg, pose, NULL, NULL, NULL, len, jac);
+    double rmax = 0;
+    for (unsigned i = 0; i < n; ++i) {
+      r[i] = lengths[i] - len[i];
+      if (fabs(r[i]) > rmax) rmax = fabs(r[i]);
+    }
+    if (rmax < cfg->fk_tolerance) break;
+    double m[6][6], g[6];
+    normal_eq(n, jac, r, cfg->fk_lambda, m, g);
+    chol6_solve(m, g);
+    pose[0] += g[0];
+    pose[1] += g[1];
+    pose[2] += g[2];
+    quat_apply_rotvec(pose + 3, g + 3);
+  }
+  orc_ik(cfg, pose, NULL, NULL, NULL, len, NULL);
+  double rmax = 0;
+  for (unsigned i = 0; i < n; ++i)
+    if (fabs(lengths[i] - len[i]) > rmax) rmax = fabs(lengths[i] - len[i]);
+  if (residual) *residual = rmax;
+  memcpy(pose_out, pose, sizeof(pose));
+  return it;
+}
+
+/* Tension distribution — [NEW], SURVEY 8(a) row 15.
+ * A = -J^T, T = Tm 1 + A^+ (w_d - A Tm 1) with A^+ = A^T (A A^T)^-1; A A^T = J^T J. */
+static int td_core(const cdpr_config_t *cfg, const double *jac, const double wd[6], double *tension) {
+  unsigned n = cfg->n_cables;
+  double tm = 0.5 * (cfg->td_f_min + cfg->td_f_max);
+  double m[6][6], g[6], ones[CDPR_MAX_CABLES];
+  for (unsigned i = 0; i < n; ++i) ones[i] = tm;
+  normal_eq(n, jac, ones, 0.0, m, g); /* g = J^T (Tm 1) = -(A Tm 1) */
+  double rhs[6];
+  for (int a = 0; a < 6; ++a) rhs[a] = wd[a] + g[a]; /* w_d - A Tm 1 */
+  chol6_solve(m, rhs);
+  int flag = 0;
+  for (unsigned i = 0; i < n; ++i) {
+    double s = 0;
+    for (int a = 0; a < 6; ++a) s += jac[i * 6 + a] * rhs[a];
+    double t = tm - s; /* A^T = -J */
+    if (t < cfg->td_f_min) {
+      t = cfg->td_f_min;
+      flag = 1;
+    } else if (t > cfg->td_f_max) {
+      t = cfg->td_f_max;
+      flag = 1;
+    }
+    tension[i] = t;
+  }
+  return flag;
+}
+
+int orc_td_wrench(const cdpr_config_t *cfg, const double pose[7], const double wrench[6], double *tension) {
+  double jac[CDPR_MAX_CABLES * 6];
+  orc_ik(cfg, pose, NULL, NULL, NULL, NULL, jac);
+  return td_core(cfg, jac, wrench, tension);
+}
+
+int orc_td_forces(const cdpr_config_t *cfg, const double pose[7], const double *f, double *tension) {
+  double jac[CDPR_MAX_CABLES * 6], wd[6];
+  orc_ik(cfg, pose, NULL, NULL, NULL, NULL, jac);
+  for (int a = 0; a < 6; ++a) {
+    double s = 0;
+    for (unsigned i = 0; i < cfg->n_cables; ++i) s += jac[i * 6 + a] * f[i];
+    wd[a] = -s; /* A f */
+  }
+  return td_core(cfg, jac, wd, tension);
+}
+
+/* ------------------------------------------------------------------ */
+/* batched simulator                                                   */
+/* ------------------------------------------------------------------ */
+typedef struct orc_robot {
+  double pose[7], twist[6];
+  orc_jfc jfc[CDPR_MAX_CABLES];
+  double fk_pose[7], fk_res;
+  int32_t fk_iters, td_flag;
+  double td_tension[CDPR_MAX_CABLES];
+  /* published observables */
+  double pub_q[CDPR_MAX_CABLES], pub_qd[CDPR_MAX_CABLES], pub_eff[CDPR_MAX_CABLES];
+  double pub_pose[7], pub_twist[6];
+  double dbg[CDPR_PID_DEBUG_AXES];
+} orc_robot;
+
+struct orc_sim {
+  cdpr_config_t cfg;
+  int deriv_mode;
+  uint64_t step;
+  double prev_publish;
+  orc_robot *rob;
+  float *vel_cmd, *pos_cmd; /* latched Joy.axes, float32 on the wire */
+  int vel_received, pos_received;
+  double ib[9], ib_inv[9]; /* body inertia and its inverse */
+};
+
+static void mat3_inv(const double m[9], double inv[9]) {
+  double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
+  double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
+  inv[0] = c0 / det;
+  inv[1] = (m[2] * m[7] - m[1] * m[8]) / det;
+  inv[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+  inv[3] = c1 / det;
+  inv[4] = (m[0] * m[8] - m[2] * m[6]) / det;
+  inv[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+  inv[6] = c2 / det;
+  inv[7] = (m[1] * m[6] - m[0] * m[7]) / det;
+  inv[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+}
+
+static void robot_reset(const orc_sim *s, orc_robot *r) {
+  memset(r, 0, sizeof(*r));
+  memcpy(r->pose, s->cfg.home_pose, sizeof(r->pose));
+  memcpy(r->fk_pose, s->cfg.home_pose, sizeof(r->fk_pose));
+  memcpy(r->pub_pose, s->cfg.home_pose, sizeof(r->pub_pose));
+  double q[CDPR_MAX_CABLES];
+  orc_ik(&s->cfg, r->pose, NULL, q, NULL, NULL, NULL);
+  for (unsigned i = 0; i < s->cfg.n_cables; ++i) jfc_init(&r->jfc[i], &s->cfg, s->deriv_mode, q[i]);
+}
+
+orc_sim *orc_create(const cdpr_config_t *cfg, int deriv_mode) {
+  if (!cfg || cfg->n_cables < 1 || cfg->n_cables > CDPR_MAX_CABLES || cfg->batch < 1) return NULL;
+  orc_sim *s = (orc_sim *)calloc(1, sizeof(*s));
+  if (!s) return NULL;
+  s->cfg = *cfg;
+  s->deriv_mode = deriv_mode;
+  s->rob = (orc_robot *)malloc(sizeof(orc_robot) * cfg->batch);
+  s->vel_cmd = (float *)calloc(cfg->batch * cfg->n_cables, sizeof(float));
+  s->pos_cmd = (float *)calloc(cfg->batch * cfg->n_cables, sizeof(float));
+  if (!s->rob || !s->vel_cmd || !s->pos_cmd) {
+    orc_destroy(s);
+    return NULL;
+  }
+  const double *in = cfg->inertia;
+  double ib[9] = {in[0], in[3], in[4], in[3], in[1], in[5], in[4], in[5], in[2]};
+  memcpy(s->ib, ib, sizeof(ib));
+  mat3_inv(ib, s->ib_inv);
+  orc_reset(s);
+  return s;
+}
+
+void orc_destroy(orc_sim *s) {
+  if (!s) return;
+  free(s->rob);
+  free(s->vel_cmd);
+  free(s->pos_cmd);
+  free(s);
+}
+
+void orc_reset(orc_sim *s) {
+  s->step = 0;
+  s->prev_publish = 0.0; /* PLG.cpp:59 */
+  s->vel_received = s->pos_received = 0;
+  for (uint64_t b = 0; b < s->cfg.batch; ++b) robot_reset(s, &s->rob[b]);
+}
+
+int orc_set_platform_state(orc_sim *s, const double *pose7, const double *twist6) {
+  for (uint64_t b = 0; b < s->cfg.batch; ++b) {
+    if (pose7) {
+      memcpy(s->rob[b].pose, pose7 + 7 * b, 7 * sizeof(double));
+      memcpy(s->rob[b].fk_pose, pose7 + 7 * b, 7 * sizeof(double));
+    }
+    if (twist6) memcpy(s->rob[b].twist, twist6 + 6 * b, 6 * sizeof(double));
+  }
+  return CDPR_OK;
+}
+
+static int latch(orc_sim *s, float *dst, const float *axes, size_t count, int *flag) {
+  /* PLG.cpp:67-83: accept iff axes.size() == cWireCount, else silently ignore */
+  size_t n = s->cfg.n_cables, B = s->cfg.batch;
+  if (count == n * B && B != 1) {
+    memcpy(dst, axes, sizeof(float) * n * B);
+  } else if (count == n) {
+    for (size_t b = 0; b < B; ++b) memcpy(dst + b * n, axes, sizeof(float) * n);
+  } else {
+    return CDPR_IGNORED;
+  }
+  *flag = 1;
+  return CDPR_OK;
+}
+
+int orc_set_velocity_command(orc_sim *s, const float *axes, size_t count) {
+  return latch(s, s->vel_cmd, axes, count, &s->vel_received);
+}
+int orc_set_position_command(orc_sim *s, const float *axes, size_t count) {
+  return latch(s, s->pos_cmd, axes, count, &s->pos_received);
+}
+
+/* One world iteration for one robot at step index k:
+ * CdprGazeboPlugin::update (PLG.cpp:202-246) on the state at t_k, then the
+ * world step to t_{k+1} (Gazebo/ODE restated). */
+static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) {
+  const cdpr_config_t *cfg = &s->cfg;
+  unsigned n = cfg->n_cables;
+  /* gazebo::common::Time: integer sec/nsec; Double() = sec + nsec*1e-9 [EXT] */
+  int64_t dt_ns = (int64_t)llround(cfg->dt * 1e9);
+  int64_t now_ns = (int64_t)k * dt_ns;
+  double now = (double)(now_ns / 1000000000LL) + (double)(now_ns % 1000000000LL) * 1e-9;
+
+  double q[CDPR_MAX_CABLES], qd[CDPR_MAX_CABLES], jac[CDPR_MAX_CABLES * 6], f[CDPR_MAX_CABLES];
+  orc_ik(cfg, r->pose, r->twist, q, qd, NULL, jac);
+
+  /* PLG.cpp:222-228: per-cable force from the state at t_k */
+  for (unsigned i = 0; i < n; ++i) f[i] = jfc_update(&r->jfc[i], now_ns, now, q[i], qd[i]);
+
+  /* `pid` debug topic: the global pidMsg keeps stale entries when a branch does
+   * not write them (Pid.cpp:139-142,158-168) */
+  {
+    const orc_jfc *j0 = &r->jfc[0];
+    const orc_pid *p = j0->last_pid == 2 ? &j0->vel : (j0->last_pid == 1 ? &j0->pos : NULL);
+    if (p) {
+      if (p->dbg_pi_written) {
+        r->dbg[0] = (float)p->dbg_p;
+        r->dbg[1] = (float)p->dbg_i;
+      }
+      if (p->dbg_d_written) r->dbg[2] = (float)p->dbg_d;
+      if (p->dbg_desired_written) r->dbg[3] = (float)p->dbg_desired;
+    }
+  }
+
+  const double *jtd = jac;
+  double jac_est[CDPR_MAX_CABLES * 6];
+  if (cfg->stages & CDPR_STAGE_FK) {
+    double lstar[CDPR_MAX_CABLES];
+    for (unsigned i = 0; i < n; ++i) lstar[i] = cfg->cable_ref_length[i] - q[i]; /* encoder lengths */
+    double est[7];
+    r->fk_iters = orc_fk(cfg, lstar, r->fk_pose, est, &r->fk_res);
+    memcpy(r->fk_pose, est, sizeof(est));
+    if (cfg->stages & CDPR_STAGE_TD) {
+      orc_ik(cfg, est, NULL, NULL, NULL, NULL, jac_est);
+      jtd = jac_est;
+    }
+  }
+  double applied[CDPR_MAX_CABLES] = {0};
+  if (cfg->stages & CDPR_STAGE_TD) {
+    double wd[6];
+    for (int a = 0; a < 6; ++a) {
+      double sum = 0;
+      for (unsigned i = 0; i < n; ++i) sum += jtd[i * 6 + a] * f[i];
+      wd[a] = -sum;
+    }
+    r->td_flag = td_core(cfg, jtd, wd, r->td_tension);
+    for (unsigned i = 0; i < n; ++i) applied[i] = r->td_tension[i];
+  } else {
+    for (unsigned i = 0; i < n; ++i) applied[i] = f[i];
+  }
+  /* Joint::SetForce clamps to the effort limit (cube.sdf:438) [EXT] */
+  if (cfg->effort_limit >= 0.0)
+    for (unsigned i = 0; i < n; ++i) applied[i] = clampd(applied[i], -cfg->effort_limit, cfg->effort_limit);
+  r->dbg[4] = (float)applied[0]; /* PLG.cpp:226 */
+
+  if (publish) { /* PLG.cpp:248-280; the frame link is static at the origin in the reduced model */
+    for (unsigned i = 0; i < n; ++i) {
+      r->pub_q[i] = q[i];
+      r->pub_qd[i] = qd[i];
+      r->pub_eff[i] = applied[i];
+    }
+    memcpy(r->pub_pose, r->pose, sizeof(r->pub_pose));
+    memcpy(r->pub_twist, r->twist, sizeof(r->pub_twist));
+  }
+
+  /* world step: explicit joint damping, wrench = -J^T T + m g, semi-implicit Euler */
+  double w[6] = {cfg->mass * cfg->gravity[0], cfg->mass * cfg->gravity[1], cfg->mass * cfg->gravity[2], 0, 0, 0};
+  for (unsigned i = 0; i < n; ++i) {
+    double t = applied[i] - cfg->joint_damping * qd[i];
+    for (int a = 0; a < 6; ++a) w[a] -= jac[i * 6 + a] * t;
+  }
+  double rm[9];
+  quat_to_rot(r->pose + 3, rm);
+  double *v = r->twist, *om = r->twist + 3;
+  for (int a = 0; a < 3; ++a) v[a] += cfg->dt * w[a] / cfg->mass;
+  double tb[3], ob[3], iob[3], gyro[3], ab[3], aw[3];
+  for (int a = 0; a < 3; ++a) {
+    tb[a] = rm[0 + a] * w[3] + rm[3 + a] * w[4] + rm[6 + a] * w[5]; /* R^T tau */
+    ob[a] = rm[0 + a] * om[0] + rm[3 + a] * om[1] + rm[6 + a] * om[2];
+  }
+  for (int a = 0; a < 3; ++a) iob[a] = s->ib[3 * a] * ob[0] + s->ib[3 * a + 1] * ob[1] + s->ib[3 * a + 2] * ob[2];
+  cross3(ob, iob, gyro);
+  for (int a = 0; a < 3; ++a) tb[a] -= gyro[a];
+  for (int a = 0; a < 3; ++a) ab[a] = s->ib_inv[3 * a] * tb[0] + s->ib_inv[3 * a + 1] * tb[1] + s->ib_inv[3 * a + 2] * tb[2];
+  for (int a = 0; a < 3; ++a) aw[a] = rm[3 * a] * ab[0] + rm[3 * a + 1] * ab[1] + rm[3 * a + 2] * ab[2];
+  for (int a = 0; a < 3; ++a) om[a] += cfg->dt * aw[a];
+  for (int a = 0; a < 3; ++a) r->pose[a] += cfg->dt * v[a];
+  {
+    double *qq = r->pose + 3;
+    double x = qq[0], y = qq[1], z = qq[2], ww = qq[3];
+    double h = 0.5 * cfg->dt;
+    double nq[4];
+    nq[0] = x + h * (ww * om[0] + om[1] * z - om[2] * y);
+    nq[1] = y + h * (ww * om[1] + om[2] * x - om[0] * z);
+    nq[2] = z + h * (ww * om[2] + om[0] * y - om[1] * x);
+    nq[3] = ww - h * (om[0] * x + om[1] * y + om[2] * z);
+    double nn = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    for (int a = 0; a < 4; ++a) qq[a] = nq[a] / nn;
+  }
+}
+
+int orc_update(orc_sim *s, int nsteps, int nthreads) {
+  if (nsteps <= 0) return CDPR_OK;
+  const unsigned n = s->cfg.n_cables;
+  const int vel_rx = s->vel_received, pos_rx = s->pos_received;
+  s->vel_received = s->pos_received = 0;
+  /* publish schedule (PLG.cpp:236-242): strict '>' against the last published stamp */
+  unsigned char *pub = (unsigned char *)malloc((size_t)nsteps);
+  if (!pub) return CDPR_ERR_NOMEM;
+  int64_t dt_ns = (int64_t)llround(s->cfg.dt * 1e9);
+  for (int k = 0; k < nsteps; ++k) {
+    int64_t now_ns = (int64_t)(s->step + (uint64_t)k) * dt_ns;
+    double now = (double)(now_ns / 1000000000LL) + (double)(now_ns % 1000000000LL) * 1e-9;
+    if ((now - s->prev_publish) > s->cfg.publish_period) {
+      s->prev_publish = now;
+      pub[k] = 1;
+    } else {
+      pub[k] = 0;
+    }
+  }
+  const uint64_t step0 = s->step;
+  const int64_t B = (int64_t)s->cfg.batch;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+  for (int64_t b = 0; b < B; ++b) {
+    orc_robot *r = &s->rob[b];
+    /* PLG.cpp:206-219: velocity command first, then position command */
+    if (vel_rx)
+      for (unsigned i = 0; i < n; ++i) jfc_set_velocity_target(&r->jfc[i], (double)s->vel_cmd[b * n + i]);
+    if (pos_rx)
+      for (unsigned i = 0; i < n; ++i) jfc_set_position_target(&r->jfc[i], (double)s->pos_cmd[b * n + i]);
+    for (int k = 0; k < nsteps; ++k) robot_step(s, r, step0 + (uint64_t)k, pub[k]);
+  }
+  (void)nthreads;
+  s->step += (uint64_t)nsteps;
+  free(pub);
+  return CDPR_OK;
+}
+
+uint64_t orc_step_count(const orc_sim *s) { return s->step; }
+
+void orc_get_joint_states(const orc_sim *s, double *position, double *velocity, double *effort) {
+  unsigned n = s->cfg.n_cables;
+  for (uint64_t b = 0; b < s->cfg.batch; ++b)
+    for (unsigned i = 0; i < n; ++i) {
+      if (position) position[b * n + i] = s->rob[b].pub_q[i];
+      if (velocity) velocity[b * n + i] = s->rob[b].pub_qd[i];
+      if (effort) effort[b * n + i] = s->rob[b].pub_eff[i];
+    }
+}
+
+void orc_get_platform_state(const orc_sim *s, double *pose7, double *twist6) {
+  for (uint64_t b = 0; b < s->cfg.batch; ++b) {
+    if (pose7) memcpy(pose7 + 7 * b, s->rob[b].pub_pose, 7 * sizeof(double));
+    if (twist6) memcpy(twist6 + 6 * b, s->rob[b].pub_twist, 6 * sizeof(double));
+  }
+}
+
+void orc_get_raw_state(const orc_sim *s, double *pose7, double *twist6) {
+  for (uint64_t b = 0; b < s->cfg.batch; ++b) {
+    if (pose7) memcpy(pose7 + 7 * b, s->rob[b].pose, 7 * sizeof(double));
+    if (twist6) memcpy(twist6 + 6 * b, s->rob[b].twist, 6 * sizeof(double));
+  }
+}
+
+void orc_get_pid_debug(const orc_sim *s, double *axes9) {
+  for (uint64_t b = 0; b < s->cfg.batch; ++b)
+    memcpy(axes9 + CDPR_PID_DEBUG_AXES * b, s->rob[b].dbg, CDPR_PID_DEBUG_AXES * sizeof(double));
+}
+
+void orc_get_fk_state(const orc_sim *s, double *pose7, double *residual, int32_t *iterations) {
+  for (uint64_t b = 0; b < s->cfg.batch; ++b) {
+    if (pose7) memcpy(pose7 + 7 * b, s->rob[b].fk_pose, 7 * sizeof(double));
+    if (residual) residual[b] = s->rob[b].fk_res;
+    if (iterations) iterations[b] = s->rob[b].fk_iters;
+  }
+}
+
+void orc_get_td_state(const orc_sim *s, double *tension, int32_t *infeasible) {
+  unsigned n = s->cfg.n_cables;
+  for (uint64_t b = 0; b < s->cfg.batch; ++b) {
+    if (tension) memcpy(tension + n * b, s->rob[b].td_tension, n * sizeof(double));
+    if (infeasible) infeasible[b] = s->rob[b].td_flag;
+  }
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

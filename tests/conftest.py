@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count():
+    try:
+        from cdpr_simulation_amd._native import lib
+
+        return lib().cdpr_device_count()
+    except Exception:
+        return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests must never pass silently without the HIP library: they are only
+    # deselected by `-m "not gpu"`; on a box with no GPU they fail at cdpr_create.
+    pass
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    import cdpr_simulation_amd
+
+    return cdpr_simulation_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as _oracle
+
+    _oracle.build()
+    return _oracle
