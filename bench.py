@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — CDPR state-steps/sec on MI355X for BASELINE.json's metric.
+
+Workload (per GPU): 65 536 independent 8-cable robots, every
+stage on (IK + Newton-Raphson FK (4 iterations) + tension distribution + per-cable PID +
+platform dynamics), fp32, 1 ms step, observables written every step, one kernel launch
+per world step.  Initial poses = home + U(+-0.05 m) + rotation vector U(+-0.1 rad),
+rng(1235); every robot follows its own sine velocity command (amp U(0.01,0.05) m/s,
+freq U(0.05,0.5) Hz, phase U(0,2pi)) refreshed every 10 steps from a schedule that is
+resident in HBM before the timed region starts.  At N > 1 GPUs every rank runs its own
+65 536 robots (config 4: weak scaling, no collective on the data path).
+
+One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per launch
+(4*(39+28n) = 1052 B per state-step at n = 8, times the robots of one
+launch) / average launch duration measured with HIP events on the engine's stream.
+`cpu_baseline` = the fp64 oracle (oracle/, "port") timed on this box's host cores on a
+bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
+    """Initial poses and the per-robot sine command schedule."""
+    from scipy.spatial.transform import Rotation
+
+    model = pkg.eight_cable_model() if n_cables == 8 else pkg.cube_model()
+    rng = np.random.default_rng(seed)
+    pose = np.tile(model.home_pose(), (batch, 1))
+    pose[:, :3] += rng.uniform(-0.05, 0.05, (batch, 3))
+    rv = rng.uniform(-0.1, 0.1, (batch, 3))
+    pose[:, 3:7] = Rotation.from_rotvec(rv).as_quat()  # x y z w
+    amp = rng.uniform(0.01, 0.05, (batch, 1))
+    freq = rng.uniform(0.05, 0.5, (batch, 1))
+    phase = rng.uniform(0.0, 2 * np.pi, (batch, 1))
+    n_cmd = (steps_total + refresh - 1) // refresh
+
+    def command(j):
+        t = j * refresh * dt
+        return np.repeat((amp * np.sin(2 * np.pi * freq * t + phase)).astype(np.float32), n_cables, axis=1)
+
+    return model, pose.astype(np.float32), command, n_cmd
+
+
+def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
+    """Time the fp64 oracle ("port" of the reference step) on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+
+    cores = oracle.lib().orc_max_threads()
+    sample_b = min(pose.shape[0], 512 * cores)
+
+    def run(nsteps):
+        cfg = pkg.Config(batch=sample_b, **cfg_kwargs)
+        sim = oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+        sim.set_platform_state(pose7=pose[:sample_b].astype(np.float64))
+        t0 = time.perf_counter()
+        done = 0
+        while done < nsteps:
+            sim.set_velocity_command(command(done // refresh)[:sample_b])
+            k = min(refresh, nsteps - done)
+            sim.update(k, cores)
+            done += k
+        dt_ = time.perf_counter() - t0
+        sim.close()
+        return dt_
+
+    probe_steps = 20
+    t_probe = run(probe_steps)
+    rate = sample_b * probe_steps / t_probe
+    nsteps = int(max(refresh, min(2000, target_seconds * rate / sample_b)))
+    t = run(nsteps)
+    return {
+        "value": sample_b * nsteps / t,
+        "unit": "state-steps/s",
+        "cores": int(cores),
+        "kind": "port",
+        "sample": f"{sample_b} robots x {nsteps} steps of the same workload, fp64 oracle (CPU restatement of the "
+                  f"cdpr_gazebo step, not Gazebo/ODE), OpenMP over robots, {t:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
+    ap.add_argument("--cables", type=int, default=8, choices=(4, 8))
+    ap.add_argument("--steps-per-launch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import cdpr_simulation_amd as pkg
+    from cdpr_simulation_amd import _abi
+    from cdpr_simulation_amd.sharding import RankContext
+
+    # torch.distributed (RCCL) only provides the rendezvous: barrier + max over ranks. No data-path collective.
+    ctx = RankContext.from_env(backend=os.environ.get("CDPR_BENCH_BACKEND", "nccl"))
+    rank, local_rank, world = ctx.rank, ctx.local_rank, ctx.world
+
+    n = args.cables
+    stages = (_abi.STAGE_FK | _abi.STAGE_TD) if n == 8 else 0
+    refresh = 10
+    total = args.warmup + args.steps
+    seed = (1235 if n == 8 else 1234) + rank
+    model, pose, command, n_cmd = make_workload(pkg, args.batch, n, seed, total, refresh)
+    cfg_kwargs = dict(model=model, stages=stages)
+    cfg = pkg.Config(batch=args.batch, **cfg_kwargs)
+    eng = pkg.Engine(cfg, device=local_rank)
+    eng.set_platform_state(pose7=pose)
+    # command schedule resident in HBM before timing starts
+    sched = [eng.device_upload(command(j)) for j in range(n_cmd)]
+    count = args.batch * n
+
+    def advance(first_step, nsteps):
+        done = 0
+        while done < nsteps:
+            s = first_step + done
+            if s % refresh == 0:
+                eng.set_velocity_command_device(sched[s // refresh], count)
+            k = min(refresh - s % refresh, nsteps - done)
+            eng.update(k, args.steps_per_launch)
+            done += k
+
+    def barrier():
+        eng.synchronize()  # hipStreamSynchronize on the engine's stream (all of this process's GPU work)
+        ctx.barrier()      # torch.cuda.synchronize() + dist.barrier() when N > 1
+
+    advance(0, args.warmup)
+    barrier()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    advance(args.warmup, args.steps)
+    ev_ms, launches = eng.profile_end()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = ctx.max_over_ranks(elapsed)
+
+    pose_end, _ = eng.platform_state()
+    finite = bool(np.isfinite(pose_end).all())
+
+    if rank == 0:
+        bytes_step = eng.bytes_per_state_step()
+        launch_s = ev_ms * 1e-3 / max(launches, 1)
+        robots_per_launch_steps = args.batch * args.steps / max(launches, 1)
+        achieved = bytes_step * robots_per_launch_steps / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"n{n}_b{args.batch}_spl{args.steps_per_launch}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CDPR sim-steps/sec (whole node), 65 536 parallel 8-cable robots, 1 ms dt",
+            "value": world * args.batch * args.steps / elapsed,
+            "unit": "state-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"config3: {args.batch} x {n}-cable robots per GPU, "
+                            + ("IK + NR-FK(4 it) + tension distribution + PID + dynamics" if n == 8 else "IK + PID + dynamics")
+                            + ", observables every step, commands refreshed every 10 steps from HBM",
+                "robots_per_gpu": args.batch,
+                "cables": n,
+                "steps_per_launch": args.steps_per_launch,
+                "mapping": "lane-per-robot",
+                "state_finite": finite,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_us": launch_s * 1e6,
+                "bytes_per_state_step": bytes_step,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    for p in sched:
+        eng.device_free(p)
+    eng.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -707,6 +707,36 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
   return CDPR_OK;
 }
 
+int cdpr_device_malloc(cdpr_handle_t h, size_t bytes, void** out) {
+  if (!h || !out) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipMalloc(out, bytes));
+  return CDPR_OK;
+}
+
+int cdpr_device_free(cdpr_handle_t h, void* ptr) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipFree(ptr));
+  return CDPR_OK;
+}
+
+int cdpr_device_upload(cdpr_handle_t h, void* dst, const void* src, size_t bytes) {
+  if (!h || !dst || !src) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CDPR_OK;
+}
+
+int cdpr_device_download(cdpr_handle_t h, void* dst, const void* src, size_t bytes) {
+  if (!h || !dst || !src) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return CDPR_OK;
+}
+
 int cdpr_profile_begin(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;

@@ -142,6 +142,17 @@ class Engine:
         self._check(lib().cdpr_get_td_state(self._h, _fp(t), f.ctypes.data_as(C.POINTER(C.c_int32))))
         return t, f
 
+    # -- caller-owned device buffers (e.g. a schedule of Joy batches resident in HBM)
+    def device_upload(self, array: np.ndarray) -> int:
+        a = np.ascontiguousarray(array)
+        ptr = C.c_void_p()
+        self._check(lib().cdpr_device_malloc(self._h, a.nbytes, C.byref(ptr)))
+        self._check(lib().cdpr_device_upload(self._h, ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return int(ptr.value)
+
+    def device_free(self, dptr: int) -> None:
+        self._check(lib().cdpr_device_free(self._h, C.c_void_p(dptr)))
+
     # -- timing (HIP events on the engine's own stream)
     def profile_begin(self) -> None:
         self._check(lib().cdpr_profile_begin(self._h))

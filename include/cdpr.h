@@ -195,6 +195,14 @@ int cdpr_get_td_state(cdpr_handle_t h, float *tension, int32_t *infeasible);
  * and tests: pose7[B][7], twist6[B][6]. */
 int cdpr_get_raw_state(cdpr_handle_t h, float *pose7, float *twist6);
 
+/* Device-buffer helpers for hosts that have no GPU runtime of their own (ctypes):
+ * allocate / free / fill a caller-owned device buffer on the handle's GPU, e.g. to keep
+ * a schedule of Joy batches resident in HBM for cdpr_set_*_command_device. */
+int cdpr_device_malloc(cdpr_handle_t h, size_t bytes, void **out);
+int cdpr_device_free(cdpr_handle_t h, void *ptr);
+int cdpr_device_upload(cdpr_handle_t h, void *dst, const void *src, size_t bytes);
+int cdpr_device_download(cdpr_handle_t h, void *dst, const void *src, size_t bytes);
+
 /* Timing of the step kernel on the handle's own stream with HIP events:
  * begin records an event, end records another, synchronises, and returns the
  * elapsed milliseconds and the number of step-kernel launches in between. */

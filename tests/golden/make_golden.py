@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ — run in the build container only
+(it reads /root/reference, which does not exist on the GPU box).
+
+  cube_model.json    DATA copied out of the reference's model files: anchors and joint
+                     constants from sdf/cube.yaml, link poses / joint axes / inertial
+                     numbers from sdf/cube.sdf (the values its generator wrote).
+  geometry.json      gen_cdpr.py's geometry formulas (lines 101-125) re-evaluated with the
+                     reference's own transformations.py imported from /root/reference
+                     (gen_cdpr.py itself is Python 2 and imports a missing module).
+  biquad.json        outputs of the reference's own Filter.h BiQuad<double>, via
+                     oracle/_ref/libref_filter.so (built by oracle/Makefile from the header
+                     where it lies).
+  pid_kat.json       spot values recorded in SURVEY.md Appendix A (survey-time probe that
+                     compiled Pid.cpp against stand-in headers; NOT reproducible under this
+                     build's rules, kept as known-answer tests, not as a parity pin).
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import yaml
+
+REF = "/root/reference/src/cdpr_gazebo"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def floats(s):
+    return [float(x) for x in s.split()]
+
+
+def cube_model():
+    y = yaml.safe_load(open(os.path.join(REF, "sdf/cube.yaml")))
+    sdf = open(os.path.join(REF, "sdf/cube.sdf")).read()
+    out = {"source": "sdf/cube.yaml + sdf/cube.sdf of balazs-bamer/cdpr-simulation (data values only)"}
+    out["yaml"] = {
+        "points": y["points"], "joints": y["joints"], "platform": y["platform"], "frame": y["frame"],
+    }
+    plat = re.search(r'<link name="platform">\s*<pose>([^<]+)</pose>', sdf)
+    out["sdf_platform_pose"] = floats(plat.group(1))
+    block = sdf[sdf.index('<link name="platform">'):sdf.index('<link name="cable0">')]
+    out["sdf_platform_inertia"] = {k: float(re.search(rf"<{k}>([^<]+)</{k}>", block).group(1)) for k in ("ixx", "iyy", "izz", "ixy", "ixz", "iyz", "mass")}
+    cables = []
+    for i in range(4):
+        link = re.search(rf'<link name="cable{i}">\s*<pose>([^<]+)</pose>', sdf)
+        jblock = sdf[sdf.index(f'<joint name="cable{i}" type="prismatic">'):]
+        jblock = jblock[:jblock.index("</joint>")]
+        cables.append({
+            "link_pose": floats(link.group(1)),
+            "joint_pose": floats(re.search(r"<pose>([^<]+)</pose>", jblock).group(1)),
+            "axis_xyz": floats(re.search(r"<xyz>([^<]+)</xyz>", jblock).group(1)),
+            "lower": float(re.search(r"<lower>([^<]+)</lower>", jblock).group(1)),
+            "upper": float(re.search(r"<upper>([^<]+)</upper>", jblock).group(1)),
+            "effort": float(re.search(r"<effort>([^<]+)</effort>", jblock).group(1)),
+            "velocity": float(re.search(r"<velocity>([^<]+)</velocity>", jblock).group(1)),
+            "damping": float(re.search(r"<damping>([^<]+)</damping>", jblock).group(1)),
+        })
+    out["sdf_cables"] = cables
+    return out
+
+
+def geometry(model):
+    sys.path.insert(0, os.path.join(REF, "sdf"))
+    import transformations as tr  # the reference's own module, imported where it lies
+
+    y = model["yaml"]
+    xyz = model["sdf_platform_pose"][:3]  # cube.sdf:310 is what is loaded (cube.yaml:17 says z = 2)
+    rpy = model["sdf_platform_pose"][3:]
+    pf_t = np.array(xyz).reshape(3, 1)
+    pf_R = tr.euler_matrix(rpy[0], rpy[1], rpy[2])[:3, :3]  # gen:102
+    l = np.linalg.norm([y["frame"]["upper"][i] - y["frame"]["lower"][i] for i in range(3)])  # gen:104
+    z = [0, 0, 1]
+    out = {"source": "gen_cdpr.py:101-125 formulas evaluated with the reference's transformations.py", "cables": []}
+    for cbl in y["points"]:
+        fp = np.array(cbl["frame"], dtype=float).reshape(3, 1)
+        pp = pf_t + np.dot(pf_R, np.array(cbl["platform"], dtype=float).reshape(3, 1))  # gen:115
+        u = (pp - fp).reshape(3)
+        L = float(np.linalg.norm(u))
+        u = u / L  # gen:117-118
+        R = tr.rotation_matrix(np.arctan2(np.linalg.norm(np.cross(z, u)), np.dot(u, z)), np.cross(z, u))  # gen:119
+        rpy_c = list(tr.euler_from_matrix(R))  # gen:121
+        a = l / (2.0 * np.linalg.norm(pp - fp))  # gen:124
+        cp = list((pp - a * (pp - fp)).reshape(3))  # gen:125
+        rb = (pp - pf_t).reshape(3)
+        out["cables"].append({
+            "length": L, "u": u.tolist(), "rpy": [float(v) for v in rpy_c], "link_position": [float(v) for v in cp],
+            "axis": (-R[:3, 2]).tolist(),  # gen:181 prismatic axis = -R[:,2]
+            "jacobian_row": u.tolist() + np.cross(rb, u).tolist(),
+        })
+    J = np.array([c["jacobian_row"] for c in out["cables"]])
+    out["rank_J_home"] = int(np.linalg.matrix_rank(J))
+    # static tension balancing gravity 9.8 on the 1 kg platform (vertical force balance, 4 equal cables)
+    out["static_tension_g9.8"] = float(model["sdf_platform_inertia"]["mass"] * 9.8 / (-J[:, 2].sum()))
+    return out
+
+
+def biquad():
+    import oracle
+
+    oracle.build()
+    rng = np.random.default_rng(20260101)
+    cases = []
+    for fc, q in ((0.1, 0.707), (0.05, 0.5), (0.25, 1.2)):
+        for name, x in (("impulse", np.r_[1.0, np.zeros(39)]), ("step", np.ones(40)), ("noise", rng.standard_normal(40))):
+            f = oracle.RefBiquad(fc, 1.0, q)
+            y = [f.process(float(v)) for v in x]
+            cases.append({"fc": fc, "fs": 1.0, "q": q, "input_name": name, "input": [float(v) for v in x], "output": y})
+    # SetValue(v) preloads every tap (Filter.h:144-147)
+    f = oracle.RefBiquad(0.1, 1.0, 0.707)
+    f.set_value(0.5)
+    cases.append({"fc": 0.1, "fs": 1.0, "q": 0.707, "input_name": "setvalue0.5_then_zeros", "preset": 0.5, "input": [0.0] * 20,
+                  "output": [f.process(0.0) for _ in range(20)]})
+    return {"source": "reference Filter.h BiQuad<double> via oracle/_ref/libref_filter.so", "cases": cases}
+
+
+def pid_kat():
+    return {
+        "source": "SURVEY.md Appendix A (survey-time probe; stand-in headers; not reproducible here)",
+        "velocity_pid_toy_plant": {
+            "plant": "qdd = F - qd, semi-implicit Euler, dt = 1e-3; Pid::update called from k = 0 with now = k*dt",
+            "command": "sinevelocitytest: float32(0.05*sin(2*pi*0.1*t)), t += 0.01 every 10 steps",
+            "first_command_sample_k1": 0.000314157194,
+            "force_zero_through_k": 9,
+            "force": {"10": 0.062837721988908, "11": 0.13902871955863},
+        },
+        "mode_switch": {
+            "scenario": "position hold from load; setVelocityTarget(0.01f) at k = 5 (same toy plant)",
+            "force": {"5": 0.0, "6": 2.00019995529, "7": 1.60031996023},
+        },
+        "derivative_weights_n11_d2": [0.129370629371, 0.0335664335664, -0.0389277389277, -0.0881118881119, -0.113986013986,
+                                      -0.11655011655, -0.0958041958042, -0.0517482517483, 0.0156177156177, 0.106293706294, 0.22027972028],
+        "home_geometry": {"L0": 0.485592422, "u0": [0.556021857, 0.556021857, -0.617802063],
+                          "J_row0": [0.556021857, 0.556021857, -0.617802063, 0.018534062, -0.018534062, 0.0],
+                          "static_tension": 3.965671444,
+                          "eight_cable_singular_values": [1.726, 1.590, 1.579, 0.0583, 0.0527, 0.0510]},
+    }
+
+
+if __name__ == "__main__":
+    m = cube_model()
+    json.dump(m, open(os.path.join(HERE, "cube_model.json"), "w"), indent=1)
+    json.dump(geometry(m), open(os.path.join(HERE, "geometry.json"), "w"), indent=1)
+    json.dump(biquad(), open(os.path.join(HERE, "biquad.json"), "w"), indent=1)
+    json.dump(pid_kat(), open(os.path.join(HERE, "pid_kat.json"), "w"), indent=1)
+    print("golden fixtures written to", HERE)

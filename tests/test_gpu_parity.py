@@ -1,0 +1,302 @@
+"""Parity tests proper: the HIP engine, called through the C-ABI, against the CPU fp64 oracle on the same
+seeded inputs.  Everything on the GPU is fp32; tolerances (absolute, stated per quantity) are
+  pose 1e-5 (m / quaternion units), twist 2e-4 (m/s, rad/s), joint position 1e-5 m, joint velocity 2e-4 m/s,
+  effort 2e-2 N (the effort range is +-100 N; the position Pid's D gain of 80 N s/m amplifies fp32 rounding of
+  the 1 ms window: measured worst case on MI355X 2.2e-3 N).
+Measured on MI355X at the sizes below: pose <= 7e-7, twist <= 1.5e-5, effort <= 2.3e-3.
+"""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"pose": 1e-5, "twist": 2e-4, "q": 1e-5, "qd": 2e-4, "eff": 2e-2}
+
+
+def compare(eng, ora, tol=TOL, where=""):
+    gp, gt = eng.platform_state()
+    op, ot = ora.platform_state()
+    gq, gqd, ge = eng.joint_states()
+    oq, oqd, oe = ora.joint_states()
+    assert np.isfinite(gp).all() and np.isfinite(ge).all(), where
+    for name, g, o in (("pose", gp, op), ("twist", gt, ot), ("q", gq, oq), ("qd", gqd, oqd), ("eff", ge, oe)):
+        err = float(np.abs(g - o).max())
+        assert err <= tol[name], f"{where}: {name} differs from the oracle by {err:.3e} (tolerance {tol[name]:.1e})"
+
+
+def pair(pkg, oracle, cfg, pose=None, twist=None):
+    eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+    if pose is not None or twist is not None:
+        p32 = None if pose is None else np.asarray(pose, dtype=np.float32)
+        t32 = None if twist is None else np.asarray(twist, dtype=np.float32)
+        eng.set_platform_state(pose7=p32, twist6=t32)
+        ora.set_platform_state(pose7=None if p32 is None else p32.astype(np.float64), twist6=None if t32 is None else t32.astype(np.float64))
+    return eng, ora
+
+
+def perturbed_poses(model, B, rng, dp=0.05, dr=0.1):
+    pose = np.tile(model.home_pose(), (B, 1))
+    pose[:, :3] += rng.uniform(-dp, dp, (B, 3))
+    pose[:, 3:] = Rotation.from_rotvec(rng.uniform(-dr, dr, (B, 3))).as_quat()
+    return pose
+
+
+def test_config1_sine_velocity_trajectory(pkg, oracle):
+    """BASELINE config 1: the shipped 4-cable robot driven by sinevelocitytest (100 Hz, zero-order hold),
+    3 000 steps of 1 ms, GPU fp32 vs oracle fp64 along the whole trajectory."""
+    cfg = pkg.Config(batch=1)
+    eng, ora = pair(pkg, oracle, cfg)
+    gen = pkg.stimulus.sine_velocity(4)
+    for k in range(300):
+        cmd = next(gen)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        eng.update(10), ora.update(10)
+        if k % 10 == 9:
+            compare(eng, ora, where=f"step {10 * (k + 1)}")
+    assert eng.step_count == ora.step_count == 3000
+
+
+def test_position_hold_from_load(pkg, oracle):
+    """No command at all: Position mode with target 0 (PLG.cpp:153-157) holds the platform against gravity."""
+    eng, ora = pair(pkg, oracle, pkg.Config(batch=2))
+    for _ in range(10):
+        eng.update(100), ora.update(100)
+        compare(eng, ora, where="hold")
+    assert 0.2 < eng.platform_state()[0][0, 2] < 0.31  # hanging under its cables, not in free fall (would be -4.6 m)
+
+
+def test_first_steps_match_exactly_in_structure(pkg, oracle):
+    """Steps 0 and 1 apply zero force (JFC.cpp:61-66, Pid.cpp:123-126); step 0 is not published."""
+    eng, ora = pair(pkg, oracle, pkg.Config(batch=1))
+    eng.update(1), ora.update(1)
+    assert np.all(eng.joint_states()[2] == 0.0)
+    assert np.array_equal(eng.platform_state()[0], np.array([[0, 0, 0.3, 0, 0, 0, 1]], dtype=np.float32))
+    eng.update(1), ora.update(1)
+    assert np.all(eng.joint_states()[2] == 0.0) and eng.platform_state()[1][0, 2] < 0.0  # falling, published now
+    eng.update(1), ora.update(1)
+    assert np.all(eng.joint_states()[2] > 0.0)
+    compare(eng, ora, where="step 3")
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 130, 1000])
+def test_config2_random_batch_four_cable(pkg, oracle, B):
+    """BASELINE config 2 at oracle-sized batches, including ragged sizes around the 64-lane wavefront."""
+    rng = np.random.default_rng(1234)
+    cfg = pkg.Config(batch=B)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng))
+    amp, freq, ph = rng.uniform(0.01, 0.05, (B, 1)), rng.uniform(0.05, 0.5, (B, 1)), rng.uniform(0, 2 * np.pi, (B, 1))
+    for j in range(20):
+        cmd = np.repeat(amp * np.sin(2 * np.pi * freq * j * 0.01 + ph), 4, axis=1).astype(np.float32)
+        assert eng.set_velocity_command(cmd) == ora.set_velocity_command(cmd) == 0
+        eng.update(10), ora.update(10)
+    compare(eng, ora, where=f"B={B}")
+
+
+@pytest.mark.parametrize("stages", [0, 1, 2, 3])
+def test_config3_eight_cable_stage_combinations(pkg, oracle, stages):
+    """BASELINE config 3 (IK + NR-FK + TD + PID + dynamics) and its stage subsets, 8 cables."""
+    B = 200
+    rng = np.random.default_rng(1235)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=stages)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng))
+    eng.update(30), ora.update(30)
+    for j in range(20):
+        cmd = rng.uniform(-0.05, 0.05, (B, 8)).astype(np.float32)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        eng.update(10), ora.update(10)
+    compare(eng, ora, where=f"stages={stages}")
+    if stages & 1:
+        gp, gr, gi = eng.fk_state()
+        op, orr, oi = ora.fk_state()
+        assert np.array_equal(gi, oi) and np.abs(gp - op).max() < 1e-5 and gr.max() < 1e-6
+        true_pose, _ = eng.platform_state()
+        assert np.abs(gp[:, :3] - true_pose[:, :3]).max() < 2e-6  # the estimator recovers the true pose
+    if stages & 2:
+        gt, gf = eng.td_state()
+        ot, of = ora.td_state()
+        assert np.array_equal(gf, of) and np.abs(gt - ot).max() < TOL["eff"]
+        assert gt.min() >= 5.0 and gt.max() <= 100.0
+
+
+def test_six_and_seven_cable_robots(pkg, oracle):
+    """Cable counts between the shipped 4 and the build-defined 8 (drop cables from the 8-cable layout)."""
+    full = pkg.eight_cable_model()
+    for keep in ([0, 1, 2, 3, 4, 6], [0, 1, 2, 3, 4, 5, 6]):
+        m = pkg.Model(full.frame_anchors[keep], full.platform_anchors[keep])
+        cfg = pkg.Config(model=m, batch=70, stages=1)
+        eng, ora = pair(pkg, oracle, cfg)
+        eng.update(100), ora.update(100)
+        compare(eng, ora, where=f"n={len(keep)}")
+
+
+def test_mode_switching_resets_the_right_pid(pkg, oracle):
+    """Velocity -> Position -> Velocity, plus both commands in one update (velocity is applied first, then
+    position: PLG.cpp:206-219), against the oracle's two-Pid JointForceCalculator."""
+    B = 40
+    rng = np.random.default_rng(77)
+    cfg = pkg.Config(batch=B)
+    eng, ora = pair(pkg, oracle, cfg)
+    script = [("run", 25), ("vel", 0.03), ("run", 40), ("pos", -0.01), ("run", 40), ("vel", -0.02), ("run", 15), ("vel", 0.01), ("run", 15),
+              ("both", (0.02, 0.005)), ("run", 40), ("pos", 0.0), ("run", 20)]
+    for kind, val in script:
+        for sim in (eng, ora):
+            if kind == "vel":
+                sim.set_velocity_command(np.full(4, val, dtype=np.float32))
+            elif kind == "pos":
+                sim.set_position_command(np.full((B, 4), val, dtype=np.float32))
+            elif kind == "both":
+                sim.set_velocity_command(np.full(4, val[0], dtype=np.float32))
+                sim.set_position_command(np.full(4, val[1], dtype=np.float32))
+            else:
+                sim.update(val)
+        if kind == "run":
+            compare(eng, ora, where=f"after {kind} {val}")
+
+
+def test_saturation_and_anti_windup(pkg, oracle):
+    """A 2 m/s velocity demand saturates the command clamp (Pid.cpp:175-186) and the SetForce effort clamp."""
+    cfg = pkg.Config(batch=3)
+    eng, ora = pair(pkg, oracle, cfg)
+    cmd = np.array([[2.0] * 4, [-2.0] * 4, [0.5, -0.5, 0.5, -0.5]], dtype=np.float32)
+    eng.update(5), ora.update(5)
+    eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+    eng.update(3), ora.update(3)
+    ge = eng.joint_states()[2]
+    assert np.all(np.abs(ge[0]) == 100.0) and np.all(np.abs(ge[1]) == 100.0)  # past the Pid clamp, held by the effort clamp
+    eng.update(30), ora.update(30)
+    compare(eng, ora, tol=dict(TOL, eff=5e-2), where="saturated")
+
+
+def test_wrong_length_commands_are_ignored(pkg, oracle):
+    """PLG.cpp:68-73,77-82: a Joy whose axes count is not n (or n*B) is dropped silently; state untouched."""
+    cfg = pkg.Config(batch=5)
+    eng, ref = pkg.Engine(cfg, 0), pkg.Engine(cfg, 0)
+    assert eng.set_velocity_command(np.ones(3, dtype=np.float32)) == pkg._abi.IGNORED
+    assert eng.set_position_command(np.ones(21, dtype=np.float32)) == pkg._abi.IGNORED
+    assert eng.set_velocity_command(np.ones(8, dtype=np.float32)) == pkg._abi.IGNORED
+    eng.update(50), ref.update(50)
+    assert np.array_equal(eng.raw_state()[0], ref.raw_state()[0]) and np.array_equal(eng.joint_states()[2], ref.joint_states()[2])
+
+
+def test_fused_launch_is_bit_identical_to_single_step_launches(pkg):
+    """steps_per_launch only changes where state lives between steps, not the arithmetic."""
+    B = 300
+    rng = np.random.default_rng(5)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    a, b = pkg.Engine(cfg, 0), pkg.Engine(cfg, 0)
+    for e in (a, b):
+        e.set_platform_state(pose7=pose)
+    cmd = rng.uniform(-0.04, 0.04, (B, 8)).astype(np.float32)
+    a.update(7), b.update(7, 7)
+    a.set_velocity_command(cmd), b.set_velocity_command(cmd)
+    a.update(64), b.update(64, 16)
+    a.update(5), b.update(5, 3)
+    for x, y in zip(a.raw_state() + a.joint_states() + a.platform_state(), b.raw_state() + b.joint_states() + b.platform_state()):
+        assert np.array_equal(x, y)
+    assert a.step_count == b.step_count == 76
+
+
+def test_publish_period_decimation(pkg, oracle):
+    cfg = pkg.Config(batch=2, publishPeriod=0.0045)
+    eng, ora = pair(pkg, oracle, cfg)
+    for k in range(23):
+        eng.update(1), ora.update(1)
+        assert np.abs(eng.platform_state()[0] - ora.platform_state()[0]).max() < 1e-6, k
+    eng2, ora2 = pair(pkg, oracle, cfg)
+    eng2.update(23, 8), ora2.update(23)
+    assert np.abs(eng2.platform_state()[0] - ora2.platform_state()[0]).max() < 1e-6
+    assert np.array_equal(eng2.platform_state()[0], eng.platform_state()[0])
+
+
+def test_pid_debug_topic(pkg, oracle):
+    cfg = pkg.Config(batch=4, stages=pkg._abi.STAGE_PID_DEBUG)
+    eng, ora = pair(pkg, oracle, cfg)
+    eng.update(2), ora.update(2)
+    assert np.all(eng.pid_debug() == 0.0) and np.all(ora.pid_debug() == 0.0)  # nothing written before the Pid really runs
+    eng.update(40), ora.update(40)
+    cmd = np.full(4, 0.02, dtype=np.float32)
+    eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+    eng.update(1), ora.update(1)  # Pid reset: first call writes nothing, old P/I/D stay on the topic (Pid.cpp:123-126)
+    g, o = eng.pid_debug(), ora.pid_debug()
+    assert np.abs(g - o).max() < 2e-2 and np.all(g[:, 4] == 0.0) and np.all(g[:, 0] != 0.0)
+    eng.update(30), ora.update(30)
+    g, o = eng.pid_debug(), ora.pid_debug()
+    assert np.abs(g - o).max() < 2e-2 and np.allclose(g[:, 3], 0.02) and np.all(g[:, 5:] == 0.0)
+
+
+def test_reset_restores_load_state(pkg):
+    cfg = pkg.Config(batch=10)
+    eng = pkg.Engine(cfg, 0)
+    eng.update(3)
+    first = eng.raw_state()[0].copy(), eng.joint_states()[2].copy()
+    eng.set_velocity_command(np.full(4, 0.03, dtype=np.float32))
+    eng.update(100)
+    eng.reset()
+    assert eng.step_count == 0
+    eng.update(3)
+    assert np.array_equal(eng.raw_state()[0], first[0]) and np.array_equal(eng.joint_states()[2], first[1])
+
+
+def test_plugin_facade_end_to_end(pkg, oracle):
+    """The drop-in surface: topic strings, callback names, message fields (PLG.h:23-28,92-102)."""
+    cfg = pkg.Config(batch=1)
+    plug = pkg.CdprGazeboPlugin()
+    plug.Load(cfg)
+    got = {"joint": [], "platform": []}
+    plug.bus.subscribe("jointStates", got["joint"].append)
+    plug.bus.subscribe("platformPose", got["platform"].append)
+    ora = oracle.OracleSim(cfg.to_struct())
+    gen = pkg.stimulus.sine_velocity(4)
+    for k in range(50):
+        cmd = next(gen)
+        plug.bus.publish("jointVelocities", pkg.Joy(axes=cmd))
+        plug.bus.publish("jointVelocities", pkg.Joy(axes=np.zeros(3)))  # wrong size: ignored
+        ora.set_velocity_command(cmd)
+        plug.update(10), ora.update(10)
+    assert len(got["joint"]) == len(got["platform"]) == 50
+    js, ps = got["joint"][-1], got["platform"][-1]
+    assert js.name == ["cable0", "cable1", "cable2", "cable3"] and js.position.shape == (1, 4)
+    oq, oqd, oe = ora.joint_states()
+    op, ot = ora.platform_state()
+    assert np.abs(js.effort - oe).max() < TOL["eff"] and np.abs(js.position - oq).max() < TOL["q"]
+    assert np.abs(ps.pose.position - op[:, :3]).max() < TOL["pose"] and np.abs(ps.pose.orientation - op[:, 3:]).max() < TOL["pose"]
+    assert np.abs(ps.velocity.linear - ot[:, :3]).max() < TOL["twist"]
+    assert abs(js.header.stamp - 0.499) < 1e-12
+
+
+def test_full_size_properties_config3(pkg):
+    """BASELINE config 3 at full size (65 536 x 8 cables): size-independent properties instead of the oracle —
+    unit quaternions, FK estimate == true pose, tensions inside [f_min, f_max], robots started identically stay
+    identical (no cross-robot leakage), and a permutation of the batch permutes the result."""
+    B = 65536
+    rng = np.random.default_rng(1235)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    pose[B // 2:] = pose[: B // 2]  # second half duplicates the first
+    cmd = rng.uniform(-0.05, 0.05, (B, 8)).astype(np.float32)
+    cmd[B // 2:] = cmd[: B // 2]
+    eng = pkg.Engine(cfg, 0)
+    eng.set_platform_state(pose7=pose)
+    eng.update(20)
+    eng.set_velocity_command(cmd)
+    eng.update(200)
+    p, t = eng.platform_state()
+    q, qd, eff = eng.joint_states()
+    assert np.isfinite(p).all() and np.isfinite(eff).all()
+    assert np.abs(np.linalg.norm(p[:, 3:], axis=1) - 1.0).max() < 1e-6
+    assert np.array_equal(p[: B // 2], p[B // 2:]) and np.array_equal(eff[: B // 2], eff[B // 2:])
+    fk_pose, res, it = eng.fk_state()
+    assert res.max() < 1e-6 and np.all(it == 4) and np.abs(fk_pose[:, :3] - p[:, :3]).max() < 5e-6
+    ten, flag = eng.td_state()
+    assert ten.min() >= 5.0 and ten.max() <= 100.0
+    # permutation equivariance on a slice
+    perm = rng.permutation(4096)
+    cfg2 = pkg.Config(model=pkg.eight_cable_model(), batch=4096, stages=3)
+    e2 = pkg.Engine(cfg2, 0)
+    e2.set_platform_state(pose7=pose[:4096][perm])
+    e2.update(20)
+    e2.set_velocity_command(cmd[:4096][perm])
+    e2.update(200)
+    assert np.array_equal(e2.platform_state()[0], p[:4096][perm])

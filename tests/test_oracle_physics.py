@@ -1,0 +1,165 @@
+"""Self-consistency known-answer tests for the stages that have no executable reference:
+the platform world step (Gazebo/ODE restated), Newton-Raphson FK and tension distribution ([NEW])."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+
+def no_control(pkg, **kw):
+    """All gains zero: forces are identically 0, the platform only feels gravity and joint damping."""
+    z = pkg.PidParameters(0.0, 0.0, 0.0, 0.0, 2, 11, 100.0, 100.0)
+    return pkg.Config(velocityController=z, positionController=pkg.PidParameters(0.0, 0.0, 0.0, 0.0, 2, 11, 100.0, 100.0), **kw)
+
+
+def test_free_fall_matches_semi_implicit_euler_closed_form(pkg, oracle):
+    m = pkg.cube_model()
+    m.joint_damping = 0.0
+    cfg = no_control(pkg, model=m, batch=1)
+    sim = oracle.OracleSim(cfg.to_struct())
+    n = 200
+    sim.update(n)
+    pose, twist = sim.raw_state()
+    dt, g = cfg.dt, 9.8
+    assert abs(twist[0, 2] - (-g * dt * n)) < 1e-12
+    assert abs(pose[0, 2] - (0.3 - g * dt * dt * n * (n + 1) / 2)) < 1e-12  # v updated before p
+    assert np.allclose(pose[0, [0, 1]], 0.0) and np.allclose(pose[0, 3:], [0, 0, 0, 1])
+
+
+def test_static_equilibrium_at_survey_tension(pkg, oracle):
+    """-J^T T + m g = 0 at the home pose for T = 3.965671444 N on each of the four cables."""
+    cfg = pkg.Config()
+    jac = oracle.ik(cfg.to_struct(), cfg.model.home_pose())[3]
+    w = -jac.T @ np.full(4, 9.8 / (-jac[:, 2].sum())) + np.array([0, 0, -9.8, 0, 0, 0])
+    assert np.abs(w).max() < 1e-14
+
+
+def test_qdot_is_minus_jacobian_times_twist_and_matches_finite_difference(pkg, oracle):
+    rng = np.random.default_rng(11)
+    for model in (pkg.cube_model(), pkg.eight_cable_model()):
+        cfg = pkg.Config(model=model)
+        s = cfg.to_struct()
+        pose = cfg.model.home_pose()
+        pose[:3] += rng.uniform(-0.05, 0.05, 3)
+        pose[3:] = Rotation.from_rotvec(rng.uniform(-0.2, 0.2, 3)).as_quat()
+        twist = rng.uniform(-0.3, 0.3, 6)
+        q0, qd, ln, jac = oracle.ik(s, pose, twist)
+        assert np.allclose(qd, -jac @ twist, atol=1e-15)
+        h = 1e-7
+        p2 = pose.copy()
+        p2[:3] += h * twist[:3]
+        p2[3:] = (Rotation.from_rotvec(h * twist[3:]) * Rotation.from_quat(pose[3:])).as_quat()
+        q1 = oracle.ik(s, p2)[0]
+        assert np.allclose((q1 - q0) / h, qd, atol=1e-6)
+
+
+def test_momentum_balance_one_step(pkg, oracle):
+    """One world step changes linear momentum by dt * (sum of cable forces + m g)."""
+    cfg = pkg.Config(batch=1)
+    sim = oracle.OracleSim(cfg.to_struct())
+    sim.update(30)
+    p0, t0 = sim.raw_state()
+    sim.update(1)
+    q, qd, eff = sim.joint_states()  # published at the step just taken: state before the integration
+    p1, t1 = sim.raw_state()
+    jac = oracle.ik(cfg.to_struct(), p0[0], t0[0])[3]
+    tension = eff[0] - cfg.model.joint_damping * qd[0]
+    w = -jac.T @ tension + np.array([0, 0, -9.8 * cfg.model.mass, 0, 0, 0])
+    assert np.allclose((t1[0, :3] - t0[0, :3]) * cfg.model.mass / cfg.dt, w[:3], atol=1e-9)
+    assert np.allclose(p1[0, :3], p0[0, :3] + cfg.dt * t1[0, :3], atol=1e-15)
+    assert abs(np.linalg.norm(p1[0, 3:]) - 1.0) < 1e-15
+
+
+def test_gyroscopic_term_conserves_angular_momentum_direction(pkg, oracle):
+    """Torque-free tumbling of an asymmetric body: |L| stays constant to O(dt) per step."""
+    m = pkg.cube_model()
+    m.inertia = (1.0, 2.0, 3.0, 0.0, 0.0, 0.0)
+    m.joint_damping = 0.0
+    cfg = no_control(pkg, model=m, batch=1, gravity=(0.0, 0.0, 0.0))
+    sim = oracle.OracleSim(cfg.to_struct())
+    sim.set_platform_state(twist6=np.array([[0, 0, 0, 0.5, 1.0, -0.7]]))
+
+    def ang_mom():
+        pose, tw = sim.raw_state()
+        r = Rotation.from_quat(pose[0, 3:]).as_matrix()
+        return r @ np.diag([1.0, 2.0, 3.0]) @ r.T @ tw[0, 3:]
+
+    l0 = ang_mom()
+    sim.update(2000)
+    l1 = ang_mom()
+    assert np.linalg.norm(l1 - l0) / np.linalg.norm(l0) < 5e-3
+
+
+def test_fk_round_trip(pkg, oracle):
+    cfg = pkg.Config(model=pkg.eight_cable_model(), stages=1, fkMaxIterations=8)
+    s = cfg.to_struct()
+    rng = np.random.default_rng(2)
+    home = cfg.model.home_pose()
+    for _ in range(50):
+        pose = home.copy()
+        pose[:3] += rng.uniform(-0.05, 0.05, 3)
+        pose[3:] = Rotation.from_rotvec(rng.uniform(-0.1, 0.1, 3)).as_quat()
+        ln = oracle.ik(s, pose)[2]
+        est, res, it = oracle.fk(s, ln, home)
+        assert res < 1e-12 and it == 8
+        assert np.allclose(est[:3], pose[:3], atol=1e-10)
+        assert abs(abs(np.dot(est[3:], pose[3:])) - 1.0) < 1e-12
+
+
+def test_fk_tolerance_stops_early(pkg, oracle):
+    cfg = pkg.Config(model=pkg.eight_cable_model(), stages=1, fkMaxIterations=20, fkTolerance=1e-9)
+    s = cfg.to_struct()
+    home = cfg.model.home_pose()
+    pose = home.copy()
+    pose[:3] += [0.02, -0.01, 0.03]
+    ln = oracle.ik(s, pose)[2]
+    est, res, it = oracle.fk(s, ln, home)
+    assert 2 <= it < 8 and res < 1e-9
+    est0, res0, it0 = oracle.fk(s, oracle.ik(s, home)[2], home)
+    assert it0 == 0 and res0 == 0.0
+
+
+def test_td_reproduces_wrench_and_is_min_norm_about_mid(pkg, oracle):
+    cfg = pkg.Config(model=pkg.eight_cable_model(), stages=2)
+    s = cfg.to_struct()
+    pose = cfg.model.home_pose()
+    jac = oracle.ik(s, pose)[3]
+    A = -jac.T
+    wd = np.array([0.3, -0.2, 9.8, 0.01, -0.02, 0.005])  # hold the platform against gravity plus a bit
+    t, flag = oracle.td_wrench(s, pose, wd)
+    assert flag == 0 and np.all(t >= 5.0) and np.all(t <= 100.0)  # gravity wrench feasible within [5, 100] N
+    assert np.abs(A @ t - wd).max() < 1e-10
+    tm = 52.5
+    ref = tm + np.linalg.pinv(A) @ (wd - A @ np.full(8, tm))
+    assert np.allclose(t, ref, atol=1e-9)
+    # forces form: same wrench as the raw forces, null-space component moved to the mid tension
+    f = np.random.default_rng(4).uniform(20, 60, 8)
+    t2, flag2 = oracle.td_forces(s, pose, f)
+    assert flag2 == 0 and np.abs(A @ t2 - A @ f).max() < 1e-9
+
+
+def test_td_flags_infeasible_and_clamps(pkg, oracle):
+    cfg = pkg.Config(model=pkg.eight_cable_model(), stages=2)
+    s = cfg.to_struct()
+    t, flag = oracle.td_wrench(s, cfg.model.home_pose(), np.array([0, 0, 900.0, 0, 0, 0]))
+    assert flag == 1 and t.min() >= 5.0 and t.max() <= 100.0 and (t.max() == 100.0 or t.min() == 5.0)
+
+
+def test_full_pipeline_tracks_and_estimates(pkg, oracle):
+    """Config-3 style run: FK estimate follows the true pose, tensions stay within bounds."""
+    B = 6
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    sim = oracle.OracleSim(cfg.to_struct())
+    rng = np.random.default_rng(9)
+    pose = np.tile(cfg.model.home_pose(), (B, 1))
+    pose[:, :3] += rng.uniform(-0.03, 0.03, (B, 3))
+    sim.set_platform_state(pose7=pose)
+    sim.update(20)
+    sim.set_velocity_command(rng.uniform(-0.02, 0.02, (B, 8)).astype(np.float32))
+    sim.update(300)
+    true_pose, _ = sim.platform_state()
+    est, res, it = sim.fk_state()
+    assert np.all(it == 4) and res.max() < 1e-9
+    assert np.abs(est[:, :3] - true_pose[:, :3]).max() < 1e-8
+    t, flag = sim.td_state()
+    assert t.min() >= 5.0 - 1e-12 and t.max() <= 100.0 + 1e-12
+    assert np.isfinite(true_pose).all()

@@ -1,0 +1,183 @@
+"""Known-answer and property tests of the oracle's controller stack (Pid.cpp, JointForceCalculator.cpp,
+the update() ordering of CdprGazeboPlugin.cpp).  The reference ships no tests for these; the numeric KATs are
+the survey-time spot values (tests/golden/pid_kat.json) — see oracle/cdpr_oracle.h for the parity status."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KAT = json.load(open(os.path.join(GOLD, "pid_kat.json")))
+
+
+def sine_cmd(k):
+    """sinevelocitytest.cpp: time accumulates 1/100 per publish; float32 on the wire."""
+    t = 0.0
+    for _ in range(k):
+        t += 1.0 / 100.0
+    return float(np.float32(0.05 * np.sin(t * 0.1 * 2 * np.pi)))
+
+
+def toy_plant_trace(pid, nsteps, cmd_of_step):
+    dt, q, qd, out = 1e-3, 0.0, 0.0, []
+    for k in range(nsteps):
+        f = pid.update(cmd_of_step(k), qd, k * dt)
+        out.append(f)
+        qd += dt * (f - qd)
+        q += dt * qd
+    return out
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_velocity_pid_kat(pkg, oracle, mode):
+    s = pkg.Config().to_struct()
+    pid = oracle.OraclePid(s.velocity_pid, mode)
+    assert abs(sine_cmd(1) - KAT["velocity_pid_toy_plant"]["first_command_sample_k1"]) < 1e-12
+    out = toy_plant_trace(pid, 14, lambda k: sine_cmd(k // 10))
+    assert all(v == 0.0 for v in out[: KAT["velocity_pid_toy_plant"]["force_zero_through_k"] + 1])
+    for k, v in KAT["velocity_pid_toy_plant"]["force"].items():
+        assert abs(out[int(k)] - v) < 1e-13 * max(1.0, abs(v)) + 2e-14, (k, out[int(k)], v)
+
+
+def test_mode_switch_kat(pkg, oracle):
+    """Velocity Pid freshly reset at k = 5 (what setVelocityTarget does on a mode change, JFC.cpp:113-115)."""
+    s = pkg.Config().to_struct()
+    pid = oracle.OraclePid(s.velocity_pid, 1)
+    dt, qd, out = 1e-3, 0.0, {}
+    target = float(np.float32(0.01))
+    for k in range(5, 8):
+        f = pid.update(target, qd, k * dt)
+        out[str(k)] = f
+        qd += dt * (f - qd)
+    for k, v in KAT["mode_switch"]["force"].items():
+        assert abs(out[k] - v) < 1e-10, (k, out[k], v)
+
+
+def test_derivative_weights_closed_form(pkg):
+    w = pkg.derivative_weights(11, 2)
+    assert np.allclose(w, KAT["derivative_weights_n11_d2"], atol=5e-13)
+    assert abs(w.sum()) < 1e-15  # a constant has zero derivative
+    assert abs((w * np.arange(11)).sum() - 1.0) < 1e-14  # a unit ramp has derivative 1 per sample
+
+
+@pytest.mark.parametrize("n,d", [(11, 2), (5, 1), (7, 3), (16, 4), (2, 1)])
+def test_derive_equals_fir_on_uniform_grid(pkg, oracle, n, d):
+    """Pid::derive + fitPolynomial on a uniform grid == the FIR the GPU kernel uses."""
+    s = pkg.Config().to_struct()
+    p = s.velocity_pid
+    p.d_buffer_length, p.d_degree = n, d
+    p.p_gain, p.i_gain, p.d_gain, p.cmd_limit, p.i_limit = 0.0, 0.0, 1.0, 1e9, 1e9
+    pid = oracle.OraclePid(p, 1)
+    rng = np.random.default_rng(n * 10 + d)
+    e = rng.standard_normal(3 * n + 5)
+    dt, w = 1e-3, pkg.derivative_weights(n, d)
+    pid.update(0.0, 0.0, 0.0)  # first call after reset: 0, no sample taken
+    for k in range(len(e)):
+        out = pid.update(e[k], 0.0, (k + 1) * dt)  # error = desired - actual = e[k]; output = D term
+        if k + 1 < n:
+            assert out == 0.0
+        else:
+            ref = (w * e[k + 1 - n : k + 1]).sum() / dt
+            assert abs(out - ref) < 1e-7 * max(1.0, abs(ref)), (k, out, ref)
+
+
+def test_faithful_fit_agrees_with_exact_for_early_times_and_drifts_later(pkg, oracle):
+    """The reference fits in ABSOLUTE sim time (Pid.cpp:224-244): accurate near t = 0, noise by t ~ 30 s."""
+    s = pkg.Config().to_struct()
+    p = s.velocity_pid
+    p.p_gain, p.i_gain, p.d_gain, p.cmd_limit, p.i_limit = 0.0, 0.0, 1.0, 1e9, 1e9
+    dt = 1e-3
+
+    def max_rel_dev(t0):
+        a, b = oracle.OraclePid(p, oracle.DERIV_FAITHFUL), oracle.OraclePid(p, oracle.DERIV_EXACT)
+        dev = 0.0
+        for k in range(40):
+            t = t0 + k * dt
+            e = np.sin(5.0 * t)
+            fa, fb = a.update(e, 0.0, t), b.update(e, 0.0, t)
+            if k > 12:
+                dev = max(dev, abs(fa - fb) / 5.0)
+        return dev
+
+    assert max_rel_dev(0.0) < 1e-9
+    assert max_rel_dev(1.0) < 1e-6
+    assert max_rel_dev(100.0) > 1e-4  # the reference's own output is numerical noise out here
+
+
+def test_first_call_after_reset_returns_zero_and_takes_no_sample(pkg, oracle):
+    s = pkg.Config().to_struct()
+    pid = oracle.OraclePid(s.position_pid, 1)
+    assert pid.update(0.1, 0.0, 0.0) == 0.0  # Pid.cpp:123-126
+    f = pid.update(0.1, 0.0, 1e-3)
+    assert abs(f - (200.0 * 0.1 + 70.0 * 1e-3 * 0.1)) < 1e-12  # P + I, D window not yet full
+    pid.reset()
+    assert pid.update(0.1, 0.0, 2e-3) == 0.0
+
+
+def test_command_clamp_and_anti_windup_overshoot(pkg, oracle):
+    """Pid.cpp:175-186: clamp to +-cmdLimit, then the anti-windup fix-up adds dt*e*Ki on top of the clamp
+    and rolls the integrator back."""
+    s = pkg.Config().to_struct()
+    pid = oracle.OraclePid(s.velocity_pid, 1)
+    pid.update(10.0, 0.0, 0.0)
+    f = pid.update(10.0, 0.0, 1e-3)  # P alone = 2000 -> clamped to 100
+    assert abs(f - (100.0 + 1e-3 * 10.0 * 20.0)) < 1e-12
+    f2 = pid.update(10.0, 0.0, 2e-3)
+    assert abs(f2 - f) < 1e-12  # integrator was rolled back, nothing accumulates while saturated
+
+
+def test_integral_clamp_back_calculation(pkg, oracle):
+    s = pkg.Config().to_struct()
+    p = s.velocity_pid
+    p.p_gain, p.d_gain, p.i_gain, p.i_limit, p.cmd_limit = 0.0, 0.0, 20.0, 1.0, 1e9
+    pid = oracle.OraclePid(p, 1)
+    pid.update(100.0, 0.0, 0.0)
+    for k in range(1, 6):
+        f = pid.update(100.0, 0.0, k * 1e-3)
+    assert abs(f - 1.0) < 1e-15  # Pid.cpp:143-146: I clamped at iLimit, Ierr back-computed
+    f = pid.update(-100.0, 0.0, 6e-3)
+    assert abs(f - (1.0 - 20.0 * 1e-3 * 100.0)) < 1e-12  # leaves the clamp at once (Ierr was I/Ki, not the raw sum)
+
+
+def test_qr_solver_matches_numpy(oracle):
+    rng = np.random.default_rng(0)
+    for n in (2, 3, 5):
+        a = rng.standard_normal((n, n))
+        b = rng.standard_normal(n)
+        assert np.allclose(oracle.qr_solve(a, b), np.linalg.solve(a, b), rtol=1e-10, atol=1e-12)
+
+
+def test_plugin_ordering_first_steps(pkg, oracle):
+    """update() at t = 0 sees stepTime = 0 -> force 0 and no Pid call (JFC.cpp:61-66); the next call is the Pid's
+    'first' (-> 0); the position Pid (target 0 after Load, PLG.cpp:153-157) acts from the third step."""
+    cfg = pkg.Config(batch=1)
+    sim = oracle.OracleSim(cfg.to_struct())
+    effs = []
+    for k in range(4):
+        sim.update(1)
+        effs.append(sim.joint_states()[2][0].copy())
+    assert np.all(effs[1] == 0.0)  # step 1 published (step 0 is not: now - prev = 0 is not > publishPeriod)
+    assert np.all(effs[2] != 0.0) and np.all(effs[3] != 0.0)
+    # free fall during the two force-free steps: q = L0 - L < 0 grows, position Pid pulls back (positive force)
+    assert np.all(effs[2] > 0.0)
+
+
+def test_wrong_length_commands_are_ignored(pkg, oracle):
+    cfg = pkg.Config(batch=2)
+    sim, ref = oracle.OracleSim(cfg.to_struct()), oracle.OracleSim(cfg.to_struct())
+    assert sim.set_velocity_command(np.zeros(3, dtype=np.float32)) == pkg._abi.IGNORED  # PLG.cpp:68-73
+    assert sim.set_position_command(np.zeros(9, dtype=np.float32)) == pkg._abi.IGNORED
+    sim.update(20), ref.update(20)
+    assert np.array_equal(sim.raw_state()[0], ref.raw_state()[0])
+
+
+def test_publish_period_decimates_observables(pkg, oracle):
+    cfg = pkg.Config(batch=1, publishPeriod=0.0045)
+    sim = oracle.OracleSim(cfg.to_struct())
+    seen = []
+    for k in range(12):
+        sim.update(1)
+        seen.append(sim.platform_state()[0][0, 2])
+    changes = [k for k in range(1, 12) if seen[k] != seen[k - 1]]
+    assert changes == [5, 10]  # published when now - prev > 0.0045: t = 0.005, 0.010

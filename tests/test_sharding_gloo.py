@@ -1,0 +1,73 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` processes, robots sharded by contiguous blocks with no data-path
+collective; only the rendezvous (barrier, max over ranks of the elapsed time) is distributed.
+Each rank advances its shard with the CPU oracle (test infrastructure) and the union must equal the unsharded run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import torch.distributed as dist
+import cdpr_simulation_amd as pkg
+from cdpr_simulation_amd.sharding import RankContext, shard_range
+import oracle
+
+ctx = RankContext.from_env(backend="gloo")
+total = 10
+lo, hi = shard_range(ctx.rank, ctx.world, total)
+rng = np.random.default_rng(42)
+pose = np.tile(pkg.cube_model().home_pose(), (total, 1)); pose[:, :3] += rng.uniform(-0.03, 0.03, (total, 3))
+cmd = rng.uniform(-0.03, 0.03, (total, 4)).astype(np.float32)
+cfg = pkg.Config(batch=hi - lo)
+sim = oracle.OracleSim(cfg.to_struct())
+sim.set_platform_state(pose7=pose[lo:hi])
+ctx.barrier()
+t0 = time.perf_counter()
+sim.update(20); sim.set_velocity_command(cmd[lo:hi]); sim.update(50)
+ctx.barrier()
+elapsed = ctx.max_over_ranks(time.perf_counter() - t0 + 0.25 * ctx.rank)
+np.save(os.path.join({out!r}, f"shard{{ctx.rank}}.npy"), sim.raw_state()[0])
+if ctx.rank == 0:
+    open(os.path.join({out!r}, "elapsed.txt"), "w").write(repr(elapsed))
+ctx.close()
+"""
+
+
+def test_two_rank_sharding_matches_unsharded(tmp_path, pkg, oracle):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    total = 10
+    rng = np.random.default_rng(42)
+    pose = np.tile(pkg.cube_model().home_pose(), (total, 1))
+    pose[:, :3] += rng.uniform(-0.03, 0.03, (total, 3))
+    cmd_arr = rng.uniform(-0.03, 0.03, (total, 4)).astype(np.float32)
+    sim = oracle.OracleSim(pkg.Config(batch=total).to_struct())
+    sim.set_platform_state(pose7=pose)
+    sim.update(20), sim.set_velocity_command(cmd_arr), sim.update(50)
+    whole = sim.raw_state()[0]
+    parts = np.concatenate([np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")])
+    assert np.array_equal(parts, whole)
+    assert float((tmp_path / "elapsed.txt").read_text()) >= 0.25  # MAX over ranks, not rank 0's own time
+
+
+def test_shard_range_covers_everything(pkg):
+    from cdpr_simulation_amd.sharding import shard_range
+
+    for total in (1, 7, 64, 524288):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(r, world, total) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
