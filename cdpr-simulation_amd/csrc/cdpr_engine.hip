@@ -14,7 +14,7 @@
 #include <vector>
 
 #include "../../include/cdpr.h"
-#include "cdpr_kernels.hpp"
+#include "cdpr_step_kernel.hpp"
 
 using namespace cdpr;
 
@@ -45,6 +45,8 @@ struct cdpr_engine {
   float4* d_state = nullptr;
   float4* d_obs = nullptr;
   float* d_dbg = nullptr;
+  float* d_geom = nullptr;  // pair-interleaved cable geometry, staged in LDS by the kernel
+  int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
   float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
   float* d_pos[2] = {nullptr, nullptr};
   bool vel_pending = false, pos_pending = false;
@@ -52,8 +54,8 @@ struct cdpr_engine {
   int mode = kModePosition;
   uint64_t step = 0;
   double prev_publish = 0.0;
-  StepConsts consts{};
-  PidConsts pid_vel{}, pid_pos{};
+  StepArgs base{};               // world/body/FK/TD constants, pointers; Pid fields filled per launch
+  StepArgs pid_vel{}, pid_pos{};  // only the Pid fields of these are used
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t launches = 0, launches_mark = 0;
   std::string err;
@@ -131,7 +133,7 @@ std::string validate(const cdpr_config_t& c) {
     snprintf(buf, sizeof buf, "invalid joint count %u (PLG.cpp:167-168; engine takes 1..%u)", c.n_cables, CDPR_MAX_CABLES);
     return buf;
   }
-  if (c.batch < 1 || c.batch > (1ull << 31)) return "batch out of range";
+  if (c.batch < 1 || c.batch > (1ull << 27)) return "batch out of range (1 .. 2^27 robots per handle)";
   if (!(c.dt > 0.0)) return "dt must be > 0";
   if (!(c.mass > 0.0)) return "mass must be > 0";
   double inv[6];
@@ -165,11 +167,12 @@ std::string fast_path_obstacle(const cdpr_config_t& c) {
   return "";
 }
 
-void fill_pid(const cdpr_pid_params_t& p, double dt, PidConsts& k) {
+void fill_pid(const cdpr_pid_params_t& p, double dt, StepArgs& k) {
   k.kf = (float)p.forward_gain;
   k.kp = (float)p.p_gain;
   k.ki = (float)p.i_gain;
   k.kd = (float)p.d_gain;
+  k.inv_ki = (p.i_gain != 0.0) ? (float)(1.0 / p.i_gain) : 0.f;
   k.imax = (float)std::fabs(p.i_limit);  // Pid.cpp:70-73 (abs -> fabs)
   k.imin = -(float)std::fabs(p.i_limit);
   k.cmax = (float)std::fabs(p.cmd_limit);
@@ -183,20 +186,17 @@ void fill_pid(const cdpr_pid_params_t& p, double dt, PidConsts& k) {
     for (uint32_t j = 0; j < p.d_buffer_length; ++j) k.w[kWin + 1 - p.d_buffer_length + j] = (float)w[j];
 }
 
-void fill_consts(const cdpr_config_t& c, StepConsts& k) {
-  memset(&k, 0, sizeof k);
-  for (uint32_t i = 0; i < c.n_cables; ++i) {
-    k.ax[i] = (float)c.frame_anchor[i][0];
-    k.ay[i] = (float)c.frame_anchor[i][1];
-    k.az[i] = (float)c.frame_anchor[i][2];
-    k.bx[i] = (float)c.platform_anchor[i][0];
-    k.by[i] = (float)c.platform_anchor[i][1];
-    k.bz[i] = (float)c.platform_anchor[i][2];
-    k.l0[i] = (float)c.cable_ref_length[i];
-  }
+void copy_pid(const StepArgs& src, StepArgs& dst) {
+  dst.kf = src.kf; dst.kp = src.kp; dst.ki = src.ki; dst.kd = src.kd; dst.inv_ki = src.inv_ki;
+  dst.imax = src.imax; dst.imin = src.imin; dst.cmax = src.cmax; dst.cmin = src.cmin; dst.inv_dt = src.inv_dt;
+  for (int j = 0; j <= kWin; ++j) dst.w[j] = src.w[j];
+  dst.nbuf = src.nbuf; dst.clamp_cmd = src.clamp_cmd;
+}
+
+void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   k.dt = (float)c.dt;
   k.half_dt = (float)(0.5 * c.dt);
-  k.inv_mass = (float)(1.0 / c.mass);
+  k.dt_inv_mass = (float)(c.dt / c.mass);
   k.fgx = (float)(c.mass * c.gravity[0]);
   k.fgy = (float)(c.mass * c.gravity[1]);
   k.fgz = (float)(c.mass * c.gravity[2]);
@@ -218,28 +218,55 @@ void fill_consts(const cdpr_config_t& c, StepConsts& k) {
 
 using StepKernel = void (*)(const StepArgs);
 
-template <int N>
+template <int N, bool SINGLE>
 StepKernel pick_stage(bool fk, bool td) {
   if constexpr (N >= 6) {
-    if (fk && td) return step_lane_per_robot<N, true, true>;
-    if (fk) return step_lane_per_robot<N, true, false>;
-    if (td) return step_lane_per_robot<N, false, true>;
+    if (fk && td) return cdpr_step_kernel<N, true, true, SINGLE>;
+    if (fk) return cdpr_step_kernel<N, true, false, SINGLE>;
+    if (td) return cdpr_step_kernel<N, false, true, SINGLE>;
   }
-  return step_lane_per_robot<N, false, false>;
+  return cdpr_step_kernel<N, false, false, SINGLE>;
 }
 
+template <bool SINGLE>
 StepKernel pick_kernel(uint32_t n, bool fk, bool td) {
   switch (n) {
-    case 1: return pick_stage<1>(fk, td);
-    case 2: return pick_stage<2>(fk, td);
-    case 3: return pick_stage<3>(fk, td);
-    case 4: return pick_stage<4>(fk, td);
-    case 5: return pick_stage<5>(fk, td);
-    case 6: return pick_stage<6>(fk, td);
-    case 7: return pick_stage<7>(fk, td);
-    case 8: return pick_stage<8>(fk, td);
+    case 1: return pick_stage<1, SINGLE>(fk, td);
+    case 2: return pick_stage<2, SINGLE>(fk, td);
+    case 3: return pick_stage<3, SINGLE>(fk, td);
+    case 4: return pick_stage<4, SINGLE>(fk, td);
+    case 5: return pick_stage<5, SINGLE>(fk, td);
+    case 6: return pick_stage<6, SINGLE>(fk, td);
+    case 7: return pick_stage<7, SINGLE>(fk, td);
+    case 8: return pick_stage<8, SINGLE>(fk, td);
   }
   return nullptr;
+}
+
+// Cable geometry as the kernel wants it in LDS: per cable pair
+// [ax0 ax1 ay0 ay1 | az0 az1 bx0 bx1 | by0 by1 bz0 bz1 | l00 l01 mask0 mask1].
+std::vector<float> geom_pairs(const cdpr_config_t& c) {
+  const int np = cable_pairs((int)c.n_cables);
+  std::vector<float> g((size_t)np * kGeomFloatsPerPair, 0.f);
+  for (int k = 0; k < np; ++k) {
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t i = 2 * k + h;
+      const bool real = i < c.n_cables;
+      // the padding cable of an odd count sits far away (finite length) and is masked to zero
+      const double a[3] = {real ? c.frame_anchor[i][0] : 7.0, real ? c.frame_anchor[i][1] : 11.0, real ? c.frame_anchor[i][2] : 13.0};
+      const double b[3] = {real ? c.platform_anchor[i][0] : 0.0, real ? c.platform_anchor[i][1] : 0.0, real ? c.platform_anchor[i][2] : 0.0};
+      float* p = &g[(size_t)k * kGeomFloatsPerPair];
+      p[0 + h] = (float)a[0];
+      p[2 + h] = (float)a[1];
+      p[4 + h] = (float)a[2];
+      p[6 + h] = (float)b[0];
+      p[8 + h] = (float)b[1];
+      p[10 + h] = (float)b[2];
+      p[12 + h] = real ? (float)c.cable_ref_length[i] : 0.f;
+      p[14 + h] = real ? 1.f : 0.f;
+    }
+  }
+  return g;
 }
 
 double sim_time(uint64_t step, double dt) {
@@ -289,6 +316,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_obs) (void)hipFree(h->d_obs);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
+  if (h->d_geom) (void)hipFree(h->d_geom);
   for (int i = 0; i < 2; ++i) {
     if (h->d_vel[i]) (void)hipFree(h->d_vel[i]);
     if (h->d_pos[i]) (void)hipFree(h->d_pos[i]);
@@ -304,6 +332,7 @@ void engine_reset_host(cdpr_engine* h) {
   h->have_vel = h->have_pos = false;
   h->mode = kModePosition;  // PLG.cpp:153-157: Position mode, target 0 after operator= -> reset()
   h->step = 0;
+  h->pid_calls = 0;
   h->prev_publish = 0.0;  // PLG.cpp:59
 }
 
@@ -359,19 +388,23 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     h->mode = kModePosition;
   }
 
-  StepKernel kern = pick_kernel(h->n, h->fk, h->td);
-  StepArgs a;
+  if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller record; rare, so done outside the step kernel
+    h->pid_calls = 0;
+    const int P = plat_slots(h->fk);
+    HIP_TRY(h, hipMemsetAsync(h->d_state + (size_t)P * h->stride, 0, (size_t)3 * h->n * h->stride * sizeof(float4), h->stream));
+  }
+  StepArgs a = h->base;
   a.state = h->d_state;
   a.obs = h->d_obs;
   a.dbg = h->dbg ? h->d_dbg : nullptr;
+  a.geom = h->d_geom;
   a.batch = h->batch;
   a.stride = h->stride;
-  a.c = h->consts;
   if (h->mode == kModeVelocity) {
-    a.pid = h->pid_vel;
+    copy_pid(h->pid_vel, a);
     a.cmd = h->d_vel[0];
   } else {
-    a.pid = h->pid_pos;
+    copy_pid(h->pid_pos, a);
     a.cmd = h->have_pos ? h->d_pos[0] : nullptr;  // target 0 until the first jointPositions message
   }
   const dim3 grid((h->batch + 63u) / 64u), block(64);
@@ -381,9 +414,9 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     const int k = std::min(per_launch, nsteps - done);
     a.nsteps = k;
     a.flags = (h->mode == kModeVelocity ? kFlagActualIsVelocity : 0u);
-    if (h->step == 0) a.flags |= kFlagFirstWorldStep;
-    if (reset_pid) a.flags |= kFlagResetPid;
-    reset_pid = false;
+    const bool first_world = (h->step == 0);
+    if (first_world) a.flags |= kFlagFirstWorldStep;
+    a.pid_calls = h->pid_calls;
     a.publish_mask = 0;
     for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
       const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
@@ -392,10 +425,12 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
         a.publish_mask |= (1ull << j);
       }
     }
+    StepKernel kern = (k == 1) ? pick_kernel<true>(h->n, h->fk, h->td) : pick_kernel<false>(h->n, h->fk, h->td);
     hipLaunchKernelGGL(kern, grid, block, 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;
+    h->pid_calls = std::min(h->pid_calls + k - (first_world ? 1 : 0), 1 << 20);
     done += k;
   }
   return CDPR_OK;
@@ -496,7 +531,8 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
   h->n_state = state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
-  fill_consts(*cfg, h->consts);
+  memset(&h->base, 0, sizeof h->base);
+  fill_consts(*cfg, h->base);
   fill_pid(cfg->velocity_pid, cfg->dt, h->pid_vel);
   fill_pid(cfg->position_pid, cfg->dt, h->pid_pos);
   engine_reset_host(h);
@@ -519,6 +555,11 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     if ((e = hipMalloc(&h->d_pos[i], cmd_bytes)) != hipSuccess) return fail("hipMalloc(cmd)", e);
     (void)hipMemset(h->d_vel[i], 0, cmd_bytes);
     (void)hipMemset(h->d_pos[i], 0, cmd_bytes);
+  }
+  {
+    std::vector<float> g = geom_pairs(*cfg);
+    if ((e = hipMalloc(&h->d_geom, g.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(geom)", e);
+    if ((e = hipMemcpy(h->d_geom, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(geom)", e);
   }
   if (h->dbg)
     if ((e = hipMalloc(&h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float))) != hipSuccess)

@@ -1,0 +1,622 @@
+// cdpr_step_kernel.hpp — the fused CDPR step kernel (gfx950, fp32), lane-per-robot mapping.
+//
+// One lane owns one robot for the whole step: the 6xn structure matrix, the 6x6 normal
+// matrix, the controller windows never leave its registers; a wavefront is 64 independent
+// robots and a workgroup is one wavefront (65 536 robots = 1 024 workgroups = one wave on
+// every SIMD of the chip).
+//
+// Design points (evidence in profiles/ and DESIGN.md):
+//   * cables are processed in PAIRS held in float2 registers so the per-cable math (IK rows,
+//     FIR windows, J^T J / J^T r partial sums, wrench accumulation) issues as v_pk_fma_f32 /
+//     v_pk_mul_f32: two cables per VALU instruction, the only way to the f32 vector peak;
+//   * every multiply-add is an explicit fma (the file is compiled with -ffp-contract=off), so
+//     the one-step and the fused multi-step instantiations perform bit-identical arithmetic;
+//   * the per-cable geometry (a_i, b_i, L0_i: 7n constants) is staged once per wave in LDS,
+//     pair-interleaved, and re-read with broadcast ds_read_b128 wherever an IK evaluation needs
+//     it; as kernel arguments these 56 values overflow the SGPR file and get spilled into VGPR
+//     lanes (v_writelane/v_readlane: > 1 200 extra VALU instructions per step, measured);
+//   * HBM sees only float4 struct-of-array slots (slot s of robot r at base[s*stride + r]): every
+//     wave-wide access is one contiguous 1 KiB dwordx4 row, addressed as SGPR row base + one
+//     shared VGPR offset;
+//   * the Pid call counter (first call after reset returns 0; derivative window full after N
+//     samples) is uniform over the batch, so it is a kernel argument and the branches on it
+//     are scalar.
+//
+// State slots (float4 each):
+//   0: px py pz qx   1: qy qz qw vx   2: vy vz wx wy   3: wz fkx fky fkz   4: fkqx fkqy fkqz fkqw (FK only)
+//   P + 3c + {0,1,2}: cable c controller record: e0..e3 | e4..e7 | e8 e9 Ierr (unused)
+// Observable slots (PLG.cpp:248-280): 0..2 pose/twist at the published step,
+//   3: wz fk_residual fk_iterations td_infeasible; 4..: joint position, velocity, effort (ceil(n/4) slots each)
+//
+// Reference paths (relative to src/cdpr_gazebo/): Pid.cpp, JFC.cpp = JointForceCalculator.cpp,
+// PLG.cpp = CdprGazeboPlugin.cpp, gen = sdf/gen_cdpr.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cdpr {
+
+constexpr int kMaxCables = 8;
+constexpr int kWin = 10;                // prior errors kept per cable (derivative window of up to 11 samples)
+constexpr int kGeomFloatsPerPair = 16;  // [ax ay | az bx | by bz | l0 mask], each entry a (cable 2k, cable 2k+1) pair
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+enum StepFlags : uint32_t {
+  kFlagFirstWorldStep = 1u << 0,    // JFC.cpp:61-66: stepTime <= 0 at t = 0 -> force 0, no Pid call
+  kFlagActualIsVelocity = 1u << 2,  // velocity mode: Pid sees joint velocity (JFC.cpp:76), else position (JFC.cpp:88)
+};
+
+struct StepArgs {
+  float4* state;
+  float4* obs;
+  const float* cmd;   // latched Joy.axes of the active mode, float[B][n]; nullptr -> desired 0 (state after Load)
+  float* dbg;         // float[B][9] `pid` debug topic, or nullptr
+  const float* geom;  // cable_pairs(n) * 16 floats, pair-interleaved cable geometry
+  uint32_t batch;
+  uint32_t stride;    // robots per slot row (batch rounded up to 64)
+  int nsteps;         // world steps fused into this launch
+  uint32_t flags;
+  uint64_t publish_mask;  // bit k: publish observables at step k of this launch (PLG.cpp:236-242)
+  int pid_calls;      // Pid::update calls since the last reset, before this launch (uniform over the batch)
+  // world / body
+  float dt, half_dt, dt_inv_mass, fgx, fgy, fgz;  // fg = m * g
+  float ib[6], ibinv[6];                           // body inertia and inverse: xx yy zz xy xz yz
+  float damping, effort;                           // joint damping; SetForce clamp (effort < 0: none)
+  // FK / TD ([NEW] stages)
+  float fk_lambda, fk_tol;
+  int fk_iters;
+  float td_min, td_max, td_mid;
+  // the active Pid (Pid.cpp:64-73)
+  float kf, kp, ki, kd, inv_ki, imax, imin, cmax, cmin, inv_dt;
+  float w[kWin + 1];  // end-point LS derivative weights, oldest..newest, zero padded at the old end
+  int nbuf, clamp_cmd;
+};
+
+__host__ __device__ constexpr int plat_slots(bool fk) { return fk ? 5 : 4; }
+__host__ __device__ constexpr int joint_groups(int n) { return (n + 3) / 4; }
+__host__ __device__ constexpr int state_slots(int n, bool fk) { return plat_slots(fk) + 3 * n; }
+__host__ __device__ constexpr int obs_slots(int n) { return 4 + 3 * joint_groups(n); }
+__host__ __device__ constexpr int cable_pairs(int n) { return (n + 1) / 2; }
+
+#define CDPR_DEV __device__ __forceinline__
+
+CDPR_DEV v2f splat(float s) { return (v2f){s, s}; }
+CDPR_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+CDPR_DEV v2f fma2(float a, v2f b, v2f c) { return __builtin_elementwise_fma(splat(a), b, c); }
+CDPR_DEV float hsum(v2f v) { return v.x + v.y; }
+CDPR_DEV v2f rsq2(v2f v) { return (v2f){__frsqrt_rn(v.x), __frsqrt_rn(v.y)}; }
+CDPR_DEV v2f min2(v2f a, v2f b) { return (v2f){fminf(a.x, b.x), fminf(a.y, b.y)}; }
+CDPR_DEV v2f max2(v2f a, v2f b) { return (v2f){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+CDPR_DEV v2f abs2(v2f a) { return (v2f){fabsf(a.x), fabsf(a.y)}; }
+CDPR_DEV float comp4(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+
+struct Rot {
+  float r00, r01, r02, r10, r11, r12, r20, r21, r22;
+};
+
+CDPR_DEV Rot quat_to_rot(float x, float y, float z, float w) {
+  const float x2 = x + x, y2 = y + y, z2 = z + z;
+  const float xx = x * x2, yy = y * y2, zz = z * z2;
+  const float xy = x * y2, xz = x * z2, yz = y * z2;
+  const float wx = w * x2, wy = w * y2, wz = w * z2;
+  Rot r;
+  r.r00 = 1.f - (yy + zz);
+  r.r01 = xy - wz;
+  r.r02 = xz + wy;
+  r.r10 = xy + wz;
+  r.r11 = 1.f - (xx + zz);
+  r.r12 = yz - wx;
+  r.r20 = xz - wy;
+  r.r21 = yz + wx;
+  r.r22 = 1.f - (xx + yy);
+  return r;
+}
+
+// q <- exp(theta / 2) (x) q, world-frame rotation increment, renormalised.
+CDPR_DEV void quat_apply_rotvec(float& qx, float& qy, float& qz, float& qw, float tx, float ty, float tz) {
+  const float a2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
+  float k, cw;
+  if (a2 < 1e-8f) {  // |theta| < 1e-4: series (exact to fp32)
+    k = fmaf(a2, -1.f / 48.f, 0.5f);
+    cw = fmaf(a2, -0.125f, 1.f);
+  } else {
+    const float a = sqrtf(a2);
+    float s;
+    __sincosf(0.5f * a, &s, &cw);
+    k = s / a;
+  }
+  const float dx = k * tx, dy = k * ty, dz = k * tz;
+  const float nw = fmaf(-dz, qz, fmaf(-dy, qy, fmaf(-dx, qx, cw * qw)));
+  const float nx = fmaf(-dz, qy, fmaf(dy, qz, fmaf(qw, dx, cw * qx)));
+  const float ny = fmaf(-dx, qz, fmaf(dz, qx, fmaf(qw, dy, cw * qy)));
+  const float nz = fmaf(-dy, qx, fmaf(dx, qy, fmaf(qw, dz, cw * qz)));
+  const float inv = __frsqrt_rn(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+  qx = nx * inv;
+  qy = ny * inv;
+  qz = nz * inv;
+  qw = nw * inv;
+}
+
+// IK rows of all cable pairs (Joint::Position / GetVelocity restated; geometry statement
+// gen:113-118): l = p + R b - a, L = |l|, u = l / L, J row = [u, (R b) x u].  Geometry from LDS.
+template <int N, bool WANT_L0>
+CDPR_DEV void ik_pairs(const float* lds, float px, float py, float pz, float qx, float qy, float qz, float qw,
+                       v2f (&len)[cable_pairs(N)], v2f (&jac)[cable_pairs(N)][6], v2f (&l0)[cable_pairs(N)]) {
+  constexpr int NP = cable_pairs(N);
+  const Rot r = quat_to_rot(qx, qy, qz, qw);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const float4 g0 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair);
+    const float4 g1 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair + 4);
+    const float4 g2 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair + 8);
+    const v2f ax = {g0.x, g0.y}, ay = {g0.z, g0.w}, az = {g1.x, g1.y};
+    const v2f bx = {g1.z, g1.w}, by = {g2.x, g2.y}, bz = {g2.z, g2.w};
+    const v2f rbx = fma2(r.r02, bz, fma2(r.r01, by, splat(r.r00) * bx));
+    const v2f rby = fma2(r.r12, bz, fma2(r.r11, by, splat(r.r10) * bx));
+    const v2f rbz = fma2(r.r22, bz, fma2(r.r21, by, splat(r.r20) * bx));
+    const v2f lx = (rbx - ax) + splat(px), ly = (rby - ay) + splat(py), lz = (rbz - az) + splat(pz);
+    const v2f l2 = fma2(lz, lz, fma2(ly, ly, lx * lx));
+    const v2f inv = rsq2(l2);
+    len[k] = l2 * inv;
+    const v2f ux = lx * inv, uy = ly * inv, uz = lz * inv;
+    jac[k][0] = ux;
+    jac[k][1] = uy;
+    jac[k][2] = uz;
+    jac[k][3] = fma2(rby, uz, -(rbz * uy));
+    jac[k][4] = fma2(rbz, ux, -(rbx * uz));
+    jac[k][5] = fma2(rbx, uy, -(rby * ux));
+    if (WANT_L0 || ((N & 1) && k == NP - 1)) {
+      const float4 g3 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair + 12);
+      l0[k] = (v2f){g3.x, g3.y};
+      if ((N & 1) && k == NP - 1) {  // odd cable count: the padding cable contributes nothing
+        const v2f mask = {g3.z, g3.w};
+        len[k] *= mask;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) jac[k][c] *= mask;
+      }
+    }
+  }
+}
+
+// g[c] = sum over cables of jac[.][c] * v[.]  (J^T v), pairs interleaved so the chains are independent
+template <int NP>
+CDPR_DEV void jt_times(const v2f (&jac)[NP][6], const v2f (&v)[NP], float (&g)[6]) {
+  v2f acc[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) acc[c] = jac[0][c] * v[0];
+#pragma unroll
+  for (int k = 1; k < NP; ++k) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] = fma2(jac[k][c], v[k], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) g[c] = hsum(acc[c]);
+}
+
+// Solve (J^T J + lambda I) x = g in place (g -> x) by Cholesky; J held as cable pairs.
+template <int NP>
+CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6]) {
+  v2f acc[21];
+#pragma unroll
+  for (int a = 0, e = 0; a < 6; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b, ++e) acc[e] = jac[0][a] * jac[0][b];
+  }
+#pragma unroll
+  for (int k = 1; k < NP; ++k) {
+#pragma unroll
+    for (int a = 0, e = 0; a < 6; ++a) {
+#pragma unroll
+      for (int b = 0; b <= a; ++b, ++e) acc[e] = fma2(jac[k][a], jac[k][b], acc[e]);
+    }
+  }
+  float m[6][6];
+#pragma unroll
+  for (int a = 0, e = 0; a < 6; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b, ++e) m[a][b] = hsum(acc[e]) + ((a == b) ? lambda : 0.f);
+  }
+  float invd[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float d = m[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d = fmaf(-m[j][k], m[j][k], d);
+    invd[j] = __frsqrt_rn(d);
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      float s = m[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s = fmaf(-m[i][k], m[j][k], s);
+      m[i][j] = s * invd[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float s = g[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s = fmaf(-m[i][k], g[k], s);
+    g[i] = s * invd[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = g[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s = fmaf(-m[k][i], g[k], s);
+    g[i] = s * invd[i];
+  }
+}
+
+struct Platform {
+  float px, py, pz, qx, qy, qz, qw;
+  float vx, vy, vz, wx, wy, wz;
+};
+
+// World step (Gazebo/ODE restated): semi-implicit Euler on the free platform
+// under the wrench w (force, torque about the platform origin, world frame).
+CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
+  const Rot r = quat_to_rot(s.qx, s.qy, s.qz, s.qw);
+  s.vx = fmaf(a.dt_inv_mass, w[0], s.vx);
+  s.vy = fmaf(a.dt_inv_mass, w[1], s.vy);
+  s.vz = fmaf(a.dt_inv_mass, w[2], s.vz);
+  // body frame: tau_b = R^T tau, w_b = R^T w
+  float tbx = fmaf(r.r20, w[5], fmaf(r.r10, w[4], r.r00 * w[3]));
+  float tby = fmaf(r.r21, w[5], fmaf(r.r11, w[4], r.r01 * w[3]));
+  float tbz = fmaf(r.r22, w[5], fmaf(r.r12, w[4], r.r02 * w[3]));
+  const float obx = fmaf(r.r20, s.wz, fmaf(r.r10, s.wy, r.r00 * s.wx));
+  const float oby = fmaf(r.r21, s.wz, fmaf(r.r11, s.wy, r.r01 * s.wx));
+  const float obz = fmaf(r.r22, s.wz, fmaf(r.r12, s.wy, r.r02 * s.wx));
+  const float iox = fmaf(a.ib[4], obz, fmaf(a.ib[3], oby, a.ib[0] * obx));
+  const float ioy = fmaf(a.ib[5], obz, fmaf(a.ib[1], oby, a.ib[3] * obx));
+  const float ioz = fmaf(a.ib[2], obz, fmaf(a.ib[5], oby, a.ib[4] * obx));
+  tbx -= fmaf(oby, ioz, -(obz * ioy));
+  tby -= fmaf(obz, iox, -(obx * ioz));
+  tbz -= fmaf(obx, ioy, -(oby * iox));
+  const float abx = fmaf(a.ibinv[4], tbz, fmaf(a.ibinv[3], tby, a.ibinv[0] * tbx));
+  const float aby = fmaf(a.ibinv[5], tbz, fmaf(a.ibinv[1], tby, a.ibinv[3] * tbx));
+  const float abz = fmaf(a.ibinv[2], tbz, fmaf(a.ibinv[5], tby, a.ibinv[4] * tbx));
+  s.wx = fmaf(a.dt, fmaf(r.r02, abz, fmaf(r.r01, aby, r.r00 * abx)), s.wx);
+  s.wy = fmaf(a.dt, fmaf(r.r12, abz, fmaf(r.r11, aby, r.r10 * abx)), s.wy);
+  s.wz = fmaf(a.dt, fmaf(r.r22, abz, fmaf(r.r21, aby, r.r20 * abx)), s.wz);
+  s.px = fmaf(a.dt, s.vx, s.px);
+  s.py = fmaf(a.dt, s.vy, s.py);
+  s.pz = fmaf(a.dt, s.vz, s.pz);
+  const float h = a.half_dt;
+  const float nx = fmaf(h, fmaf(-s.wz, s.qy, fmaf(s.wy, s.qz, s.qw * s.wx)), s.qx);
+  const float ny = fmaf(h, fmaf(-s.wx, s.qz, fmaf(s.wz, s.qx, s.qw * s.wy)), s.qy);
+  const float nz = fmaf(h, fmaf(-s.wy, s.qx, fmaf(s.wx, s.qy, s.qw * s.wz)), s.qz);
+  const float nw = fmaf(-h, fmaf(s.wz, s.qz, fmaf(s.wy, s.qy, s.wx * s.qx)), s.qw);
+  const float inv = __frsqrt_rn(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+  s.qx = nx * inv;
+  s.qy = ny * inv;
+  s.qz = nz * inv;
+  s.qw = nw * inv;
+}
+
+// Slot row `slot` of robot at byte offset `off` (= 16 * robot, 32-bit): SGPR row base + one shared VGPR
+// offset, so 30 rows cost one address register instead of 30 64-bit pointers.
+CDPR_DEV float4 load_slot(const float4* base, size_t stride, int slot, uint32_t off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base + (size_t)slot * stride) + off);
+}
+CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, const float4& v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base + (size_t)slot * stride) + off) = v;
+}
+
+template <int N, bool FK, bool TD, bool SINGLE>
+__global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
+  constexpr int NP = cable_pairs(N);
+  constexpr int P = plat_slots(FK);
+  constexpr int G = joint_groups(N);
+  __shared__ __attribute__((aligned(16))) float lds[NP * kGeomFloatsPerPair];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t r = blockIdx.x * 64u + lane;
+  const uint32_t rr = (r < a.batch) ? r : (a.batch - 1u);  // tail lanes shadow the last robot, stores are masked
+  const bool live = r < a.batch;
+  const size_t st = a.stride;
+
+  // geometry load first (oldest outstanding load), then the robot's whole record: the LDS fill
+  // below waits for the geometry only, the record stays in flight behind it
+  const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
+
+  const uint32_t off = rr * 16u;   // byte offset of this robot inside every slot row
+  const uint32_t woff = r * 16u;   // same for stores (only used when live)
+  const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off),
+               p2 = load_slot(a.state, st, 2, off), p3 = load_slot(a.state, st, 3, off);
+  float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
+  if (FK) p4 = load_slot(a.state, st, 4, off);
+  float4 craw[N][3];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) craw[i][k] = load_slot(a.state, st, P + 3 * i + k, off);
+  }
+  v2f desired[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
+  if (a.cmd) {
+    const float* cp = a.cmd + (size_t)rr * N;
+    if (N % 4 == 0) {
+#pragma unroll
+      for (int g = 0; g < N / 4; ++g) {
+        const float4 v = reinterpret_cast<const float4*>(cp)[g];
+        desired[2 * g] = (v2f){v.x, v.y};
+        desired[2 * g + 1] = (v2f){v.z, v.w};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        if (i & 1)
+          desired[i / 2].y = cp[i];
+        else
+          desired[i / 2].x = cp[i];
+      }
+    }
+  }
+
+  if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
+  // single-wave workgroup: LDS operations of one wave execute in order, so the broadcast reads
+  // below see the fill without an s_barrier (and without the vmcnt(0) a __syncthreads implies)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  Platform s;
+  s.px = p0.x; s.py = p0.y; s.pz = p0.z; s.qx = p0.w;
+  s.qy = p1.x; s.qz = p1.y; s.qw = p1.z; s.vx = p1.w;
+  s.vy = p2.x; s.vz = p2.y; s.wx = p2.z; s.wy = p2.w;
+  s.wz = p3.x;
+  float fkx = p3.y, fky = p3.z, fkz = p3.w, fkqx = p4.x, fkqy = p4.y, fkqz = p4.z, fkqw = p4.w;
+
+  // controller records as cable pairs: window e[j] (oldest..newest), integral
+  v2f win[NP][kWin], ierr[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int i0 = 2 * k, i1 = (2 * k + 1 < N) ? 2 * k + 1 : 2 * k;
+    const bool has1 = (2 * k + 1 < N);
+#pragma unroll
+    for (int j = 0; j < kWin; ++j) {
+      const float e0 = comp4(craw[i0][j / 4], j % 4);
+      const float e1 = has1 ? comp4(craw[i1][j / 4], j % 4) : 0.f;
+      win[k][j] = (v2f){e0, e1};
+    }
+    ierr[k] = (v2f){craw[i0][2].z, has1 ? craw[i1][2].z : 0.f};
+  }
+  const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
+  int calls = a.pid_calls;
+
+  for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
+    // ---- IK on the state at t_k
+    v2f len[NP], jac[NP][6], l0[NP], q[NP], qd[NP];
+    ik_pairs<N, true>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      q[k] = l0[k] - len[k];
+      qd[k] = -fma2(s.wz, jac[k][5], fma2(s.wy, jac[k][4], fma2(s.wx, jac[k][3],
+                    fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
+    }
+
+    // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191), two cables per instruction
+    v2f f[NP], e_new[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      f[k] = splat(0.f);
+      e_new[k] = splat(0.f);
+    }
+    float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
+    bool dbg_wrote = false;
+    const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
+    if (!first_world) {
+      if (calls != 0) {  // not the first call since reset (Pid.cpp:123-126: that one returns 0)
+        const bool full = calls >= a.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
+        v2f error[NP], acc[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          error[k] = desired[k] - (actual_is_vel ? qd[k] : q[k]);
+          acc[k] = splat(a.w[kWin]) * error[k];
+        }
+        // closed-form end-point LS derivative (Pid.cpp:193-247); j outer so the NP chains interleave
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) acc[k] = fma2(a.w[j], win[k][j], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const v2f p_term = splat(a.kp) * error[k];
+          const v2f prev_ierr = ierr[k];
+          v2f ie = fma2(a.dt, error[k], prev_ierr);
+          const v2f i_term = splat(a.ki) * ie;
+          const v2f i_cl = max2(min2(i_term, splat(a.imax)), splat(a.imin));  // Pid.cpp:143-152
+          const v2f ie_cl = i_cl * splat(a.inv_ki);
+          ie.x = (i_cl.x != i_term.x) ? ie_cl.x : ie.x;
+          ie.y = (i_cl.y != i_term.y) ? ie_cl.y : ie.y;
+          const v2f derived = full ? acc[k] * splat(a.inv_dt) : splat(0.f);
+          const v2f d_term = splat(a.kd) * derived;
+          const v2f cmd = fma2(a.kf, desired[k], p_term) + i_cl + d_term;
+          v2f out = a.clamp_cmd ? max2(min2(cmd, splat(a.cmax)), splat(a.cmin)) : cmd;  // Pid.cpp:175-177
+          const v2f bumped = fma2(splat(a.dt) * error[k], splat(a.ki), out);             // Pid.cpp:181-184
+          ie.x = (out.x != cmd.x) ? prev_ierr.x : ie.x;
+          ie.y = (out.y != cmd.y) ? prev_ierr.y : ie.y;
+          out.x = (out.x != cmd.x) ? bumped.x : out.x;
+          out.y = (out.y != cmd.y) ? bumped.y : out.y;
+          ierr[k] = ie;
+          f[k] = out;
+          e_new[k] = error[k];
+          if (k == 0) {
+            dbg_p = p_term.x;
+            dbg_i = i_term.x;
+            dbg_d = d_term.x;
+          }
+        }
+        dbg_wrote = true;
+      }
+      ++calls;
+    }
+
+    // When no sample was taken (first call after a reset, or t = 0) e_new is 0 and the window is all
+    // zeros (Pid::reset zeroed it), so the unconditional shift below leaves it unchanged.
+    if (SINGLE) {
+      // controller records are final: store them now, window shift folded into the store
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const int k = i / 2;
+          float e[kWin + 1];
+#pragma unroll
+          for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
+          e[kWin] = (i & 1) ? e_new[k].y : e_new[k].x;
+          const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
+          store_slot(a.state, st, P + 3 * i + 0, woff, make_float4(e[1], e[2], e[3], e[4]));
+          store_slot(a.state, st, P + 3 * i + 1, woff, make_float4(e[5], e[6], e[7], e[8]));
+          store_slot(a.state, st, P + 3 * i + 2, woff, make_float4(e[9], e[10], ie, 0.f));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+#pragma unroll
+        for (int j = 0; j + 1 < kWin; ++j) win[k][j] = win[k][j + 1];
+        win[k][kWin - 1] = e_new[k];
+      }
+    }
+
+    // ---- optional estimator (Newton-Raphson FK, [NEW] SURVEY 8(a) row 14)
+    v2f applied[NP];
+    float fk_res = 0.f;
+    int fk_it = 0, td_flag = 0;
+    v2f jest[NP][6];
+    if (FK) {
+      v2f elen[NP], unused[NP];
+      bool active = true;
+      for (int it = 0; it < a.fk_iters; ++it) {
+        ik_pairs<N, false>(lds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+        v2f res[NP];
+        v2f rm = splat(0.f);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          res[k] = len[k] - elen[k];
+          rm = max2(rm, abs2(res[k]));
+        }
+        active = active && !(fmaxf(rm.x, rm.y) < a.fk_tol);
+        float g[6];
+        jt_times<NP>(jest, res, g);
+        normal_solve<NP>(jest, a.fk_lambda, g);
+        if (active) {
+          fkx += g[0];
+          fky += g[1];
+          fkz += g[2];
+          quat_apply_rotvec(fkqx, fkqy, fkqz, fkqw, g[3], g[4], g[5]);
+          ++fk_it;
+        }
+      }
+      ik_pairs<N, false>(lds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+      v2f rm = splat(0.f);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
+      fk_res = fmaxf(rm.x, rm.y);
+    }
+
+    // ---- optional tension distribution ([NEW] SURVEY 8(a) row 15):
+    //      T = Tm 1 + J (J^T J)^-1 J^T (f - Tm 1), J at the FK estimate when there is one, then bounds
+    if (TD) {
+      v2f df[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) df[k] = f[k] - splat(a.td_mid);
+      float g[6];
+      if (FK) {
+        jt_times<NP>(jest, df, g);
+        normal_solve<NP>(jest, 0.f, g);
+      } else {
+        jt_times<NP>(jac, df, g);
+        normal_solve<NP>(jac, 0.f, g);
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        v2f t = splat(a.td_mid);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t = fma2(g[c], FK ? jest[k][c] : jac[k][c], t);
+        const v2f tc = max2(min2(t, splat(a.td_max)), splat(a.td_min));
+        td_flag |= (tc.x != t.x) ? 1 : 0;
+        if (2 * k + 1 < N) td_flag |= (tc.y != t.y) ? 1 : 0;
+        applied[k] = tc;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) applied[k] = f[k];
+    }
+    if (a.effort >= 0.f) {  // Joint::SetForce clamp (cube.sdf:438)
+#pragma unroll
+      for (int k = 0; k < NP; ++k) applied[k] = max2(min2(applied[k], splat(a.effort)), splat(-a.effort));
+    }
+
+    if (a.dbg && live) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
+      float* d = a.dbg + (size_t)r * 9;
+      if (dbg_wrote) {
+        d[0] = dbg_p;
+        d[1] = dbg_i;
+        d[2] = dbg_d;
+        d[3] = desired[0].x;
+      }
+      d[4] = applied[0].x;
+    }
+
+    // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
+    if (((a.publish_mask >> step) & 1ull) && live) {
+      store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+      store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+      store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+      store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+        const bool has = (2 * g + 1 < NP);
+        store_slot(a.obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
+        store_slot(a.obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
+        store_slot(a.obs, st, 4 + 2 * G + g, woff,
+                   make_float4(applied[k0].x, applied[k0].y, has ? applied[k1].x : 0.f, has ? applied[k1].y : 0.f));
+      }
+    }
+
+    // ---- world step to t_{k+1}: wrench = -J^T (applied - d qdot) + m g
+    {
+      v2f tens[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) tens[k] = fma2(-a.damping, qd[k], applied[k]);
+      float w[6];
+      jt_times<NP>(jac, tens, w);
+      w[0] = a.fgx - w[0];
+      w[1] = a.fgy - w[1];
+      w[2] = a.fgz - w[2];
+      w[3] = -w[3];
+      w[4] = -w[4];
+      w[5] = -w[5];
+      integrate(a, s, w);
+    }
+  }
+
+  // ---- store
+  if (live) {
+    store_slot(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    store_slot(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    store_slot(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+    store_slot(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
+    if (FK) store_slot(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+    if (!SINGLE) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int k = i / 2;
+        float e[kWin];
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
+        const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
+        store_slot(a.state, st, P + 3 * i + 0, woff, make_float4(e[0], e[1], e[2], e[3]));
+        store_slot(a.state, st, P + 3 * i + 1, woff, make_float4(e[4], e[5], e[6], e[7]));
+        store_slot(a.state, st, P + 3 * i + 2, woff, make_float4(e[8], e[9], ie, 0.f));
+      }
+    }
+  }
+}
+
+}  // namespace cdpr
