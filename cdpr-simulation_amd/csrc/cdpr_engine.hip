@@ -15,6 +15,7 @@
 
 #include "../../include/cdpr.h"
 #include "cdpr_step_kernel.hpp"
+#include "cdpr_general_ctrl.hpp"
 
 using namespace cdpr;
 
@@ -47,6 +48,13 @@ struct cdpr_engine {
   float* d_dbg = nullptr;
   float* d_geom = nullptr;  // pair-interleaved cable geometry, staged in LDS by the kernel
   int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
+  // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
+  bool general = false;
+  float* d_rec = nullptr;    // [last_pos][position Pid block][velocity Pid block]
+  float* d_force = nullptr;  // raw forces handed from the controller kernel to the platform kernel
+  float* d_cable = nullptr;  // plain per-cable geometry, 7 rows of n
+  size_t tstride = 0;
+  GenPid gpid[2]{};
   float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
   float* d_pos[2] = {nullptr, nullptr};
   bool vel_pending = false, pos_pending = false;
@@ -216,7 +224,49 @@ void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   k.td_mid = (float)(0.5 * (c.td_f_min + c.td_f_max));
 }
 
+void fill_gen_pid(const cdpr_pid_params_t& p, GenPid& g) {
+  g.kf = (float)p.forward_gain; g.kp = (float)p.p_gain; g.ki = (float)p.i_gain; g.kd = (float)p.d_gain;
+  g.imax = (float)std::fabs(p.i_limit); g.imin = -(float)std::fabs(p.i_limit);
+  g.cmax = (float)std::fabs(p.cmd_limit); g.cmin = -(float)std::fabs(p.cmd_limit);
+  g.nbuf = (int)p.d_buffer_length; g.degree = (int)p.d_degree;
+  g.pcas = (int)p.p_filter.cascade; g.dcas = (int)p.d_filter.cascade;
+  auto biquad = [](const cdpr_filter_params_t& f, float& a0, float& a1, float& a2, float& b1, float& b2) {
+    // BiQuad::SetFc(fc, fs = 1.0, q), Filter.h:130-140
+    const double k = std::tan(M_PI * f.rel_cutoff / 1.0);
+    const double den = k * k + k / f.quality + 1.0;
+    a0 = (float)(k * k / den); a1 = (float)(2.0 * (k * k / den)); a2 = a0;
+    b1 = (float)(2.0 * (k * k - 1.0) / den); b2 = (float)((k * k - k / f.quality + 1.0) / den);
+  };
+  g.pa0 = g.pa1 = g.pa2 = g.pb1 = g.pb2 = g.da0 = g.da1 = g.da2 = g.db1 = g.db2 = 0.f;
+  if (g.pcas) biquad(p.p_filter, g.pa0, g.pa1, g.pa2, g.pb1, g.pb2);
+  if (g.dcas) biquad(p.d_filter, g.da0, g.da1, g.da2, g.db1, g.db2);
+}
+
 using StepKernel = void (*)(const StepArgs);
+
+template <int N>
+StepKernel pick_ext_stage(bool fk, bool td) {
+  if constexpr (N >= 6) {
+    if (fk && td) return cdpr_step_kernel<N, true, true, true, true>;
+    if (fk) return cdpr_step_kernel<N, true, false, true, true>;
+    if (td) return cdpr_step_kernel<N, false, true, true, true>;
+  }
+  return cdpr_step_kernel<N, false, false, true, true>;
+}
+
+StepKernel pick_ext_kernel(uint32_t n, bool fk, bool td) {
+  switch (n) {
+    case 1: return pick_ext_stage<1>(fk, td);
+    case 2: return pick_ext_stage<2>(fk, td);
+    case 3: return pick_ext_stage<3>(fk, td);
+    case 4: return pick_ext_stage<4>(fk, td);
+    case 5: return pick_ext_stage<5>(fk, td);
+    case 6: return pick_ext_stage<6>(fk, td);
+    case 7: return pick_ext_stage<7>(fk, td);
+    case 8: return pick_ext_stage<8>(fk, td);
+  }
+  return nullptr;
+}
 
 template <int N, bool SINGLE>
 StepKernel pick_stage(bool fk, bool td) {
@@ -306,6 +356,7 @@ int upload_home(cdpr_engine* h) {
   }
   HIP_TRY(h, hipMemcpyAsync(h->d_obs, o.data(), o.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   if (h->d_dbg) HIP_TRY(h, hipMemsetAsync(h->d_dbg, 0, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float), h->stream));
+  if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows() * h->tstride * sizeof(float), h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return CDPR_OK;
 }
@@ -317,6 +368,9 @@ void free_all(cdpr_engine* h) {
   if (h->d_obs) (void)hipFree(h->d_obs);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->d_geom) (void)hipFree(h->d_geom);
+  if (h->d_rec) (void)hipFree(h->d_rec);
+  if (h->d_force) (void)hipFree(h->d_force);
+  if (h->d_cable) (void)hipFree(h->d_cable);
   for (int i = 0; i < 2; ++i) {
     if (h->d_vel[i]) (void)hipFree(h->d_vel[i]);
     if (h->d_pos[i]) (void)hipFree(h->d_pos[i]);
@@ -362,6 +416,58 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
   return CDPR_OK;
 }
 
+int run_steps_general(cdpr_engine* h, int nsteps) {
+  StepArgs a = h->base;
+  a.state = h->d_state;
+  a.obs = h->d_obs;
+  a.cmd = nullptr;
+  a.force = h->d_force;
+  a.dbg = h->dbg ? h->d_dbg : nullptr;
+  a.geom = h->d_geom;
+  a.batch = h->batch;
+  a.stride = h->stride;
+  a.nsteps = 1;
+  a.pid_calls = 0;
+  copy_pid(h->pid_pos, a);  // unused by the EXT kernel
+  GenArgs g{};
+  g.state = h->d_state;
+  g.stride = h->stride;
+  g.batch = h->batch;
+  g.n = h->n;
+  g.cable = h->d_cable;
+  g.vel_cmd = h->have_vel ? h->d_vel[0] : nullptr;
+  g.pos_cmd = h->have_pos ? h->d_pos[0] : nullptr;
+  g.rec = h->d_rec;
+  g.tstride = h->tstride;
+  g.force = h->d_force;
+  g.dbg = a.dbg;
+  g.mode = h->mode;
+  g.eps = (float)h->cfg.velocity_epsilon;
+  g.dt = (float)h->cfg.dt;
+  g.pid[0] = h->gpid[0];
+  g.pid[1] = h->gpid[1];
+  StepKernel plat = pick_ext_kernel(h->n, h->fk, h->td);
+  const uint32_t total = h->batch * h->n;
+  for (int k = 0; k < nsteps; ++k) {
+    const bool first_world = (h->step == 0);
+    g.first_world = first_world ? 1 : 0;
+    g.now_step = (int)h->step;
+    hipLaunchKernelGGL(cdpr_general_ctrl_kernel, dim3((total + 255u) / 256u), dim3(256), 0, h->stream, g);
+    a.flags = first_world ? kFlagFirstWorldStep : 0u;
+    const double now = sim_time(h->step, h->cfg.dt);
+    a.publish_mask = 0;
+    if ((now - h->prev_publish) > h->cfg.publish_period) {  // PLG.cpp:236-242
+      h->prev_publish = now;
+      a.publish_mask = 1ull;
+    }
+    hipLaunchKernelGGL(plat, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    ++h->launches;
+    ++h->step;
+  }
+  return CDPR_OK;
+}
+
 int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
   if (!h) return CDPR_ERR_INVALID;
   if (nsteps < 0 || per_launch < 1 || per_launch > 64) {
@@ -373,20 +479,26 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
 
   // --- PLG.cpp:206-219: latch pending commands, velocity first, then position
   bool reset_pid = false;
+  auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path)
+    return hipMemsetAsync(h->d_rec + h->tstride * (1 + (size_t)which * kGfRows), 0, (size_t)kGfRows * h->tstride * sizeof(float), h->stream);
+  };
   if (h->vel_pending) {
     std::swap(h->d_vel[0], h->d_vel[1]);
     h->vel_pending = false;
     h->have_vel = true;
     reset_pid = (h->mode != kModeVelocity);  // JFC.cpp:113-115
+    if (h->general && reset_pid) HIP_TRY(h, reset_block(1));
     h->mode = kModeVelocity;
   }
   if (h->pos_pending) {
     std::swap(h->d_pos[0], h->d_pos[1]);
     h->pos_pending = false;
     h->have_pos = true;
-    reset_pid = (h->mode != kModePosition);  // JFC.cpp:101-103 (single record: it now belongs to the position Pid)
+    reset_pid = (h->mode != kModePosition);  // JFC.cpp:101-103 (fast path: the single record now belongs to the position Pid)
+    if (h->general && reset_pid) HIP_TRY(h, reset_block(0));
     h->mode = kModePosition;
   }
+  if (h->general) return run_steps_general(h, nsteps);
 
   if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller record; rare, so done outside the step kernel
     h->pid_calls = 0;
@@ -501,11 +613,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     g_create_error = why;
     return CDPR_ERR_INVALID;
   }
-  why = fast_path_obstacle(*cfg);
-  if (!why.empty()) {
-    g_create_error = "configuration needs the general controller path, not built yet: " + why;
-    return CDPR_ERR_UNSUPPORTED;
-  }
+  const bool general = !fast_path_obstacle(*cfg).empty();
   if (cfg->mapping == CDPR_MAP_LANE_PER_CABLE) {
     g_create_error = "lane-per-cable mapping not built yet";
     return CDPR_ERR_UNSUPPORTED;
@@ -529,7 +637,8 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->fk = (cfg->stages & CDPR_STAGE_FK) != 0;
   h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
-  h->n_state = state_slots((int)h->n, h->fk);
+  h->general = general;
+  h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
   memset(&h->base, 0, sizeof h->base);
   fill_consts(*cfg, h->base);
@@ -560,6 +669,24 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     std::vector<float> g = geom_pairs(*cfg);
     if ((e = hipMalloc(&h->d_geom, g.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(geom)", e);
     if ((e = hipMemcpy(h->d_geom, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(geom)", e);
+  }
+  if (h->general) {
+    const size_t total = (size_t)h->batch * h->n;
+    h->tstride = (total + 63) & ~(size_t)63;
+    if ((e = hipMalloc(&h->d_rec, gen_record_rows() * h->tstride * sizeof(float))) != hipSuccess) return fail("hipMalloc(rec)", e);
+    if ((e = hipMalloc(&h->d_force, total * sizeof(float))) != hipSuccess) return fail("hipMalloc(force)", e);
+    std::vector<float> cg((size_t)7 * h->n);
+    for (uint32_t i = 0; i < h->n; ++i) {
+      for (int k = 0; k < 3; ++k) {
+        cg[(size_t)k * h->n + i] = (float)cfg->frame_anchor[i][k];
+        cg[(size_t)(3 + k) * h->n + i] = (float)cfg->platform_anchor[i][k];
+      }
+      cg[(size_t)6 * h->n + i] = (float)cfg->cable_ref_length[i];
+    }
+    if ((e = hipMalloc(&h->d_cable, cg.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(cable)", e);
+    if ((e = hipMemcpy(h->d_cable, cg.data(), cg.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(cable)", e);
+    fill_gen_pid(cfg->position_pid, h->gpid[0]);
+    fill_gen_pid(cfg->velocity_pid, h->gpid[1]);
   }
   if (h->dbg)
     if ((e = hipMalloc(&h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float))) != hipSuccess)

@@ -1,0 +1,288 @@
+// cdpr_general_ctrl.hpp — general controller path (gfx950): everything the register-resident
+// fast path of cdpr_step_kernel.hpp cannot represent.
+//
+//   * position-hold branch of JointForceCalculator::update (JFC.cpp:78-82, velocityEpsilon >= 0):
+//     both Pids of a cable stay alive in Velocity mode and are sampled at non-uniform times;
+//   * biquad cascades on the P and D inputs (Pid::CascadeFilter, Pid.cpp:27-44; Filter.h:130-165);
+//   * derivative windows up to 32 samples / degree 4, fitted on the real sample stamps
+//     (Pid::derive + fitPolynomial, Pid.cpp:193-247) instead of the uniform-grid FIR;
+//   * cmdLimit == 0 (no command clamp: mCmd keeps its old value, Pid.cpp:175-186).
+//
+// One thread owns one (robot, cable): it evaluates the cable's IK row on the state at t_k, runs the
+// mode machine and the Pid, and writes the raw force.  The platform kernel (cdpr_step_kernel with
+// EXT = true) then reads the forces and does FK / TD / observables / world step.  Records live in
+// HBM as struct-of-arrays over T = B*n threads, one contiguous block per Pid so a Pid::reset of the
+// whole batch is one memset.  The polynomial fit is done in fp64 on centred, scaled stamps.
+#pragma once
+#include "cdpr_step_kernel.hpp"
+
+namespace cdpr {
+
+constexpr int kGenMaxBuf = 32;   // CDPR_MAX_D_BUFFER
+constexpr int kGenMaxDeg = 4;    // CDPR_MAX_D_DEGREE
+constexpr int kGenMaxCas = 4;    // CDPR_MAX_CASCADE
+
+// fields of one Pid record (each a row of T floats)
+enum GenField : int {
+  kGfWasLast = 0,  // Pid::mWasLastTime
+  kGfLastStep,     // Pid::mLastTime as a world-step index
+  kGfIerr,
+  kGfDerr,
+  kGfCmd,
+  kGfCount,        // samples pushed since reset (mDbufferLength - mDbufferMissing, saturating)
+  kGfHead,         // ring index of the newest sample
+  kGfWinVal,       // kGenMaxBuf rows: mDbufferY
+  kGfWinStamp = kGfWinVal + kGenMaxBuf,           // kGenMaxBuf rows: mDbufferX as world-step indices
+  kGfPFilt = kGfWinStamp + kGenMaxBuf,            // kGenMaxCas x (x1 x2 y1 y2)
+  kGfDFilt = kGfPFilt + 4 * kGenMaxCas,
+  kGfRows = kGfDFilt + 4 * kGenMaxCas
+};
+
+struct GenPid {
+  float kf, kp, ki, kd, imax, imin, cmax, cmin;
+  int nbuf, degree, pcas, dcas;
+  float pa0, pa1, pa2, pb1, pb2;  // BiQuad::SetFc(relCutoff, 1.0, quality), Filter.h:130-140
+  float da0, da1, da2, db1, db2;
+};
+
+struct GenArgs {
+  const float4* state;  // platform slots of the step kernel
+  size_t stride;
+  uint32_t batch, n;
+  const float* cable;   // plain per-cable geometry: ax ay az bx by bz l0, 7 rows of n
+  const float* vel_cmd; // latched jointVelocities, float[B][n] (or nullptr)
+  const float* pos_cmd; // latched jointPositions, float[B][n] (or nullptr -> target 0)
+  float* rec;           // [last_pos row][pos Pid block][vel Pid block], rows of `tstride` floats
+  size_t tstride;
+  float* force;         // out: raw force per cable, float[B][n]
+  float* dbg;           // `pid` topic (cable 0), float[B][9], or nullptr
+  int mode;             // 1 = Position, 2 = Velocity (JFC.h:35-37)
+  int first_world;      // t = 0: stepTime <= 0 -> force 0, nothing else (JFC.cpp:61-66)
+  int now_step;
+  float eps, dt;
+  GenPid pid[2];        // [0] position Pid, [1] velocity Pid
+};
+
+__host__ __device__ constexpr size_t gen_record_rows() { return 1 + 2 * (size_t)kGfRows; }
+
+struct GenRec {
+  float* base;  // this thread's column of its Pid block
+  size_t ts;
+  __device__ __forceinline__ float& f(int row) { return base[(size_t)row * ts]; }
+};
+
+__device__ __forceinline__ float gen_cascade(GenRec& r, int first_row, int cascade, float a0, float a1, float a2, float b1,
+                                             float b2, float x) {
+  // Pid::CascadeFilter::update (Pid.cpp:38-44) over BiQuad::process (Filter.h:152-165)
+  float out = x;
+  for (int c = 0; c < cascade; ++c) {
+    float& x1 = r.f(first_row + 4 * c + 0);
+    float& x2 = r.f(first_row + 4 * c + 1);
+    float& y1 = r.f(first_row + 4 * c + 2);
+    float& y2 = r.f(first_row + 4 * c + 3);
+    const float y0 = a0 * out + a1 * x1 + a2 * x2 - b1 * y1 - b2 * y2;
+    x2 = x1;
+    x1 = out;
+    y2 = y1;
+    y1 = y0;
+    out = y0;
+  }
+  return out;
+}
+
+// Pid::derive + fitPolynomial (Pid.cpp:193-247) on the real stamps, fp64, centred and scaled time.
+__device__ __forceinline__ float gen_derive(const GenPid& p, GenRec& r, float value, int now_step, float dt) {
+  const int nbuf = p.nbuf;
+  int head = (int)r.f(kGfHead);
+  int count = (int)r.f(kGfCount);
+  head = (count == 0) ? 0 : ((head + 1 == nbuf) ? 0 : head + 1);
+  r.f(kGfWinVal + head) = value;
+  r.f(kGfWinStamp + head) = (float)now_step;  // exact up to 2^24 steps (4.6 h of sim time at 1 ms)
+  r.f(kGfHead) = (float)head;
+  if (count < nbuf) ++count;
+  r.f(kGfCount) = (float)count;
+  if (count < nbuf) return 0.f;  // mDbufferMissing != 0 (Pid.cpp:200-203)
+
+  // oldest sample sits right after the head in the ring
+  const int oldest = (head + 1 == nbuf) ? 0 : head + 1;
+  const double t_new = (double)now_step, t_old = (double)r.f(kGfWinStamp + oldest);
+  double mean = 0.0;
+  for (int j = 0; j < nbuf; ++j) mean += (double)r.f(kGfWinStamp + j);
+  mean /= (double)nbuf;
+  double h = (t_new - t_old) / (double)(nbuf - 1);
+  if (!(h > 0.0)) h = 1.0;
+  const int m = p.degree + 1;
+  double sx[2 * kGenMaxDeg + 1], sb[kGenMaxDeg + 1];
+  for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) sx[i] = 0.0;
+  for (int i = 0; i < kGenMaxDeg + 1; ++i) sb[i] = 0.0;
+  for (int j = 0; j < nbuf; ++j) {
+    const double x = ((double)r.f(kGfWinStamp + j) - mean) / h;
+    const double y = (double)r.f(kGfWinVal + j);
+    double pw = 1.0;
+    for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) {
+      if (i < 2 * m - 1) sx[i] += pw;
+      if (i < m) sb[i] += pw * y;
+      pw *= x;
+    }
+  }
+  double a[kGenMaxDeg + 1][kGenMaxDeg + 2];
+  for (int i = 0; i < kGenMaxDeg + 1; ++i)
+    for (int j = 0; j < kGenMaxDeg + 2; ++j) a[i][j] = 0.0;
+  for (int i = 0; i < kGenMaxDeg + 1; ++i) {
+    for (int j = 0; j < kGenMaxDeg + 1; ++j)
+      if (i < m && j < m) a[i][j] = sx[i + j];
+    if (i < m) a[i][kGenMaxDeg + 1] = sb[i];
+    if (i >= m) a[i][i] = 1.0;  // inert rows keep the elimination branch-free in its bounds
+  }
+  // Gaussian elimination with partial pivoting (the system is SPD and tiny)
+  for (int col = 0; col < kGenMaxDeg + 1; ++col) {
+    int piv = col;
+    double best = fabs(a[col][col]);
+    for (int rr = col + 1; rr < kGenMaxDeg + 1; ++rr)
+      if (fabs(a[rr][col]) > best) {
+        best = fabs(a[rr][col]);
+        piv = rr;
+      }
+    if (piv != col)
+      for (int k = 0; k < kGenMaxDeg + 2; ++k) {
+        const double t = a[piv][k];
+        a[piv][k] = a[col][k];
+        a[col][k] = t;
+      }
+    const double inv = 1.0 / a[col][col];
+    for (int rr = 0; rr < kGenMaxDeg + 1; ++rr) {
+      if (rr == col) continue;
+      const double fct = a[rr][col] * inv;
+      for (int k = col; k < kGenMaxDeg + 2; ++k) a[rr][k] -= fct * a[col][k];
+    }
+  }
+  // derivative of the fitted polynomial at the newest stamp (Pid.cpp:205-212), back to seconds
+  const double xn = (t_new - mean) / h;
+  double deriv = 0.0, pw = 1.0;
+  for (int i = 1; i < kGenMaxDeg + 1; ++i) {
+    if (i < m) deriv += (double)i * (a[i][kGenMaxDeg + 1] / a[i][i]) * pw;
+    pw *= xn;
+  }
+  return (float)(deriv / (h * (double)dt));
+}
+
+struct GenTerms {
+  float p, i, d, desired;
+  bool pi_written, d_written, desired_written;
+};
+
+// Pid::update (Pid.cpp:122-191)
+__device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, float desired, float actual, int now_step,
+                                                float dt_step, GenTerms& t) {
+  t.pi_written = t.d_written = t.desired_written = false;
+  float cmd_out;
+  if (r.f(kGfWasLast) == 0.f) {
+    r.f(kGfWasLast) = 1.f;
+    r.f(kGfCmd) = 0.f;
+    cmd_out = 0.f;
+  } else {
+    const float f_term = p.kf * desired;
+    const float error = desired - actual;
+    const float dt = (float)(now_step - (int)r.f(kGfLastStep)) * dt_step;
+    const float perr = gen_cascade(r, kGfPFilt, p.pcas, p.pa0, p.pa1, p.pa2, p.pb1, p.pb2, error);
+    const float p_term = p.kp * perr;
+    const float prev_ierr = r.f(kGfIerr);
+    float ierr = fmaf(dt, error, prev_ierr);
+    float i_term = p.ki * ierr;
+    t.p = p_term;
+    t.i = i_term;
+    t.pi_written = true;
+    if (i_term > p.imax) {
+      i_term = p.imax;
+      ierr = i_term / p.ki;
+    } else if (i_term < p.imin) {
+      i_term = p.imin;
+      ierr = i_term / p.ki;
+    }
+    float derr = r.f(kGfDerr);
+    if (dt > 0.f) {
+      const float derived = gen_derive(p, r, error, now_step, dt_step);
+      derr = gen_cascade(r, kGfDFilt, p.dcas, p.da0, p.da1, p.da2, p.db1, p.db2, derived);
+      r.f(kGfDerr) = derr;
+      t.desired = desired;
+      t.desired_written = true;
+    }
+    const float d_term = p.kd * derr;
+    t.d = d_term;
+    t.d_written = true;
+    const float cmd = f_term + p_term + i_term + d_term;
+    float out = r.f(kGfCmd);
+    if (p.cmax > p.cmin) out = fmaxf(fminf(cmd, p.cmax), p.cmin);
+    if (out != cmd) {
+      ierr = prev_ierr;
+      out = fmaf(dt * error, p.ki, out);
+    }
+    r.f(kGfIerr) = ierr;
+    r.f(kGfCmd) = out;
+    cmd_out = out;
+  }
+  r.f(kGfLastStep) = (float)now_step;
+  return cmd_out;
+}
+
+__global__ __launch_bounds__(256) void cdpr_general_ctrl_kernel(const GenArgs a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t total = a.batch * a.n;
+  if (t >= total) return;
+  const uint32_t r = t / a.n, i = t - r * a.n;
+  if (a.first_world) {  // JFC.cpp:61-66: nothing but the time stamp moves at t = 0
+    a.force[t] = 0.f;
+    if (a.dbg && i == 0) a.dbg[(size_t)r * 9 + 4] = 0.f;
+    return;
+  }
+  // IK row of this cable on the state at t_k
+  const float4 p0 = a.state[0 * a.stride + r], p1 = a.state[1 * a.stride + r], p2 = a.state[2 * a.stride + r],
+               p3 = a.state[3 * a.stride + r];
+  const Rot rot = quat_to_rot(p0.w, p1.x, p1.y, p1.z);
+  const float ax = a.cable[0 * a.n + i], ay = a.cable[1 * a.n + i], az = a.cable[2 * a.n + i];
+  const float bx = a.cable[3 * a.n + i], by = a.cable[4 * a.n + i], bz = a.cable[5 * a.n + i];
+  const float l0 = a.cable[6 * a.n + i];
+  const float rbx = fmaf(rot.r02, bz, fmaf(rot.r01, by, rot.r00 * bx));
+  const float rby = fmaf(rot.r12, bz, fmaf(rot.r11, by, rot.r10 * bx));
+  const float rbz = fmaf(rot.r22, bz, fmaf(rot.r21, by, rot.r20 * bx));
+  const float lx = (rbx - ax) + p0.x, ly = (rby - ay) + p0.y, lz = (rbz - az) + p0.z;
+  const float l2 = fmaf(lz, lz, fmaf(ly, ly, lx * lx));
+  const float inv = __frsqrt_rn(l2);
+  const float len = l2 * inv;
+  const float ux = lx * inv, uy = ly * inv, uz = lz * inv;
+  const float j3 = fmaf(rby, uz, -(rbz * uy)), j4 = fmaf(rbz, ux, -(rbx * uz)), j5 = fmaf(rbx, uy, -(rby * ux));
+  const float q = l0 - len;
+  const float qd = -fmaf(p3.x, j5, fmaf(p2.w, j4, fmaf(p2.z, j3, fmaf(p2.y, uz, fmaf(p2.x, uy, p1.w * ux)))));
+
+  float* last_pos = a.rec + t;
+  GenRec pos{a.rec + a.tstride * 1 + t, a.tstride};
+  GenRec vel{a.rec + a.tstride * (1 + (size_t)kGfRows) + t, a.tstride};
+  GenTerms terms;
+  terms.pi_written = terms.d_written = terms.desired_written = false;
+  float force = 0.f;
+  if (a.mode == 2) {  // Velocity (JFC.cpp:71-83)
+    const float vt = a.vel_cmd ? a.vel_cmd[t] : 0.f;
+    if (fabsf(vt) > a.eps) {
+      *last_pos = q;
+      force = gen_pid_update(a.pid[1], vel, vt, qd, a.now_step, a.dt, terms);
+    } else {
+      force = gen_pid_update(a.pid[0], pos, *last_pos, q, a.now_step, a.dt, terms);
+    }
+  } else {  // Position (JFC.cpp:84-89)
+    const float target = a.pos_cmd ? a.pos_cmd[t] : 0.f;
+    *last_pos = q;
+    force = gen_pid_update(a.pid[0], pos, target, q, a.now_step, a.dt, terms);
+  }
+  a.force[t] = force;
+  if (a.dbg && i == 0) {  // `pid` topic: stale entries stay (Pid.cpp:139-142,158-168)
+    float* d = a.dbg + (size_t)r * 9;
+    if (terms.pi_written) {
+      d[0] = terms.p;
+      d[1] = terms.i;
+    }
+    if (terms.d_written) d[2] = terms.d;
+    if (terms.desired_written) d[3] = terms.desired;
+  }
+}
+
+}  // namespace cdpr

@@ -53,6 +53,7 @@ struct StepArgs {
   const float* cmd;   // latched Joy.axes of the active mode, float[B][n]; nullptr -> desired 0 (state after Load)
   float* dbg;         // float[B][9] `pid` debug topic, or nullptr
   const float* geom;  // cable_pairs(n) * 16 floats, pair-interleaved cable geometry
+  const float* force; // EXT only: raw per-cable forces from the general controller kernel, float[B][n]
   uint32_t batch;
   uint32_t stride;    // robots per slot row (batch rounded up to 64)
   int nsteps;         // world steps fused into this launch
@@ -303,7 +304,9 @@ CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, co
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base + (size_t)slot * stride) + off) = v;
 }
 
-template <int N, bool FK, bool TD, bool SINGLE>
+// EXT = true: the controller ran in cdpr_general_ctrl_kernel; forces come from a.force and the state has
+// no controller records (platform slots only).
+template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
@@ -327,16 +330,19 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
   if (FK) p4 = load_slot(a.state, st, 4, off);
   float4 craw[N][3];
+  if (!EXT) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
+    for (int i = 0; i < N; ++i) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) craw[i][k] = load_slot(a.state, st, P + 3 * i + k, off);
+      for (int k = 0; k < 3; ++k) craw[i][k] = load_slot(a.state, st, P + 3 * i + k, off);
+    }
   }
-  v2f desired[NP];
+  v2f desired[NP];  // EXT: the raw forces instead of the Joy targets
 #pragma unroll
   for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
-  if (a.cmd) {
-    const float* cp = a.cmd + (size_t)rr * N;
+  const float* vec_in = EXT ? a.force : a.cmd;
+  if (vec_in) {
+    const float* cp = vec_in + (size_t)rr * N;
     if (N % 4 == 0) {
 #pragma unroll
       for (int g = 0; g < N / 4; ++g) {
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   // controller records as cable pairs: window e[j] (oldest..newest), integral
   v2f win[NP][kWin], ierr[NP];
 #pragma unroll
-  for (int k = 0; k < NP; ++k) {
+  for (int k = 0; k < (EXT ? 0 : NP); ++k) {
     const int i0 = 2 * k, i1 = (2 * k + 1 < N) ? 2 * k + 1 : 2 * k;
     const bool has1 = (2 * k + 1 < N);
 #pragma unroll
@@ -407,7 +413,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
     float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
     bool dbg_wrote = false;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
-    if (!first_world) {
+    if (EXT) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) f[k] = first_world ? splat(0.f) : desired[k];
+    } else if (!first_world) {
       if (calls != 0) {  // not the first call since reset (Pid.cpp:123-126: that one returns 0)
         const bool full = calls >= a.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
         v2f error[NP], acc[NP];
@@ -457,7 +466,9 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
 
     // When no sample was taken (first call after a reset, or t = 0) e_new is 0 and the window is all
     // zeros (Pid::reset zeroed it), so the unconditional shift below leaves it unchanged.
-    if (SINGLE) {
+    if (EXT) {
+      // no controller records on this path
+    } else if (SINGLE) {
       // controller records are final: store them now, window shift folded into the store
       if (live) {
 #pragma unroll
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
     store_slot(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
     store_slot(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
     if (FK) store_slot(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
-    if (!SINGLE) {
+    if (!SINGLE && !EXT) {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int k = i / 2;

@@ -300,3 +300,105 @@ def test_full_size_properties_config3(pkg):
     e2.set_velocity_command(cmd[:4096][perm])
     e2.update(200)
     assert np.array_equal(e2.platform_state()[0], p[:4096][perm])
+
+
+# ---------------------------------------------------------------------------------------------
+# general controller path (cdpr_general_ctrl.hpp): hold branch, biquad cascades, long windows, cmdLimit 0
+# ---------------------------------------------------------------------------------------------
+def run_script(eng, ora, script, tol=TOL, label=""):
+    for kind, val in script:
+        for sim in (eng, ora):
+            if kind == "vel":
+                sim.set_velocity_command(val)
+            elif kind == "pos":
+                sim.set_position_command(val)
+            else:
+                sim.update(val)
+        if kind == "run":
+            compare(eng, ora, tol=tol, where=f"{label} after run {val}")
+
+
+def test_general_path_position_hold_branch(pkg, oracle):
+    """velocityEpsilon > 0: cables whose |target| <= eps hold position with the POSITION Pid while the others keep
+    their velocity Pid (JFC.cpp:72-82); both Pids stay alive and are sampled at non-uniform times."""
+    B = 50
+    rng = np.random.default_rng(21)
+    cfg = pkg.Config(batch=B, velocityEpsilon=0.01)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng, 0.02, 0.05))
+    script = [("run", 15)]
+    for j in range(12):
+        cmd = rng.uniform(-0.03, 0.03, (B, 4)).astype(np.float32)
+        cmd[rng.random((B, 4)) < 0.4] *= 0.1  # a good share below eps -> hold branch
+        script += [("vel", cmd), ("run", 7 + j)]
+    script += [("pos", np.full(4, 0.002, dtype=np.float32)), ("run", 30), ("vel", np.zeros(4, dtype=np.float32)), ("run", 30)]
+    run_script(eng, ora, script, label="hold")
+
+
+@pytest.mark.parametrize("cascade", [1, 2])
+def test_general_path_biquad_cascades(pkg, oracle, cascade):
+    """P and D inputs of the velocity Pid through 1 or 2 low-pass biquads (Pid.cpp:27-44, Filter.h:130-165)."""
+    B = 40
+    rng = np.random.default_rng(22 + cascade)
+    cfg = pkg.Config(batch=B)
+    cfg.velocityController.pFilter.cascade = cascade
+    cfg.velocityController.dFilter.cascade = cascade
+    eng, ora = pair(pkg, oracle, cfg)
+    # The filters' phase lag makes this velocity loop unstable (in the oracle too: efforts rail at +-100 N after
+    # ~50 steps and any rounding difference is amplified from then on), so the comparison covers the 30 steps
+    # before that, where GPU and oracle agree to 5e-3 N, and then only checks that both saturate alike.
+    script = [("run", 20)]
+    for j in range(3):
+        script += [("vel", rng.uniform(-0.04, 0.04, (B, 4)).astype(np.float32)), ("run", 10)]
+    run_script(eng, ora, script, tol=dict(TOL, eff=5e-3), label=f"cascade{cascade}")
+    eng.update(60), ora.update(60)
+    ge, oe = eng.joint_states()[2], ora.joint_states()[2]
+    assert np.abs(ge - oe).max() < 0.5 and np.abs(eng.platform_state()[0] - ora.platform_state()[0]).max() < 1e-5
+    # a gentle (stable) loop through the same filters, long horizon
+    cfg2 = pkg.Config(batch=B)
+    for f in (cfg2.velocityController.pFilter, cfg2.velocityController.dFilter):
+        f.cascade, f.relCutoff, f.quality = cascade, 0.05, 0.5
+    cfg2.velocityController.pGain, cfg2.velocityController.iGain, cfg2.velocityController.dGain = 4.0, 40.0, 0.01
+    eng2, ora2 = pair(pkg, oracle, cfg2)
+    script = [("run", 20)]
+    for j in range(20):
+        script += [("vel", rng.uniform(-0.02, 0.02, (B, 4)).astype(np.float32)), ("run", 10)]
+    run_script(eng2, ora2, script, label=f"gentle cascade{cascade}")
+
+
+@pytest.mark.parametrize("nbuf,deg", [(21, 3), (32, 4), (5, 1)])
+def test_general_path_long_windows_and_degrees(pkg, oracle, nbuf, deg):
+    B = 30
+    rng = np.random.default_rng(nbuf)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, velocityEpsilon=0.0)
+    for p in (cfg.velocityController, cfg.positionController):
+        p.dBufferLength, p.dDegree = nbuf, deg
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng, 0.03, 0.05))
+    script = [("run", 40), ("vel", rng.uniform(0.005, 0.04, (B, 8)).astype(np.float32)), ("run", 60), ("pos", np.zeros(8, dtype=np.float32)), ("run", 60)]
+    run_script(eng, ora, script, tol=dict(TOL, eff=5e-2), label=f"N{nbuf}d{deg}")
+
+
+def test_general_path_command_clamp_disabled(pkg, oracle):
+    """cmdLimit = 0: mCmdMax == mCmdMin, so mCmd keeps its old value and the anti-windup branch integrates it
+    (Pid.cpp:175-186) — a reference quirk the general path reproduces."""
+    cfg = pkg.Config(batch=8)
+    cfg.velocityController.cmdLimit = 0.0
+    eng, ora = pair(pkg, oracle, cfg)
+    script = [("run", 10), ("vel", np.full(4, 0.02, dtype=np.float32)), ("run", 100)]
+    run_script(eng, ora, script, label="cmdlimit0")
+
+
+def test_general_and_fast_path_agree_on_the_shipped_config(pkg, oracle):
+    """velocityEpsilon = 0 with non-zero targets takes the same branches as the shipped -0.001 but forces the general
+    kernels: both GPU paths must agree with each other to fp32 rounding and with the oracle."""
+    B = 64
+    rng = np.random.default_rng(31)
+    pose = perturbed_poses(pkg.cube_model(), B, rng, 0.02, 0.05)
+    cmd = rng.uniform(0.005, 0.04, (B, 4)).astype(np.float32) * rng.choice([-1.0, 1.0], (B, 4)).astype(np.float32)
+    res = []
+    for eps in (-0.001, 0.0):
+        cfg = pkg.Config(batch=B, velocityEpsilon=eps, stages=pkg._abi.STAGE_PID_DEBUG)
+        eng, ora = pair(pkg, oracle, cfg, pose)
+        run_script(eng, ora, [("run", 20), ("vel", cmd), ("run", 80)], label=f"eps{eps}")
+        assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 2e-2
+        res.append((eng.platform_state()[0], eng.joint_states()[2]))
+    assert np.abs(res[0][0] - res[1][0]).max() < 2e-6 and np.abs(res[0][1] - res[1][1]).max() < 5e-3
