@@ -142,6 +142,32 @@ class Engine:
         self._check(lib().cdpr_get_td_state(self._h, _fp(t), f.ctypes.data_as(C.POINTER(C.c_int32))))
         return t, f
 
+    # -- one-shot batched kinematics on caller data
+    def solve_ik(self, pose7, twist6=None):
+        """Joint::Position / GetVelocity restated: q[B,n], qdot[B,n], J[B,n,6] for the given poses (and twists)."""
+        p = np.ascontiguousarray(pose7, dtype=np.float32).reshape(self.B, 7)
+        t = None if twist6 is None else np.ascontiguousarray(twist6, dtype=np.float32).reshape(self.B, 6)
+        q, qd = np.empty((self.B, self.n), dtype=np.float32), np.empty((self.B, self.n), dtype=np.float32)
+        jac = np.empty((self.B, self.n, 6), dtype=np.float32)
+        self._check(lib().cdpr_solve_ik(self._h, _fp(p), _fp(t), _fp(q), _fp(qd), _fp(jac)))
+        return q, qd, jac
+
+    def solve_fk(self, lengths, seed7):
+        """Newton-Raphson forward kinematics: pose7[B,7], residual[B], iterations[B]."""
+        ln = np.ascontiguousarray(lengths, dtype=np.float32).reshape(self.B, self.n)
+        sd = np.ascontiguousarray(seed7, dtype=np.float32).reshape(self.B, 7)
+        pose, res, it = np.empty((self.B, 7), dtype=np.float32), np.empty(self.B, dtype=np.float32), np.empty(self.B, dtype=np.int32)
+        self._check(lib().cdpr_solve_fk(self._h, _fp(ln), _fp(sd), _fp(pose), _fp(res), it.ctypes.data_as(C.POINTER(C.c_int32))))
+        return pose, res, it
+
+    def solve_td(self, pose7, wrench6):
+        """Tension distribution for the wrench the cables must apply: tension[B,n], infeasible[B]."""
+        p = np.ascontiguousarray(pose7, dtype=np.float32).reshape(self.B, 7)
+        w = np.ascontiguousarray(wrench6, dtype=np.float32).reshape(self.B, 6)
+        t, f = np.empty((self.B, self.n), dtype=np.float32), np.empty(self.B, dtype=np.int32)
+        self._check(lib().cdpr_solve_td(self._h, _fp(p), _fp(w), _fp(t), f.ctypes.data_as(C.POINTER(C.c_int32))))
+        return t, f
+
     # -- caller-owned device buffers (e.g. a schedule of Joy batches resident in HBM)
     def device_upload(self, array: np.ndarray) -> int:
         a = np.ascontiguousarray(array)

@@ -402,3 +402,72 @@ def test_general_and_fast_path_agree_on_the_shipped_config(pkg, oracle):
         assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 2e-2
         res.append((eng.platform_state()[0], eng.joint_states()[2]))
     assert np.abs(res[0][0] - res[1][0]).max() < 2e-6 and np.abs(res[0][1] - res[1][1]).max() < 5e-3
+
+
+# ---------------------------------------------------------------------------------------------
+# one-shot solvers (cdpr_solve_ik / cdpr_solve_fk / cdpr_solve_td)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model_name", ["cube", "eight"])
+def test_solve_ik_matches_oracle(pkg, oracle, model_name):
+    model = pkg.cube_model() if model_name == "cube" else pkg.eight_cable_model()
+    B = 133
+    rng = np.random.default_rng(3)
+    cfg = pkg.Config(model=model, batch=B)
+    s = cfg.to_struct()
+    pose = perturbed_poses(model, B, rng).astype(np.float32)
+    twist = rng.uniform(-0.3, 0.3, (B, 6)).astype(np.float32)
+    eng = pkg.Engine(cfg, 0)
+    q, qd, jac = eng.solve_ik(pose, twist)
+    for r in range(0, B, 7):
+        oq, oqd, oln, ojac = oracle.ik(s, pose[r].astype(np.float64), twist[r].astype(np.float64))
+        assert np.abs(q[r] - oq).max() < 2e-7 and np.abs(qd[r] - oqd).max() < 2e-7 and np.abs(jac[r] - ojac).max() < 2e-7
+    q2, _, _ = eng.solve_ik(pose)  # twist optional
+    assert np.array_equal(q, q2)
+
+
+def test_solve_fk_round_trip_and_oracle(pkg, oracle):
+    """FK(IK(x)) = x on random poses, iteration counts equal to the oracle's (tolerance-controlled early exit)."""
+    B = 500
+    rng = np.random.default_rng(14)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=1, fkMaxIterations=8, fkTolerance=1e-6)
+    s = cfg.to_struct()
+    eng = pkg.Engine(cfg, 0)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    q, _, _ = eng.solve_ik(pose)
+    lengths = cfg.model.reference_lengths()[None, :].astype(np.float32) - q
+    seed = np.tile(cfg.model.home_pose(), (B, 1)).astype(np.float32)
+    est, res, it = eng.solve_fk(lengths, seed)
+    assert res.max() < 1e-6 and np.abs(est[:, :3] - pose[:, :3]).max() < 5e-6
+    assert np.abs(np.abs((est[:, 3:] * pose[:, 3:]).sum(axis=1)) - 1.0).max() < 1e-6
+    for r in range(0, B, 25):
+        oest, ores, oit = oracle.fk(s, lengths[r].astype(np.float64), seed[r].astype(np.float64))
+        assert abs(int(it[r]) - oit) <= 1 and np.abs(est[r] - oest).max() < 5e-6
+    est0, res0, it0 = eng.solve_fk(np.tile(cfg.model.reference_lengths(), (B, 1)), seed)
+    assert np.all(it0 == 0) and res0.max() < 1e-6  # already converged at the seed: no iteration taken
+
+
+def test_solve_td_matches_oracle_and_flags_infeasible(pkg, oracle):
+    B = 96
+    rng = np.random.default_rng(15)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=2)
+    s = cfg.to_struct()
+    eng = pkg.Engine(cfg, 0)
+    pose = perturbed_poses(cfg.model, B, rng, 0.03, 0.05).astype(np.float32)
+    wrench = np.tile([0, 0, 9.8, 0, 0, 0], (B, 1)).astype(np.float32) + rng.uniform(-0.5, 0.5, (B, 6)).astype(np.float32) * [1, 1, 1, 0.02, 0.02, 0.02]
+    wrench[-1] = [0, 0, 900.0, 0, 0, 0]  # cannot be balanced inside [5, 100] N
+    wrench = wrench.astype(np.float32)
+    t, flag = eng.solve_td(pose, wrench)
+    _, _, jac = eng.solve_ik(pose)
+    for r in range(B):
+        ot, oflag = oracle.td_wrench(s, pose[r].astype(np.float64), wrench[r].astype(np.float64))
+        assert int(flag[r]) == oflag and np.abs(t[r] - ot).max() < 5e-3
+        if not oflag:
+            assert np.abs(-jac[r].T.astype(np.float64) @ t[r] - wrench[r]).max() < 2e-3  # A T = w_d
+    assert flag[-1] == 1 and flag[:-1].sum() == 0 and t.min() >= 5.0 and t.max() <= 100.0
+
+
+def test_solvers_reject_robots_with_fewer_than_six_cables(pkg):
+    eng = pkg.Engine(pkg.Config(batch=4), 0)
+    with pytest.raises(pkg.CdprError) as ei:
+        eng.solve_fk(np.ones((4, 4)), np.tile(pkg.cube_model().home_pose(), (4, 1)))
+    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
