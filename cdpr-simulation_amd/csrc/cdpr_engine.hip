@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,17 @@ struct cdpr_engine {
   float* d_cable = nullptr;  // plain per-cable geometry, 7 rows of n
   size_t tstride = 0;
   GenPid gpid[2]{};
+  // hipGraph cache: chains of identical steady-state launches (see run_steps)
+  struct GraphEntry {
+    void* kern;
+    const float* cmd;
+    int steps_per_launch, launches;
+    uint32_t flags;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs;
+  bool use_graphs = true;
   float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
   float* d_pos[2] = {nullptr, nullptr};
   bool vel_pending = false, pos_pending = false;
@@ -410,6 +422,10 @@ void free_all(cdpr_engine* h) {
     if (h->d_vel[i]) (void)hipFree(h->d_vel[i]);
     if (h->d_pos[i]) (void)hipFree(h->d_pos[i]);
   }
+  for (auto& g : h->graphs) {
+    (void)hipGraphExecDestroy(g.exec);
+    (void)hipGraphDestroy(g.graph);
+  }
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -556,6 +572,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
   }
   const dim3 grid((h->batch + 63u) / 64u), block(64);
 
+  constexpr int kGraphChunk = 16;  // launches per captured graph
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
@@ -563,7 +580,45 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     a.flags = (h->mode == kModeVelocity ? kFlagActualIsVelocity : 0u);
     const bool first_world = (h->step == 0);
     if (first_world) a.flags |= kFlagFirstWorldStep;
-    a.pid_calls = h->pid_calls;
+    // the kernel only tests calls != 0 and calls >= nbuf: clamp so steady-state launches are identical
+    a.pid_calls = std::min(h->pid_calls, a.nbuf);
+    StepKernel kern = (k == 1) ? pick_kernel<true>(h->n, h->fk, h->td) : pick_kernel<false>(h->n, h->fk, h->td);
+
+    // Steady state (every step published, derivative window full, not t = 0): the next launches are
+    // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
+    // (measured on MI355X: 3.57 -> 3.41 us/step at 4 096 x 4 cables; at 65 536 x 8 cables the 15 us kernels already
+    // hide the host launch and the replay's fixed cost makes it 2 % slower, so only small batches use it)
+    const bool steady = h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && h->pid_calls >= a.nbuf && h->cfg.publish_period == 0.0 &&
+                        (nsteps - done) >= kGraphChunk * k;
+    if (steady) {
+      a.publish_mask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+      cdpr_engine::GraphEntry* ge = nullptr;
+      for (auto& g : h->graphs)
+        if (g.kern == (void*)kern && g.cmd == a.cmd && g.steps_per_launch == k && g.flags == a.flags) ge = &g;
+      if (!ge) {
+        cdpr_engine::GraphEntry g{(void*)kern, a.cmd, k, kGraphChunk, a.flags, nullptr, nullptr};
+        HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        for (int j = 0; j < kGraphChunk; ++j) hipLaunchKernelGGL(kern, grid, block, 0, h->stream, a);
+        HIP_TRY(h, hipStreamEndCapture(h->stream, &g.graph));
+        HIP_TRY(h, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        if (h->graphs.size() >= 8) {  // tiny cache: drop the oldest
+          (void)hipGraphExecDestroy(h->graphs.front().exec);
+          (void)hipGraphDestroy(h->graphs.front().graph);
+          h->graphs.erase(h->graphs.begin());
+        }
+        h->graphs.push_back(g);
+        ge = &h->graphs.back();
+      }
+      HIP_TRY(h, hipGraphLaunch(ge->exec, h->stream));
+      const int steps = kGraphChunk * k;
+      h->launches += kGraphChunk;
+      h->step += (uint64_t)steps;
+      h->pid_calls = std::min(h->pid_calls + steps, 1 << 20);
+      h->prev_publish = sim_time(h->step - 1, h->cfg.dt);
+      done += steps;
+      continue;
+    }
+
     a.publish_mask = 0;
     for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
       const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
@@ -572,7 +627,6 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
         a.publish_mask |= (1ull << j);
       }
     }
-    StepKernel kern = (k == 1) ? pick_kernel<true>(h->n, h->fk, h->td) : pick_kernel<false>(h->n, h->fk, h->td);
     hipLaunchKernelGGL(kern, grid, block, 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
@@ -680,6 +734,10 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   fill_pid(cfg->velocity_pid, cfg->dt, h->pid_vel);
   fill_pid(cfg->position_pid, cfg->dt, h->pid_pos);
   engine_reset_host(h);
+  {
+    const char* ng = std::getenv("CDPR_NO_GRAPH");
+    h->use_graphs = !(ng && ng[0] == '1');
+  }
 
   auto fail = [&](const char* what, hipError_t code) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(code);

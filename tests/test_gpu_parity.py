@@ -471,3 +471,27 @@ def test_solvers_reject_robots_with_fewer_than_six_cables(pkg):
     with pytest.raises(pkg.CdprError) as ei:
         eng.solve_fk(np.ones((4, 4)), np.tile(pkg.cube_model().home_pose(), (4, 1)))
     assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+
+
+def test_graph_replay_is_bit_identical_to_eager_launches(pkg):
+    """update(n) replays captured hipGraphs of 16 launches once the controller is in steady state; the result must
+    be bit-identical to n separate update(1) calls (which never form a chain long enough to be captured)."""
+    B = 700  # small enough for the graph path (batch * n <= 131072)
+    rng = np.random.default_rng(8)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    a, b = pkg.Engine(cfg, 0), pkg.Engine(cfg, 0)
+    for e in (a, b):
+        e.set_platform_state(pose7=pose)
+    for rnd in range(3):
+        cmd = rng.uniform(-0.04, 0.04, (B, 8)).astype(np.float32)
+        a.set_velocity_command(cmd), b.set_velocity_command(cmd)
+        a.update(100)
+        for _ in range(100):
+            b.update(1)
+        for x, y in zip(a.raw_state() + a.joint_states() + a.platform_state(), b.raw_state() + b.joint_states() + b.platform_state()):
+            assert np.array_equal(x, y), rnd
+    a.update(70, 2)
+    for _ in range(35):
+        b.update(2, 2)
+    assert np.array_equal(a.raw_state()[0], b.raw_state()[0]) and a.step_count == b.step_count == 370
