@@ -332,6 +332,30 @@ std::vector<float> geom_pairs(const cdpr_config_t& c) {
   return g;
 }
 
+template <int N>
+StepKernel pick_rollout_stage(bool fk, bool td) {
+  if constexpr (N >= 6) {
+    if (fk && td) return cdpr_step_kernel<N, true, true, false, false, true>;
+    if (fk) return cdpr_step_kernel<N, true, false, false, false, true>;
+    if (td) return cdpr_step_kernel<N, false, true, false, false, true>;
+  }
+  return cdpr_step_kernel<N, false, false, false, false, true>;
+}
+
+StepKernel pick_rollout_kernel(uint32_t n, bool fk, bool td) {
+  switch (n) {
+    case 1: return pick_rollout_stage<1>(fk, td);
+    case 2: return pick_rollout_stage<2>(fk, td);
+    case 3: return pick_rollout_stage<3>(fk, td);
+    case 4: return pick_rollout_stage<4>(fk, td);
+    case 5: return pick_rollout_stage<5>(fk, td);
+    case 6: return pick_rollout_stage<6>(fk, td);
+    case 7: return pick_rollout_stage<7>(fk, td);
+    case 8: return pick_rollout_stage<8>(fk, td);
+  }
+  return nullptr;
+}
+
 using SolveKernel = void (*)(const SolveArgs);
 
 template <int N>
@@ -965,6 +989,57 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
     if (rc != CDPR_OK) return rc;
     for (uint32_t r = 0; r < h->batch; ++r) infeasible[r] = (int32_t)o[3 * (size_t)h->stride + r].w;
   }
+  return CDPR_OK;
+}
+
+int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* ref_position,
+                          float* cost) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (samples < 1 || horizon < 1 || !d_commands || !ref_position || !cost) {
+    h->err = "cdpr_rollout_velocity: samples, horizon >= 1 and all buffers are required";
+    return CDPR_ERR_INVALID;
+  }
+  if (h->general) {
+    h->err = "cdpr_rollout_velocity: not available on the general controller path";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
+  if (traj > (1ull << 30)) {
+    h->err = "cdpr_rollout_velocity: too many trajectories";
+    return CDPR_ERR_INVALID;
+  }
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  DevBuf dref, dcost;
+  HIP_TRY(h, dref.alloc((size_t)h->batch * 3 * sizeof(float)));
+  HIP_TRY(h, dcost.alloc((size_t)traj * sizeof(float)));
+  HIP_TRY(h, hipMemcpyAsync(dref.p, ref_position, (size_t)h->batch * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  StepArgs a = h->base;
+  a.state = h->d_state;
+  a.obs = h->d_obs;
+  a.cmd = nullptr;
+  a.dbg = nullptr;
+  a.geom = h->d_geom;
+  a.batch = h->batch;
+  a.stride = h->stride;
+  a.nsteps = horizon;
+  a.publish_mask = 0;
+  copy_pid(h->pid_vel, a);
+  a.flags = kFlagActualIsVelocity;
+  if (h->step == 0) a.flags |= kFlagFirstWorldStep;
+  // a Joy on jointVelocities while in Position mode resets the velocity Pid (JFC.cpp:113-115); the handle's own
+  // records stay untouched, the rollout starts from zeroed copies
+  if (h->mode != kModeVelocity) a.flags |= kFlagRolloutResetPid;
+  a.pid_calls = (h->mode == kModeVelocity) ? std::min(h->pid_calls, a.nbuf) : 0;
+  a.roll_cmd = d_commands;
+  a.roll_ref = dref.as<float>();
+  a.roll_cost = dcost.as<float>();
+  a.roll_samples = (uint32_t)samples;
+  StepKernel kern = pick_rollout_kernel(h->n, h->fk, h->td);
+  hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  ++h->launches;
+  HIP_TRY(h, hipMemcpyAsync(cost, dcost.p, (size_t)traj * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return CDPR_OK;
 }
 

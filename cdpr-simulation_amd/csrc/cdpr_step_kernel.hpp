@@ -44,6 +44,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 enum StepFlags : uint32_t {
   kFlagFirstWorldStep = 1u << 0,    // JFC.cpp:61-66: stepTime <= 0 at t = 0 -> force 0, no Pid call
+  kFlagRolloutResetPid = 1u << 1,   // rollout entered from Position mode: setVelocityTarget resets the Pid (JFC.cpp:113-115)
   kFlagActualIsVelocity = 1u << 2,  // velocity mode: Pid sees joint velocity (JFC.cpp:76), else position (JFC.cpp:88)
 };
 
@@ -54,6 +55,11 @@ struct StepArgs {
   float* dbg;         // float[B][9] `pid` debug topic, or nullptr
   const float* geom;  // cable_pairs(n) * 16 floats, pair-interleaved cable geometry
   const float* force; // EXT only: raw per-cable forces from the general controller kernel, float[B][n]
+  // ROLLOUT only: S sampled command sequences per robot over `nsteps` steps, nothing written but one cost per trajectory
+  const float* roll_cmd;  // float[B][H][S][n]: per robot and step, a batch of S Joy.axes
+  const float* roll_ref;  // float[B][3] reference position
+  float* roll_cost;       // float[B][S]: sum over the horizon of |p(t_{k+1}) - p_ref|^2
+  uint32_t roll_samples;
   uint32_t batch;
   uint32_t stride;    // robots per slot row (batch rounded up to 64)
   int nsteps;         // world steps fused into this launch
@@ -306,7 +312,9 @@ CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, co
 
 // EXT = true: the controller ran in cdpr_general_ctrl_kernel; forces come from a.force and the state has
 // no controller records (platform slots only).
-template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false>
+// ROLLOUT = true: MPC fan-out (BASELINE config 5): one lane = one (robot, sampled command sequence); the robot's
+// current state is the common start, commands change every step, state never leaves the chip.
+template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
@@ -314,9 +322,12 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[NP * kGeomFloatsPerPair];
 
   const uint32_t lane = threadIdx.x;
-  const uint32_t r = blockIdx.x * 64u + lane;
-  const uint32_t rr = (r < a.batch) ? r : (a.batch - 1u);  // tail lanes shadow the last robot, stores are masked
-  const bool live = r < a.batch;
+  const uint32_t r = blockIdx.x * 64u + lane;  // robot, or trajectory index in a rollout
+  const uint32_t units = ROLLOUT ? a.batch * a.roll_samples : a.batch;
+  const uint32_t ru = (r < units) ? r : (units - 1u);  // tail lanes shadow the last unit, stores are masked
+  const uint32_t rr = ROLLOUT ? ru / a.roll_samples : ru;  // robot whose record this lane reads
+  const uint32_t sample = ROLLOUT ? ru - rr * a.roll_samples : 0u;
+  const bool live = r < units;
   const size_t st = a.stride;
 
   // geometry load first (oldest outstanding load), then the robot's whole record: the LDS fill
@@ -391,8 +402,42 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   }
   const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
   int calls = a.pid_calls;
+  float cost = 0.f, refx = 0.f, refy = 0.f, refz = 0.f;
+  if (ROLLOUT) {
+    refx = a.roll_ref[(size_t)rr * 3 + 0];
+    refy = a.roll_ref[(size_t)rr * 3 + 1];
+    refz = a.roll_ref[(size_t)rr * 3 + 2];
+    if (a.flags & kFlagRolloutResetPid) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) win[k][j] = splat(0.f);
+        ierr[k] = splat(0.f);
+      }
+      calls = 0;
+    }
+  }
 
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
+    if (ROLLOUT) {  // this step's Joy for this trajectory
+      const float* cp = a.roll_cmd + (((size_t)rr * a.nsteps + step) * a.roll_samples + sample) * N;
+      if (N % 4 == 0) {
+#pragma unroll
+        for (int g = 0; g < N / 4; ++g) {
+          const float4 v = reinterpret_cast<const float4*>(cp)[g];
+          desired[2 * g] = (v2f){v.x, v.y};
+          desired[2 * g + 1] = (v2f){v.z, v.w};
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          if (i & 1)
+            desired[i / 2].y = cp[i];
+          else
+            desired[i / 2].x = cp[i];
+        }
+      }
+    }
     // ---- IK on the state at t_k
     v2f len[NP], jac[NP][6], l0[NP], q[NP], qd[NP];
     ik_pairs<N, true>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
@@ -562,7 +607,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
       for (int k = 0; k < NP; ++k) applied[k] = max2(min2(applied[k], splat(a.effort)), splat(-a.effort));
     }
 
-    if (a.dbg && live) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
+    if (!ROLLOUT && a.dbg && live) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
       float* d = a.dbg + (size_t)r * 9;
       if (dbg_wrote) {
         d[0] = dbg_p;
@@ -574,7 +619,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
     }
 
     // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
-    if (((a.publish_mask >> step) & 1ull) && live) {
+    if (!ROLLOUT && ((a.publish_mask >> step) & 1ull) && live) {
       store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
       store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
       store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
@@ -605,6 +650,14 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
       w[5] = -w[5];
       integrate(a, s, w);
     }
+    if (ROLLOUT) {
+      const float ex = s.px - refx, ey = s.py - refy, ez = s.pz - refz;
+      cost = fmaf(ez, ez, fmaf(ey, ey, fmaf(ex, ex, cost)));
+    }
+  }
+  if (ROLLOUT) {
+    if (live) a.roll_cost[r] = cost;
+    return;
   }
 
   // ---- store

@@ -168,6 +168,27 @@ class Engine:
         self._check(lib().cdpr_solve_td(self._h, _fp(p), _fp(w), _fp(t), f.ctypes.data_as(C.POINTER(C.c_int32))))
         return t, f
 
+    # -- MPC fan-out
+    def rollout_velocity(self, commands, ref_position) -> np.ndarray:
+        """commands[B, H, S, n] (host array, or a (device_pointer, S, H) tuple for a buffer already in HBM),
+        ref_position[B, 3] -> cost[B, S]; the engine's own state is left untouched."""
+        ref = np.ascontiguousarray(ref_position, dtype=np.float32).reshape(self.B, 3)
+        if isinstance(commands, tuple):
+            dptr, S, H = commands
+            owned = False
+        else:
+            c = np.ascontiguousarray(commands, dtype=np.float32)
+            assert c.ndim == 4 and c.shape[0] == self.B and c.shape[3] == self.n, "commands must be [B, H, S, n]"
+            H, S = int(c.shape[1]), int(c.shape[2])
+            dptr, owned = self.device_upload(c), True
+        cost = np.empty((self.B, S), dtype=np.float32)
+        try:
+            self._check(lib().cdpr_rollout_velocity(self._h, S, H, C.c_void_p(dptr), _fp(ref), _fp(cost)))
+        finally:
+            if owned:
+                self.device_free(dptr)
+        return cost
+
     # -- caller-owned device buffers (e.g. a schedule of Joy batches resident in HBM)
     def device_upload(self, array: np.ndarray) -> int:
         a = np.ascontiguousarray(array)

@@ -195,6 +195,15 @@ int cdpr_get_td_state(cdpr_handle_t h, float *tension, int32_t *infeasible);
  * and tests: pose7[B][7], twist6[B][6]. */
 int cdpr_get_raw_state(cdpr_handle_t h, float *pose7, float *twist6);
 
+/* MPC fan-out (BASELINE config 5): from every robot's CURRENT state run `samples` hypothetical trajectories of
+ * `horizon` world steps, each driven by its own jointVelocities sequence, and return one cost per trajectory,
+ * cost[B][samples] = sum over the horizon of |p(t_{k+1}) - ref_position|^2.  d_commands is a DEVICE buffer
+ * float[B][horizon][samples][n] (per robot and step, a batch of `samples` Joy.axes); ref_position[B][3] and cost
+ * are host buffers.  The handle's state is not modified; trajectories never leave the chip.  Every stage the
+ * handle was created with (FK, TD) runs in every step.  Synchronous. */
+int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float *d_commands,
+                          const float *ref_position, float *cost);
+
 /* Device-buffer helpers for hosts that have no GPU runtime of their own (ctypes):
  * allocate / free / fill a caller-owned device buffer on the handle's GPU, e.g. to keep
  * a schedule of Joy batches resident in HBM for cdpr_set_*_command_device. */

@@ -824,6 +824,36 @@ int orc_update(orc_sim *s, int nsteps, int nthreads) {
   return CDPR_OK;
 }
 
+/* MPC fan-out (BASELINE config 5, [NEW]): from each robot's current state, `samples` hypothetical trajectories of
+ * `horizon` steps, each with its own jointVelocities sequence commands[B][H][S][n]; cost = sum |p(t_{k+1}) - ref|^2.
+ * The simulator's own state is left untouched. */
+int orc_rollout_velocity(const orc_sim *s, int samples, int horizon, const float *commands, const double *ref,
+                         double *cost, int nthreads) {
+  const unsigned n = s->cfg.n_cables;
+  const int64_t B = (int64_t)s->cfg.batch;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+  for (int64_t t = 0; t < B * samples; ++t) {
+    const int64_t b = t / samples, sm = t % samples;
+    orc_robot *r = (orc_robot *)malloc(sizeof(orc_robot));
+    memcpy(r, &s->rob[b], sizeof(orc_robot));
+    double c = 0.0;
+    for (int k = 0; k < horizon; ++k) {
+      const float *cmd = commands + ((((size_t)b * horizon + k) * samples + sm) * n);
+      for (unsigned i = 0; i < n; ++i) jfc_set_velocity_target(&r->jfc[i], (double)cmd[i]); /* PLG.cpp:206-211 */
+      robot_step(s, r, s->step + (uint64_t)k, 0);
+      const double ex = r->pose[0] - ref[3 * b], ey = r->pose[1] - ref[3 * b + 1], ez = r->pose[2] - ref[3 * b + 2];
+      c += ex * ex + ey * ey + ez * ez;
+    }
+    cost[t] = c;
+    free(r);
+  }
+  (void)nthreads;
+  return CDPR_OK;
+}
+
 uint64_t orc_step_count(const orc_sim *s) { return s->step; }
 
 void orc_get_joint_states(const orc_sim *s, double *position, double *velocity, double *effort) {

@@ -91,6 +91,8 @@ int orc_set_platform_state(orc_sim *s, const double *pose7, const double *twist6
 int orc_set_velocity_command(orc_sim *s, const float *axes, size_t count); /* PLG.cpp:67-74 */
 int orc_set_position_command(orc_sim *s, const float *axes, size_t count); /* PLG.cpp:76-83 */
 int orc_update(orc_sim *s, int nsteps, int nthreads);                      /* PLG.cpp:202-246 + world step */
+int orc_rollout_velocity(const orc_sim *s, int samples, int horizon, const float *commands, const double *ref,
+                         double *cost, int nthreads);
 uint64_t orc_step_count(const orc_sim *s);
 void orc_get_joint_states(const orc_sim *s, double *position, double *velocity, double *effort);
 void orc_get_platform_state(const orc_sim *s, double *pose7, double *twist6);

@@ -42,6 +42,7 @@ def lib():
         L.orc_set_velocity_command.argtypes = [C.c_void_p, fp, C.c_size_t]
         L.orc_set_position_command.argtypes = [C.c_void_p, fp, C.c_size_t]
         L.orc_update.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_rollout_velocity.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, dp, dp, C.c_int]
         L.orc_step_count.restype = C.c_uint64
         L.orc_step_count.argtypes = [C.c_void_p]
         L.orc_get_joint_states.argtypes = [C.c_void_p, dp, dp, dp]
@@ -122,6 +123,14 @@ class OracleSim:
 
     def update(self, nsteps=1, nthreads=0):
         return lib().orc_update(self._h, int(nsteps), int(nthreads))
+
+    def rollout_velocity(self, commands, ref_position, nthreads=0):
+        c = np.ascontiguousarray(commands, dtype=np.float32)
+        H, S = int(c.shape[1]), int(c.shape[2])
+        ref = np.ascontiguousarray(ref_position, dtype=np.float64).reshape(self.B, 3)
+        cost = np.empty((self.B, S))
+        lib().orc_rollout_velocity(self._h, S, H, c.ctypes.data_as(C.POINTER(C.c_float)), _dp(ref), _dp(cost), int(nthreads))
+        return cost
 
     @property
     def step_count(self):

@@ -495,3 +495,53 @@ def test_graph_replay_is_bit_identical_to_eager_launches(pkg):
     for _ in range(35):
         b.update(2, 2)
     assert np.array_equal(a.raw_state()[0], b.raw_state()[0]) and a.step_count == b.step_count == 370
+
+
+# ---------------------------------------------------------------------------------------------
+# MPC rollout (BASELINE config 5)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("start_mode", ["position", "velocity"])
+def test_rollout_velocity_matches_oracle_and_leaves_state_untouched(pkg, oracle, start_mode):
+    B, S, H = 12, 16, 24
+    rng = np.random.default_rng(1236)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng, 0.03, 0.05))
+    eng.update(30), ora.update(30)
+    if start_mode == "velocity":  # controller already warm in Velocity mode: no reset at rollout entry
+        cmd0 = rng.uniform(-0.02, 0.02, (B, 8)).astype(np.float32)
+        eng.set_velocity_command(cmd0), ora.set_velocity_command(cmd0)
+        eng.update(25), ora.update(25)
+    nominal = rng.uniform(-0.03, 0.03, (B, H, 1, 8))
+    commands = (nominal + rng.normal(0.0, 0.01, (B, H, S, 8))).astype(np.float32)
+    ref = eng.raw_state()[0][:, :3].astype(np.float64) + [0.0, 0.0, 0.01]
+    before = eng.raw_state() + eng.joint_states()
+    gc = eng.rollout_velocity(commands, ref)
+    oc = ora.rollout_velocity(commands, ref)
+    assert gc.shape == (B, S)
+    assert np.abs(gc - oc).max() < 1e-6 + 2e-4 * np.abs(oc).max(), (np.abs(gc - oc).max(), np.abs(oc).max())
+    assert (gc.argmin(axis=1) == oc.argmin(axis=1)).mean() > 0.9  # the MPC would pick the same sample
+    after = eng.raw_state() + eng.joint_states()
+    for x, y in zip(before, after):
+        assert np.array_equal(x, y)
+    eng.update(10), ora.update(10)  # and the engine carries on as if nothing happened
+    compare(eng, ora, where="after rollout")
+
+
+def test_rollout_of_identical_samples_equals_plain_stepping(pkg):
+    """Size-independent property: S copies of one command sequence give S equal costs, equal to stepping the engine."""
+    B, S, H = 130, 4, 20
+    rng = np.random.default_rng(5)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    eng = pkg.Engine(cfg, 0)
+    eng.set_platform_state(pose7=perturbed_poses(cfg.model, B, rng).astype(np.float32))
+    eng.update(40)
+    seq = rng.uniform(-0.03, 0.03, (B, H, 1, 8)).astype(np.float32)
+    ref = np.zeros((B, 3))
+    cost = eng.rollout_velocity(np.repeat(seq, S, axis=2), ref)
+    assert np.array_equal(cost[:, 0], cost[:, 1]) and np.array_equal(cost[:, 0], cost[:, S - 1])
+    acc = np.zeros(B)
+    for k in range(H):
+        eng.set_velocity_command(seq[:, k, 0, :])
+        eng.update(1)
+        acc += (eng.raw_state()[0][:, :3].astype(np.float64) ** 2).sum(axis=1)
+    assert np.abs(cost[:, 0] - acc).max() < 1e-4 * acc.max()
