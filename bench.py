@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--cables", type=int, default=8, choices=(4, 8))
     ap.add_argument("--steps-per-launch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the fused / rollout secondary figures")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -151,6 +152,64 @@ def main():
     pose_end, _ = eng.platform_state()
     finite = bool(np.isfinite(pose_end).all())
 
+    # ---- secondary figures (rank 0, outside the timed region above; never substituted for `value`)
+    secondary = {}
+    if rank == 0 and world == 1 and args.steps_per_launch == 1 and not args.no_secondary:
+        # (a) same workload with the 10 steps of each command hold fused into one launch: state stays on chip
+        #     between the steps, observables are still written every step
+        spl = refresh
+        steps2 = (args.steps // refresh) * refresh
+        start = args.warmup + args.steps
+        sched2 = [eng.device_upload(command((start + j * refresh) // refresh)) for j in range(steps2 // refresh)]
+        eng.synchronize()
+        eng.profile_begin()
+        t0 = time.perf_counter()
+        for j in range(steps2 // refresh):
+            eng.set_velocity_command_device(sched2[j], count)
+            eng.update(refresh, spl)
+        ms2, launches2 = eng.profile_end()
+        el2 = time.perf_counter() - t0
+        for p_ in sched2:
+            eng.device_free(p_)
+        # per launch: command n + state round trip 2*(13+12n) + spl * observables (13+3n), in floats
+        bytes_launch = 4 * (n + 2 * (13 + 12 * n) + spl * (13 + 3 * n))
+        secondary["fused"] = {
+            "steps_per_launch": spl,
+            "value": args.batch * steps2 / el2,
+            "unit": "state-steps/s",
+            "kernel_us": ms2 * 1e3 / max(launches2, 1),
+            "bytes_per_state_step": bytes_launch / spl,
+            "achieved_GBps": bytes_launch * args.batch / (ms2 * 1e-3 / max(launches2, 1)) / 1e9,
+            "note": "compute (f32 VALU) bound: state never leaves the registers between the fused steps",
+        }
+        # (b) MPC rollout, one GPU's share of BASELINE config 5: 512 robots x 128 samples x 64 steps
+        if n == 8:
+            Br, S, H = 512, 128, 64
+            rng = np.random.default_rng(1236)
+            cfg_r = pkg.Config(batch=Br, **cfg_kwargs)
+            er = pkg.Engine(cfg_r, device=local_rank)
+            er.set_platform_state(pose7=pose[:Br])
+            er.update(20)
+            nominal = rng.uniform(-0.03, 0.03, (Br, H, 1, n))
+            cmds = (nominal + rng.normal(0.0, 0.01, (Br, H, S, n))).astype(np.float32)
+            dptr = er.device_upload(cmds)
+            ref = pose[:Br, :3].astype(np.float32)
+            er.rollout_velocity((dptr, S, H), ref)  # warm-up
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                cost = er.rollout_velocity((dptr, S, H), ref)
+            elr = (time.perf_counter() - t0) / reps
+            er.device_free(dptr)
+            er.close()
+            secondary["rollout"] = {
+                "workload": f"{Br} robots x {S} sampled sequences x {H}-step horizon (one GPU's share of config 5), cost copied back",
+                "value": Br * S * H / elr,
+                "unit": "state-steps/s",
+                "ms_per_rollout": elr * 1e3,
+                "cost_finite": bool(np.isfinite(cost).all()),
+            }
+
     if rank == 0:
         bytes_step = eng.bytes_per_state_step()
         launch_s = ev_ms * 1e-3 / max(launches, 1)
@@ -197,6 +256,7 @@ def main():
                 "bytes_per_state_step": bytes_step,
             },
         }
+        out.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, args.cpu_seconds)
         print(json.dumps(out), flush=True)
