@@ -105,6 +105,7 @@ def main():
 
     import cdpr_simulation_amd as pkg
     from cdpr_simulation_amd import _abi
+    from cdpr_simulation_amd._native import lib
     from cdpr_simulation_amd.sharding import RankContext
 
     # torch.distributed (RCCL) only provides the rendezvous: barrier + max over ranks. No data-path collective.
@@ -119,7 +120,9 @@ def main():
     model, pose, command, n_cmd = make_workload(pkg, args.batch, n, seed, total, refresh)
     cfg_kwargs = dict(model=model, stages=stages)
     cfg = pkg.Config(batch=args.batch, **cfg_kwargs)
-    eng = pkg.Engine(cfg, device=local_rank)
+    ndev = lib().cdpr_device_count()
+    device = local_rank % max(ndev, 1)  # one rank per GPU; ranks only share a GPU on a box with fewer GPUs than ranks
+    eng = pkg.Engine(cfg, device=device)
     eng.set_platform_state(pose7=pose)
     # command schedule resident in HBM before timing starts
     sched = [eng.device_upload(command(j)) for j in range(n_cmd)]
@@ -187,7 +190,7 @@ def main():
             Br, S, H = 512, 128, 64
             rng = np.random.default_rng(1236)
             cfg_r = pkg.Config(batch=Br, **cfg_kwargs)
-            er = pkg.Engine(cfg_r, device=local_rank)
+            er = pkg.Engine(cfg_r, device=device)
             er.set_platform_state(pose7=pose[:Br])
             er.update(20)
             nominal = rng.uniform(-0.03, 0.03, (Br, H, 1, n))

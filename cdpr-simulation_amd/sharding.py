@@ -33,11 +33,11 @@ class RankContext:
         import torch
         import torch.distributed as dist
 
-        if backend == "nccl":  # "nccl" is RCCL on ROCm
-            torch.cuda.set_device(local_rank)
+        if backend == "nccl" and torch.cuda.is_available() and torch.cuda.device_count() > local_rank:
+            torch.cuda.set_device(local_rank)  # "nccl" is RCCL on ROCm
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
+        else:  # CPU-only box, or more ranks than GPUs: the rendezvous does not need the GPU
+            dist.init_process_group(backend="gloo")
         return cls(rank, local_rank, world, dist)
 
     def barrier(self) -> None:
