@@ -9,11 +9,12 @@ thousands of independent robots per GPU.  Host code is Python over a ctypes C-AB
 from . import _abi, stimulus
 from .config import Config, FilterParameters, Model, PidParameters, cube_model, eight_cable_model
 from .engine import CdprError, Engine, derivative_weights
+from .model_io import load_sdf, load_yaml
 from .messages import Header, JointState, Joy, PlatformState, Pose, Twist
 from .plugin import CdprGazeboPlugin, TopicBus
 
 __all__ = [
     "Config", "FilterParameters", "Model", "PidParameters", "cube_model", "eight_cable_model",
-    "Engine", "CdprError", "derivative_weights", "CdprGazeboPlugin", "TopicBus",
+    "load_sdf", "load_yaml", "Engine", "CdprError", "derivative_weights", "CdprGazeboPlugin", "TopicBus",
     "Header", "JointState", "Joy", "PlatformState", "Pose", "Twist", "stimulus", "_abi",
 ]  # fmt: skip

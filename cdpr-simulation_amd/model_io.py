@@ -1,0 +1,108 @@
+"""Model loaders: read a CDPR description in the reference's own file formats instead of transcribed constants.
+
+* `load_yaml`  — the upstream `cdpr` package layout that `sdf/cube.yaml` uses (cube.yaml:1-29): `points: [{frame,
+  platform}]`, `platform: {mass, inertia, position: {xyz, rpy}}`, `joints: {actuated: {damping, effort, min}}`.
+  Any cable count 1..8, so an 8-cable robot is data, not code.
+* `load_sdf`   — the SDF that `gen_cdpr.py` emits and Gazebo loads (`sdf/cube.sdf`): the platform link's pose and
+  inertial (cube.sdf:309-342), the frame-side anchor = pose of link `virt_X<i>` (gen_cdpr.py:140-150 puts it at the
+  frame attach point), the platform-side anchor = pose of link `virt_Xpf<i>` at spawn, damping / effort of the
+  prismatic joint `cable<i>` (cube.sdf:429-445).  The spawn pose in the SDF is authoritative (cube.yaml's z = 2 is
+  not what is loaded).
+"""
+from __future__ import annotations
+
+import math
+import re
+import xml.etree.ElementTree as ET
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .config import Model, quat_to_matrix
+
+
+def rpy_to_quat(roll: float, pitch: float, yaw: float) -> np.ndarray:
+    """Fixed-axis roll-pitch-yaw (SDF / `transformations.euler_matrix(..., 'sxyz')`) to quaternion x y z w."""
+    cr, sr = math.cos(roll / 2), math.sin(roll / 2)
+    cp, sp = math.cos(pitch / 2), math.sin(pitch / 2)
+    cy, sy = math.cos(yaw / 2), math.sin(yaw / 2)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+
+
+def load_yaml(path_or_text: str, home_xyz: Optional[Sequence[float]] = None) -> Model:
+    """`home_xyz` overrides `platform.position.xyz` (for cube.yaml pass (0, 0, 0.3): the SDF that is actually loaded
+    has the platform there, cube.sdf:310, while the yaml still says z = 2)."""
+    import yaml
+
+    text = open(path_or_text).read() if "\n" not in path_or_text else path_or_text
+    y = yaml.safe_load(text)
+    pts = y["points"]
+    fa = np.array([p["frame"] for p in pts], dtype=np.float64)
+    pa = np.array([p["platform"] for p in pts], dtype=np.float64)
+    plat = y.get("platform", {})
+    pos = plat.get("position", {})
+    xyz = list(home_xyz) if home_xyz is not None else list(pos.get("xyz", [0.0, 0.0, 0.0]))
+    rpy = list(pos.get("rpy", [0.0, 0.0, 0.0]))
+    act = y.get("joints", {}).get("actuated", {})
+    return Model(
+        frame_anchors=fa,
+        platform_anchors=pa,
+        home_position=tuple(float(v) for v in xyz),
+        home_quaternion=tuple(rpy_to_quat(*[float(v) for v in rpy])),
+        mass=float(plat.get("mass", 1.0)),
+        inertia=tuple(float(v) for v in plat.get("inertia", [1, 1, 1, 0, 0, 0])),
+        joint_damping=float(act.get("damping", 1.0)),
+        effort_limit=float(act.get("effort", 100.0)),
+        f_min=float(act.get("min", 5.0)),
+        f_max=float(act.get("effort", 100.0)),
+    )
+
+
+def _pose(elem) -> np.ndarray:
+    p = elem.find("pose")
+    return np.array([float(v) for v in p.text.split()]) if p is not None else np.zeros(6)
+
+
+def load_sdf(path_or_text: str, f_min: float = 5.0) -> Model:
+    text = open(path_or_text).read() if "<" not in path_or_text else path_or_text
+    root = ET.fromstring(text)
+    model = root.find("model") if root.tag == "sdf" else root
+    links = {l.get("name"): l for l in model.findall("link")}
+    joints = {j.get("name"): j for j in model.findall("joint")}
+    if "platform" not in links:
+        raise ValueError("SDF has no link named 'platform' (CdprGazeboPlugin.h:31)")
+    frame_pose = _pose(links["frame"]) if "frame" in links else np.zeros(6)
+    if np.abs(frame_pose).max() > 0:
+        raise ValueError("frame link must sit at the model origin (the engine simulates in frame coordinates)")
+    plat = links["platform"]
+    ppose = _pose(plat)
+    q = rpy_to_quat(*ppose[3:])
+    r = quat_to_matrix(q)
+    inertial = plat.find("inertial")
+    inert = inertial.find("inertia")
+    mass = float(inertial.find("mass").text)
+    inertia = tuple(float(inert.find(k).text) for k in ("ixx", "iyy", "izz", "ixy", "ixz", "iyz"))
+    # actuated joints: names starting with `cable`, index = numeric suffix (CdprGazeboPlugin.cpp:146-152)
+    idx = sorted(int(re.sub(r"^cable", "", n)) for n, j in joints.items() if n.startswith("cable") and j.get("type") == "prismatic")
+    if not idx or idx != list(range(len(idx))):
+        raise ValueError("invalid joint count")  # CdprGazeboPlugin.cpp:167-168
+    fa, pa, damping, effort = [], [], None, None
+    for i in idx:
+        fa.append(_pose(links[f"virt_X{i}"])[:3])
+        world_attach = _pose(links[f"virt_Xpf{i}"])[:3]
+        pa.append(r.T @ (world_attach - ppose[:3]))
+        axis = joints[f"cable{i}"].find("axis")
+        damping = float(axis.find("dynamics/damping").text)
+        effort = float(axis.find("limit/effort").text)
+    return Model(
+        frame_anchors=np.array(fa),
+        platform_anchors=np.array(pa),
+        home_position=tuple(ppose[:3]),
+        home_quaternion=tuple(q),
+        mass=mass,
+        inertia=inertia,
+        joint_damping=damping,
+        effort_limit=effort,
+        f_min=f_min,
+        f_max=effort,
+    )

@@ -1,0 +1,95 @@
+"""Model loaders: the upstream YAML layout and the generated SDF, n cables as data."""
+import os
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/src/cdpr_gazebo/sdf"
+
+EIGHT_YAML = """
+cable: {radius: 0.005}
+frame: {type: box, lower: [-0.3, -0.3, 0], upper: [0.3, 0.3, 0.6]}
+joints:
+  actuated: {damping: 1, effort: 100, min: 5, velocity: 10}
+  passive: {damping: 0.01, effort: 100, velocity: 10}
+platform:
+  mass: 1
+  inertia: [1, 1, 1, 0, 0, 0]
+  position: {rpy: [0, 0, 0], xyz: [0, 0, 0.3]}
+  size: [0.06, 0.06, 0.015]
+points:
+- {frame: [-0.3, -0.3, 0.6], platform: [0.03, -0.03, -0.0075]}
+- {frame: [-0.3, 0.3, 0.6], platform: [-0.03, 0.03, -0.0075]}
+- {frame: [0.3, 0.3, 0.6], platform: [0.03, 0.03, -0.0075]}
+- {frame: [0.3, -0.3, 0.6], platform: [-0.03, -0.03, -0.0075]}
+- {frame: [-0.3, -0.3, 0.0], platform: [-0.03, -0.03, 0.0075]}
+- {frame: [-0.3, 0.3, 0.0], platform: [-0.03, 0.03, 0.0075]}
+- {frame: [0.3, 0.3, 0.0], platform: [0.03, -0.03, 0.0075]}
+- {frame: [0.3, -0.3, 0.0], platform: [0.03, 0.03, 0.0075]}
+"""
+
+
+def mini_sdf(anchors_f, anchors_p_world, plat_pose):
+    links = "".join(
+        f'<link name="virt_X{i}"><pose>{a[0]} {a[1]} {a[2]} 0 0 0</pose></link>'
+        f'<link name="virt_Xpf{i}"><pose>{b[0]} {b[1]} {b[2]} 0 0 0</pose></link>'
+        f'<joint name="cable{i}" type="prismatic"><parent>virt_Y{i}</parent><child>cable{i}</child><axis><xyz>0 0 1</xyz>'
+        f"<limit><lower>-0.5</lower><upper>0.5</upper><effort>80</effort><velocity>10</velocity></limit>"
+        f"<dynamics><damping>0.7</damping></dynamics></axis></joint>"
+        for i, (a, b) in enumerate(zip(anchors_f, anchors_p_world))
+    )
+    return (
+        '<?xml version="1.0"?><sdf version="1.4"><model name="m"><link name="frame"><pose>0 0 0 0 0 0</pose></link>'
+        f'<link name="platform"><pose>{" ".join(str(v) for v in plat_pose)}</pose><inertial><inertia><ixx>1.5</ixx><iyy>2</iyy><izz>2.5</izz>'
+        "<ixy>0.1</ixy><ixz>0</ixz><iyz>0</iyz></inertia><mass>3</mass></inertial></link>" + links + "</model></sdf>"
+    )
+
+
+def test_yaml_eight_cable_equals_builtin_model(pkg):
+    m = pkg.load_yaml(EIGHT_YAML)
+    ref = pkg.eight_cable_model()
+    assert m.n_cables == 8
+    assert np.allclose(m.frame_anchors, ref.frame_anchors) and np.allclose(m.platform_anchors, ref.platform_anchors)
+    assert (m.mass, m.joint_damping, m.effort_limit, m.f_min, m.f_max) == (1.0, 1.0, 100.0, 5.0, 100.0)
+    assert np.allclose(m.reference_lengths(), ref.reference_lengths())
+    pkg.Config(model=m, stages=3).to_struct()  # validates
+
+
+def test_sdf_loader_recovers_anchors_through_a_rotated_spawn_pose(pkg):
+    rng = np.random.default_rng(0)
+    fa = rng.uniform(-0.3, 0.3, (6, 3)) + [0, 0, 0.5]
+    pb = rng.uniform(-0.05, 0.05, (6, 3))
+    pose = [0.01, -0.02, 0.3, 0.1, -0.2, 0.3]
+    q = pkg.model_io.rpy_to_quat(*pose[3:])
+    r = pkg.config.quat_to_matrix(q)
+    world = pose[:3] + pb @ r.T
+    m = pkg.load_sdf(mini_sdf(fa, world, pose))
+    assert m.n_cables == 6 and np.allclose(m.frame_anchors, fa) and np.allclose(m.platform_anchors, pb, atol=1e-12)
+    assert m.mass == 3.0 and m.inertia == (1.5, 2.0, 2.5, 0.1, 0.0, 0.0) and m.joint_damping == 0.7 and m.effort_limit == 80.0
+    assert np.allclose(m.home_quaternion, q) and np.allclose(m.reference_lengths(), np.linalg.norm(world - fa, axis=1))
+
+
+def test_sdf_without_contiguous_cable_joints_is_rejected(pkg):
+    bad = mini_sdf([[0, 0, 1]], [[0, 0, 0.3]], [0, 0, 0.3, 0, 0, 0]).replace('name="cable0"', 'name="cable3"')
+    with pytest.raises(ValueError, match="invalid joint count"):
+        pkg.load_sdf(bad)
+
+
+def test_rpy_convention_matches_scipy(pkg):
+    from scipy.spatial.transform import Rotation
+
+    for rpy in ([0.3, -0.2, 1.1], [-2.408778, 0.589592, -1.338805]):
+        q = pkg.model_io.rpy_to_quat(*rpy)
+        assert np.allclose(pkg.config.quat_to_matrix(q), Rotation.from_euler("xyz", rpy).as_matrix(), atol=1e-12)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_files_load_to_the_transcribed_model(pkg):
+    ref = pkg.cube_model()
+    for m in (pkg.load_sdf(os.path.join(REF, "cube.sdf")), pkg.load_yaml(os.path.join(REF, "cube.yaml"), home_xyz=(0, 0, 0.3))):
+        assert m.n_cables == 4
+        assert np.allclose(m.frame_anchors, ref.frame_anchors, atol=1e-6) and np.allclose(m.platform_anchors, ref.platform_anchors, atol=1e-6)
+        assert np.allclose(m.home_position, ref.home_position) and np.allclose(m.home_quaternion, ref.home_quaternion)
+        assert (m.mass, tuple(m.inertia), m.joint_damping, m.effort_limit) == (ref.mass, tuple(ref.inertia), ref.joint_damping, ref.effort_limit)
+        assert np.allclose(m.reference_lengths(), 0.485592422, atol=1e-6)
+    assert pkg.load_yaml(os.path.join(REF, "cube.yaml")).home_position == (0.0, 0.0, 2.0)  # what the yaml itself says (cube.yaml:17)
