@@ -10,7 +10,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcdpr_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("CDPR_LIB", "libcdpr_hip.so"))  # CDPR_LIB: experimental builds (A/B runs)
 
 # every symbol include/cdpr.h declares
 EXPORTS = [

@@ -16,6 +16,7 @@
 
 #include "../../include/cdpr.h"
 #include "cdpr_step_kernel.hpp"
+#include "cdpr_step_kernel_pair.hpp"
 #include "cdpr_general_ctrl.hpp"
 #include "cdpr_solvers.hpp"
 
@@ -50,6 +51,7 @@ struct cdpr_engine {
   float* d_dbg = nullptr;
   float* d_geom = nullptr;  // pair-interleaved cable geometry, staged in LDS by the kernel
   int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
+  bool lane_pair = false;   // two lanes per robot (cdpr_step_kernel_pair.hpp) instead of one
   // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
   bool general = false;
   float* d_rec = nullptr;    // [last_pos][position Pid block][velocity Pid block]
@@ -170,7 +172,8 @@ std::string validate(const cdpr_config_t& c) {
   if ((c.stages & (CDPR_STAGE_FK | CDPR_STAGE_TD)) && c.n_cables < 6) return "FK / tension distribution need >= 6 cables";
   if ((c.stages & CDPR_STAGE_FK) && (c.fk_max_iterations < 1 || c.fk_max_iterations > 64)) return "fk_max_iterations out of range";
   if ((c.stages & CDPR_STAGE_TD) && !(c.td_f_max > c.td_f_min)) return "td_f_max must exceed td_f_min";
-  if (c.mapping > CDPR_MAP_LANE_PER_CABLE) return "unknown mapping";
+  if (c.mapping > CDPR_MAP_LANE_PAIR) return "unknown mapping";
+  if (c.mapping == CDPR_MAP_LANE_PAIR && c.n_cables != 4 && c.n_cables != 8) return "the lane-pair mapping needs 4 or 8 cables";
   return "";
 }
 
@@ -332,6 +335,21 @@ std::vector<float> geom_pairs(const cdpr_config_t& c) {
   return g;
 }
 
+template <int N, bool SINGLE>
+StepKernel pick_pair_stage(bool fk, bool td) {
+  if constexpr (N >= 6) {
+    if (fk && td) return cdpr_step_kernel_pair<N, true, true, SINGLE>;
+    if (fk) return cdpr_step_kernel_pair<N, true, false, SINGLE>;
+    if (td) return cdpr_step_kernel_pair<N, false, true, SINGLE>;
+  }
+  return cdpr_step_kernel_pair<N, false, false, SINGLE>;
+}
+
+template <bool SINGLE>
+StepKernel pick_pair_kernel(uint32_t n, bool fk, bool td) {
+  return n == 4 ? pick_pair_stage<4, SINGLE>(fk, td) : pick_pair_stage<8, SINGLE>(fk, td);
+}
+
 template <int N>
 StepKernel pick_rollout_stage(bool fk, bool td) {
   if constexpr (N >= 6) {
@@ -427,6 +445,10 @@ int upload_home(cdpr_engine* h) {
   }
   HIP_TRY(h, hipMemcpyAsync(h->d_obs, o.data(), o.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   if (h->d_dbg) HIP_TRY(h, hipMemsetAsync(h->d_dbg, 0, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float), h->stream));
+  for (int i = 0; i < 2; ++i) {  // latched and pending Joy buffers: target 0 after Load / reset
+    HIP_TRY(h, hipMemsetAsync(h->d_vel[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
+  }
   if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows() * h->tstride * sizeof(float), h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return CDPR_OK;
@@ -592,9 +614,10 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     a.cmd = h->d_vel[0];
   } else {
     copy_pid(h->pid_pos, a);
-    a.cmd = h->have_pos ? h->d_pos[0] : nullptr;  // target 0 until the first jointPositions message
+    a.cmd = h->d_pos[0];  // all zeros until the first jointPositions message: target 0 (PLG.cpp:153-157)
   }
-  const dim3 grid((h->batch + 63u) / 64u), block(64);
+  const uint32_t robots_per_block = h->lane_pair ? 32u : 64u;
+  const dim3 grid((h->batch + robots_per_block - 1u) / robots_per_block), block(64);
 
   constexpr int kGraphChunk = 16;  // launches per captured graph
   int done = 0;
@@ -606,7 +629,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     if (first_world) a.flags |= kFlagFirstWorldStep;
     // the kernel only tests calls != 0 and calls >= nbuf: clamp so steady-state launches are identical
     a.pid_calls = std::min(h->pid_calls, a.nbuf);
-    StepKernel kern = (k == 1) ? pick_kernel<true>(h->n, h->fk, h->td) : pick_kernel<false>(h->n, h->fk, h->td);
+    StepKernel kern = h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
+                                   : ((k == 1) ? pick_kernel<true>(h->n, h->fk, h->td) : pick_kernel<false>(h->n, h->fk, h->td));
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
@@ -727,10 +751,6 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     return CDPR_ERR_INVALID;
   }
   const bool general = !fast_path_obstacle(*cfg).empty();
-  if (cfg->mapping == CDPR_MAP_LANE_PER_CABLE) {
-    g_create_error = "lane-per-cable mapping not built yet";
-    return CDPR_ERR_UNSUPPORTED;
-  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -751,6 +771,20 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
   h->general = general;
+  {
+    // Mapping: measured on MI355X (scripts/ab_bench.py), two lanes per robot win while the batch leaves SIMDs
+    // under-filled (16 384 x 8 cables: 9.0 vs 10.2 us/step; 4 096 x 4: 3.0 vs 3.4) and lose from 65 536 robots on
+    // (16.4 vs 15.7 us/step: the duplicated 6x6 solves cost more than the second wave per SIMD hides), so AUTO
+    // takes the pair mapping up to 32 768 robots (n = 4 or 8).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
+    const bool can_pair = !general && (cfg->n_cables == 4 || cfg->n_cables == 8);
+    uint32_t mapping = cfg->mapping;
+    if (mapping == CDPR_MAP_AUTO) {
+      const char* mv = std::getenv("CDPR_MAPPING");
+      if (mv && (mv[0] == '1' || mv[0] == '2')) mapping = (uint32_t)(mv[0] - '0');
+    }
+    if (mapping == CDPR_MAP_AUTO) mapping = (can_pair && cfg->batch <= 32768u) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
+    h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
+  }
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
   memset(&h->base, 0, sizeof h->base);

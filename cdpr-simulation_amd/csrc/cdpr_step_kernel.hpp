@@ -51,7 +51,7 @@ enum StepFlags : uint32_t {
 struct StepArgs {
   float4* state;
   float4* obs;
-  const float* cmd;   // latched Joy.axes of the active mode, float[B][n]; nullptr -> desired 0 (state after Load)
+  const float* cmd;   // latched Joy.axes of the active mode, float[B][n] (all zeros until the first message: target 0 after Load)
   float* dbg;         // float[B][9] `pid` debug topic, or nullptr
   const float* geom;  // cable_pairs(n) * 16 floats, pair-interleaved cable geometry
   const float* force; // EXT only: raw per-cable forces from the general controller kernel, float[B][n]
@@ -147,10 +147,9 @@ CDPR_DEV void quat_apply_rotvec(float& qx, float& qy, float& qz, float& qw, floa
 
 // IK rows of all cable pairs (Joint::Position / GetVelocity restated; geometry statement
 // gen:113-118): l = p + R b - a, L = |l|, u = l / L, J row = [u, (R b) x u].  Geometry from LDS.
-template <int N, bool WANT_L0>
-CDPR_DEV void ik_pairs(const float* lds, float px, float py, float pz, float qx, float qy, float qz, float qw,
-                       v2f (&len)[cable_pairs(N)], v2f (&jac)[cable_pairs(N)][6], v2f (&l0)[cable_pairs(N)]) {
-  constexpr int NP = cable_pairs(N);
+template <int NP, bool ODD, bool WANT_L0>
+CDPR_DEV void ik_rows(const float* lds, float px, float py, float pz, float qx, float qy, float qz, float qw,
+                      v2f (&len)[NP], v2f (&jac)[NP][6], v2f (&l0)[NP]) {
   const Rot r = quat_to_rot(qx, qy, qz, qw);
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -173,10 +172,10 @@ CDPR_DEV void ik_pairs(const float* lds, float px, float py, float pz, float qx,
     jac[k][3] = fma2(rby, uz, -(rbz * uy));
     jac[k][4] = fma2(rbz, ux, -(rbx * uz));
     jac[k][5] = fma2(rbx, uy, -(rby * ux));
-    if (WANT_L0 || ((N & 1) && k == NP - 1)) {
+    if (WANT_L0 || (ODD && k == NP - 1)) {
       const float4 g3 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair + 12);
       l0[k] = (v2f){g3.x, g3.y};
-      if ((N & 1) && k == NP - 1) {  // odd cable count: the padding cable contributes nothing
+      if (ODD && k == NP - 1) {  // odd cable count: the padding cable contributes nothing
         const v2f mask = {g3.z, g3.w};
         len[k] *= mask;
 #pragma unroll
@@ -186,10 +185,15 @@ CDPR_DEV void ik_pairs(const float* lds, float px, float py, float pz, float qx,
   }
 }
 
+template <int N, bool WANT_L0>
+CDPR_DEV void ik_pairs(const float* lds, float px, float py, float pz, float qx, float qy, float qz, float qw,
+                       v2f (&len)[cable_pairs(N)], v2f (&jac)[cable_pairs(N)][6], v2f (&l0)[cable_pairs(N)]) {
+  ik_rows<cable_pairs(N), (N & 1) != 0, WANT_L0>(lds, px, py, pz, qx, qy, qz, qw, len, jac, l0);
+}
+
 // g[c] = sum over cables of jac[.][c] * v[.]  (J^T v), pairs interleaved so the chains are independent
 template <int NP>
-CDPR_DEV void jt_times(const v2f (&jac)[NP][6], const v2f (&v)[NP], float (&g)[6]) {
-  v2f acc[6];
+CDPR_DEV void jt_partial(const v2f (&jac)[NP][6], const v2f (&v)[NP], v2f (&acc)[6]) {
 #pragma unroll
   for (int c = 0; c < 6; ++c) acc[c] = jac[0][c] * v[0];
 #pragma unroll
@@ -197,14 +201,19 @@ CDPR_DEV void jt_times(const v2f (&jac)[NP][6], const v2f (&v)[NP], float (&g)[6
 #pragma unroll
     for (int c = 0; c < 6; ++c) acc[c] = fma2(jac[k][c], v[k], acc[c]);
   }
+}
+
+template <int NP>
+CDPR_DEV void jt_times(const v2f (&jac)[NP][6], const v2f (&v)[NP], float (&g)[6]) {
+  v2f acc[6];
+  jt_partial<NP>(jac, v, acc);
 #pragma unroll
   for (int c = 0; c < 6; ++c) g[c] = hsum(acc[c]);
 }
 
-// Solve (J^T J + lambda I) x = g in place (g -> x) by Cholesky; J held as cable pairs.
+// Lower triangle of J^T J as 21 float2 partial sums over the cable pairs (entry e = a(a+1)/2 + b, b <= a).
 template <int NP>
-CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6]) {
-  v2f acc[21];
+CDPR_DEV void gram_partial(const v2f (&jac)[NP][6], v2f (&acc)[21]) {
 #pragma unroll
   for (int a = 0, e = 0; a < 6; ++a) {
 #pragma unroll
@@ -218,12 +227,10 @@ CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6])
       for (int b = 0; b <= a; ++b, ++e) acc[e] = fma2(jac[k][a], jac[k][b], acc[e]);
     }
   }
-  float m[6][6];
-#pragma unroll
-  for (int a = 0, e = 0; a < 6; ++a) {
-#pragma unroll
-    for (int b = 0; b <= a; ++b, ++e) m[a][b] = hsum(acc[e]) + ((a == b) ? lambda : 0.f);
-  }
+}
+
+// In-place Cholesky solve of the SPD 6x6 system m x = g (lower triangle of m given, g -> x).
+CDPR_DEV void chol_solve(float (&m)[6][6], float (&g)[6]) {
   float invd[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -253,6 +260,20 @@ CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6])
     for (int k = i + 1; k < 6; ++k) s = fmaf(-m[k][i], g[k], s);
     g[i] = s * invd[i];
   }
+}
+
+// Solve (J^T J + lambda I) x = g in place (g -> x); J held as cable pairs.
+template <int NP>
+CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6]) {
+  v2f acc[21];
+  gram_partial<NP>(jac, acc);
+  float m[6][6];
+#pragma unroll
+  for (int a = 0, e = 0; a < 6; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b, ++e) m[a][b] = hsum(acc[e]) + ((a == b) ? lambda : 0.f);
+  }
+  chol_solve(m, g);
 }
 
 struct Platform {
@@ -306,8 +327,22 @@ CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
 CDPR_DEV float4 load_slot(const float4* base, size_t stride, int slot, uint32_t off) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base + (size_t)slot * stride) + off);
 }
+#ifndef CDPR_STORE_AUX
+#define CDPR_STORE_AUX 2  // cache policy of the row stores: 0 plain, 2 nt, 16 sc1 (write-through), 17 sc0 sc1.
+                          // Measured on MI355X, 65 536 x 8 cables, one launch per step: plain 15.84, nt 15.05,
+                          // sc1 16.89, sc0 sc1 16.71 us/step -> nt
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, const float4& v) {
+#if CDPR_STORE_AUX == 0
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base + (size_t)slot * stride) + off) = v;
+#else
+  // one buffer descriptor per slot row (wave-uniform: SGPRs only), 32-bit lane offset, explicit cache policy
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)slot * stride, 0, (int)(stride * sizeof(float4)), 0x00020000);
+  const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+                   __builtin_bit_cast(unsigned, v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off, 0, CDPR_STORE_AUX);
+#endif
 }
 
 // EXT = true: the controller ran in cdpr_general_ctrl_kernel; forces come from a.force and the state has
@@ -351,8 +386,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   v2f desired[NP];  // EXT: the raw forces instead of the Joy targets
 #pragma unroll
   for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
-  const float* vec_in = EXT ? a.force : a.cmd;
-  if (vec_in) {
+  const float* vec_in = EXT ? a.force : a.cmd;  // never null: before the first Joy the latched buffer holds zeros
+  if (!ROLLOUT) {
     const float* cp = vec_in + (size_t)rr * N;
     if (N % 4 == 0) {
 #pragma unroll

@@ -1,0 +1,363 @@
+// cdpr_step_kernel_pair.hpp — "two lanes per robot" mapping of the fused CDPR step (gfx950).
+//
+// Why: with one lane per robot, 65 536 robots are 1 024 wavefronts = ONE wave per SIMD; the profile
+// (profiles/r01_b_*) shows what that costs: every VALU instruction issues at 4 cycles instead of 2 and
+// every dependent latency (the serial 6x6 Cholesky, v_rsq) is exposed — 44 % of the wave's cycles
+// issuing, 32 % dependency stalls, nothing to switch to.  Here adjacent lanes (2r, 2r+1) share robot
+// r: lane parity p owns cable pairs [p*NPL, (p+1)*NPL) — half the cables — so the per-cable work (IK
+// rows, FIR windows, PID, Gram partial sums, wrench partial sums, controller rows in HBM) halves per
+// lane and the machine runs TWO waves per SIMD.  Partial sums meet through one DPP quad_perm add
+// (lane ^ 1); fp addition commutes, so both lanes hold bit-identical sums and run the small serial
+// part (6x6 Cholesky, quaternion update, integration) redundantly on identical data.
+//
+// HBM layout is exactly the lane-per-robot one (cdpr_step_kernel.hpp): the two mappings are
+// interchangeable on the same state.  Built for n = 4 and n = 8 (an even number of cable pairs).
+#pragma once
+#include "cdpr_step_kernel.hpp"
+
+namespace cdpr {
+
+// value of the partner lane (lane ^ 1)
+CDPR_DEV float partner(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+CDPR_DEV float pair_sum(float x) { return x + partner(x); }
+CDPR_DEV float pair_max(float x) { return fmaxf(x, partner(x)); }
+
+// Solve (J^T J + lambda I) x = g in place; J^T J summed over this lane's pairs and the partner's.
+template <int NPL>
+CDPR_DEV void normal_solve_shared(const v2f (&jac)[NPL][6], float lambda, float (&g)[6]) {
+  v2f acc[21];
+  gram_partial<NPL>(jac, acc);
+  float m[6][6];
+#pragma unroll
+  for (int a = 0, e = 0; a < 6; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b, ++e) m[a][b] = pair_sum(hsum(acc[e])) + ((a == b) ? lambda : 0.f);
+  }
+  chol_solve(m, g);
+}
+
+template <int NPL>
+CDPR_DEV void jt_times_shared(const v2f (&jac)[NPL][6], const v2f (&v)[NPL], float (&g)[6]) {
+  v2f acc[6];
+  jt_partial<NPL>(jac, v, acc);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) g[c] = pair_sum(hsum(acc[c]));
+}
+
+template <int N, bool FK, bool TD, bool SINGLE>
+__global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a) {
+  static_assert(N == 4 || N == 8, "the lane-pair mapping needs an even number of cable pairs");
+  constexpr int NP = N / 2;    // cable pairs of the robot
+  constexpr int NPL = NP / 2;  // cable pairs owned by one lane
+  constexpr int NL = N / 2;    // cables owned by one lane
+  constexpr int P = plat_slots(FK);
+  constexpr int G = joint_groups(N);
+  __shared__ __attribute__((aligned(16))) float lds[NP * kGeomFloatsPerPair];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t par = lane & 1u;                       // which half of the cables
+  const uint32_t r = blockIdx.x * 32u + (lane >> 1);    // robot
+  const uint32_t rr = (r < a.batch) ? r : (a.batch - 1u);
+  const bool live = r < a.batch;
+  const size_t st = a.stride;
+  const int c0 = (int)par * NL;                         // first cable of this lane
+
+  const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
+  const uint32_t off = rr * 16u, woff = r * 16u;
+  const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off),
+               p2 = load_slot(a.state, st, 2, off), p3 = load_slot(a.state, st, 3, off);
+  float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
+  if (FK) p4 = load_slot(a.state, st, 4, off);
+  // controller rows of this lane's cables: the row index depends on the lane parity, so these are
+  // per-lane addresses (two 512-B runs per wave instruction)
+  const float4* crow = a.state + (size_t)(P + 3 * c0) * st + rr;
+  float4 craw[NL][3];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) craw[i][k] = crow[(size_t)(3 * i + k) * st];
+  }
+  v2f desired[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) desired[k] = splat(0.f);
+  {
+    const float* cp = a.cmd + (size_t)rr * N + c0;
+    if (NL == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(cp);
+      desired[0] = (v2f){v.x, v.y};
+      desired[NPL - 1] = (v2f){v.z, v.w};
+    } else {
+      const float2 v = *reinterpret_cast<const float2*>(cp);
+      desired[0] = (v2f){v.x, v.y};
+    }
+  }
+
+  if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const float* mylds = lds + par * (NPL * kGeomFloatsPerPair);
+
+  Platform s;
+  s.px = p0.x; s.py = p0.y; s.pz = p0.z; s.qx = p0.w;
+  s.qy = p1.x; s.qz = p1.y; s.qw = p1.z; s.vx = p1.w;
+  s.vy = p2.x; s.vz = p2.y; s.wx = p2.z; s.wy = p2.w;
+  s.wz = p3.x;
+  float fkx = p3.y, fky = p3.z, fkz = p3.w, fkqx = p4.x, fkqy = p4.y, fkqz = p4.z, fkqw = p4.w;
+
+  v2f win[NPL][kWin], ierr[NPL];
+#pragma unroll
+  for (int k = 0; k < NPL; ++k) {
+#pragma unroll
+    for (int j = 0; j < kWin; ++j) win[k][j] = (v2f){comp4(craw[2 * k][j / 4], j % 4), comp4(craw[2 * k + 1][j / 4], j % 4)};
+    ierr[k] = (v2f){craw[2 * k][2].z, craw[2 * k + 1][2].z};
+  }
+  const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
+  int calls = a.pid_calls;
+
+  for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
+    // ---- IK rows of this lane's cables on the state at t_k
+    v2f len[NPL], jac[NPL][6], l0[NPL], q[NPL], qd[NPL];
+    ik_rows<NPL, false, true>(mylds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      q[k] = l0[k] - len[k];
+      qd[k] = -fma2(s.wz, jac[k][5], fma2(s.wy, jac[k][4], fma2(s.wx, jac[k][3],
+                    fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
+    }
+
+    // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
+    v2f f[NPL], e_new[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      f[k] = splat(0.f);
+      e_new[k] = splat(0.f);
+    }
+    float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
+    bool dbg_wrote = false;
+    const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
+    if (!first_world) {
+      if (calls != 0) {
+        const bool full = calls >= a.nbuf;
+        v2f error[NPL], acc[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          error[k] = desired[k] - (actual_is_vel ? qd[k] : q[k]);
+          acc[k] = splat(a.w[kWin]) * error[k];
+        }
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) {
+#pragma unroll
+          for (int k = 0; k < NPL; ++k) acc[k] = fma2(a.w[j], win[k][j], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const v2f p_term = splat(a.kp) * error[k];
+          const v2f prev_ierr = ierr[k];
+          v2f ie = fma2(a.dt, error[k], prev_ierr);
+          const v2f i_term = splat(a.ki) * ie;
+          const v2f i_cl = max2(min2(i_term, splat(a.imax)), splat(a.imin));
+          const v2f ie_cl = i_cl * splat(a.inv_ki);
+          ie.x = (i_cl.x != i_term.x) ? ie_cl.x : ie.x;
+          ie.y = (i_cl.y != i_term.y) ? ie_cl.y : ie.y;
+          const v2f derived = full ? acc[k] * splat(a.inv_dt) : splat(0.f);
+          const v2f d_term = splat(a.kd) * derived;
+          const v2f cmd = fma2(a.kf, desired[k], p_term) + i_cl + d_term;
+          v2f out = a.clamp_cmd ? max2(min2(cmd, splat(a.cmax)), splat(a.cmin)) : cmd;
+          const v2f bumped = fma2(splat(a.dt) * error[k], splat(a.ki), out);
+          ie.x = (out.x != cmd.x) ? prev_ierr.x : ie.x;
+          ie.y = (out.y != cmd.y) ? prev_ierr.y : ie.y;
+          out.x = (out.x != cmd.x) ? bumped.x : out.x;
+          out.y = (out.y != cmd.y) ? bumped.y : out.y;
+          ierr[k] = ie;
+          f[k] = out;
+          e_new[k] = error[k];
+          if (k == 0) {
+            dbg_p = p_term.x;
+            dbg_i = i_term.x;
+            dbg_d = d_term.x;
+          }
+        }
+        dbg_wrote = true;
+      }
+      ++calls;
+    }
+
+    if (SINGLE) {
+      if (live) {
+        float4* wrow = a.state + (size_t)(P + 3 * c0) * st + r;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+          const int k = i / 2;
+          float e[kWin + 1];
+#pragma unroll
+          for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
+          e[kWin] = (i & 1) ? e_new[k].y : e_new[k].x;
+          const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
+          wrow[(size_t)(3 * i + 0) * st] = make_float4(e[1], e[2], e[3], e[4]);
+          wrow[(size_t)(3 * i + 1) * st] = make_float4(e[5], e[6], e[7], e[8]);
+          wrow[(size_t)(3 * i + 2) * st] = make_float4(e[9], e[10], ie, 0.f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+#pragma unroll
+        for (int j = 0; j + 1 < kWin; ++j) win[k][j] = win[k][j + 1];
+        win[k][kWin - 1] = e_new[k];
+      }
+    }
+
+    // ---- Newton-Raphson FK: the two lanes iterate on identical estimates
+    v2f applied[NPL];
+    float fk_res = 0.f;
+    int fk_it = 0, td_flag = 0;
+    v2f jest[NPL][6];
+    if (FK) {
+      v2f elen[NPL], unused[NPL];
+      bool active = true;
+      for (int it = 0; it < a.fk_iters; ++it) {
+        ik_rows<NPL, false, false>(mylds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+        v2f res[NPL];
+        v2f rm = splat(0.f);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          res[k] = len[k] - elen[k];
+          rm = max2(rm, abs2(res[k]));
+        }
+        active = active && !(pair_max(fmaxf(rm.x, rm.y)) < a.fk_tol);
+        float g[6];
+        jt_times_shared<NPL>(jest, res, g);
+        normal_solve_shared<NPL>(jest, a.fk_lambda, g);
+        if (active) {
+          fkx += g[0];
+          fky += g[1];
+          fkz += g[2];
+          quat_apply_rotvec(fkqx, fkqy, fkqz, fkqw, g[3], g[4], g[5]);
+          ++fk_it;
+        }
+      }
+      ik_rows<NPL, false, false>(mylds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+      v2f rm = splat(0.f);
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
+      fk_res = pair_max(fmaxf(rm.x, rm.y));
+    }
+
+    // ---- tension distribution
+    if (TD) {
+      v2f df[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) df[k] = f[k] - splat(a.td_mid);
+      float g[6];
+      if (FK) {
+        jt_times_shared<NPL>(jest, df, g);
+        normal_solve_shared<NPL>(jest, 0.f, g);
+      } else {
+        jt_times_shared<NPL>(jac, df, g);
+        normal_solve_shared<NPL>(jac, 0.f, g);
+      }
+      float flagf = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        v2f t = splat(a.td_mid);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t = fma2(g[c], FK ? jest[k][c] : jac[k][c], t);
+        const v2f tc = max2(min2(t, splat(a.td_max)), splat(a.td_min));
+        flagf = ((tc.x != t.x) || (tc.y != t.y)) ? 1.f : flagf;
+        applied[k] = tc;
+      }
+      td_flag = (pair_max(flagf) != 0.f) ? 1 : 0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) applied[k] = f[k];
+    }
+    if (a.effort >= 0.f) {
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) applied[k] = max2(min2(applied[k], splat(a.effort)), splat(-a.effort));
+    }
+
+    if (a.dbg && live && par == 0u) {  // `pid` topic, cable 0 only
+      float* d = a.dbg + (size_t)r * 9;
+      if (dbg_wrote) {
+        d[0] = dbg_p;
+        d[1] = dbg_i;
+        d[2] = dbg_d;
+        d[3] = desired[0].x;
+      }
+      d[4] = applied[0].x;
+    }
+
+    // ---- observables of step t_k: lane 0 writes the platform rows, each lane its own joint group
+    if (((a.publish_mask >> step) & 1ull) && live) {
+      if (par == 0u) {
+        store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+        store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+      } else {
+        store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+        store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+      }
+      if (NL == 4) {  // n = 8: group g = this lane's four cables
+        float4* orow = a.obs + (size_t)(4 + par) * st + r;
+        orow[0] = make_float4(q[0].x, q[0].y, q[NPL - 1].x, q[NPL - 1].y);
+        orow[(size_t)G * st] = make_float4(qd[0].x, qd[0].y, qd[NPL - 1].x, qd[NPL - 1].y);
+        orow[(size_t)2 * G * st] = make_float4(applied[0].x, applied[0].y, applied[NPL - 1].x, applied[NPL - 1].y);
+      }
+    }
+    if (NL == 2) {  // n = 4: one group of four = both lanes' pairs; lane 0 collects the partner's pair
+      const float oq0 = partner(q[0].x), oq1 = partner(q[0].y), ov0 = partner(qd[0].x), ov1 = partner(qd[0].y);
+      const float oa0 = partner(applied[0].x), oa1 = partner(applied[0].y);
+      if (((a.publish_mask >> step) & 1ull) && live && par == 0u) {
+        store_slot(a.obs, st, 4, woff, make_float4(q[0].x, q[0].y, oq0, oq1));
+        store_slot(a.obs, st, 4 + G, woff, make_float4(qd[0].x, qd[0].y, ov0, ov1));
+        store_slot(a.obs, st, 4 + 2 * G, woff, make_float4(applied[0].x, applied[0].y, oa0, oa1));
+      }
+    }
+
+    // ---- world step: wrench partial sums meet through the DPP add, both lanes integrate identically
+    {
+      v2f tens[NPL];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) tens[k] = fma2(-a.damping, qd[k], applied[k]);
+      float w[6];
+      jt_times_shared<NPL>(jac, tens, w);
+      w[0] = a.fgx - w[0];
+      w[1] = a.fgy - w[1];
+      w[2] = a.fgz - w[2];
+      w[3] = -w[3];
+      w[4] = -w[4];
+      w[5] = -w[5];
+      integrate(a, s, w);
+    }
+  }
+
+  // ---- store (platform rows split between the two lanes)
+  if (live) {
+    if (par == 0u) {
+      store_slot(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+      store_slot(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+      if (FK) store_slot(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+    } else {
+      store_slot(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+      store_slot(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
+    }
+    if (!SINGLE) {
+      float4* wrow = a.state + (size_t)(P + 3 * c0) * st + r;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int k = i / 2;
+        float e[kWin];
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
+        const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
+        wrow[(size_t)(3 * i + 0) * st] = make_float4(e[0], e[1], e[2], e[3]);
+        wrow[(size_t)(3 * i + 1) * st] = make_float4(e[4], e[5], e[6], e[7]);
+        wrow[(size_t)(3 * i + 2) * st] = make_float4(e[8], e[9], ie, 0.f);
+      }
+    }
+  }
+}
+
+}  // namespace cdpr

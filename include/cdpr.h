@@ -58,8 +58,9 @@ extern "C" {
 
 /* cdpr_config_t.mapping: how robots are laid onto wavefronts */
 #define CDPR_MAP_AUTO 0u
-#define CDPR_MAP_LANE_PER_ROBOT 1u  /* one lane owns one robot, state in float4 SoA            */
-#define CDPR_MAP_LANE_PER_CABLE 2u  /* n lanes own one robot, J rows in LDS, DPP row reductions */
+#define CDPR_MAP_LANE_PER_ROBOT 1u  /* one lane owns one robot                                               */
+#define CDPR_MAP_LANE_PAIR 2u       /* two adjacent lanes share a robot, half the cables each (n = 4 or 8):   */
+                                    /* twice the wavefronts, partial sums meet through a DPP add             */
 
 /* Pid::FilterParameters (Pid.h:64-68) */
 typedef struct cdpr_filter_params {

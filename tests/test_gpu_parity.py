@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 TOL = {"pose": 1e-5, "twist": 2e-4, "q": 1e-5, "qd": 2e-4, "eff": 2e-2}
 
 
+@pytest.fixture(autouse=True, params=["lane_per_robot", "lane_pair"])
+def mapping(request, monkeypatch):
+    """Every test runs under both wavefront mappings (CDPR_MAPPING overrides CDPR_MAP_AUTO at cdpr_create): one lane
+    per robot, and two lanes per robot (n = 4 or 8; other cable counts and the general controller path fall back to
+    one lane per robot by themselves)."""
+    monkeypatch.setenv("CDPR_MAPPING", "1" if request.param == "lane_per_robot" else "2")
+    return request.param
+
+
 def compare(eng, ora, tol=TOL, where=""):
     gp, gt = eng.platform_state()
     op, ot = ora.platform_state()
