@@ -16,6 +16,104 @@ def shard_range(rank: int, world: int, total: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class ShardedEngine:
+    """One process, several GPUs: robots [lo, hi) of the batch live on device d (contiguous blocks, BASELINE config 4:
+    524 288 robots = 8 x 65 536).  Every call fans out to the per-device engines; launches are asynchronous, so one
+    host thread keeps all GPUs busy and nothing crosses between devices.  Same methods as `Engine`; batched arrays
+    are split / concatenated along the robot axis."""
+
+    def __init__(self, config, devices):
+        from dataclasses import replace
+
+        from .engine import Engine
+
+        self.config = config
+        self.devices = list(devices)
+        self.B, self.n = int(config.batch), config.n_cables
+        self.spans = [shard_range(i, len(self.devices), self.B) for i in range(len(self.devices))]
+        if any(hi - lo < 1 for lo, hi in self.spans):
+            raise ValueError("fewer robots than devices")
+        self.engines = [Engine(replace(config, batch=hi - lo), device=d) for (lo, hi), d in zip(self.spans, self.devices)]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _split(self, a, width):
+        import numpy as np
+
+        a = np.asarray(a, dtype=np.float32)
+        if a.size == width:  # one message broadcast to every robot
+            return [a] * len(self.engines)
+        a = a.reshape(self.B, width)
+        return [a[lo:hi] for lo, hi in self.spans]
+
+    def set_platform_state(self, pose7=None, twist6=None):
+        ps = [None] * len(self.engines) if pose7 is None else self._split(pose7, 7)
+        ts = [None] * len(self.engines) if twist6 is None else self._split(twist6, 6)
+        for e, p, t in zip(self.engines, ps, ts):
+            e.set_platform_state(p, t)
+
+    def set_velocity_command(self, axes):
+        import numpy as np
+
+        a = np.asarray(axes, dtype=np.float32)
+        if a.size not in (self.n, self.n * self.B):
+            return 1  # CDPR_IGNORED, as every shard would answer (PLG.cpp:68-73)
+        return max(e.set_velocity_command(x) for e, x in zip(self.engines, self._split(a, self.n)))
+
+    def set_position_command(self, axes):
+        import numpy as np
+
+        a = np.asarray(axes, dtype=np.float32)
+        if a.size not in (self.n, self.n * self.B):
+            return 1
+        return max(e.set_position_command(x) for e, x in zip(self.engines, self._split(a, self.n)))
+
+    def update(self, nsteps=1, steps_per_launch=1):
+        for e in self.engines:  # asynchronous: all devices run concurrently
+            e.update(nsteps, steps_per_launch)
+
+    def synchronize(self):
+        for e in self.engines:
+            e.synchronize()
+
+    def reset(self):
+        for e in self.engines:
+            e.reset()
+
+    @property
+    def step_count(self):
+        return self.engines[0].step_count
+
+    def _gather(self, name):
+        import numpy as np
+
+        parts = [getattr(e, name)() for e in self.engines]
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(len(parts[0])))
+
+    def joint_states(self):
+        return self._gather("joint_states")
+
+    def platform_state(self):
+        return self._gather("platform_state")
+
+    def raw_state(self):
+        return self._gather("raw_state")
+
+    def fk_state(self):
+        return self._gather("fk_state")
+
+    def td_state(self):
+        return self._gather("td_state")
+
+
 @dataclass
 class RankContext:
     rank: int = 0

@@ -554,3 +554,27 @@ def test_rollout_of_identical_samples_equals_plain_stepping(pkg):
         eng.update(1)
         acc += (eng.raw_state()[0][:, :3].astype(np.float64) ** 2).sum(axis=1)
     assert np.abs(cost[:, 0] - acc).max() < 1e-4 * acc.max()
+
+
+def test_sharded_engine_equals_single_engine(pkg):
+    """Config-4 style placement in one process: contiguous robot blocks on several handles (here all on GPU 0, the box
+    has one), no exchange between them; result identical to one handle holding the whole batch."""
+    B = 333
+    rng = np.random.default_rng(44)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, mapping=pkg._abi.MAP_LANE_PER_ROBOT)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    cmd = rng.uniform(-0.04, 0.04, (B, 8)).astype(np.float32)
+    one = pkg.Engine(cfg, 0)
+    many = pkg.ShardedEngine(cfg, devices=[0, 0, 0])
+    assert [hi - lo for lo, hi in many.spans] == [111, 111, 111]
+    for e in (one, many):
+        e.set_platform_state(pose7=pose)
+        e.update(20)
+        assert e.set_velocity_command(cmd) == 0 and e.set_velocity_command(np.zeros(5)) == 1
+        e.update(60)
+        e.set_position_command(np.zeros(8, dtype=np.float32))
+        e.update(30, 5)
+    for x, y in zip(one.raw_state() + one.joint_states() + one.fk_state(), many.raw_state() + many.joint_states() + many.fk_state()):
+        assert np.array_equal(x, y)
+    assert many.step_count == one.step_count == 110
+    many.close()
