@@ -1077,6 +1077,15 @@ int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float
   return CDPR_OK;
 }
 
+#ifdef CDPR_STAMPS
+// diagnostic builds only: point the step kernel at a stamp buffer (uint64[blocks][8]); nullptr disables
+int cdpr_debug_set_stamps(cdpr_handle_t h, unsigned long long* d_stamps) {
+  if (!h) return CDPR_ERR_INVALID;
+  h->base.stamps = d_stamps;
+  return CDPR_OK;
+}
+#endif
+
 int cdpr_device_malloc(cdpr_handle_t h, size_t bytes, void** out) {
   if (!h || !out) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;

@@ -60,6 +60,7 @@ struct StepArgs {
   const float* roll_ref;  // float[B][3] reference position
   float* roll_cost;       // float[B][S]: sum over the horizon of |p(t_{k+1}) - p_ref|^2
   uint32_t roll_samples;
+  unsigned long long* stamps;  // diagnostic builds only (CDPR_STAMPS)
   uint32_t batch;
   uint32_t stride;    // robots per slot row (batch rounded up to 64)
   int nsteps;         // world steps fused into this launch
@@ -87,6 +88,20 @@ __host__ __device__ constexpr int obs_slots(int n) { return 4 + 3 * joint_groups
 __host__ __device__ constexpr int cable_pairs(int n) { return (n + 1) / 2; }
 
 #define CDPR_DEV __device__ __forceinline__
+
+// Diagnostic build only (-DCDPR_STAMPS, scripts/stamp_probe.py): per-wave s_memrealtime stamps (100 MHz) at the
+// phase boundaries of the step kernel, written to a buffer of their own (StepArgs.stamps); never compiled into
+// the shipped library.
+#ifdef CDPR_STAMPS
+#define CDPR_STAMP(i)                                                                           \
+  do {                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+#else
+#define CDPR_STAMP(i) do { } while (0)
+#endif
 
 CDPR_DEV v2f splat(float s) { return (v2f){s, s}; }
 CDPR_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -367,6 +382,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
 
   // geometry load first (oldest outstanding load), then the robot's whole record: the LDS fill
   // below waits for the geometry only, the record stays in flight behind it
+  CDPR_STAMP(0);
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
 
   const uint32_t off = rr * 16u;   // byte offset of this robot inside every slot row
@@ -473,6 +489,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
         }
       }
     }
+    CDPR_STAMP(1);
     // ---- IK on the state at t_k
     v2f len[NP], jac[NP][6], l0[NP], q[NP], qd[NP];
     ik_pairs<N, true>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
@@ -483,6 +500,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
                     fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
     }
 
+    CDPR_STAMP(2);
     // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191), two cables per instruction
     v2f f[NP], e_new[NP];
 #pragma unroll
@@ -573,6 +591,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
       }
     }
 
+    CDPR_STAMP(3);
     // ---- optional estimator (Newton-Raphson FK, [NEW] SURVEY 8(a) row 14)
     v2f applied[NP];
     float fk_res = 0.f;
@@ -609,6 +628,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
       fk_res = fmaxf(rm.x, rm.y);
     }
 
+    CDPR_STAMP(4);
     // ---- optional tension distribution ([NEW] SURVEY 8(a) row 15):
     //      T = Tm 1 + J (J^T J)^-1 J^T (f - Tm 1), J at the FK estimate when there is one, then bounds
     if (TD) {
@@ -653,6 +673,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
       d[4] = applied[0].x;
     }
 
+    CDPR_STAMP(5);
     // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
     if (!ROLLOUT && ((a.publish_mask >> step) & 1ull) && live) {
       store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
@@ -695,6 +716,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
     return;
   }
 
+  CDPR_STAMP(6);
   // ---- store
   if (live) {
     store_slot(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
@@ -716,6 +738,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
       }
     }
   }
+  CDPR_STAMP(7);
 }
 
 }  // namespace cdpr
