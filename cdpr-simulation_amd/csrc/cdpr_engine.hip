@@ -79,6 +79,7 @@ struct cdpr_engine {
   double prev_publish = 0.0;
   StepArgs base{};               // world/body/FK/TD constants, pointers; Pid fields filled per launch
   StepArgs pid_vel{}, pid_pos{};  // only the Pid fields of these are used
+  float* d_wtab = nullptr;        // [velocity | position] rotated derivative-weight tables, kWin * (kWin + 2) floats each
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t launches = 0, launches_mark = 0;
   std::string err;
@@ -191,7 +192,7 @@ std::string fast_path_obstacle(const cdpr_config_t& c) {
   return "";
 }
 
-void fill_pid(const cdpr_pid_params_t& p, double dt, StepArgs& k) {
+void fill_pid(const cdpr_pid_params_t& p, double dt, StepArgs& k, float* wtab_host) {
   k.kf = (float)p.forward_gain;
   k.kp = (float)p.p_gain;
   k.ki = (float)p.i_gain;
@@ -204,16 +205,29 @@ void fill_pid(const cdpr_pid_params_t& p, double dt, StepArgs& k) {
   k.inv_dt = (float)(1.0 / dt);
   k.nbuf = (int)p.d_buffer_length;
   k.clamp_cmd = k.cmax > k.cmin;
+  // end-point LS derivative weights, oldest..newest, zero padded at the old end to kWin + 1 entries
   double w[CDPR_MAX_D_BUFFER];
-  for (int j = 0; j <= kWin; ++j) k.w[j] = 0.f;
+  float wpad[kWin + 1];
+  for (int j = 0; j <= kWin; ++j) wpad[j] = 0.f;
   if (derivative_weights(p.d_buffer_length, p.d_degree, w) == CDPR_OK && p.d_buffer_length <= (uint32_t)kWin + 1)
-    for (uint32_t j = 0; j < p.d_buffer_length; ++j) k.w[kWin + 1 - p.d_buffer_length + j] = (float)w[j];
+    for (uint32_t j = 0; j < p.d_buffer_length; ++j) wpad[kWin + 1 - p.d_buffer_length + j] = (float)w[j];
+  // ring: when the new error goes to slot ws, slot (ws - j) mod 10 holds the error of j steps ago (j = 1..10;
+  // j = 10 is slot ws itself, the sample about to be overwritten), whose weight is wpad[10 - j]
+  for (int ws = 0; ws < kWin; ++ws) {
+    for (int s = 0; s < kWin; ++s) {
+      int j = ((ws - s) % kWin + kWin) % kWin;
+      if (j == 0) j = kWin;
+      wtab_host[ws * (kWin + 2) + s] = wpad[kWin - j];
+    }
+    wtab_host[ws * (kWin + 2) + kWin] = wpad[kWin];
+    wtab_host[ws * (kWin + 2) + kWin + 1] = 0.f;
+  }
 }
 
 void copy_pid(const StepArgs& src, StepArgs& dst) {
   dst.kf = src.kf; dst.kp = src.kp; dst.ki = src.ki; dst.kd = src.kd; dst.inv_ki = src.inv_ki;
   dst.imax = src.imax; dst.imin = src.imin; dst.cmax = src.cmax; dst.cmin = src.cmin; dst.inv_dt = src.inv_dt;
-  for (int j = 0; j <= kWin; ++j) dst.w[j] = src.w[j];
+  dst.wtab = src.wtab;
   dst.nbuf = src.nbuf; dst.clamp_cmd = src.clamp_cmd;
 }
 
@@ -461,6 +475,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_obs) (void)hipFree(h->d_obs);
   if (h->d_dbg) (void)hipFree(h->d_dbg);
   if (h->d_geom) (void)hipFree(h->d_geom);
+  if (h->d_wtab) (void)hipFree(h->d_wtab);
   if (h->d_rec) (void)hipFree(h->d_rec);
   if (h->d_force) (void)hipFree(h->d_force);
   if (h->d_cable) (void)hipFree(h->d_cable);
@@ -600,7 +615,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
   if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller record; rare, so done outside the step kernel
     h->pid_calls = 0;
     const int P = plat_slots(h->fk);
-    HIP_TRY(h, hipMemsetAsync(h->d_state + (size_t)P * h->stride, 0, (size_t)3 * h->n * h->stride * sizeof(float4), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_state + (size_t)P * h->stride, 0, (size_t)ctrl_slots((int)h->n) * h->stride * sizeof(float4), h->stream));
   }
   StepArgs a = h->base;
   a.state = h->d_state;
@@ -619,7 +634,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
   const uint32_t robots_per_block = h->lane_pair ? 32u : 64u;
   const dim3 grid((h->batch + robots_per_block - 1u) / robots_per_block), block(64);
 
-  constexpr int kGraphChunk = 16;  // launches per captured graph
+  constexpr int kGraphChunk = 20;  // launches per captured graph (a multiple of the ring period 10)
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
@@ -627,8 +642,9 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     a.flags = (h->mode == kModeVelocity ? kFlagActualIsVelocity : 0u);
     const bool first_world = (h->step == 0);
     if (first_world) a.flags |= kFlagFirstWorldStep;
-    // the kernel only tests calls != 0 and calls >= nbuf: clamp so steady-state launches are identical
-    a.pid_calls = std::min(h->pid_calls, a.nbuf);
+    // the kernel uses calls != 0, calls >= nbuf (<= 32) and the ring position (calls - 1) % 10: fold large counts
+    // into [60, 70) so they stay small and steady-state launch sequences repeat with period 10
+    a.pid_calls = h->pid_calls < 70 ? h->pid_calls : 60 + h->pid_calls % 10;
     StepKernel kern = h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
                                    : ((k == 1) ? pick_kernel<true>(h->n, h->fk, h->td) : pick_kernel<false>(h->n, h->fk, h->td));
 
@@ -636,7 +652,9 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
     // (measured on MI355X: 3.57 -> 3.41 us/step at 4 096 x 4 cables; at 65 536 x 8 cables the 15 us kernels already
     // hide the host launch and the replay's fixed cost makes it 2 % slower, so only small batches use it)
-    const bool steady = h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && h->pid_calls >= a.nbuf && h->cfg.publish_period == 0.0 &&
+    // (the ring position advances with every step, so a captured chain is only valid from the same position: chains
+    //  are captured and replayed at a.pid_calls == 60, i.e. window full and ring position 9 -> 0)
+    const bool steady = h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && a.pid_calls == 60 && (10 % k == 0) && h->cfg.publish_period == 0.0 &&
                         (nsteps - done) >= kGraphChunk * k;
     if (steady) {
       a.publish_mask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -646,7 +664,11 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
       if (!ge) {
         cdpr_engine::GraphEntry g{(void*)kern, a.cmd, k, kGraphChunk, a.flags, nullptr, nullptr};
         HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        for (int j = 0; j < kGraphChunk; ++j) hipLaunchKernelGGL(kern, grid, block, 0, h->stream, a);
+        for (int j = 0; j < kGraphChunk; ++j) {
+          StepArgs aj = a;  // each node carries its own ring position
+          aj.pid_calls = 60 + (j * k) % 10;
+          hipLaunchKernelGGL(kern, grid, block, 0, h->stream, aj);
+        }
         HIP_TRY(h, hipStreamEndCapture(h->stream, &g.graph));
         HIP_TRY(h, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
         if (h->graphs.size() >= 8) {  // tiny cache: drop the oldest
@@ -789,8 +811,9 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->n_obs = obs_slots((int)h->n);
   memset(&h->base, 0, sizeof h->base);
   fill_consts(*cfg, h->base);
-  fill_pid(cfg->velocity_pid, cfg->dt, h->pid_vel);
-  fill_pid(cfg->position_pid, cfg->dt, h->pid_pos);
+  float wtab_host[2][kWin * (kWin + 2)];
+  fill_pid(cfg->velocity_pid, cfg->dt, h->pid_vel, wtab_host[0]);
+  fill_pid(cfg->position_pid, cfg->dt, h->pid_pos, wtab_host[1]);
   engine_reset_host(h);
   {
     const char* ng = std::getenv("CDPR_NO_GRAPH");
@@ -816,6 +839,10 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     (void)hipMemset(h->d_vel[i], 0, cmd_bytes);
     (void)hipMemset(h->d_pos[i], 0, cmd_bytes);
   }
+  if ((e = hipMalloc(&h->d_wtab, sizeof wtab_host)) != hipSuccess) return fail("hipMalloc(wtab)", e);
+  if ((e = hipMemcpy(h->d_wtab, wtab_host, sizeof wtab_host, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(wtab)", e);
+  h->pid_vel.wtab = h->d_wtab;
+  h->pid_pos.wtab = h->d_wtab + kWin * (kWin + 2);
   {
     std::vector<float> g = geom_pairs(*cfg);
     if ((e = hipMalloc(&h->d_geom, g.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(geom)", e);
@@ -1063,7 +1090,7 @@ int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float
   // a Joy on jointVelocities while in Position mode resets the velocity Pid (JFC.cpp:113-115); the handle's own
   // records stay untouched, the rollout starts from zeroed copies
   if (h->mode != kModeVelocity) a.flags |= kFlagRolloutResetPid;
-  a.pid_calls = (h->mode == kModeVelocity) ? std::min(h->pid_calls, a.nbuf) : 0;
+  a.pid_calls = (h->mode == kModeVelocity) ? (h->pid_calls < 70 ? h->pid_calls : 60 + h->pid_calls % 10) : 0;
   a.roll_cmd = d_commands;
   a.roll_ref = dref.as<float>();
   a.roll_cost = dcost.as<float>();

@@ -24,7 +24,12 @@
 //
 // State slots (float4 each):
 //   0: px py pz qx   1: qy qz qw vx   2: vy vz wx wy   3: wz fkx fky fkz   4: fkqx fkqy fkqz fkqw (FK only)
-//   P + 3c + {0,1,2}: cable c controller record: e0..e3 | e4..e7 | e8 e9 Ierr (unused)
+//   controller records, per CABLE PAIR k (cables A = 2k, B = 2k+1), the derivative window as a RING of 10 slots:
+//     P + 5k + m (m = 0..4): A[2m] A[2m+1] B[2m] B[2m+1]      (ring slots 2m and 2m+1 of both cables)
+//     P + 5*NP + g:          Ierr of pairs 2g, 2g+1: A B A B   ("hot" rows, rewritten every step)
+//   One step rewrites ONE ring row per pair (the slot the new error goes to) plus the hot rows: 6 rows at n = 8
+//   instead of the 24 a shifted window would cost; the ring position is uniform over the batch, so it comes
+//   from the kernel argument pid_calls and the FIR weights are looked up pre-rotated (StepArgs.wtab).
 // Observable slots (PLG.cpp:248-280): 0..2 pose/twist at the published step,
 //   3: wz fk_residual fk_iterations td_infeasible; 4..: joint position, velocity, effort (ceil(n/4) slots each)
 //
@@ -77,15 +82,19 @@ struct StepArgs {
   float td_min, td_max, td_mid;
   // the active Pid (Pid.cpp:64-73)
   float kf, kp, ki, kd, inv_ki, imax, imin, cmax, cmin, inv_dt;
-  float w[kWin + 1];  // end-point LS derivative weights, oldest..newest, zero padded at the old end
+  // wtab[ws*12 + s], s < 10: end-point LS derivative weight of ring slot s when the new error goes to slot ws;
+  // wtab[ws*12 + 10]: weight of the new error itself (closed form of Pid::derive, Pid.cpp:193-247).  A device
+  // buffer, not a kernel-argument array: indexing a by-value argument with a run-time slot sends it to scratch.
+  const float* wtab;
   int nbuf, clamp_cmd;
 };
 
 __host__ __device__ constexpr int plat_slots(bool fk) { return fk ? 5 : 4; }
 __host__ __device__ constexpr int joint_groups(int n) { return (n + 3) / 4; }
-__host__ __device__ constexpr int state_slots(int n, bool fk) { return plat_slots(fk) + 3 * n; }
-__host__ __device__ constexpr int obs_slots(int n) { return 4 + 3 * joint_groups(n); }
 __host__ __device__ constexpr int cable_pairs(int n) { return (n + 1) / 2; }
+__host__ __device__ constexpr int ctrl_slots(int n) { return 5 * cable_pairs(n) + (cable_pairs(n) + 1) / 2; }
+__host__ __device__ constexpr int state_slots(int n, bool fk) { return plat_slots(fk) + ctrl_slots(n); }
+__host__ __device__ constexpr int obs_slots(int n) { return 4 + 3 * joint_groups(n); }
 
 #define CDPR_DEV __device__ __forceinline__
 
@@ -360,6 +369,29 @@ CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, co
 #endif
 }
 
+// win[k][slot] = e[k] for a wave-uniform ring slot, written as per-slot selects: a switch (or if-chain) over the
+// slot gets merged by LLVM into ONE store through a run-time index into the register array, which sends the
+// whole window to scratch memory (seen in the ISA: 256 B of scratch per lane); selects keep everything in VGPRs.
+template <int NPX>
+CDPR_DEV void ring_push(v2f (&win)[NPX][kWin], const v2f (&e)[NPX], int slot) {
+#pragma unroll
+  for (int j = 0; j < kWin; ++j) {
+    const bool hit = (j == slot);
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      win[k][j].x = hit ? e[k].x : win[k][j].x;
+      win[k][j].y = hit ? e[k].y : win[k][j].y;
+    }
+  }
+}
+
+// Ring row m of one cable pair as it lies in HBM: A[2m] A[2m+1] B[2m] B[2m+1], with the new error e (A, B) put
+// into ring slot `slot` if that slot lies in this row.
+CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
+  const bool lo = (slot == 2 * m), hi = (slot == 2 * m + 1);
+  return make_float4(lo ? e.x : w[2 * m].x, hi ? e.x : w[2 * m + 1].x, lo ? e.y : w[2 * m].y, hi ? e.y : w[2 * m + 1].y);
+}
+
 // EXT = true: the controller ran in cdpr_general_ctrl_kernel; forces come from a.force and the state has
 // no controller records (platform slots only).
 // ROLLOUT = true: MPC fan-out (BASELINE config 5): one lane = one (robot, sampled command sequence); the robot's
@@ -391,13 +423,16 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
                p2 = load_slot(a.state, st, 2, off), p3 = load_slot(a.state, st, 3, off);
   float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
   if (FK) p4 = load_slot(a.state, st, 4, off);
-  float4 craw[N][3];
+  constexpr int NH = (NP + 1) / 2;  // hot rows
+  float4 wraw[NP][5], hraw[NH];
   if (!EXT) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
+    for (int k = 0; k < NP; ++k) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) craw[i][k] = load_slot(a.state, st, P + 3 * i + k, off);
+      for (int m = 0; m < 5; ++m) wraw[k][m] = load_slot(a.state, st, P + 5 * k + m, off);
     }
+#pragma unroll
+    for (int g = 0; g < NH; ++g) hraw[g] = load_slot(a.state, st, P + 5 * NP + g, off);
   }
   v2f desired[NP];  // EXT: the raw forces instead of the Joy targets
 #pragma unroll
@@ -437,19 +472,16 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   s.wz = p3.x;
   float fkx = p3.y, fky = p3.z, fkz = p3.w, fkqx = p4.x, fkqy = p4.y, fkqz = p4.z, fkqw = p4.w;
 
-  // controller records as cable pairs: window e[j] (oldest..newest), integral
+  // controller records as cable pairs: ring of the last 10 errors, integral
   v2f win[NP][kWin], ierr[NP];
 #pragma unroll
   for (int k = 0; k < (EXT ? 0 : NP); ++k) {
-    const int i0 = 2 * k, i1 = (2 * k + 1 < N) ? 2 * k + 1 : 2 * k;
-    const bool has1 = (2 * k + 1 < N);
 #pragma unroll
-    for (int j = 0; j < kWin; ++j) {
-      const float e0 = comp4(craw[i0][j / 4], j % 4);
-      const float e1 = has1 ? comp4(craw[i1][j / 4], j % 4) : 0.f;
-      win[k][j] = (v2f){e0, e1};
+    for (int m = 0; m < 5; ++m) {
+      win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].z};
+      win[k][2 * m + 1] = (v2f){wraw[k][m].y, wraw[k][m].w};
     }
-    ierr[k] = (v2f){craw[i0][2].z, has1 ? craw[i1][2].z : 0.f};
+    ierr[k] = (k & 1) ? (v2f){hraw[k / 2].z, hraw[k / 2].w} : (v2f){hraw[k / 2].x, hraw[k / 2].y};
   }
   const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
   int calls = a.pid_calls;
@@ -511,23 +543,26 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
     float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
     bool dbg_wrote = false;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
+    int ring_slot = -1;  // ring slot this step's error goes to (-1: no sample taken)
     if (EXT) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) f[k] = first_world ? splat(0.f) : desired[k];
     } else if (!first_world) {
       if (calls != 0) {  // not the first call since reset (Pid.cpp:123-126: that one returns 0)
         const bool full = calls >= a.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
+        ring_slot = (calls - 1) % kWin;     // the oldest sample sits there and is overwritten below
+        const float* wt = a.wtab + ring_slot * (kWin + 2);  // weights pre-rotated for this ring position (scalar loads)
         v2f error[NP], acc[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
           error[k] = desired[k] - (actual_is_vel ? qd[k] : q[k]);
-          acc[k] = splat(a.w[kWin]) * error[k];
+          acc[k] = splat(wt[kWin]) * error[k];
         }
-        // closed-form end-point LS derivative (Pid.cpp:193-247); j outer so the NP chains interleave
+        // closed-form end-point LS derivative (Pid.cpp:193-247); slot outer so the NP chains interleave
 #pragma unroll
         for (int j = 0; j < kWin; ++j) {
 #pragma unroll
-          for (int k = 0; k < NP; ++k) acc[k] = fma2(a.w[j], win[k][j], acc[k]);
+          for (int k = 0; k < NP; ++k) acc[k] = fma2(wt[j], win[k][j], acc[k]);
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -562,32 +597,22 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
       ++calls;
     }
 
-    // When no sample was taken (first call after a reset, or t = 0) e_new is 0 and the window is all
-    // zeros (Pid::reset zeroed it), so the unconditional shift below leaves it unchanged.
-    if (EXT) {
-      // no controller records on this path
-    } else if (SINGLE) {
-      // controller records are final: store them now, window shift folded into the store
-      if (live) {
+    if (!EXT && !SINGLE && ring_slot >= 0) ring_push<NP>(win, e_new, ring_slot);
+    if (!EXT && SINGLE && live) {
+      // controller records are final: one ring row per cable pair (the one that takes the new error) + the hot rows
+      if (ring_slot >= 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          const int k = i / 2;
-          float e[kWin + 1];
+        for (int m = 0; m < 5; ++m) {
+          if (m == (ring_slot >> 1)) {
 #pragma unroll
-          for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
-          e[kWin] = (i & 1) ? e_new[k].y : e_new[k].x;
-          const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
-          store_slot(a.state, st, P + 3 * i + 0, woff, make_float4(e[1], e[2], e[3], e[4]));
-          store_slot(a.state, st, P + 3 * i + 1, woff, make_float4(e[5], e[6], e[7], e[8]));
-          store_slot(a.state, st, P + 3 * i + 2, woff, make_float4(e[9], e[10], ie, 0.f));
+            for (int k = 0; k < NP; ++k) store_slot(a.state, st, P + 5 * k + m, woff, ring_row(win[k], m, e_new[k], ring_slot));
+          }
         }
       }
-    } else {
 #pragma unroll
-      for (int k = 0; k < NP; ++k) {
-#pragma unroll
-        for (int j = 0; j + 1 < kWin; ++j) win[k][j] = win[k][j + 1];
-        win[k][kWin - 1] = e_new[k];
+      for (int g = 0; g < NH; ++g) {
+        const int k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+        store_slot(a.state, st, P + 5 * NP + g, woff, make_float4(ierr[2 * g].x, ierr[2 * g].y, ierr[k1].x, ierr[k1].y));
       }
     }
 
@@ -726,15 +751,14 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
     if (FK) store_slot(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
     if (!SINGLE && !EXT) {
 #pragma unroll
-      for (int i = 0; i < N; ++i) {
-        const int k = i / 2;
-        float e[kWin];
+      for (int k = 0; k < NP; ++k) {
 #pragma unroll
-        for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
-        const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
-        store_slot(a.state, st, P + 3 * i + 0, woff, make_float4(e[0], e[1], e[2], e[3]));
-        store_slot(a.state, st, P + 3 * i + 1, woff, make_float4(e[4], e[5], e[6], e[7]));
-        store_slot(a.state, st, P + 3 * i + 2, woff, make_float4(e[8], e[9], ie, 0.f));
+        for (int m = 0; m < 5; ++m) store_slot(a.state, st, P + 5 * k + m, woff, ring_row(win[k], m, splat(0.f), -1));
+      }
+#pragma unroll
+      for (int g = 0; g < NH; ++g) {
+        const int k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+        store_slot(a.state, st, P + 5 * NP + g, woff, make_float4(ierr[2 * g].x, ierr[2 * g].y, ierr[k1].x, ierr[k1].y));
       }
     }
   }

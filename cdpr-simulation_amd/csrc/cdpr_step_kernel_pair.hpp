@@ -70,15 +70,18 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
                p2 = load_slot(a.state, st, 2, off), p3 = load_slot(a.state, st, 3, off);
   float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
   if (FK) p4 = load_slot(a.state, st, 4, off);
-  // controller rows of this lane's cables: the row index depends on the lane parity, so these are
-  // per-lane addresses (two 512-B runs per wave instruction)
-  const float4* crow = a.state + (size_t)(P + 3 * c0) * st + rr;
-  float4 craw[NL][3];
+  // controller rows of this lane's cable pairs: the row index depends on the lane parity, so these are per-lane
+  // addresses (two 512-B runs per wave instruction).  Layout: see cdpr_step_kernel.hpp (ring rows + hot rows).
+  const int k0 = (int)par * NPL;  // first cable pair of this lane
+  const float4* crow = a.state + (size_t)(P + 5 * k0) * st + rr;
+  float4 wraw[NPL][5];
 #pragma unroll
-  for (int i = 0; i < NL; ++i) {
+  for (int k = 0; k < NPL; ++k) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) craw[i][k] = crow[(size_t)(3 * i + k) * st];
+    for (int m = 0; m < 5; ++m) wraw[k][m] = crow[(size_t)(5 * k + m) * st];
   }
+  // hot row: n = 8 -> row `par` holds exactly this lane's two pairs; n = 4 -> one row shared by both lanes
+  const float4 hraw = (a.state + (size_t)(P + 5 * NP + (NPL == 2 ? par : 0u)) * st)[rr];
   v2f desired[NPL];
 #pragma unroll
   for (int k = 0; k < NPL; ++k) desired[k] = splat(0.f);
@@ -111,8 +114,16 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
 #pragma unroll
   for (int k = 0; k < NPL; ++k) {
 #pragma unroll
-    for (int j = 0; j < kWin; ++j) win[k][j] = (v2f){comp4(craw[2 * k][j / 4], j % 4), comp4(craw[2 * k + 1][j / 4], j % 4)};
-    ierr[k] = (v2f){craw[2 * k][2].z, craw[2 * k + 1][2].z};
+    for (int m = 0; m < 5; ++m) {
+      win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].z};
+      win[k][2 * m + 1] = (v2f){wraw[k][m].y, wraw[k][m].w};
+    }
+  }
+  if (NPL == 2) {
+    ierr[0] = (v2f){hraw.x, hraw.y};
+    ierr[NPL - 1] = (v2f){hraw.z, hraw.w};
+  } else {
+    ierr[0] = par ? (v2f){hraw.z, hraw.w} : (v2f){hraw.x, hraw.y};
   }
   const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
   int calls = a.pid_calls;
@@ -138,19 +149,22 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
     float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
     bool dbg_wrote = false;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
+    int ring_slot = -1;
     if (!first_world) {
       if (calls != 0) {
         const bool full = calls >= a.nbuf;
+        ring_slot = (calls - 1) % kWin;
+        const float* wt = a.wtab + ring_slot * (kWin + 2);
         v2f error[NPL], acc[NPL];
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
           error[k] = desired[k] - (actual_is_vel ? qd[k] : q[k]);
-          acc[k] = splat(a.w[kWin]) * error[k];
+          acc[k] = splat(wt[kWin]) * error[k];
         }
 #pragma unroll
         for (int j = 0; j < kWin; ++j) {
 #pragma unroll
-          for (int k = 0; k < NPL; ++k) acc[k] = fma2(a.w[j], win[k][j], acc[k]);
+          for (int k = 0; k < NPL; ++k) acc[k] = fma2(wt[j], win[k][j], acc[k]);
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
@@ -185,28 +199,26 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       ++calls;
     }
 
-    if (SINGLE) {
-      if (live) {
-        float4* wrow = a.state + (size_t)(P + 3 * c0) * st + r;
+    if (!SINGLE && ring_slot >= 0) ring_push<NPL>(win, e_new, ring_slot);
+    {
+      // hot row of n = 4 is shared: lane 0 collects the partner's pair (DPP outside any divergent branch)
+      const float oi0 = partner(ierr[0].x), oi1 = partner(ierr[0].y);
+      if (SINGLE && live) {
+        float4* wrow = a.state + (size_t)(P + 5 * k0) * st + r;
+        if (ring_slot >= 0) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-          const int k = i / 2;
-          float e[kWin + 1];
+          for (int m = 0; m < 5; ++m) {
+            if (m == (ring_slot >> 1)) {
 #pragma unroll
-          for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
-          e[kWin] = (i & 1) ? e_new[k].y : e_new[k].x;
-          const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
-          wrow[(size_t)(3 * i + 0) * st] = make_float4(e[1], e[2], e[3], e[4]);
-          wrow[(size_t)(3 * i + 1) * st] = make_float4(e[5], e[6], e[7], e[8]);
-          wrow[(size_t)(3 * i + 2) * st] = make_float4(e[9], e[10], ie, 0.f);
+              for (int k = 0; k < NPL; ++k) wrow[(size_t)(5 * k + m) * st] = ring_row(win[k], m, e_new[k], ring_slot);
+            }
+          }
         }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NPL; ++k) {
-#pragma unroll
-        for (int j = 0; j + 1 < kWin; ++j) win[k][j] = win[k][j + 1];
-        win[k][kWin - 1] = e_new[k];
+        if (NPL == 2) {
+          (a.state + (size_t)(P + 5 * NP + par) * st)[r] = make_float4(ierr[0].x, ierr[0].y, ierr[NPL - 1].x, ierr[NPL - 1].y);
+        } else if (par == 0u) {
+          (a.state + (size_t)(P + 5 * NP) * st)[r] = make_float4(ierr[0].x, ierr[0].y, oi0, oi1);
+        }
       }
     }
 
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
   }
 
   // ---- store (platform rows split between the two lanes)
+  const float oi_final0 = partner(ierr[0].x), oi_final1 = partner(ierr[0].y);
   if (live) {
     if (par == 0u) {
       store_slot(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
@@ -344,17 +357,16 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       store_slot(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
     }
     if (!SINGLE) {
-      float4* wrow = a.state + (size_t)(P + 3 * c0) * st + r;
+      float4* wrow = a.state + (size_t)(P + 5 * k0) * st + r;
 #pragma unroll
-      for (int i = 0; i < NL; ++i) {
-        const int k = i / 2;
-        float e[kWin];
+      for (int k = 0; k < NPL; ++k) {
 #pragma unroll
-        for (int j = 0; j < kWin; ++j) e[j] = (i & 1) ? win[k][j].y : win[k][j].x;
-        const float ie = (i & 1) ? ierr[k].y : ierr[k].x;
-        wrow[(size_t)(3 * i + 0) * st] = make_float4(e[0], e[1], e[2], e[3]);
-        wrow[(size_t)(3 * i + 1) * st] = make_float4(e[4], e[5], e[6], e[7]);
-        wrow[(size_t)(3 * i + 2) * st] = make_float4(e[8], e[9], ie, 0.f);
+        for (int m = 0; m < 5; ++m) wrow[(size_t)(5 * k + m) * st] = ring_row(win[k], m, splat(0.f), -1);
+      }
+      if (NPL == 2) {
+        (a.state + (size_t)(P + 5 * NP + par) * st)[r] = make_float4(ierr[0].x, ierr[0].y, ierr[NPL - 1].x, ierr[NPL - 1].y);
+      } else if (par == 0u) {
+        (a.state + (size_t)(P + 5 * NP) * st)[r] = make_float4(ierr[0].x, ierr[0].y, oi_final0, oi_final1);
       }
     }
   }
