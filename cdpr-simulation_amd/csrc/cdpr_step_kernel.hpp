@@ -25,7 +25,7 @@
 // State slots (float4 each):
 //   0: px py pz qx   1: qy qz qw vx   2: vy vz wx wy   3: wz fkx fky fkz   4: fkqx fkqy fkqz fkqw (FK only)
 //   controller records, per CABLE PAIR k (cables A = 2k, B = 2k+1), the derivative window as a RING of 10 slots:
-//     P + 5k + m (m = 0..4): A[2m] A[2m+1] B[2m] B[2m+1]      (ring slots 2m and 2m+1 of both cables)
+//     P + 5k + m (m = 0..4): A[2m] B[2m] A[2m+1] B[2m+1]      (ring slots 2m and 2m+1 of both cables)
 //     P + 5*NP + g:          Ierr of pairs 2g, 2g+1: A B A B   ("hot" rows, rewritten every step)
 //   One step rewrites ONE ring row per pair (the slot the new error goes to) plus the hot rows: 6 rows at n = 8
 //   instead of the 24 a shifted window would cost; the ring position is uniform over the batch, so it comes
@@ -385,11 +385,12 @@ CDPR_DEV void ring_push(v2f (&win)[NPX][kWin], const v2f (&e)[NPX], int slot) {
   }
 }
 
-// Ring row m of one cable pair as it lies in HBM: A[2m] A[2m+1] B[2m] B[2m+1], with the new error e (A, B) put
-// into ring slot `slot` if that slot lies in this row.
+// Ring row m of one cable pair as it lies in HBM: A[2m] B[2m] A[2m+1] B[2m+1] (each half of the float4 is one
+// (A, B) register pair, so loads need no unpacking moves), with the new error e = (A, B) put into ring slot `slot`
+// if that slot lies in this row.
 CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
   const bool lo = (slot == 2 * m), hi = (slot == 2 * m + 1);
-  return make_float4(lo ? e.x : w[2 * m].x, hi ? e.x : w[2 * m + 1].x, lo ? e.y : w[2 * m].y, hi ? e.y : w[2 * m + 1].y);
+  return make_float4(lo ? e.x : w[2 * m].x, lo ? e.y : w[2 * m].y, hi ? e.x : w[2 * m + 1].x, hi ? e.y : w[2 * m + 1].y);
 }
 
 // EXT = true: the controller ran in cdpr_general_ctrl_kernel; forces come from a.force and the state has
@@ -478,8 +479,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
   for (int k = 0; k < (EXT ? 0 : NP); ++k) {
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].z};
-      win[k][2 * m + 1] = (v2f){wraw[k][m].y, wraw[k][m].w};
+      win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].y};      // register pairs as loaded: no moves
+      win[k][2 * m + 1] = (v2f){wraw[k][m].z, wraw[k][m].w};
     }
     ierr[k] = (k & 1) ? (v2f){hraw[k / 2].z, hraw[k / 2].w} : (v2f){hraw[k / 2].x, hraw[k / 2].y};
   }

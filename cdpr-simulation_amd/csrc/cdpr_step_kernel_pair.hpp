@@ -115,8 +115,8 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
   for (int k = 0; k < NPL; ++k) {
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
-      win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].z};
-      win[k][2 * m + 1] = (v2f){wraw[k][m].y, wraw[k][m].w};
+      win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].y};      // register pairs as loaded: no moves
+      win[k][2 * m + 1] = (v2f){wraw[k][m].z, wraw[k][m].w};
     }
   }
   if (NPL == 2) {
