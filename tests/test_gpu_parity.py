@@ -578,3 +578,44 @@ def test_sharded_engine_equals_single_engine(pkg):
         assert np.array_equal(x, y)
     assert many.step_count == one.step_count == 110
     many.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# randomised configurations: every constant the step depends on, not only the shipped ones
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_randomised_model_and_controller_parameters(pkg, oracle, seed):
+    """Random mass / full inertia tensor / gravity direction / damping / effort limit / dt / gains / window length
+    (fast path: N <= 11) / FK iteration count and tolerance / tension bounds, on 4-, 6- and 8-cable robots."""
+    rng = np.random.default_rng(100 + seed)
+    base = pkg.eight_cable_model()
+    n = [4, 6, 8][seed % 3]
+    if n == 4:
+        model = pkg.cube_model()
+    else:
+        keep = list(range(8)) if n == 8 else [0, 1, 2, 3, 4, 6]
+        model = pkg.Model(base.frame_anchors[keep] + rng.uniform(-0.01, 0.01, (n, 3)), base.platform_anchors[keep] * rng.uniform(0.8, 1.3))
+    a = rng.uniform(0.5, 2.0, 3)
+    off = rng.uniform(-0.1, 0.1, 3)
+    model.mass = float(rng.uniform(0.5, 3.0))
+    model.inertia = (a[0], a[1], a[2], off[0], off[1], off[2])  # full symmetric tensor -> gyroscopic term active
+    model.joint_damping = float(rng.uniform(0.0, 3.0))
+    model.effort_limit = float(rng.choice([50.0, 100.0, -1.0]))  # -1: SetForce clamp disabled
+    stages = 0 if n == 4 else int(rng.integers(0, 4))
+    cfg = pkg.Config(model=model, batch=90, stages=stages, dt=float(rng.choice([5e-4, 1e-3, 2e-3])),
+                     gravity=tuple(rng.normal(0, 1, 3) * [1.0, 1.0, 0.2] + [0, 0, -9.8]),
+                     fkMaxIterations=int(rng.integers(1, 7)), fkTolerance=float(rng.choice([0.0, 1e-6])),
+                     tdFMin=float(rng.uniform(1.0, 8.0)), tdFMax=float(rng.uniform(60.0, 150.0)))
+    for p in (cfg.velocityController, cfg.positionController):
+        p.pGain, p.iGain, p.dGain = float(rng.uniform(50, 250)), float(rng.uniform(0, 80)), float(rng.uniform(0, 40)) * (0.05 if p is cfg.velocityController else 1.0)
+        p.dBufferLength = int(rng.integers(3, 12))
+        p.dDegree = int(rng.integers(1, min(3, p.dBufferLength - 1) + 1))
+        p.iLimit, p.cmdLimit = float(rng.uniform(5, 100)), float(rng.uniform(40, 120))
+    cfg.velocityController.forwardGain = float(rng.uniform(0, 20))
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, 90, rng, 0.03, 0.08), rng.uniform(-0.02, 0.02, (90, 6)))
+    script = [("run", 17)]
+    for j in range(6):
+        kind = "vel" if j != 3 else "pos"
+        amp = 0.04 if kind == "vel" else 0.004
+        script += [(kind, rng.uniform(-amp, amp, (90, n)).astype(np.float32)), ("run", 9 + j)]
+    run_script(eng, ora, script, tol=dict(TOL, eff=5e-2, twist=5e-4, qd=5e-4), label=f"seed{seed} n={n} stages={stages}")
