@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
   const size_t st = a.stride;
   const int c0 = (int)par * NL;                         // first cable of this lane
 
+  CDPR_STAMP(0);
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
   const uint32_t off = rr * 16u, woff = r * 16u;
   const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off),
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
   int calls = a.pid_calls;
 
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
+    CDPR_STAMP(1);
     // ---- IK rows of this lane's cables on the state at t_k
     v2f len[NPL], jac[NPL][6], l0[NPL], q[NPL], qd[NPL];
     ik_rows<NPL, false, true>(mylds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
                     fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
     }
 
+    CDPR_STAMP(2);
     // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
     v2f f[NPL], e_new[NPL];
 #pragma unroll
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       }
     }
 
+    CDPR_STAMP(3);
     // ---- Newton-Raphson FK: the two lanes iterate on identical estimates
     v2f applied[NPL];
     float fk_res = 0.f;
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       fk_res = pair_max(fmaxf(rm.x, rm.y));
     }
 
+    CDPR_STAMP(4);
     // ---- tension distribution
     if (TD) {
       v2f df[NPL];
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       d[4] = applied[0].x;
     }
 
+    CDPR_STAMP(5);
     // ---- observables of step t_k: lane 0 writes the platform rows, each lane its own joint group
     if (((a.publish_mask >> step) & 1ull) && live) {
       if (par == 0u) {
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
     }
   }
 
+  CDPR_STAMP(6);
   // ---- store (platform rows split between the two lanes)
   const float oi_final0 = partner(ierr[0].x), oi_final1 = partner(ierr[0].y);
   if (live) {
@@ -370,6 +377,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       }
     }
   }
+  CDPR_STAMP(7);
 }
 
 }  // namespace cdpr

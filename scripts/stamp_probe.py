@@ -1,6 +1,6 @@
 """Diagnostic: where does one launch of the one-step kernel spend its time? (s_memrealtime stamps per wave)"""
 import os, sys, ctypes as C
-os.environ["CDPR_LIB"] = "libcdpr_hip_stamps.so"; os.environ["CDPR_MAPPING"] = "1"
+os.environ["CDPR_LIB"] = "libcdpr_hip_stamps.so"; os.environ["CDPR_MAPPING"] = os.environ.get("MAPSEL", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -12,7 +12,7 @@ for stages in (3, 0):
     model, pose, command, n_cmd = bench.make_workload(pkg, B, n, 1235, 10)
     eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=stages), 0)
     eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
-    nb = B // 64
+    nb = B // (64 if os.environ.get("MAPSEL","1")=="1" else 32)
     buf = np.zeros((nb, 8), dtype=np.uint64)
     dptr = eng.device_upload(buf)
     L.cdpr_debug_set_stamps(eng._h, C.c_void_p(dptr))
