@@ -619,3 +619,48 @@ def test_randomised_model_and_controller_parameters(pkg, oracle, seed):
         amp = 0.04 if kind == "vel" else 0.004
         script += [(kind, rng.uniform(-amp, amp, (90, n)).astype(np.float32)), ("run", 9 + j)]
     run_script(eng, ora, script, tol=dict(TOL, eff=5e-2, twist=5e-4, qd=5e-4), label=f"seed{seed} n={n} stages={stages}")
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's other stimulus publishers, end to end through the facade
+# ---------------------------------------------------------------------------------------------
+def test_square_position_publisher_end_to_end(pkg, oracle):
+    """squarepositiontest.cpp: 10 Hz square wave of +-0.05 m on jointPositions -> Position mode, position Pid
+    (200 / 70 / 80), 100 world steps per command sample."""
+    cfg = pkg.Config(batch=1)
+    plug = pkg.CdprGazeboPlugin()
+    plug.Load(cfg)
+    ora = oracle.OracleSim(cfg.to_struct())
+    gen = pkg.stimulus.square_position(4, amp=0.01)  # 0.05 m would rail the 100 N effort limit for most of the run
+    last = []
+    plug.bus.subscribe("jointStates", last.append)
+    for k in range(12):
+        cmd = next(gen)
+        plug.bus.publish("jointPositions", pkg.Joy(axes=cmd))
+        ora.set_position_command(cmd)
+        plug.update(100), ora.update(100)
+    oq, oqd, oe = ora.joint_states()
+    assert np.abs(last[-1].position - oq).max() < TOL["q"] and np.abs(last[-1].effort - oe).max() < 5e-2
+    assert np.all(last[-1].effort > 0.0)  # pulling towards the commanded (shorter) lengths against gravity
+
+
+def test_square_velocity_publisher_with_position_hold(pkg, oracle):
+    """squarevelocitytest.cpp (+-0.06 m/s gated by |sin| >= sqrt(1/2), else 0) with a POSITIVE velocityEpsilon: during
+    the zero phases JointForceCalculator holds the last position with the position Pid (JFC.cpp:78-82) — the branch
+    that is dead at the shipped epsilon of -0.001."""
+    cfg = pkg.Config(batch=2, velocityEpsilon=0.001)
+    plug = pkg.CdprGazeboPlugin()
+    plug.Load(cfg)
+    ora = oracle.OracleSim(cfg.to_struct())
+    gen = pkg.stimulus.square_velocity(4, amp=0.02)
+    got = []
+    plug.bus.subscribe("platformPose", got.append)
+    for k in range(60):  # 6 s: zero phase, +0.02 phase, zero phase (hold), ...
+        cmd = next(gen)
+        plug.bus.publish("jointVelocities", pkg.Joy(axes=cmd))
+        ora.set_velocity_command(cmd)
+        plug.update(100), ora.update(100)
+        if k % 10 == 9:
+            op, ot = ora.platform_state()
+            assert np.abs(got[-1].pose.position - op[:, :3]).max() < TOL["pose"], k
+            assert np.abs(plug.engine.joint_states()[2] - ora.joint_states()[2]).max() < 5e-2, k
