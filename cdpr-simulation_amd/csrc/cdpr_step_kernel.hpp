@@ -393,12 +393,16 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
   return make_float4(lo ? e.x : w[2 * m].x, lo ? e.y : w[2 * m].y, hi ? e.x : w[2 * m + 1].x, hi ? e.y : w[2 * m + 1].y);
 }
 
+#ifndef CDPR_LPR_WAVES
+#define CDPR_LPR_WAVES 1  // minimum waves per SIMD the lane-per-robot kernel is compiled for (register budget 512 / this)
+#endif
+
 // EXT = true: the controller ran in cdpr_general_ctrl_kernel; forces come from a.force and the state has
 // no controller records (platform slots only).
 // ROLLOUT = true: MPC fan-out (BASELINE config 5): one lane = one (robot, sampled command sequence); the robot's
 // current state is the common start, commands change every step, state never leaves the chip.
 template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false>
-__global__ __launch_bounds__(64) void cdpr_step_kernel(const StepArgs a) {
+__global__ __launch_bounds__(64, CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
   constexpr int G = joint_groups(N);
