@@ -664,3 +664,20 @@ def test_square_velocity_publisher_with_position_hold(pkg, oracle):
             op, ot = ora.platform_state()
             assert np.abs(got[-1].pose.position - op[:, :3]).max() < TOL["pose"], k
             assert np.abs(plug.engine.joint_states()[2] - ora.joint_states()[2]).max() < 5e-2, k
+
+
+def test_long_horizon_stays_on_the_oracle(pkg, oracle):
+    """20 000 world steps (20 s of sim time) of the sine stimulus: fp32 rounding must not accumulate into drift — the
+    ring window, the call counter folding (pid_calls -> [60, 70)) and the hipGraph replay all cycle thousands of times."""
+    cfg = pkg.Config(batch=6)
+    eng, ora = pair(pkg, oracle, cfg)
+    gen = pkg.stimulus.sine_velocity(4)
+    for k in range(200):
+        cmd = next(gen)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        eng.update(100), ora.update(100)
+        for _ in range(99):
+            next(gen)  # the publisher ticks every 10 ms; this test latches one sample per 100 ms
+        if k % 40 == 39:
+            compare(eng, ora, tol=dict(TOL, pose=5e-5, q=5e-5), where=f"t = {(k + 1) * 0.1:.1f} s")
+    assert eng.step_count == 20000
