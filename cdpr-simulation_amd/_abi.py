@@ -62,6 +62,9 @@ class ConfigStruct(C.Structure):
         ("gravity", C.c_double * 3),
         ("joint_damping", C.c_double),
         ("effort_limit", C.c_double),
+        ("velocity_limit", C.c_double),
+        ("unilateral_cables", C.c_uint32),
+        ("reserved2_", C.c_uint32),
         ("velocity_pid", PidParams),
         ("position_pid", PidParams),
         ("velocity_epsilon", C.c_double),

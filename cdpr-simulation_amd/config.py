@@ -60,6 +60,8 @@ class Model:
     inertia: Sequence[float] = (1.0, 1.0, 1.0, 0.0, 0.0, 0.0)  # ixx iyy izz ixy ixz iyz, cube.sdf:332-339
     joint_damping: float = 1.0  # cube.sdf:442 / cube.yaml:9
     effort_limit: float = 100.0  # cube.sdf:438 / cube.yaml:9
+    velocity_limit: float = -1.0  # cube.sdf:439 has 10; < 0 = not modelled (the contract's reduced model)
+    unilateral_cables: bool = False  # [NEW] option: cables cannot push
     f_min: float = 5.0  # cube.yaml:9 `min`
     f_max: float = 100.0  # cube.yaml:9 `effort`
 
@@ -245,6 +247,8 @@ class Config:
             s.gravity[k] = float(self.gravity[k])
         s.joint_damping = float(m.joint_damping)
         s.effort_limit = float(m.effort_limit)
+        s.velocity_limit = float(m.velocity_limit)
+        s.unilateral_cables = 1 if m.unilateral_cables else 0
         _fill_pid(s.velocity_pid, self.velocityController)
         _fill_pid(s.position_pid, self.effective_position_pid())
         s.velocity_epsilon = float(self.velocityEpsilon)

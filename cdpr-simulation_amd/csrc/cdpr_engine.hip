@@ -246,6 +246,8 @@ void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   }
   k.damping = (float)c.joint_damping;
   k.effort = (float)c.effort_limit;
+  k.vel_limit = (float)c.velocity_limit;
+  k.unilateral = c.unilateral_cables ? 1 : 0;
   k.fk_lambda = (float)c.fk_lambda;
   k.fk_tol = (float)c.fk_tolerance;
   k.fk_iters = (int)c.fk_max_iterations;

@@ -76,6 +76,8 @@ struct StepArgs {
   float dt, half_dt, dt_inv_mass, fgx, fgy, fgz;  // fg = m * g
   float ib[6], ibinv[6];                           // body inertia and inverse: xx yy zz xy xz yz
   float damping, effort;                           // joint damping; SetForce clamp (effort < 0: none)
+  float vel_limit;                                 // SetForce velocity truncation (<= 0: none)
+  int unilateral;                                  // cables cannot push
   // FK / TD ([NEW] stages)
   float fk_lambda, fk_tol;
   int fk_iters;
@@ -687,6 +689,13 @@ __global__ __launch_bounds__(64, CDPR_LPR_WAVES) void cdpr_step_kernel(const Ste
 #pragma unroll
       for (int k = 0; k < NP; ++k) applied[k] = f[k];
     }
+    if (a.vel_limit > 0.f) {  // Joint::SetForce velocity truncation [EXT]: no pushing a runaway joint further out
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        applied[k].x = (qd[k].x > a.vel_limit && applied[k].x > 0.f) || (qd[k].x < -a.vel_limit && applied[k].x < 0.f) ? 0.f : applied[k].x;
+        applied[k].y = (qd[k].y > a.vel_limit && applied[k].y > 0.f) || (qd[k].y < -a.vel_limit && applied[k].y < 0.f) ? 0.f : applied[k].y;
+      }
+    }
     if (a.effort >= 0.f) {  // Joint::SetForce clamp (cube.sdf:438)
 #pragma unroll
       for (int k = 0; k < NP; ++k) applied[k] = max2(min2(applied[k], splat(a.effort)), splat(-a.effort));
@@ -725,7 +734,10 @@ __global__ __launch_bounds__(64, CDPR_LPR_WAVES) void cdpr_step_kernel(const Ste
     {
       v2f tens[NP];
 #pragma unroll
-      for (int k = 0; k < NP; ++k) tens[k] = fma2(-a.damping, qd[k], applied[k]);
+      for (int k = 0; k < NP; ++k) {
+        tens[k] = fma2(-a.damping, qd[k], applied[k]);
+        if (a.unilateral) tens[k] = max2(tens[k], splat(0.f));  // [NEW] option: a cable cannot push
+      }
       float w[6];
       jt_times<NP>(jac, tens, w);
       w[0] = a.fgx - w[0];

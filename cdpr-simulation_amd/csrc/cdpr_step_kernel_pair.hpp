@@ -291,6 +291,13 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
 #pragma unroll
       for (int k = 0; k < NPL; ++k) applied[k] = f[k];
     }
+    if (a.vel_limit > 0.f) {  // Joint::SetForce velocity truncation [EXT]: no pushing a runaway joint further out
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        applied[k].x = (qd[k].x > a.vel_limit && applied[k].x > 0.f) || (qd[k].x < -a.vel_limit && applied[k].x < 0.f) ? 0.f : applied[k].x;
+        applied[k].y = (qd[k].y > a.vel_limit && applied[k].y > 0.f) || (qd[k].y < -a.vel_limit && applied[k].y < 0.f) ? 0.f : applied[k].y;
+      }
+    }
     if (a.effort >= 0.f) {
 #pragma unroll
       for (int k = 0; k < NPL; ++k) applied[k] = max2(min2(applied[k], splat(a.effort)), splat(-a.effort));
@@ -338,7 +345,10 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
     {
       v2f tens[NPL];
 #pragma unroll
-      for (int k = 0; k < NPL; ++k) tens[k] = fma2(-a.damping, qd[k], applied[k]);
+      for (int k = 0; k < NPL; ++k) {
+        tens[k] = fma2(-a.damping, qd[k], applied[k]);
+        if (a.unilateral) tens[k] = max2(tens[k], splat(0.f));  // [NEW] option: a cable cannot push
+      }
       float w[6];
       jt_times_shared<NPL>(jac, tens, w);
       w[0] = a.fgx - w[0];

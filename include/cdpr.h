@@ -106,6 +106,11 @@ typedef struct cdpr_config {
   double gravity[3];                /* frame coords; Gazebo default (0,0,-9.8) */
   double joint_damping;             /* cube.sdf:442 actuated-joint damping */
   double effort_limit;              /* cube.sdf:438; Joint::SetForce clamp; < 0 disables */
+  double velocity_limit;            /* cube.sdf:439 (10); Joint::SetForce drops a force that pushes a joint already past
+                                       +-limit further out [EXT Gazebo]; <= 0 disables (the contract's reduced model,
+                                       and what a zero-initialised struct gets) */
+  uint32_t unilateral_cables;       /* 1: a cable cannot push, axial force max(T, 0) ([NEW]; the reference has no slack model) */
+  uint32_t reserved2_;
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */

@@ -733,7 +733,15 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
   } else {
     for (unsigned i = 0; i < n; ++i) applied[i] = f[i];
   }
-  /* Joint::SetForce clamps to the effort limit (cube.sdf:438) [EXT] */
+  /* Joint::SetForce -> CheckAndTruncateForce [EXT]: a force that drives a joint already beyond its velocity limit
+   * further out is dropped, then the effort limit clamps (cube.sdf:438-439) */
+  if (cfg->velocity_limit > 0.0)
+    for (unsigned i = 0; i < n; ++i) {
+      if (qd[i] > cfg->velocity_limit)
+        applied[i] = applied[i] > 0 ? 0.0 : applied[i];
+      else if (qd[i] < -cfg->velocity_limit)
+        applied[i] = applied[i] < 0 ? 0.0 : applied[i];
+    }
   if (cfg->effort_limit >= 0.0)
     for (unsigned i = 0; i < n; ++i) applied[i] = clampd(applied[i], -cfg->effort_limit, cfg->effort_limit);
   r->dbg[4] = (float)applied[0]; /* PLG.cpp:226 */
@@ -752,6 +760,7 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
   double w[6] = {cfg->mass * cfg->gravity[0], cfg->mass * cfg->gravity[1], cfg->mass * cfg->gravity[2], 0, 0, 0};
   for (unsigned i = 0; i < n; ++i) {
     double t = applied[i] - cfg->joint_damping * qd[i];
+    if (cfg->unilateral_cables && t < 0.0) t = 0.0; /* [NEW] option: a cable cannot push */
     for (int a = 0; a < 6; ++a) w[a] -= jac[i * 6 + a] * t;
   }
   double rm[9];

@@ -681,3 +681,25 @@ def test_long_horizon_stays_on_the_oracle(pkg, oracle):
         if k % 40 == 39:
             compare(eng, ora, tol=dict(TOL, pose=5e-5, q=5e-5), where=f"t = {(k + 1) * 0.1:.1f} s")
     assert eng.step_count == 20000
+
+
+def test_optional_physics_terms_velocity_limit_and_unilateral_cables(pkg, oracle):
+    """SURVEY 8(f) rank 3, two optional terms: Joint::SetForce's velocity truncation [EXT] and cables that cannot push
+    [NEW].  Both must actually change the run (vs the reduced model) and still match the oracle."""
+    B = 80
+    rng = np.random.default_rng(61)
+    results = {}
+    for name, vlim, uni in (("reduced", -1.0, False), ("both", 0.01, True)):
+        model = pkg.cube_model()
+        model.velocity_limit, model.unilateral_cables = vlim, uni
+        cfg = pkg.Config(model=model, batch=B)
+        rng2 = np.random.default_rng(61)
+        eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng2, 0.03, 0.08))
+        script = [("run", 20)]
+        for j in range(8):
+            script += [("vel", rng2.uniform(-0.05, 0.05, (B, 4)).astype(np.float32)), ("run", 15)]
+        run_script(eng, ora, script, tol=dict(TOL, eff=5e-2), label=name)
+        results[name] = eng.platform_state()[0]
+    assert np.abs(results["both"] - results["reduced"]).max() > 1e-4  # the options were exercised
+    z = pkg.Config().to_struct()
+    assert z.velocity_limit <= 0 and z.unilateral_cables == 0  # off by default: the contract's reduced model
