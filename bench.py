@@ -52,24 +52,44 @@ def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
     return model, pose.astype(np.float32), command, n_cmd
 
 
+def effective_cpu_count():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (on the GPU box
+    `nproc` says 256 while cpu.max grants 16; spinning 256 OpenMP threads on 16 CPUs throttles them all)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
     """Time the fp64 oracle ("port" of the reference step) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
 
-    cores = oracle.lib().orc_max_threads()
+    cores = min(oracle.lib().orc_max_threads(), effective_cpu_count())
     sample_b = min(pose.shape[0], 512 * cores)
 
-    def run(nsteps):
-        cfg = pkg.Config(batch=sample_b, **cfg_kwargs)
+    def run(nsteps, nb=None, threads=None):
+        nb = sample_b if nb is None else nb
+        cfg = pkg.Config(batch=nb, **cfg_kwargs)
         sim = oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
-        sim.set_platform_state(pose7=pose[:sample_b].astype(np.float64))
+        sim.set_platform_state(pose7=pose[:nb].astype(np.float64))
         t0 = time.perf_counter()
         done = 0
         while done < nsteps:
-            sim.set_velocity_command(command(done // refresh)[:sample_b])
+            sim.set_velocity_command(command(done // refresh)[:nb])
             k = min(refresh, nsteps - done)
-            sim.update(k, cores)
+            sim.update(k, cores if threads is None else threads)
             done += k
         dt_ = time.perf_counter() - t0
         sim.close()
@@ -80,8 +100,11 @@ def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
     rate = sample_b * probe_steps / t_probe
     nsteps = int(max(refresh, min(2000, target_seconds * rate / sample_b)))
     t = run(nsteps)
+    one_b, one_steps = 256, 100  # single-core figure on a small sample (about 1 s)
+    t1 = run(one_steps, one_b, 1)
     return {
         "value": sample_b * nsteps / t,
+        "value_1core": one_b * one_steps / t1,
         "unit": "state-steps/s",
         "cores": int(cores),
         "kind": "port",
