@@ -23,6 +23,13 @@ def mapping(request, monkeypatch):
     return request.param
 
 
+def once(mapping):
+    """For code paths that do not depend on the wavefront mapping (general controller path, one-shot solvers,
+    rollout): run them under one fixture value only."""
+    if mapping != "lane_per_robot":
+        pytest.skip("independent of the wavefront mapping: run once")
+
+
 def compare(eng, ora, tol=TOL, where=""):
     gp, gt = eng.platform_state()
     op, ot = ora.platform_state()
@@ -128,8 +135,9 @@ def test_config3_eight_cable_stage_combinations(pkg, oracle, stages):
         assert gt.min() >= 5.0 and gt.max() <= 100.0
 
 
-def test_six_and_seven_cable_robots(pkg, oracle):
+def test_six_and_seven_cable_robots(pkg, oracle, mapping):
     """Cable counts between the shipped 4 and the build-defined 8 (drop cables from the 8-cable layout)."""
+    once(mapping)
     full = pkg.eight_cable_model()
     for keep in ([0, 1, 2, 3, 4, 6], [0, 1, 2, 3, 4, 5, 6]):
         m = pkg.Model(full.frame_anchors[keep], full.platform_anchors[keep])
@@ -327,9 +335,10 @@ def run_script(eng, ora, script, tol=TOL, label=""):
             compare(eng, ora, tol=tol, where=f"{label} after run {val}")
 
 
-def test_general_path_position_hold_branch(pkg, oracle):
+def test_general_path_position_hold_branch(pkg, oracle, mapping):
     """velocityEpsilon > 0: cables whose |target| <= eps hold position with the POSITION Pid while the others keep
     their velocity Pid (JFC.cpp:72-82); both Pids stay alive and are sampled at non-uniform times."""
+    once(mapping)
     B = 50
     rng = np.random.default_rng(21)
     cfg = pkg.Config(batch=B, velocityEpsilon=0.01)
@@ -344,8 +353,9 @@ def test_general_path_position_hold_branch(pkg, oracle):
 
 
 @pytest.mark.parametrize("cascade", [1, 2])
-def test_general_path_biquad_cascades(pkg, oracle, cascade):
+def test_general_path_biquad_cascades(pkg, oracle, cascade, mapping):
     """P and D inputs of the velocity Pid through 1 or 2 low-pass biquads (Pid.cpp:27-44, Filter.h:130-165)."""
+    once(mapping)
     B = 40
     rng = np.random.default_rng(22 + cascade)
     cfg = pkg.Config(batch=B)
@@ -375,7 +385,8 @@ def test_general_path_biquad_cascades(pkg, oracle, cascade):
 
 
 @pytest.mark.parametrize("nbuf,deg", [(21, 3), (32, 4), (5, 1)])
-def test_general_path_long_windows_and_degrees(pkg, oracle, nbuf, deg):
+def test_general_path_long_windows_and_degrees(pkg, oracle, nbuf, deg, mapping):
+    once(mapping)
     B = 30
     rng = np.random.default_rng(nbuf)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, velocityEpsilon=0.0)
@@ -386,9 +397,10 @@ def test_general_path_long_windows_and_degrees(pkg, oracle, nbuf, deg):
     run_script(eng, ora, script, tol=dict(TOL, eff=5e-2), label=f"N{nbuf}d{deg}")
 
 
-def test_general_path_command_clamp_disabled(pkg, oracle):
+def test_general_path_command_clamp_disabled(pkg, oracle, mapping):
     """cmdLimit = 0: mCmdMax == mCmdMin, so mCmd keeps its old value and the anti-windup branch integrates it
     (Pid.cpp:175-186) — a reference quirk the general path reproduces."""
+    once(mapping)
     cfg = pkg.Config(batch=8)
     cfg.velocityController.cmdLimit = 0.0
     eng, ora = pair(pkg, oracle, cfg)
@@ -417,7 +429,8 @@ def test_general_and_fast_path_agree_on_the_shipped_config(pkg, oracle):
 # one-shot solvers (cdpr_solve_ik / cdpr_solve_fk / cdpr_solve_td)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("model_name", ["cube", "eight"])
-def test_solve_ik_matches_oracle(pkg, oracle, model_name):
+def test_solve_ik_matches_oracle(pkg, oracle, model_name, mapping):
+    once(mapping)
     model = pkg.cube_model() if model_name == "cube" else pkg.eight_cable_model()
     B = 133
     rng = np.random.default_rng(3)
@@ -434,8 +447,9 @@ def test_solve_ik_matches_oracle(pkg, oracle, model_name):
     assert np.array_equal(q, q2)
 
 
-def test_solve_fk_round_trip_and_oracle(pkg, oracle):
+def test_solve_fk_round_trip_and_oracle(pkg, oracle, mapping):
     """FK(IK(x)) = x on random poses, iteration counts equal to the oracle's (tolerance-controlled early exit)."""
+    once(mapping)
     B = 500
     rng = np.random.default_rng(14)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=1, fkMaxIterations=8, fkTolerance=1e-6)
@@ -455,7 +469,8 @@ def test_solve_fk_round_trip_and_oracle(pkg, oracle):
     assert np.all(it0 == 0) and res0.max() < 1e-6  # already converged at the seed: no iteration taken
 
 
-def test_solve_td_matches_oracle_and_flags_infeasible(pkg, oracle):
+def test_solve_td_matches_oracle_and_flags_infeasible(pkg, oracle, mapping):
+    once(mapping)
     B = 96
     rng = np.random.default_rng(15)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=2)
@@ -475,7 +490,8 @@ def test_solve_td_matches_oracle_and_flags_infeasible(pkg, oracle):
     assert flag[-1] == 1 and flag[:-1].sum() == 0 and t.min() >= 5.0 and t.max() <= 100.0
 
 
-def test_solvers_reject_robots_with_fewer_than_six_cables(pkg):
+def test_solvers_reject_robots_with_fewer_than_six_cables(pkg, mapping):
+    once(mapping)
     eng = pkg.Engine(pkg.Config(batch=4), 0)
     with pytest.raises(pkg.CdprError) as ei:
         eng.solve_fk(np.ones((4, 4)), np.tile(pkg.cube_model().home_pose(), (4, 1)))
@@ -510,7 +526,8 @@ def test_graph_replay_is_bit_identical_to_eager_launches(pkg):
 # MPC rollout (BASELINE config 5)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("start_mode", ["position", "velocity"])
-def test_rollout_velocity_matches_oracle_and_leaves_state_untouched(pkg, oracle, start_mode):
+def test_rollout_velocity_matches_oracle_and_leaves_state_untouched(pkg, oracle, start_mode, mapping):
+    once(mapping)
     B, S, H = 12, 16, 24
     rng = np.random.default_rng(1236)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
@@ -536,8 +553,9 @@ def test_rollout_velocity_matches_oracle_and_leaves_state_untouched(pkg, oracle,
     compare(eng, ora, where="after rollout")
 
 
-def test_rollout_of_identical_samples_equals_plain_stepping(pkg):
+def test_rollout_of_identical_samples_equals_plain_stepping(pkg, mapping):
     """Size-independent property: S copies of one command sequence give S equal costs, equal to stepping the engine."""
+    once(mapping)
     B, S, H = 130, 4, 20
     rng = np.random.default_rng(5)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
@@ -556,9 +574,10 @@ def test_rollout_of_identical_samples_equals_plain_stepping(pkg):
     assert np.abs(cost[:, 0] - acc).max() < 1e-4 * acc.max()
 
 
-def test_sharded_engine_equals_single_engine(pkg):
+def test_sharded_engine_equals_single_engine(pkg, mapping):
     """Config-4 style placement in one process: contiguous robot blocks on several handles (here all on GPU 0, the box
     has one), no exchange between them; result identical to one handle holding the whole batch."""
+    once(mapping)
     B = 333
     rng = np.random.default_rng(44)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, mapping=pkg._abi.MAP_LANE_PER_ROBOT)
@@ -644,10 +663,11 @@ def test_square_position_publisher_end_to_end(pkg, oracle):
     assert np.all(last[-1].effort > 0.0)  # pulling towards the commanded (shorter) lengths against gravity
 
 
-def test_square_velocity_publisher_with_position_hold(pkg, oracle):
+def test_square_velocity_publisher_with_position_hold(pkg, oracle, mapping):
     """squarevelocitytest.cpp (+-0.06 m/s gated by |sin| >= sqrt(1/2), else 0) with a POSITIVE velocityEpsilon: during
     the zero phases JointForceCalculator holds the last position with the position Pid (JFC.cpp:78-82) — the branch
     that is dead at the shipped epsilon of -0.001."""
+    once(mapping)
     cfg = pkg.Config(batch=2, velocityEpsilon=0.001)
     plug = pkg.CdprGazeboPlugin()
     plug.Load(cfg)
