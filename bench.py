@@ -262,13 +262,13 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"config3: {args.batch} x {n}-cable robots per GPU, "
+                "workload": f"{'config3' if n == 8 else 'config2'}: {args.batch} x {n}-cable robots per GPU, "
                             + ("IK + NR-FK(4 it) + tension distribution + PID + dynamics" if n == 8 else "IK + PID + dynamics")
                             + ", observables every step, commands refreshed every 10 steps from HBM",
                 "robots_per_gpu": args.batch,
                 "cables": n,
                 "steps_per_launch": args.steps_per_launch,
-                "mapping": "lane-per-robot",
+                "mapping": eng.mapping,
                 "state_finite": finite,
             },
             "roofline": {

@@ -961,6 +961,8 @@ int cdpr_synchronize(cdpr_handle_t h) {
   return CDPR_OK;
 }
 
+uint32_t cdpr_mapping(cdpr_handle_t h) { return !h ? CDPR_MAP_AUTO : (h->lane_pair ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT); }
+
 uint64_t cdpr_step_count(cdpr_handle_t h) { return h ? h->step : 0; }
 
 int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, float* effort) {

@@ -108,6 +108,10 @@ class Engine:
         return int(lib().cdpr_step_count(self._h))
 
     @property
+    def mapping(self) -> str:
+        return {_abi.MAP_LANE_PER_ROBOT: "lane-per-robot", _abi.MAP_LANE_PAIR: "lane-pair"}.get(int(lib().cdpr_mapping(self._h)), "auto")
+
+    @property
     def sim_time(self) -> float:
         return self.step_count * self.config.dt
 

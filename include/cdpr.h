@@ -176,6 +176,7 @@ int cdpr_update(cdpr_handle_t h, int nsteps);
  * (state stays on chip between them; observables still written every step). */
 int cdpr_update_fused(cdpr_handle_t h, int nsteps, int steps_per_launch);
 int cdpr_synchronize(cdpr_handle_t h);
+uint32_t cdpr_mapping(cdpr_handle_t h);              /* CDPR_MAP_* actually in use (what CDPR_MAP_AUTO resolved to) */
 uint64_t cdpr_step_count(cdpr_handle_t h);           /* world steps since create/reset; sim time = count * dt */
 
 /* Replaces publishJointStates (PLG.cpp:248-256): sensor_msgs/JointState
