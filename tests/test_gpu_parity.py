@@ -723,3 +723,20 @@ def test_optional_physics_terms_velocity_limit_and_unilateral_cables(pkg, oracle
     assert np.abs(results["both"] - results["reduced"]).max() > 1e-4  # the options were exercised
     z = pkg.Config().to_struct()
     assert z.velocity_limit <= 0 and z.unilateral_cables == 0  # off by default: the contract's reduced model
+
+
+def test_matches_the_reference_style_fit_while_it_is_accurate(pkg, oracle, mapping):
+    """The oracle's FAITHFUL mode evaluates Pid::fitPolynomial exactly as the reference writes it (normal equations in
+    absolute sim time, pow(), pivoted QR; Pid.cpp:219-247).  That fit is accurate for t <~ 2 s and degrades after
+    (tests/test_oracle_pid.py); inside that window the GPU's closed-form FIR must agree with it too."""
+    once(mapping)
+    cfg = pkg.Config(batch=2)
+    eng = pkg.Engine(cfg, 0)
+    ora = oracle.OracleSim(cfg.to_struct(), oracle.DERIV_FAITHFUL)
+    gen = pkg.stimulus.sine_velocity(4)
+    for k in range(200):  # 2 s
+        cmd = next(gen)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        eng.update(10), ora.update(10)
+        if k % 25 == 24:
+            compare(eng, ora, where=f"faithful, t = {(k + 1) * 0.01:.2f} s")
