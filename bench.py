@@ -28,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide
+# flop per state-step counted from the gfx950 ISA of the shipped kernels
+FLOP_PER_STATE_STEP = {8: 6325, 4: 648}
 
 
 def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
@@ -206,6 +209,8 @@ def main():
             "kernel_us": ms2 * 1e3 / max(launches2, 1),
             "bytes_per_state_step": bytes_launch / spl,
             "achieved_GBps": bytes_launch * args.batch / (ms2 * 1e-3 / max(launches2, 1)) / 1e9,
+            "f32_tflops": args.batch * steps2 / el2 * FLOP_PER_STATE_STEP[n] / 1e12,
+            "f32_vector_frac": args.batch * steps2 / el2 * FLOP_PER_STATE_STEP[n] / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
             "note": "compute (f32 VALU) bound: state never leaves the registers between the fused steps",
         }
         # (b) MPC rollout, one GPU's share of BASELINE config 5: 512 robots x 128 samples x 64 steps
@@ -233,6 +238,8 @@ def main():
                 "value": Br * S * H / elr,
                 "unit": "state-steps/s",
                 "ms_per_rollout": elr * 1e3,
+                "f32_tflops": Br * S * H / elr * FLOP_PER_STATE_STEP[n] / 1e12,
+                "f32_vector_frac": Br * S * H / elr * FLOP_PER_STATE_STEP[n] / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                 "cost_finite": bool(np.isfinite(cost).all()),
             }
 
