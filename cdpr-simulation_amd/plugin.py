@@ -149,7 +149,9 @@ class CdprGazeboPlugin:
             eng.set_position_command(self.mPositionCommand.axes)
             self.mPositionCommandReceived = False
         first = eng.step_count
-        eng.update(nsteps)
+        # several world steps under one held command: fuse them into launches of up to 16 steps (state stays on chip
+        # between them; bit-identical to single-step launches, tests/test_gpu_parity.py)
+        eng.update(nsteps, min(max(nsteps, 1), 16))
         # stamps of the steps just run: t_k = k * dt; the engine applied the same
         # throttle on the device (PLG.cpp:236-242), here it gates the host-side publish
         now = (first + nsteps - 1) * self.config.dt
