@@ -8,7 +8,8 @@
 // Design points (evidence in profiles/ and DESIGN.md):
 //   * cables are processed in PAIRS held in float2 registers so the per-cable math (IK rows,
 //     FIR windows, J^T J / J^T r partial sums, wrench accumulation) issues as v_pk_fma_f32 /
-//     v_pk_mul_f32: two cables per VALU instruction, the only way to the f32 vector peak;
+//     v_pk_mul_f32: two cables per VALU instruction.  A packed f32 op holds the SIMD 4 cycles, so this halves
+//     the ISSUE slots, not the ALU cycles — which is what counts with one wave per SIMD (4-cycle issue);
 //   * every multiply-add is an explicit fma (the file is compiled with -ffp-contract=off), so
 //     the one-step and the fused multi-step instantiations perform bit-identical arithmetic;
 //   * the per-cable geometry (a_i, b_i, L0_i: 7n constants) is staged once per wave in LDS,
