@@ -98,6 +98,15 @@ class ShardedEngine:
         parts = [getattr(e, name)() for e in self.engines]
         return tuple(np.concatenate([p[k] for p in parts]) for k in range(len(parts[0])))
 
+    def rollout_velocity(self, commands, ref_position):
+        """MPC fan-out over all devices (BASELINE config 5: 4 096 robots x 128 samples x 64 steps, 512 robots per GPU):
+        commands[B, H, S, n], ref_position[B, 3] -> cost[B, S].  Each device rolls out its own robots."""
+        import numpy as np
+
+        c = np.asarray(commands, dtype=np.float32)
+        ref = np.asarray(ref_position, dtype=np.float32).reshape(self.B, 3)
+        return np.concatenate([e.rollout_velocity(c[lo:hi], ref[lo:hi]) for e, (lo, hi) in zip(self.engines, self.spans)])
+
     def joint_states(self):
         return self._gather("joint_states")
 

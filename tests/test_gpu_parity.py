@@ -596,6 +596,9 @@ def test_sharded_engine_equals_single_engine(pkg, mapping):
     for x, y in zip(one.raw_state() + one.joint_states() + one.fk_state(), many.raw_state() + many.joint_states() + many.fk_state()):
         assert np.array_equal(x, y)
     assert many.step_count == one.step_count == 110
+    cmds = rng.uniform(-0.03, 0.03, (B, 6, 3, 8)).astype(np.float32)
+    ref = np.zeros((B, 3), dtype=np.float32)
+    assert np.array_equal(one.rollout_velocity(cmds, ref), many.rollout_velocity(cmds, ref))
     many.close()
 
 
