@@ -17,7 +17,7 @@ EXPORTS = [
     "cdpr_abi_version", "cdpr_config_size", "cdpr_device_count", "cdpr_bytes_per_state_step", "cdpr_derivative_weights",
     "cdpr_create", "cdpr_destroy", "cdpr_reset", "cdpr_last_error", "cdpr_set_platform_state",
     "cdpr_set_velocity_command", "cdpr_set_position_command", "cdpr_set_velocity_command_device",
-    "cdpr_set_position_command_device", "cdpr_update", "cdpr_update_fused", "cdpr_synchronize", "cdpr_mapping", "cdpr_step_count",
+    "cdpr_set_position_command_device", "cdpr_update", "cdpr_update_fused", "cdpr_observable_image_bytes", "cdpr_update_record", "cdpr_decode_observables", "cdpr_synchronize", "cdpr_mapping", "cdpr_step_count",
     "cdpr_get_joint_states", "cdpr_get_platform_state", "cdpr_get_pid_debug", "cdpr_get_fk_state", "cdpr_get_td_state",
     "cdpr_get_raw_state", "cdpr_rollout_velocity", "cdpr_device_malloc", "cdpr_device_free", "cdpr_device_upload", "cdpr_device_download",
     "cdpr_profile_begin", "cdpr_profile_end", "cdpr_solve_ik", "cdpr_solve_fk", "cdpr_solve_td",
@@ -63,6 +63,9 @@ def lib():
         getattr(L, name).argtypes = [H, C.c_void_p, C.c_size_t]
     L.cdpr_update.argtypes = [H, C.c_int]
     L.cdpr_update_fused.argtypes = [H, C.c_int, C.c_int]
+    L.cdpr_observable_image_bytes.argtypes = [H, C.POINTER(C.c_size_t)]
+    L.cdpr_update_record.argtypes = [H, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.cdpr_decode_observables.argtypes = [H, C.c_void_p, fp, fp, fp, fp, fp]
     L.cdpr_synchronize.argtypes = [H]
     L.cdpr_mapping.argtypes = [H]
     L.cdpr_mapping.restype = C.c_uint32

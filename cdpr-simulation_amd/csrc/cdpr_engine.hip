@@ -582,7 +582,7 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
   return CDPR_OK;
 }
 
-int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
+int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullptr) {
   if (!h) return CDPR_ERR_INVALID;
   if (nsteps < 0 || per_launch < 1 || per_launch > 64) {
     h->err = "nsteps must be >= 0 and steps_per_launch in 1..64";
@@ -626,6 +626,9 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
   a.geom = h->d_geom;
   a.batch = h->batch;
   a.stride = h->stride;
+  // trajectory record: the observable image of step j of the call goes to record + j * n_obs * stride
+  const size_t image = (size_t)h->n_obs * h->stride;
+  a.obs_step_stride = record ? image : 0;
   if (h->mode == kModeVelocity) {
     copy_pid(h->pid_vel, a);
     a.cmd = h->d_vel[0];
@@ -656,7 +659,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     // hide the host launch and the replay's fixed cost makes it 2 % slower, so only small batches use it)
     // (the ring position advances with every step, so a captured chain is only valid from the same position: chains
     //  are captured and replayed at a.pid_calls == 60, i.e. window full and ring position 9 -> 0)
-    const bool steady = h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && a.pid_calls == 60 && (10 % k == 0) && h->cfg.publish_period == 0.0 &&
+    if (record) a.obs = record + (size_t)done * image;
+    const bool steady = !record && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && a.pid_calls == 60 && (10 % k == 0) && h->cfg.publish_period == 0.0 &&
                         (nsteps - done) >= kGraphChunk * k;
     if (steady) {
       a.publish_mask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -706,6 +710,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch) {
     h->pid_calls = std::min(h->pid_calls + k - (first_world ? 1 : 0), 1 << 20);
     done += k;
   }
+  if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
+    HIP_TRY(h, hipMemcpyAsync(h->d_obs, record + (size_t)(nsteps - 1) * image, image * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
   return CDPR_OK;
 }
 
@@ -953,6 +959,56 @@ int cdpr_set_position_command_device(cdpr_handle_t h, const float* d_axes, size_
 int cdpr_update(cdpr_handle_t h, int nsteps) { return run_steps(h, nsteps, 1); }
 
 int cdpr_update_fused(cdpr_handle_t h, int nsteps, int steps_per_launch) { return run_steps(h, nsteps, steps_per_launch); }
+
+int cdpr_observable_image_bytes(cdpr_handle_t h, size_t* bytes) {
+  if (!h || !bytes) return CDPR_ERR_INVALID;
+  *bytes = (size_t)h->n_obs * h->stride * sizeof(float4);
+  return CDPR_OK;
+}
+
+int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void* d_record, size_t record_bytes) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (h->general) {
+    h->err = "cdpr_update_record: not available on the general controller path";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (h->cfg.publish_period != 0.0) {
+    h->err = "cdpr_update_record needs publish_period == 0 (every step published)";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  const size_t image = (size_t)h->n_obs * h->stride * sizeof(float4);
+  if (!d_record || nsteps < 0 || record_bytes < image * (size_t)nsteps) {
+    h->err = "cdpr_update_record: record buffer missing or smaller than nsteps observable images";
+    return CDPR_ERR_INVALID;
+  }
+  return run_steps(h, nsteps, steps_per_launch, static_cast<float4*>(d_record));
+}
+
+int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position, float* velocity, float* effort,
+                            float* pose7, float* twist6) {
+  if (!h || !image) return CDPR_ERR_INVALID;
+  const float4* o = static_cast<const float4*>(image);
+  const size_t st = h->stride;
+  const int G = joint_groups((int)h->n);
+  float* dst[3] = {position, velocity, effort};
+  for (int f = 0; f < 3; ++f) {
+    if (!dst[f]) continue;
+    for (uint32_t r = 0; r < h->batch; ++r)
+      for (uint32_t i = 0; i < h->n; ++i) dst[f][(size_t)r * h->n + i] = comp(o[(size_t)(4 + f * G + i / 4) * st + r], i % 4);
+  }
+  for (uint32_t r = 0; r < h->batch; ++r) {
+    const float4 a = o[0 * st + r], b = o[1 * st + r], c = o[2 * st + r], d = o[3 * st + r];
+    if (pose7) {
+      float* p = pose7 + (size_t)r * 7;
+      p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z;
+    }
+    if (twist6) {
+      float* t = twist6 + (size_t)r * 6;
+      t[0] = b.w; t[1] = c.x; t[2] = c.y; t[3] = c.z; t[4] = c.w; t[5] = d.x;
+    }
+  }
+  return CDPR_OK;
+}
 
 int cdpr_synchronize(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;

@@ -72,6 +72,8 @@ struct StepArgs {
   int nsteps;         // world steps fused into this launch
   uint32_t flags;
   uint64_t publish_mask;  // bit k: publish observables at step k of this launch (PLG.cpp:236-242)
+  size_t obs_step_stride; // float4 elements between the observable images of consecutive steps (0: every step
+                          // overwrites the same image, as a topic does; > 0: a trajectory record keeps them all)
   int pid_calls;      // Pid::update calls since the last reset, before this launch (uniform over the batch)
   // world / body
   float dt, half_dt, dt_inv_mass, fgx, fgy, fgz;  // fg = m * g
@@ -729,17 +731,18 @@ __global__ __launch_bounds__(64, CDPR_LPR_WAVES) void cdpr_step_kernel(const Ste
     CDPR_STAMP(5);
     // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
     if (!ROLLOUT && ((a.publish_mask >> step) & 1ull) && live) {
-      store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
-      store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
-      store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
-      store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+      float4* const obs = a.obs + (size_t)step * a.obs_step_stride;
+      store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+      store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+      store_slot(obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+      store_slot(obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
         const bool has = (2 * g + 1 < NP);
-        store_slot(a.obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
-        store_slot(a.obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
-        store_slot(a.obs, st, 4 + 2 * G + g, woff,
+        store_slot(obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
+        store_slot(obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
+        store_slot(obs, st, 4 + 2 * G + g, woff,
                    make_float4(applied[k0].x, applied[k0].y, has ? applied[k1].x : 0.f, has ? applied[k1].y : 0.f));
       }
     }

@@ -316,16 +316,17 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
 
     CDPR_STAMP(5);
     // ---- observables of step t_k: lane 0 writes the platform rows, each lane its own joint group
+    float4* const obs = a.obs + (size_t)step * a.obs_step_stride;
     if (((a.publish_mask >> step) & 1ull) && live) {
       if (par == 0u) {
-        store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
-        store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+        store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+        store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
       } else {
-        store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
-        store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+        store_slot(obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+        store_slot(obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
       }
       if (NL == 4) {  // n = 8: group g = this lane's four cables
-        float4* orow = a.obs + (size_t)(4 + par) * st + r;
+        float4* orow = obs + (size_t)(4 + par) * st + r;
         orow[0] = make_float4(q[0].x, q[0].y, q[NPL - 1].x, q[NPL - 1].y);
         orow[(size_t)G * st] = make_float4(qd[0].x, qd[0].y, qd[NPL - 1].x, qd[NPL - 1].y);
         orow[(size_t)2 * G * st] = make_float4(applied[0].x, applied[0].y, applied[NPL - 1].x, applied[NPL - 1].y);
@@ -335,9 +336,9 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       const float oq0 = partner(q[0].x), oq1 = partner(q[0].y), ov0 = partner(qd[0].x), ov1 = partner(qd[0].y);
       const float oa0 = partner(applied[0].x), oa1 = partner(applied[0].y);
       if (((a.publish_mask >> step) & 1ull) && live && par == 0u) {
-        store_slot(a.obs, st, 4, woff, make_float4(q[0].x, q[0].y, oq0, oq1));
-        store_slot(a.obs, st, 4 + G, woff, make_float4(qd[0].x, qd[0].y, ov0, ov1));
-        store_slot(a.obs, st, 4 + 2 * G, woff, make_float4(applied[0].x, applied[0].y, oa0, oa1));
+        store_slot(obs, st, 4, woff, make_float4(q[0].x, q[0].y, oq0, oq1));
+        store_slot(obs, st, 4 + G, woff, make_float4(qd[0].x, qd[0].y, ov0, ov1));
+        store_slot(obs, st, 4 + 2 * G, woff, make_float4(applied[0].x, applied[0].y, oa0, oa1));
       }
     }
 

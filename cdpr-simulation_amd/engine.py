@@ -100,6 +100,36 @@ class Engine:
         else:
             self._check(lib().cdpr_update_fused(self._h, int(nsteps), int(steps_per_launch)))
 
+    def observable_image_bytes(self) -> int:
+        nbytes = C.c_size_t()
+        self._check(lib().cdpr_observable_image_bytes(self._h, C.byref(nbytes)))
+        return int(nbytes.value)
+
+    def update_record_device(self, nsteps: int, steps_per_launch: int, d_record: int, record_bytes: int) -> None:
+        """As update_record, into a caller-owned device buffer (nothing is copied back)."""
+        self._check(lib().cdpr_update_record(self._h, int(nsteps), int(steps_per_launch), C.c_void_p(d_record), record_bytes))
+
+    def update_record(self, nsteps: int, steps_per_launch: int = 10):
+        """Advance nsteps world steps (fused launches) and return the observables of EVERY step:
+        dict of arrays position/velocity/effort [nsteps, B, n], pose [nsteps, B, 7], twist [nsteps, B, 6]."""
+        nbytes = C.c_size_t()
+        self._check(lib().cdpr_observable_image_bytes(self._h, C.byref(nbytes)))
+        image = int(nbytes.value)
+        dptr = C.c_void_p()
+        self._check(lib().cdpr_device_malloc(self._h, image * nsteps, C.byref(dptr)))
+        try:
+            self._check(lib().cdpr_update_record(self._h, int(nsteps), int(steps_per_launch), dptr, image * nsteps))
+            raw = np.empty(image * nsteps, dtype=np.uint8)
+            self._check(lib().cdpr_device_download(self._h, raw.ctypes.data_as(C.c_void_p), dptr, raw.nbytes))
+        finally:
+            lib().cdpr_device_free(self._h, dptr)
+        out = {k: np.empty((nsteps, self.B, w), dtype=np.float32) for k, w in (("position", self.n), ("velocity", self.n), ("effort", self.n), ("pose", 7), ("twist", 6))}
+        for j in range(nsteps):
+            img = raw[j * image:(j + 1) * image]
+            self._check(lib().cdpr_decode_observables(self._h, img.ctypes.data_as(C.c_void_p), _fp(out["position"][j]), _fp(out["velocity"][j]),
+                                                      _fp(out["effort"][j]), _fp(out["pose"][j]), _fp(out["twist"][j])))
+        return out
+
     def synchronize(self) -> None:
         self._check(lib().cdpr_synchronize(self._h))
 

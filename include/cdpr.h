@@ -175,6 +175,15 @@ int cdpr_update(cdpr_handle_t h, int nsteps);
 /* Same loop with `steps_per_launch` world steps fused into each kernel launch
  * (state stays on chip between them; observables still written every step). */
 int cdpr_update_fused(cdpr_handle_t h, int nsteps, int steps_per_launch);
+/* Trajectory record: like cdpr_update_fused, but the observables of EVERY step are kept instead of each step
+ * overwriting the last (what a subscriber with a deep queue would have collected from jointStates / platformPose at
+ * publishPeriod 0).  d_record is a caller-owned DEVICE buffer of nsteps observable images
+ * (cdpr_observable_image_bytes each); image j belongs to world step first+j.  Step 0 of a fresh handle is not
+ * published (PLG.cpp:237), its image is left untouched.  Decode a downloaded image with cdpr_decode_observables. */
+int cdpr_observable_image_bytes(cdpr_handle_t h, size_t *bytes);
+int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void *d_record, size_t record_bytes);
+int cdpr_decode_observables(cdpr_handle_t h, const void *image, float *position, float *velocity, float *effort,
+                            float *pose7, float *twist6);
 int cdpr_synchronize(cdpr_handle_t h);
 uint32_t cdpr_mapping(cdpr_handle_t h);              /* CDPR_MAP_* actually in use (what CDPR_MAP_AUTO resolved to) */
 uint64_t cdpr_step_count(cdpr_handle_t h);           /* world steps since create/reset; sim time = count * dt */

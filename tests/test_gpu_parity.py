@@ -774,3 +774,32 @@ def test_error_codes_of_the_c_abi(pkg, mapping):
     cfg = pkg.Config(mapping=pkg._abi.MAP_LANE_PAIR, model=pkg.Model(pkg.eight_cable_model().frame_anchors[:6], pkg.eight_cable_model().platform_anchors[:6]))
     with pytest.raises(ValueError, match="lane-pair"):
         pkg.Engine(cfg, 0)
+
+
+def test_trajectory_record_keeps_every_published_step(pkg, oracle):
+    """cdpr_update_record: fused launches, yet nothing a subscriber would have received is lost — the observables of
+    every world step, identical to stepping one at a time and reading the topic after each step."""
+    B, T = 97, 35
+    rng = np.random.default_rng(12)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    a, b = pkg.Engine(cfg, 0), pkg.Engine(cfg, 0)
+    cmd = rng.uniform(-0.03, 0.03, (B, 8)).astype(np.float32)
+    for e in (a, b):
+        e.set_platform_state(pose7=pose)
+        e.update(12)
+        e.set_velocity_command(cmd)
+    rec = a.update_record(T, steps_per_launch=10)
+    for j in range(T):
+        b.update(1)
+        q, qd, eff = b.joint_states()
+        p, t = b.platform_state()
+        assert np.array_equal(rec["position"][j], q) and np.array_equal(rec["effort"][j], eff), j
+        assert np.array_equal(rec["pose"][j], p) and np.array_equal(rec["twist"][j], t) and np.array_equal(rec["velocity"][j], qd), j
+    assert np.array_equal(a.raw_state()[0], b.raw_state()[0])
+    assert np.array_equal(a.platform_state()[0], b.platform_state()[0])  # the engine's own topic image follows
+    ora = oracle.OracleSim(cfg.to_struct())  # and the recorded trajectory is the oracle's
+    ora.set_platform_state(pose7=pose.astype(np.float64))
+    ora.update(12), ora.set_velocity_command(cmd), ora.update(T)
+    assert np.abs(rec["pose"][-1] - ora.platform_state()[0]).max() < TOL["pose"]
+    assert a.step_count == 12 + T
