@@ -805,14 +805,15 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     // Mapping: measured on MI355X (scripts/ab_bench.py), two lanes per robot win while the batch leaves SIMDs
     // under-filled (16 384 x 8 cables: 9.0 vs 10.2 us/step; 4 096 x 4: 3.0 vs 3.4) and lose from 65 536 robots on
     // (16.4 vs 15.7 us/step: the duplicated 6x6 solves cost more than the second wave per SIMD hides), so AUTO
-    // takes the pair mapping up to 32 768 robots (n = 4 or 8).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
+    // takes the pair mapping up to 32 768 robots at n = 8 (32 768: 9.5 vs 10.5 us/step; 49 152: 13.6 vs 11.2) and up
+    // to 65 536 at n = 4 (65 536: 4.9 vs 5.2; 131 072: 8.5 vs 8.1).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
     const bool can_pair = !general && (cfg->n_cables == 4 || cfg->n_cables == 8);
     uint32_t mapping = cfg->mapping;
     if (mapping == CDPR_MAP_AUTO) {
       const char* mv = std::getenv("CDPR_MAPPING");
       if (mv && (mv[0] == '1' || mv[0] == '2')) mapping = (uint32_t)(mv[0] - '0');
     }
-    if (mapping == CDPR_MAP_AUTO) mapping = (can_pair && cfg->batch <= 32768u) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
+    if (mapping == CDPR_MAP_AUTO) mapping = (can_pair && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
     h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
   }
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);

@@ -21,6 +21,8 @@ def t(eng, steps, spl):
 
 variants = sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2"]
 cases = [(65536, 8, 3), (65536, 8, 0), (4096, 4, 0), (16384, 8, 3), (131072, 8, 3), (262144, 8, 3), (524288, 8, 3)]
+if os.environ.get("AB_CASES"):
+    cases = [tuple(int(x) for x in c.split("x")) for c in os.environ["AB_CASES"].split(",")]
 for (B, n, stages) in cases:
     engs = {v: make(B, n, stages, v) for v in variants}
     for spl in (1, 10):
