@@ -291,6 +291,10 @@ def main():
                 "traffic": traffic,
                 "kernel_us": launch_s * 1e6,
                 "bytes_per_state_step": bytes_step,
+                # the same launch priced by the bytes it really moved (rocprofv3 PMC, profiles/): the ring-buffer window
+                # rewrites 6 controller rows per step where the contract's accounting assumes 24
+                "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
+                "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
             },
         }
         out.update(secondary)
