@@ -119,8 +119,8 @@ def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=5000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
     ap.add_argument("--cables", type=int, default=8, choices=(4, 8))
     ap.add_argument("--steps-per-launch", type=int, default=1)
