@@ -52,6 +52,7 @@ struct cdpr_engine {
   float* d_geom = nullptr;  // pair-interleaved cable geometry, staged in LDS by the kernel
   int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
   bool lane_pair = false;   // two lanes per robot (cdpr_step_kernel_pair.hpp) instead of one
+  bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
   // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
   bool general = false;
   float* d_rec = nullptr;    // [last_pos][position Pid block][velocity Pid block]
@@ -366,6 +367,16 @@ StepKernel pick_pair_kernel(uint32_t n, bool fk, bool td) {
   return n == 4 ? pick_pair_stage<4, SINGLE>(fk, td) : pick_pair_stage<8, SINGLE>(fk, td);
 }
 
+// one-step kernels compiled for two waves per SIMD (FK on, n >= 6): see LOWREG in cdpr_step_kernel.hpp
+StepKernel pick_lowreg_kernel(uint32_t n, bool td) {
+  switch (n) {
+    case 6: return td ? cdpr_step_kernel<6, true, true, true, false, false, true> : cdpr_step_kernel<6, true, false, true, false, false, true>;
+    case 7: return td ? cdpr_step_kernel<7, true, true, true, false, false, true> : cdpr_step_kernel<7, true, false, true, false, false, true>;
+    case 8: return td ? cdpr_step_kernel<8, true, true, true, false, false, true> : cdpr_step_kernel<8, true, false, true, false, false, true>;
+  }
+  return nullptr;
+}
+
 template <int N>
 StepKernel pick_rollout_stage(bool fk, bool td) {
   if constexpr (N >= 6) {
@@ -651,7 +662,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // into [60, 70) so they stay small and steady-state launch sequences repeat with period 10
     a.pid_calls = h->pid_calls < 70 ? h->pid_calls : 60 + h->pid_calls % 10;
     StepKernel kern = h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
-                                   : ((k == 1) ? pick_kernel<true>(h->n, h->fk, h->td) : pick_kernel<false>(h->n, h->fk, h->td));
+                                   : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td) : pick_kernel<true>(h->n, h->fk, h->td))
+                                               : pick_kernel<false>(h->n, h->fk, h->td));
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
@@ -815,6 +827,11 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     }
     if (mapping == CDPR_MAP_AUTO) mapping = (can_pair && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
     h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
+    // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
+    // Measured (scripts/lowreg_probe.py, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
+    // 131 072: 29.9 -> 27.0; 196 608: 41.2 -> 36.3; 524 288: 89.9 -> 79.0 (6.6e9 state-steps/s)
+    h->lowreg = !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
+    if (const char* lr = std::getenv("CDPR_LOWREG")) h->lowreg = (lr[0] == '1') && !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
   }
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);

@@ -419,8 +419,11 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
 #define CDPR_STORE_STATE store_slot
 #endif
 
-template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false>
-__global__ __launch_bounds__(64, CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a) {
+// LOWREG = true (one-step kernel, large batches): fit two waves per SIMD (<= 256 registers) by NOT keeping what can be
+// recomputed: the cable constants are re-read from LDS in every Newton iteration instead of being hoisted into 48
+// registers, and the true structure matrix is rebuilt after the Newton stage instead of living through it.
+template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false, bool LOWREG = false>
+__global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
   constexpr int G = joint_groups(N);
@@ -649,7 +652,9 @@ __global__ __launch_bounds__(64, CDPR_LPR_WAVES) void cdpr_step_kernel(const Ste
       v2f elen[NP], unused[NP];
       bool active = true;
       for (int it = 0; it < a.fk_iters; ++it) {
-        ik_pairs<N, false>(lds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+        const float* lds_it = lds;
+        if (LOWREG) asm volatile("" : "+v"(lds_it));  // opaque per iteration: the geometry reads stay inside the loop
+        ik_pairs<N, false>(lds_it, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
         v2f res[NP];
         v2f rm = splat(0.f);
 #pragma unroll
@@ -754,6 +759,10 @@ __global__ __launch_bounds__(64, CDPR_LPR_WAVES) void cdpr_step_kernel(const Ste
       for (int k = 0; k < NP; ++k) {
         tens[k] = fma2(-a.damping, qd[k], applied[k]);
         if (a.unilateral) tens[k] = max2(tens[k], splat(0.f));  // [NEW] option: a cable cannot push
+      }
+      if (LOWREG && FK) {  // rebuild the true structure matrix (it was not kept alive through the Newton stage)
+        v2f len2[NP], l02[NP];
+        ik_pairs<N, false>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len2, jac, l02);
       }
       float w[6];
       jt_times<NP>(jac, tens, w);

@@ -803,3 +803,26 @@ def test_trajectory_record_keeps_every_published_step(pkg, oracle):
     ora.update(12), ora.set_velocity_command(cmd), ora.update(T)
     assert np.abs(rec["pose"][-1] - ora.platform_state()[0]).max() < TOL["pose"]
     assert a.step_count == 12 + T
+
+
+def test_low_register_build_is_bit_identical(pkg, monkeypatch, mapping):
+    """Batches above ~82 000 robots use the one-step kernel compiled for two waves per SIMD (cable constants re-read
+    from LDS per Newton iteration, true J rebuilt after the Newton stage): same arithmetic, so bit-identical results."""
+    once(mapping)
+    B = 450
+    rng = np.random.default_rng(17)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    cmd = rng.uniform(-0.04, 0.04, (B, 8)).astype(np.float32)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("CDPR_LOWREG", flag)
+        e = pkg.Engine(cfg, 0)
+        e.set_platform_state(pose7=pose)
+        e.update(15)
+        e.set_velocity_command(cmd)
+        for _ in range(40):
+            e.update(1)
+        out.append(e.raw_state() + e.joint_states() + e.fk_state())
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
