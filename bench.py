@@ -7,18 +7,27 @@ platform dynamics), fp32, 1 ms step, observables written every step, one kernel 
 per world step.  Initial poses = home + U(+-0.05 m) + rotation vector U(+-0.1 rad),
 rng(1235); every robot follows its own sine velocity command (amp U(0.01,0.05) m/s,
 freq U(0.05,0.5) Hz, phase U(0,2pi)) refreshed every 10 steps from a schedule that is
-resident in HBM before the timed region starts.  At N > 1 GPUs every rank runs its own
-65 536 robots (config 4: weak scaling, no collective on the data path).
+resident in HBM before the timed region starts.  `--config 2` selects config 2 instead
+(4 096 x 4-cable, IK + PID + dynamics).
 
-One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per launch
-(4*(39+28n) = 1052 B per state-step at n = 8, times the robots of one
-launch) / average launch duration measured with HIP events on the engine's stream.
-`cpu_baseline` = the fp64 oracle (oracle/, "port") timed on this box's host cores on a
-bounded sample of the same workload (rank 0, N = 1 only).
+Multi-GPU (config 4: 524 288 robots = 8 x 65 536; weak scaling, no collective on the data
+path): `python bench.py --gpus N` starts N rank processes itself, one per GPU, BEFORE it
+touches the GPU (the parent never does); under `torch.distributed.run` (WORLD_SIZE set)
+it is one of those ranks.  torch.distributed is only the rendezvous: barrier and max of
+the elapsed time over ranks.
+
+One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes (SURVEY.md
+8(d): 4*(39+28n) = 1052 B per state-step at n = 8) x per-GPU state-steps/s, i.e.
+BASELINE.md section 3's `state_steps_per_s x bytes(n) / 8.0e12`; `roofline.achieved_kernel`
+prices the same bytes by the average launch duration measured with HIP events on the
+engine's stream.  `cpu_baseline` = the fp64 oracle (oracle/, "port") timed on this box's
+host cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,6 +40,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide
 # flop per state-step counted from the gfx950 ISA of the shipped kernels
 FLOP_PER_STATE_STEP = {8: 6325, 4: 648}
+METRIC = "CDPR sim-steps/sec (whole node), 65 536 parallel 8-cable robots, 1 ms dt"
+CONFIGS = {2: dict(batch=4096, cables=4), 3: dict(batch=65536, cables=8)}
+ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
 
 
 def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
@@ -55,6 +67,13 @@ def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
     return model, pose.astype(np.float32), command, n_cmd
 
 
+def make_rollout_commands(n_robots, horizon, samples, n_cables, seed=1236):
+    """nominal command + N(0, 0.01^2) per cable per step, [B][H][S][n]."""
+    rng = np.random.default_rng(seed)
+    nominal = rng.uniform(-0.03, 0.03, (n_robots, horizon, 1, n_cables))
+    return (nominal + rng.normal(0.0, 0.01, (n_robots, horizon, samples, n_cables))).astype(np.float32)
+
+
 def effective_cpu_count():
     """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (on the GPU box
     `nproc` says 256 while cpu.max grants 16; spinning 256 OpenMP threads on 16 CPUs throttles them all)."""
@@ -75,17 +94,19 @@ def effective_cpu_count():
 
 
 def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
-    """Time the fp64 oracle ("port" of the reference step) on the host cores, bounded sample."""
+    """Time the fp64 oracle ("port" of the reference step) on the host cores, bounded sample.  Two derivative modes
+    (BASELINE.md section 3): `fir`-equivalent EXACT (same least-squares problem in centred time; the headline `value`)
+    and FAITHFUL (per-step normal equations in absolute time + pow() + column-pivoted QR, as Pid.cpp:219-247)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
 
     cores = min(oracle.lib().orc_max_threads(), effective_cpu_count())
     sample_b = min(pose.shape[0], 512 * cores)
 
-    def run(nsteps, nb=None, threads=None):
+    def run(nsteps, nb=None, threads=None, mode=oracle.DERIV_EXACT):
         nb = sample_b if nb is None else nb
         cfg = pkg.Config(batch=nb, **cfg_kwargs)
-        sim = oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+        sim = oracle.OracleSim(cfg.to_struct(), mode)
         sim.set_platform_state(pose7=pose[:nb].astype(np.float64))
         t0 = time.perf_counter()
         done = 0
@@ -103,44 +124,118 @@ def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
     rate = sample_b * probe_steps / t_probe
     nsteps = int(max(refresh, min(2000, target_seconds * rate / sample_b)))
     t = run(nsteps)
-    one_b, one_steps = 256, 100  # single-core figure on a small sample (about 1 s)
+    t_probe_f = run(probe_steps, mode=oracle.DERIV_FAITHFUL)
+    nsteps_f = int(max(refresh, min(2000, 0.5 * target_seconds * (sample_b * probe_steps / t_probe_f) / sample_b)))
+    t_f = run(nsteps_f, mode=oracle.DERIV_FAITHFUL)
+    one_b, one_steps = min(256, pose.shape[0]), 100  # single-core figures on a small sample (about 1 s each)
     t1 = run(one_steps, one_b, 1)
+    t1_f = run(one_steps, one_b, 1, mode=oracle.DERIV_FAITHFUL)
     return {
         "value": sample_b * nsteps / t,
         "value_1core": one_b * one_steps / t1,
+        "value_faithful": sample_b * nsteps_f / t_f,
+        "value_faithful_1core": one_b * one_steps / t1_f,
         "unit": "state-steps/s",
         "cores": int(cores),
         "kind": "port",
         "sample": f"{sample_b} robots x {nsteps} steps of the same workload, fp64 oracle (CPU restatement of the "
-                  f"cdpr_gazebo step, not Gazebo/ODE), OpenMP over robots, {t:.1f} s",
+                  f"cdpr_gazebo step, not Gazebo/ODE), OpenMP over robots, {t:.1f} s; value_faithful: {nsteps_f} steps with the "
+                  f"reference-style per-step polynomial fit (Pid.cpp:219-247), {t_f:.1f} s",
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5000)
     ap.add_argument("--warmup", type=int, default=500)
-    ap.add_argument("--batch", type=int, default=65536, help="robots per GPU")
-    ap.add_argument("--cables", type=int, default=8, choices=(4, 8))
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="BASELINE config: 3 = 65 536 x 8-cable (metric), 2 = 4 096 x 4-cable")
+    ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default: the config's)")
+    ap.add_argument("--cables", type=int, default=None, choices=(4, 8))
     ap.add_argument("--steps-per-launch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fused / rollout secondary figures")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (spawn, rendezvous, report): no GPU work, value 0")
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = CONFIGS[args.config]["batch"]
+    if args.cables is None:
+        args.cables = CONFIGS[args.config]["cables"]
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
 
-    import cdpr_simulation_amd as pkg
-    from cdpr_simulation_amd import _abi
-    from cdpr_simulation_amd._native import lib
+
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` with no launcher around it: start N rank processes (one per GPU) and wait.  Runs
+    before this process has loaded the HIP library or torch, so the parent never touches the GPU; rank 0's stdout is
+    the parent's, so the one JSON line comes out unchanged."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n_ranks))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0:
+                        rc = rc or code
+            if rc != 0:  # a rank failed: the others would wait in the rendezvous for ever
+                for r in pending:
+                    procs[r].kill()
+                break
+            time.sleep(0.02)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     from cdpr_simulation_amd.sharding import RankContext
 
     # torch.distributed (RCCL) only provides the rendezvous: barrier + max over ranks. No data-path collective.
     ctx = RankContext.from_env(backend=os.environ.get("CDPR_BENCH_BACKEND", "nccl"))
     rank, local_rank, world = ctx.rank, ctx.local_rank, ctx.world
-
     n = args.cables
-    stages = (_abi.STAGE_FK | _abi.STAGE_TD) if n == 8 else 0
     refresh = 10
+
+    if args.dry_run:  # exercises exactly the rank plumbing (used by the CPU test suite; nothing is measured)
+        ctx.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01)
+        ctx.barrier()
+        elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                              "config": {"workload": "dry run: rank plumbing only, no GPU work"}}), flush=True)
+        ctx.close()
+        return
+
+    import cdpr_simulation_amd as pkg
+    from cdpr_simulation_amd import _abi
+    from cdpr_simulation_amd._native import lib
+
+    stages = (_abi.STAGE_FK | _abi.STAGE_TD) if n == 8 else 0
     total = args.warmup + args.steps
     seed = (1235 if n == 8 else 1234) + rank
     model, pose, command, n_cmd = make_workload(pkg, args.batch, n, seed, total, refresh)
@@ -181,77 +276,97 @@ def main():
     pose_end, _ = eng.platform_state()
     finite = bool(np.isfinite(pose_end).all())
 
-    # ---- secondary figures (rank 0, outside the timed region above; never substituted for `value`)
+    # ---- secondary figures (every rank runs them, outside the timed region above; never substituted for `value`)
     secondary = {}
-    if rank == 0 and world == 1 and args.steps_per_launch == 1 and not args.no_secondary:
+    if args.steps_per_launch == 1 and not args.no_secondary:
         # (a) same workload with the 10 steps of each command hold fused into one launch: state stays on chip
         #     between the steps, observables are still written every step
         spl = refresh
-        steps2 = (args.steps // refresh) * refresh
+        steps2 = max((min(args.steps, 2000) // refresh) * refresh, refresh)
         start = args.warmup + args.steps
         sched2 = [eng.device_upload(command((start + j * refresh) // refresh)) for j in range(steps2 // refresh)]
         image = eng.observable_image_bytes()
         d_rec = eng.device_upload(np.zeros(image * refresh, dtype=np.uint8))  # trajectory record of one command hold
-        eng.synchronize()
+        barrier()
         eng.profile_begin()
         t0 = time.perf_counter()
         for j in range(steps2 // refresh):
             eng.set_velocity_command_device(sched2[j], count)
             eng.update_record_device(refresh, spl, d_rec, image * refresh)  # every step's observables stay in HBM
         ms2, launches2 = eng.profile_end()
-        el2 = time.perf_counter() - t0
+        barrier()
+        el2 = ctx.max_over_ranks(time.perf_counter() - t0)
         eng.device_free(d_rec)
         for p_ in sched2:
             eng.device_free(p_)
         # per launch: command n + state round trip 2*(13+12n) + spl * observables (13+3n), in floats
         bytes_launch = 4 * (n + 2 * (13 + 12 * n) + spl * (13 + 3 * n))
+        v2 = world * args.batch * steps2 / el2
         secondary["fused"] = {
             "steps_per_launch": spl,
-            "value": args.batch * steps2 / el2,
+            "value": v2,
             "unit": "state-steps/s",
             "kernel_us": ms2 * 1e3 / max(launches2, 1),
             "bytes_per_state_step": bytes_launch / spl,
             "achieved_GBps": bytes_launch * args.batch / (ms2 * 1e-3 / max(launches2, 1)) / 1e9,
-            "f32_tflops": args.batch * steps2 / el2 * FLOP_PER_STATE_STEP[n] / 1e12,
-            "f32_vector_frac": args.batch * steps2 / el2 * FLOP_PER_STATE_STEP[n] / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            "f32_tflops": v2 / world * FLOP_PER_STATE_STEP[n] / 1e12,
+            "f32_vector_frac": v2 / world * FLOP_PER_STATE_STEP[n] / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
             "note": "compute (f32 VALU) bound: state never leaves the registers between the fused steps; the observables "
                     "of every step are kept in a trajectory record in HBM (cdpr_update_record), nothing published is dropped",
         }
-        # (b) MPC rollout, one GPU's share of BASELINE config 5: 512 robots x 128 samples x 64 steps
+        # (b) MPC rollout, BASELINE config 5: 512 robots x 128 samples x 64 steps on every GPU (4 096 robots on 8)
         if n == 8:
-            Br, S, H = 512, 128, 64
-            rng = np.random.default_rng(1236)
+            Br, S, H = ROLLOUT_SHAPE
             cfg_r = pkg.Config(batch=Br, **cfg_kwargs)
             er = pkg.Engine(cfg_r, device=device)
             er.set_platform_state(pose7=pose[:Br])
             er.update(20)
-            nominal = rng.uniform(-0.03, 0.03, (Br, H, 1, n))
-            cmds = (nominal + rng.normal(0.0, 0.01, (Br, H, S, n))).astype(np.float32)
+            cmds = make_rollout_commands(Br, H, S, n, seed=1236 + rank)
             dptr = er.device_upload(cmds)
             ref = pose[:Br, :3].astype(np.float32)
-            er.rollout_velocity((dptr, S, H), ref)  # warm-up
-            reps = 5
+            cost = er.rollout_velocity((dptr, S, H), ref)  # warm-up (also sizes the persistent scratch)
+            reps = 10
+            er.synchronize()
+            ctx.barrier()
             t0 = time.perf_counter()
             for _ in range(reps):
-                cost = er.rollout_velocity((dptr, S, H), ref)
-            elr = (time.perf_counter() - t0) / reps
-            er.device_free(dptr)
+                cost = er.rollout_velocity((dptr, S, H), ref)  # ref upload + kernel + cost download, synchronous
+            ctx.barrier()
+            elr = ctx.max_over_ranks(time.perf_counter() - t0) / reps
+            # kernel alone: device-resident reference and costs, HIP events on the engine's stream
+            d_ref = er.device_upload(ref)
+            d_cost = er.device_alloc(Br * S * 4)
+            er.rollout_velocity_device(dptr, S, H, d_ref, d_cost)
+            er.synchronize()
+            er.profile_begin()
+            for _ in range(reps):
+                er.rollout_velocity_device(dptr, S, H, d_ref, d_cost)
+            msr, nl = er.profile_end()
+            cost_dev = er.device_download(d_cost, (Br, S))
+            for p_ in (dptr, d_ref, d_cost):
+                er.device_free(p_)
             er.close()
+            kern_s = msr * 1e-3 / max(nl, 1)
             secondary["rollout"] = {
-                "workload": f"{Br} robots x {S} sampled sequences x {H}-step horizon (one GPU's share of config 5), cost copied back",
-                "value": Br * S * H / elr,
+                "workload": f"config5: {world} x {Br} robots x {S} sampled sequences x {H}-step horizon, cost copied back to the host",
+                "value": world * Br * S * H / elr,
                 "unit": "state-steps/s",
                 "ms_per_rollout": elr * 1e3,
-                "f32_tflops": Br * S * H / elr * FLOP_PER_STATE_STEP[n] / 1e12,
-                "f32_vector_frac": Br * S * H / elr * FLOP_PER_STATE_STEP[n] / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                "kernel_us": kern_s * 1e6,
+                "kernel_value_per_gpu": Br * S * H / kern_s,
+                "f32_tflops": Br * S * H / kern_s * FLOP_PER_STATE_STEP[n] / 1e12,
+                "f32_vector_frac": Br * S * H / kern_s * FLOP_PER_STATE_STEP[n] / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                 "cost_finite": bool(np.isfinite(cost).all()),
+                "device_path_identical": bool(np.array_equal(cost, cost_dev)),
             }
 
     if rank == 0:
         bytes_step = eng.bytes_per_state_step()
         launch_s = ev_ms * 1e-3 / max(launches, 1)
         robots_per_launch_steps = args.batch * args.steps / max(launches, 1)
-        achieved = bytes_step * robots_per_launch_steps / launch_s / 1e9
+        achieved_kernel = bytes_step * robots_per_launch_steps / launch_s / 1e9
+        value = world * args.batch * args.steps / elapsed
+        achieved = value / world * bytes_step / 1e9  # BASELINE.md section 3, per GPU
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -260,8 +375,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "CDPR sim-steps/sec (whole node), 65 536 parallel 8-cable robots, 1 ms dt",
-            "value": world * args.batch * args.steps / elapsed,
+            "metric": METRIC,
+            "value": value,
             "unit": "state-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -284,17 +399,23 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
+                # per-GPU state-steps/s x algorithmic bytes per state-step
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "basis": "algorithmic bytes (SURVEY 8(d), shifted-window accounting) x wall-clock state-steps/s per GPU",
                 "traffic": traffic,
-                "kernel_us": launch_s * 1e6,
                 "bytes_per_state_step": bytes_step,
+                # the same algorithmic bytes over the kernel's own average duration (HIP events on the engine's stream)
+                "kernel_us": launch_s * 1e6,
+                "achieved_kernel": achieved_kernel,
+                "frac_kernel": achieved_kernel / HBM_PEAK_GBS,
                 # the same launch priced by the bytes it really moved (rocprofv3 PMC, profiles/): the ring-buffer window
                 # rewrites 6 controller rows per step where the contract's accounting assumes 24
                 "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
                 "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "limiter": "latency of one robot's serial chain at one wave per SIMD (DESIGN.md section 4), not HBM bandwidth",
             },
         }
         out.update(secondary)

@@ -83,6 +83,11 @@ struct cdpr_engine {
   float* d_wtab = nullptr;        // [velocity | position] rotated derivative-weight tables, kWin * (kWin + 2) floats each
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t launches = 0, launches_mark = 0;
+  // MPC rollout scratch, persistent and grow-only (no hipMalloc / hipFree inside a rollout)
+  float* d_roll_ref = nullptr;   // float[B][3]
+  float* d_roll_cost = nullptr;  // float[B][samples]
+  size_t roll_cost_cap = 0;      // trajectories d_roll_cost can hold
+  uint64_t roll_pending = 0;     // trajectories of the launched, not yet fetched rollout
   std::string err;
 };
 
@@ -492,6 +497,8 @@ void free_all(cdpr_engine* h) {
   if (h->d_rec) (void)hipFree(h->d_rec);
   if (h->d_force) (void)hipFree(h->d_force);
   if (h->d_cable) (void)hipFree(h->d_cable);
+  if (h->d_roll_ref) (void)hipFree(h->d_roll_ref);
+  if (h->d_roll_cost) (void)hipFree(h->d_roll_cost);
   for (int i = 0; i < 2; ++i) {
     if (h->d_vel[i]) (void)hipFree(h->d_vel[i]);
     if (h->d_pos[i]) (void)hipFree(h->d_pos[i]);
@@ -541,7 +548,15 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
   return CDPR_OK;
 }
 
+// The stored Pid call counter only matters through calls != 0, calls >= nbuf (<= 11 on the fast path) and the ring
+// position (calls - 1) % 10: fold it into [60, 70) so it never saturates and never loses its phase.
+inline int fold_pid_calls(int calls) { return calls < 70 ? calls : 60 + calls % 10; }
+
 int run_steps_general(cdpr_engine* h, int nsteps) {
+  if (h->step + (uint64_t)nsteps >= (1ull << 31)) {  // world-step stamps are int32 in the controller records
+    h->err = "general controller path: world-step counter would pass 2^31";
+    return CDPR_ERR_UNSUPPORTED;
+  }
   StepArgs a = h->base;
   a.state = h->d_state;
   a.obs = h->d_obs;
@@ -660,7 +675,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     if (first_world) a.flags |= kFlagFirstWorldStep;
     // the kernel uses calls != 0, calls >= nbuf (<= 32) and the ring position (calls - 1) % 10: fold large counts
     // into [60, 70) so they stay small and steady-state launch sequences repeat with period 10
-    a.pid_calls = h->pid_calls < 70 ? h->pid_calls : 60 + h->pid_calls % 10;
+    a.pid_calls = fold_pid_calls(h->pid_calls);
     StepKernel kern = h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
                                    : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td) : pick_kernel<true>(h->n, h->fk, h->td))
                                                : pick_kernel<false>(h->n, h->fk, h->td));
@@ -681,14 +696,26 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         if (g.kern == (void*)kern && g.cmd == a.cmd && g.steps_per_launch == k && g.flags == a.flags) ge = &g;
       if (!ge) {
         cdpr_engine::GraphEntry g{(void*)kern, a.cmd, k, kGraphChunk, a.flags, nullptr, nullptr};
-        HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        for (int j = 0; j < kGraphChunk; ++j) {
-          StepArgs aj = a;  // each node carries its own ring position
-          aj.pid_calls = 60 + (j * k) % 10;
-          hipLaunchKernelGGL(kern, grid, block, 0, h->stream, aj);
+        // any failure inside the capture: end it, drop the partial graph, stop using graphs on this handle and
+        // fall through to the eager launches below (the stream must never be left capturing)
+        bool captured = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (captured) {
+          bool launched = true;
+          for (int j = 0; j < kGraphChunk; ++j) {
+            StepArgs aj = a;  // each node carries its own ring position
+            aj.pid_calls = 60 + (j * k) % 10;
+            hipLaunchKernelGGL(kern, grid, block, 0, h->stream, aj);
+            launched = launched && (hipGetLastError() == hipSuccess);
+          }
+          captured = (hipStreamEndCapture(h->stream, &g.graph) == hipSuccess) && launched && g.graph;
+          if (captured && hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) != hipSuccess) captured = false;
+          if (!captured && g.graph) (void)hipGraphDestroy(g.graph);
         }
-        HIP_TRY(h, hipStreamEndCapture(h->stream, &g.graph));
-        HIP_TRY(h, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        if (!captured) {
+          (void)hipGetLastError();
+          h->use_graphs = false;
+          continue;  // same `done`: this chunk is launched eagerly on the next pass
+        }
         if (h->graphs.size() >= 8) {  // tiny cache: drop the oldest
           (void)hipGraphExecDestroy(h->graphs.front().exec);
           (void)hipGraphDestroy(h->graphs.front().graph);
@@ -701,7 +728,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       const int steps = kGraphChunk * k;
       h->launches += kGraphChunk;
       h->step += (uint64_t)steps;
-      h->pid_calls = std::min(h->pid_calls + steps, 1 << 20);
+      h->pid_calls = fold_pid_calls(h->pid_calls + steps);
       h->prev_publish = sim_time(h->step - 1, h->cfg.dt);
       done += steps;
       continue;
@@ -719,7 +746,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;
-    h->pid_calls = std::min(h->pid_calls + k - (first_world ? 1 : 0), 1 << 20);
+    h->pid_calls = fold_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
     done += k;
   }
   if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
@@ -828,7 +855,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     if (mapping == CDPR_MAP_AUTO) mapping = (can_pair && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
     h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
     // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
-    // Measured (scripts/lowreg_probe.py, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
+    // Measured (scripts/ab_bench.py with CDPR_LOWREG=0|1, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
     // 131 072: 29.9 -> 27.0; 196 608: 41.2 -> 36.3; 524 288: 89.9 -> 79.0 (6.6e9 state-steps/s)
     h->lowreg = !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
     if (const char* lr = std::getenv("CDPR_LOWREG")) h->lowreg = (lr[0] == '1') && !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
@@ -1131,27 +1158,9 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
   return CDPR_OK;
 }
 
-int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* ref_position,
-                          float* cost) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (samples < 1 || horizon < 1 || !d_commands || !ref_position || !cost) {
-    h->err = "cdpr_rollout_velocity: samples, horizon >= 1 and all buffers are required";
-    return CDPR_ERR_INVALID;
-  }
-  if (h->general) {
-    h->err = "cdpr_rollout_velocity: not available on the general controller path";
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  if (traj > (1ull << 30)) {
-    h->err = "cdpr_rollout_velocity: too many trajectories";
-    return CDPR_ERR_INVALID;
-  }
-  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  DevBuf dref, dcost;
-  HIP_TRY(h, dref.alloc((size_t)h->batch * 3 * sizeof(float)));
-  HIP_TRY(h, dcost.alloc((size_t)traj * sizeof(float)));
-  HIP_TRY(h, hipMemcpyAsync(dref.p, ref_position, (size_t)h->batch * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+// Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in
+// DEVICE buffers.  Nothing is allocated, copied or synchronised here.
+static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float* d_commands, const float* d_ref, float* d_cost) {
   StepArgs a = h->base;
   a.state = h->d_state;
   a.obs = h->d_obs;
@@ -1168,18 +1177,95 @@ int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float
   // a Joy on jointVelocities while in Position mode resets the velocity Pid (JFC.cpp:113-115); the handle's own
   // records stay untouched, the rollout starts from zeroed copies
   if (h->mode != kModeVelocity) a.flags |= kFlagRolloutResetPid;
-  a.pid_calls = (h->mode == kModeVelocity) ? (h->pid_calls < 70 ? h->pid_calls : 60 + h->pid_calls % 10) : 0;
+  a.pid_calls = (h->mode == kModeVelocity) ? fold_pid_calls(h->pid_calls) : 0;
   a.roll_cmd = d_commands;
-  a.roll_ref = dref.as<float>();
-  a.roll_cost = dcost.as<float>();
+  a.roll_ref = d_ref;
+  a.roll_cost = d_cost;
   a.roll_samples = (uint32_t)samples;
+  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
   StepKernel kern = pick_rollout_kernel(h->n, h->fk, h->td);
   hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   ++h->launches;
-  HIP_TRY(h, hipMemcpyAsync(cost, dcost.p, (size_t)traj * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return CDPR_OK;
+}
+
+static int rollout_check(cdpr_engine* h, int samples, int horizon, const void* d_commands) {
+  if (samples < 1 || horizon < 1 || !d_commands) {
+    h->err = "rollout: samples, horizon >= 1 and the command buffer are required";
+    return CDPR_ERR_INVALID;
+  }
+  if (h->general) {
+    h->err = "rollout: not available on the general controller path";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if ((uint64_t)h->batch * (uint64_t)samples > (1ull << 30)) {
+    h->err = "rollout: too many trajectories";
+    return CDPR_ERR_INVALID;
+  }
+  return set_device(h);
+}
+
+int cdpr_rollout_velocity_device(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* d_ref_position,
+                                 float* d_cost) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = rollout_check(h, samples, horizon, d_commands);
+  if (rc != CDPR_OK) return rc;
+  if (!d_ref_position || !d_cost) {
+    h->err = "cdpr_rollout_velocity_device: d_ref_position and d_cost are required";
+    return CDPR_ERR_INVALID;
+  }
+  return rollout_enqueue(h, samples, horizon, d_commands, d_ref_position, d_cost);
+}
+
+int cdpr_rollout_velocity_launch(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* ref_position) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = rollout_check(h, samples, horizon, d_commands);
+  if (rc != CDPR_OK) return rc;
+  if (!ref_position) {
+    h->err = "cdpr_rollout_velocity_launch: ref_position is required";
+    return CDPR_ERR_INVALID;
+  }
+  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
+  if (!h->d_roll_ref) HIP_TRY(h, hipMalloc(&h->d_roll_ref, (size_t)h->batch * 3 * sizeof(float)));
+  if (h->roll_cost_cap < traj) {  // grow-only; the stream may still be reading the old buffer
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->d_roll_cost) (void)hipFree(h->d_roll_cost);
+    h->d_roll_cost = nullptr;
+    h->roll_cost_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_roll_cost, (size_t)traj * sizeof(float)));
+    h->roll_cost_cap = traj;
+  }
+  // the caller may reuse ref_position on return: a pageable source is staged before hipMemcpyAsync returns
+  HIP_TRY(h, hipMemcpyAsync(h->d_roll_ref, ref_position, (size_t)h->batch * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  rc = rollout_enqueue(h, samples, horizon, d_commands, h->d_roll_ref, h->d_roll_cost);
+  if (rc == CDPR_OK) h->roll_pending = traj;
+  return rc;
+}
+
+int cdpr_rollout_velocity_fetch(cdpr_handle_t h, float* cost) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (!cost || h->roll_pending == 0) {
+    h->err = "cdpr_rollout_velocity_fetch: no rollout pending (or null cost buffer)";
+    return CDPR_ERR_INVALID;
+  }
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  HIP_TRY(h, hipMemcpyAsync(cost, h->d_roll_cost, (size_t)h->roll_pending * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->roll_pending = 0;
+  return CDPR_OK;
+}
+
+int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* ref_position,
+                          float* cost) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (!cost) {
+    h->err = "cdpr_rollout_velocity: cost is required";
+    return CDPR_ERR_INVALID;
+  }
+  int rc = cdpr_rollout_velocity_launch(h, samples, horizon, d_commands, ref_position);
+  if (rc != CDPR_OK) return rc;
+  return cdpr_rollout_velocity_fetch(h, cost);
 }
 
 #ifdef CDPR_STAMPS

@@ -69,6 +69,11 @@ struct GenRec {
   float* base;  // this thread's column of its Pid block
   size_t ts;
   __device__ __forceinline__ float& f(int row) { return base[(size_t)row * ts]; }
+  // integer-valued fields (world-step stamps, ring head, sample count) are kept as int32 bit patterns in the
+  // float rows: a float holds integers exactly only up to 2^24 (4.6 h of sim time at 1 ms), an int32 to 2^31;
+  // an all-zero row (Pid::reset = memset) reads as 0 either way
+  __device__ __forceinline__ int geti(int row) { return __float_as_int(base[(size_t)row * ts]); }
+  __device__ __forceinline__ void seti(int row, int v) { base[(size_t)row * ts] = __int_as_float(v); }
 };
 
 __device__ __forceinline__ float gen_cascade(GenRec& r, int first_row, int cascade, float a0, float a1, float a2, float b1,
@@ -93,21 +98,21 @@ __device__ __forceinline__ float gen_cascade(GenRec& r, int first_row, int casca
 // Pid::derive + fitPolynomial (Pid.cpp:193-247) on the real stamps, fp64, centred and scaled time.
 __device__ __forceinline__ float gen_derive(const GenPid& p, GenRec& r, float value, int now_step, float dt) {
   const int nbuf = p.nbuf;
-  int head = (int)r.f(kGfHead);
-  int count = (int)r.f(kGfCount);
+  int head = r.geti(kGfHead);
+  int count = r.geti(kGfCount);
   head = (count == 0) ? 0 : ((head + 1 == nbuf) ? 0 : head + 1);
   r.f(kGfWinVal + head) = value;
-  r.f(kGfWinStamp + head) = (float)now_step;  // exact up to 2^24 steps (4.6 h of sim time at 1 ms)
-  r.f(kGfHead) = (float)head;
+  r.seti(kGfWinStamp + head, now_step);
+  r.seti(kGfHead, head);
   if (count < nbuf) ++count;
-  r.f(kGfCount) = (float)count;
+  r.seti(kGfCount, count);
   if (count < nbuf) return 0.f;  // mDbufferMissing != 0 (Pid.cpp:200-203)
 
   // oldest sample sits right after the head in the ring
   const int oldest = (head + 1 == nbuf) ? 0 : head + 1;
-  const double t_new = (double)now_step, t_old = (double)r.f(kGfWinStamp + oldest);
+  const double t_new = (double)now_step, t_old = (double)r.geti(kGfWinStamp + oldest);
   double mean = 0.0;
-  for (int j = 0; j < nbuf; ++j) mean += (double)r.f(kGfWinStamp + j);
+  for (int j = 0; j < nbuf; ++j) mean += (double)r.geti(kGfWinStamp + j);
   mean /= (double)nbuf;
   double h = (t_new - t_old) / (double)(nbuf - 1);
   if (!(h > 0.0)) h = 1.0;
@@ -116,7 +121,7 @@ __device__ __forceinline__ float gen_derive(const GenPid& p, GenRec& r, float va
   for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) sx[i] = 0.0;
   for (int i = 0; i < kGenMaxDeg + 1; ++i) sb[i] = 0.0;
   for (int j = 0; j < nbuf; ++j) {
-    const double x = ((double)r.f(kGfWinStamp + j) - mean) / h;
+    const double x = ((double)r.geti(kGfWinStamp + j) - mean) / h;
     const double y = (double)r.f(kGfWinVal + j);
     double pw = 1.0;
     for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) {
@@ -183,7 +188,7 @@ __device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, floa
   } else {
     const float f_term = p.kf * desired;
     const float error = desired - actual;
-    const float dt = (float)(now_step - (int)r.f(kGfLastStep)) * dt_step;
+    const float dt = (float)(now_step - r.geti(kGfLastStep)) * dt_step;
     const float perr = gen_cascade(r, kGfPFilt, p.pcas, p.pa0, p.pa1, p.pa2, p.pb1, p.pb2, error);
     const float p_term = p.kp * perr;
     const float prev_ierr = r.f(kGfIerr);
@@ -221,7 +226,7 @@ __device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, floa
     r.f(kGfCmd) = out;
     cmd_out = out;
   }
-  r.f(kGfLastStep) = (float)now_step;
+  r.seti(kGfLastStep, now_step);
   return cmd_out;
 }
 

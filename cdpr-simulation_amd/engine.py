@@ -39,6 +39,7 @@ class Engine:
         self.n = config.n_cables
         self.B = int(config.batch)
         self._h = C.c_void_p()
+        self._rollout_pending = None
         rc = lib().cdpr_create(C.byref(self._cfg), int(device), C.byref(self._h))
         if rc != _abi.OK:
             msg = lib().cdpr_last_error(None).decode()
@@ -203,25 +204,48 @@ class Engine:
         return t, f
 
     # -- MPC fan-out
-    def rollout_velocity(self, commands, ref_position) -> np.ndarray:
-        """commands[B, H, S, n] (host array, or a (device_pointer, S, H) tuple for a buffer already in HBM),
-        ref_position[B, 3] -> cost[B, S]; the engine's own state is left untouched."""
+    def rollout_launch(self, commands, ref_position):
+        """Queue one rollout and return at once (cdpr_rollout_velocity_launch): commands[B, H, S, n] as a host array
+        (uploaded here, freed by rollout_fetch) or a (device_pointer, S, H) tuple for a buffer already in HBM."""
         ref = np.ascontiguousarray(ref_position, dtype=np.float32).reshape(self.B, 3)
         if isinstance(commands, tuple):
             dptr, S, H = commands
-            owned = False
+            owned = None
         else:
             c = np.ascontiguousarray(commands, dtype=np.float32)
             assert c.ndim == 4 and c.shape[0] == self.B and c.shape[3] == self.n, "commands must be [B, H, S, n]"
             H, S = int(c.shape[1]), int(c.shape[2])
-            dptr, owned = self.device_upload(c), True
+            dptr = owned = self.device_upload(c)
+        try:
+            self._check(lib().cdpr_rollout_velocity_launch(self._h, int(S), int(H), C.c_void_p(dptr), _fp(ref)))
+        except Exception:
+            if owned is not None:
+                self.device_free(owned)
+            raise
+        self._rollout_pending = (int(S), owned)
+
+    def rollout_fetch(self) -> np.ndarray:
+        """cost[B, S] of the rollout queued by rollout_launch (synchronises the stream)."""
+        S, owned = self._rollout_pending
         cost = np.empty((self.B, S), dtype=np.float32)
         try:
-            self._check(lib().cdpr_rollout_velocity(self._h, S, H, C.c_void_p(dptr), _fp(ref), _fp(cost)))
+            self._check(lib().cdpr_rollout_velocity_fetch(self._h, _fp(cost)))
         finally:
-            if owned:
-                self.device_free(dptr)
+            self._rollout_pending = None
+            if owned is not None:
+                self.device_free(owned)
         return cost
+
+    def rollout_velocity(self, commands, ref_position) -> np.ndarray:
+        """commands[B, H, S, n] (host array, or a (device_pointer, S, H) tuple for a buffer already in HBM),
+        ref_position[B, 3] -> cost[B, S]; the engine's own state is left untouched."""
+        self.rollout_launch(commands, ref_position)
+        return self.rollout_fetch()
+
+    def rollout_velocity_device(self, d_commands: int, samples: int, horizon: int, d_ref: int, d_cost: int) -> None:
+        """Device-resident rollout: nothing copied, asynchronous on the engine's stream."""
+        self._check(lib().cdpr_rollout_velocity_device(self._h, int(samples), int(horizon), C.c_void_p(d_commands), C.c_void_p(d_ref),
+                                                       C.c_void_p(d_cost)))
 
     # -- caller-owned device buffers (e.g. a schedule of Joy batches resident in HBM)
     def device_upload(self, array: np.ndarray) -> int:
@@ -230,6 +254,16 @@ class Engine:
         self._check(lib().cdpr_device_malloc(self._h, a.nbytes, C.byref(ptr)))
         self._check(lib().cdpr_device_upload(self._h, ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
         return int(ptr.value)
+
+    def device_alloc(self, nbytes: int) -> int:
+        ptr = C.c_void_p()
+        self._check(lib().cdpr_device_malloc(self._h, int(nbytes), C.byref(ptr)))
+        return int(ptr.value)
+
+    def device_download(self, dptr: int, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        self._check(lib().cdpr_device_download(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), out.nbytes))
+        return out
 
     def device_free(self, dptr: int) -> None:
         self._check(lib().cdpr_device_free(self._h, C.c_void_p(dptr)))

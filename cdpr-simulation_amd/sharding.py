@@ -105,7 +105,10 @@ class ShardedEngine:
 
         c = np.asarray(commands, dtype=np.float32)
         ref = np.asarray(ref_position, dtype=np.float32).reshape(self.B, 3)
-        return np.concatenate([e.rollout_velocity(c[lo:hi], ref[lo:hi]) for e, (lo, hi) in zip(self.engines, self.spans)])
+        # queue on every device first (upload + launch return at once), then collect: the GPUs run concurrently
+        for e, (lo, hi) in zip(self.engines, self.spans):
+            e.rollout_launch(c[lo:hi], ref[lo:hi])
+        return np.concatenate([e.rollout_fetch() for e in self.engines])
 
     def joint_states(self):
         return self._gather("joint_states")
@@ -140,7 +143,10 @@ class RankContext:
         import torch
         import torch.distributed as dist
 
-        if backend == "nccl" and torch.cuda.is_available() and torch.cuda.device_count() > local_rank:
+        # RCCL only when every local rank has a GPU of its own; the decision must be the same on every rank
+        # (device_count() does not initialise the GPU), else the rendezvous would mix backends and hang
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if backend == "nccl" and torch.cuda.device_count() >= local_world:
             torch.cuda.set_device(local_rank)  # "nccl" is RCCL on ROCm
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:  # CPU-only box, or more ranks than GPUs: the rendezvous does not need the GPU

@@ -219,6 +219,17 @@ int cdpr_get_raw_state(cdpr_handle_t h, float *pose7, float *twist6);
  * handle was created with (FK, TD) runs in every step.  Synchronous. */
 int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float *d_commands,
                           const float *ref_position, float *cost);
+/* The same rollout split for hosts that drive several GPUs from one thread (one handle per GPU): _launch stages
+ * ref_position and queues the kernel on the handle's stream and returns at once (no allocation in steady state: the
+ * scratch buffers are persistent); _fetch copies cost[B][samples] of the pending rollout back and synchronises.
+ * Launch on every handle first, then fetch from each: all GPUs run concurrently. */
+int cdpr_rollout_velocity_launch(cdpr_handle_t h, int samples, int horizon, const float *d_commands,
+                                 const float *ref_position);
+int cdpr_rollout_velocity_fetch(cdpr_handle_t h, float *cost);
+/* Fully device-resident form: reference positions float[B][3] and costs float[B][samples] in caller-owned DEVICE
+ * buffers; asynchronous on the handle's stream, nothing copied (an MPC loop that keeps its sampler on the GPU). */
+int cdpr_rollout_velocity_device(cdpr_handle_t h, int samples, int horizon, const float *d_commands,
+                                 const float *d_ref_position, float *d_cost);
 
 /* Device-buffer helpers for hosts that have no GPU runtime of their own (ctypes):
  * allocate / free / fill a caller-owned device buffer on the handle's GPU, e.g. to keep

@@ -1,0 +1,56 @@
+"""One profiled workload per invocation (run under rocprofv3 by scripts/profile_kernels.sh):
+  fused      65 536 x 8, all stages, 10 steps per launch into a trajectory record (cdpr_update_record)
+  rollout    512 x 128 x 64 MPC rollout, device-resident reference and costs (kernel only)
+  config2m1  4 096 x 4, lane-per-robot          config2m2  4 096 x 4, lane-pair
+  lowreg     524 288 x 8, all stages, one launch per step (auto-selected low-register kernel)
+  general    16 384 x 8 on the general controller path (velocityEpsilon = 0.001: hold branch live)
+  onestep    65 536 x 8, all stages, one launch per step (the headline kernel)
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import cdpr_simulation_amd as pkg
+import bench
+
+case = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+if case in ("fused", "onestep", "lowreg"):
+    B = 524288 if case == "lowreg" else 65536
+    model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 10)
+    eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3), 0)
+    eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
+    if case == "fused":
+        image = eng.observable_image_bytes()
+        d_rec = eng.device_alloc(image * 10)
+        for _ in range(reps):
+            eng.update_record_device(10, 10, d_rec, image * 10)
+    else:
+        eng.update(reps if case == "lowreg" else reps * 3)
+    eng.synchronize()
+elif case == "rollout":
+    Br, S, H = bench.ROLLOUT_SHAPE
+    model, pose, command, _ = bench.make_workload(pkg, Br, 8, 1235, 10)
+    er = pkg.Engine(pkg.Config(model=model, batch=Br, stages=3), 0)
+    er.set_platform_state(pose7=pose); er.update(20)
+    dptr = er.device_upload(bench.make_rollout_commands(Br, H, S, 8))
+    d_ref, d_cost = er.device_upload(pose[:, :3].copy()), er.device_alloc(Br * S * 4)
+    for _ in range(max(reps // 5, 10)):
+        er.rollout_velocity_device(dptr, S, H, d_ref, d_cost)
+    er.synchronize()
+elif case in ("config2m1", "config2m2"):
+    os.environ["CDPR_MAPPING"] = case[-1]
+    os.environ["CDPR_NO_GRAPH"] = "1"  # eager launches so every dispatch is a traced kernel of its own
+    model, pose, command, _ = bench.make_workload(pkg, 4096, 4, 1234, 10)
+    eng = pkg.Engine(pkg.Config(model=model, batch=4096), 0)
+    eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
+    eng.update(reps * 3); eng.synchronize()
+elif case == "general":
+    B = 16384
+    model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 10)
+    eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3, velocityEpsilon=0.001), 0)
+    eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
+    eng.update(reps * 2); eng.synchronize()
+else:
+    raise SystemExit(f"unknown case {case}")
+print("done", case, flush=True)

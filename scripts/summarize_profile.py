@@ -21,7 +21,7 @@ counters = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(out, "pmc_*/**/*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        if "cdpr_step_kernel" not in name:
+        if "cdpr_" not in name:
             continue
         counters[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 pm = {}

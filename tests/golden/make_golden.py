@@ -117,8 +117,43 @@ def biquad():
     return {"source": "reference Filter.h BiQuad<double> via oracle/_ref/libref_filter.so", "cases": cases}
 
 
+SINE_C = r"""
+/* the arithmetic of sinevelocitytest.cpp:34-48 for the shipped constants: double accumulation of 1/rate,
+   double sin, float32 Joy axis */
+#include <math.h>
+#include <stdio.h>
+int main(void) {
+  const double rate = 100.0, amp = 0.05, freq = 0.1;
+  const int want[] = {1, 7, 250, 1000, 1234, 2500};
+  double time = 0.0;
+  int w = 0;
+  for (int k = 0; k <= 2500; ++k) {
+    float axis = (float)(amp * sin(time * freq * 2 * M_PI));
+    if (k == want[w]) { printf("%d %.9g\n", k, (double)axis); ++w; }
+    time += 1.0 / rate;
+  }
+  return 0;
+}
+"""
+
+
+def sine_spot_values():
+    """Five-plus spot values of the config-1 command stream, from a C program (gcc, libm) that repeats the
+    publisher's arithmetic; not from numpy and not from cdpr_simulation_amd.stimulus."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "sine.c"), os.path.join(d, "sine")
+        open(src, "w").write(SINE_C)
+        subprocess.run(["gcc", "-O0", "-o", exe, src, "-lm"], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    return {k: float(v) for k, v in (ln.split() for ln in out.splitlines())}
+
+
 def pid_kat():
     return {
+        "sine_velocity_spot_values": sine_spot_values(),
         "source": "SURVEY.md Appendix A (survey-time probe; stand-in headers; not reproducible here)",
         "velocity_pid_toy_plant": {
             "plant": "qdd = F - qd, semi-implicit Euler, dt = 1e-3; Pid::update called from k = 0 with now = k*dt",

@@ -35,3 +35,65 @@ def test_cpu_baseline_runs_on_a_bounded_sample(pkg):
     out = bench.cpu_baseline(pkg, dict(model=model, stages=3), pose, command, 10, target_seconds=0.3)
     assert out["kind"] == "port" and out["unit"] == "state-steps/s" and out["value"] > 1e3 and out["value_1core"] > 1e3
     assert 1 <= out["cores"] <= (os.cpu_count() or 1) and "robots x" in out["sample"]
+
+
+def test_cpu_baseline_reports_the_faithful_mode_too(pkg):
+    import bench
+
+    model, pose, command, n_cmd = bench.make_workload(pkg, 64, 4, 1234, 40)
+    out = bench.cpu_baseline(pkg, dict(model=model, stages=0), pose, command, 10, target_seconds=0.2)
+    # `faithful` = per-step polynomial fit as Pid.cpp:219-247, next to the FIR-equivalent mode
+    assert out["value_faithful"] > 1e3 and out["value_faithful_1core"] > 1e3 and "value_faithful" in out["sample"]
+
+
+def test_config_switch_selects_the_baseline_shapes():
+    import bench
+
+    a = bench.parse_args(["--config", "2"])
+    assert (a.batch, a.cables) == (4096, 4)
+    a = bench.parse_args([])
+    assert (a.batch, a.cables, a.gpus) == (65536, 8, 1)
+    a = bench.parse_args(["--config", "2", "--batch", "128"])
+    assert (a.batch, a.cables) == (128, 4)
+
+
+def _run_bench(extra, timeout=300):
+    import json
+    import subprocess
+
+    env = dict(os.environ, CDPR_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must itself become two ranks (gloo rendezvous on a
+    CPU-only box; --dry-run skips the GPU work, everything else is the real path) and report n_gpus = 2."""
+    out = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"])
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["steps"] == 20 and out["scaling"] == "weak"
+    assert out["metric"].startswith("CDPR sim-steps/sec")
+
+
+def test_bench_single_rank_needs_no_rendezvous():
+    out = _run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"])
+    assert out["n_gpus"] == 1
+
+
+def test_bench_fails_loudly_without_a_gpu(pkg):
+    """No CPU fallback: on a box without a GPU the real bench must exit non-zero, not print a number."""
+    import subprocess
+
+    from cdpr_simulation_amd._native import lib
+
+    if lib().cdpr_device_count() > 0:
+        import pytest
+
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
