@@ -16,6 +16,7 @@
 
 #include "../../include/cdpr.h"
 #include "cdpr_step_kernel.hpp"
+#include "cdpr_onestep_kernel.hpp"
 #include "cdpr_step_kernel_pair.hpp"
 #include "cdpr_general_ctrl.hpp"
 #include "cdpr_solvers.hpp"
@@ -53,6 +54,7 @@ struct cdpr_engine {
   int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
   bool lane_pair = false;   // two lanes per robot (cdpr_step_kernel_pair.hpp) instead of one
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
+  bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
   // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
   bool general = false;
   float* d_rec = nullptr;    // [last_pos][position Pid block][velocity Pid block]
@@ -81,6 +83,7 @@ struct cdpr_engine {
   StepArgs base{};               // world/body/FK/TD constants, pointers; Pid fields filled per launch
   StepArgs pid_vel{}, pid_pos{};  // only the Pid fields of these are used
   float* d_wtab = nullptr;        // [velocity | position] rotated derivative-weight tables, kWin * (kWin + 2) floats each
+  float wtab_host[2][kWin * (kWin + 2)]{};  // the same tables on the host: one-step launches take their row by value
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t launches = 0, launches_mark = 0;
   // MPC rollout scratch, persistent and grow-only (no hipMalloc / hipFree inside a rollout)
@@ -372,6 +375,31 @@ StepKernel pick_pair_kernel(uint32_t n, bool fk, bool td) {
   return n == 4 ? pick_pair_stage<4, SINGLE>(fk, td) : pick_pair_stage<8, SINGLE>(fk, td);
 }
 
+// second-generation one-step kernel (controller rows staged through LDS, cdpr_onestep_kernel.hpp)
+template <int N>
+StepKernel pick_onestep_stage(bool fk, bool td) {
+  if constexpr (N >= 6) {
+    if (fk && td) return cdpr_onestep_kernel<N, true, true>;
+    if (fk) return cdpr_onestep_kernel<N, true, false>;
+    if (td) return cdpr_onestep_kernel<N, false, true>;
+  }
+  return cdpr_onestep_kernel<N, false, false>;
+}
+
+StepKernel pick_onestep_kernel(uint32_t n, bool fk, bool td) {
+  switch (n) {
+    case 1: return pick_onestep_stage<1>(fk, td);
+    case 2: return pick_onestep_stage<2>(fk, td);
+    case 3: return pick_onestep_stage<3>(fk, td);
+    case 4: return pick_onestep_stage<4>(fk, td);
+    case 5: return pick_onestep_stage<5>(fk, td);
+    case 6: return pick_onestep_stage<6>(fk, td);
+    case 7: return pick_onestep_stage<7>(fk, td);
+    case 8: return pick_onestep_stage<8>(fk, td);
+  }
+  return nullptr;
+}
+
 // one-step kernels compiled for two waves per SIMD (FK on, n >= 6): see LOWREG in cdpr_step_kernel.hpp
 StepKernel pick_lowreg_kernel(uint32_t n, bool td) {
   switch (n) {
@@ -552,6 +580,12 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
 // position (calls - 1) % 10: fold it into [60, 70) so it never saturates and never loses its phase.
 inline int fold_pid_calls(int calls) { return calls < 70 ? calls : 60 + calls % 10; }
 
+// Weights of the ring position a launch starts at, copied into its arguments (see StepArgs::wrow).
+inline void set_weight_row(const cdpr_engine* h, StepArgs& a) {
+  const int slot = a.pid_calls > 0 ? (a.pid_calls - 1) % kWin : 0;
+  memcpy(a.wrow, &h->wtab_host[h->mode == kModeVelocity ? 0 : 1][slot * (kWin + 2)], sizeof a.wrow);
+}
+
 int run_steps_general(cdpr_engine* h, int nsteps) {
   if (h->step + (uint64_t)nsteps >= (1ull << 31)) {  // world-step stamps are int32 in the controller records
     h->err = "general controller path: world-step counter would pass 2^31";
@@ -676,8 +710,10 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // the kernel uses calls != 0, calls >= nbuf (<= 32) and the ring position (calls - 1) % 10: fold large counts
     // into [60, 70) so they stay small and steady-state launch sequences repeat with period 10
     a.pid_calls = fold_pid_calls(h->pid_calls);
+    set_weight_row(h, a);
     StepKernel kern = h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
-                                   : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td) : pick_kernel<true>(h->n, h->fk, h->td))
+                                   : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
+                                                            : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_kernel<true>(h->n, h->fk, h->td)))
                                                : pick_kernel<false>(h->n, h->fk, h->td));
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
@@ -704,6 +740,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
           for (int j = 0; j < kGraphChunk; ++j) {
             StepArgs aj = a;  // each node carries its own ring position
             aj.pid_calls = 60 + (j * k) % 10;
+            set_weight_row(h, aj);
             hipLaunchKernelGGL(kern, grid, block, 0, h->stream, aj);
             launched = launched && (hipGetLastError() == hipSuccess);
           }
@@ -860,11 +897,12 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     h->lowreg = !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
     if (const char* lr = std::getenv("CDPR_LOWREG")) h->lowreg = (lr[0] == '1') && !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
   }
+  if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
   memset(&h->base, 0, sizeof h->base);
   fill_consts(*cfg, h->base);
-  float wtab_host[2][kWin * (kWin + 2)];
+  auto& wtab_host = h->wtab_host;
   fill_pid(cfg->velocity_pid, cfg->dt, h->pid_vel, wtab_host[0]);
   fill_pid(cfg->position_pid, cfg->dt, h->pid_pos, wtab_host[1]);
   engine_reset_host(h);

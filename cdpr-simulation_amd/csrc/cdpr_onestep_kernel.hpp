@@ -1,0 +1,383 @@
+// cdpr_onestep_kernel.hpp — the one-world-step-per-launch kernel (gfx950, fp32, lane-per-robot), second generation.
+//
+// Same arithmetic as cdpr_step_kernel<N, FK, TD, SINGLE = true> (the device functions are shared, the file is
+// compiled with -ffp-contract=off, so the two are bit-identical — tested), re-staged around what the profile of the
+// first generation showed (profiles/r02a_onestep_summary.json: one wave per SIMD, 47 % of wave cycles issuing,
+// 27 % waiting on memory, 25 % dependent-issue stalls):
+//
+//   * the controller rows (20 ring rows + 2 integral rows at n = 8: 22 of the 29 rows a robot reads) are NOT needed
+//     until the per-cable PID, but as ordinary loads they either stall the wave right away or sit in 88 VGPRs while
+//     the Newton stage wants every register.  They go global -> LDS directly (global_load_lds_dwordx4: one 1 KiB
+//     row per wave-instruction, lane-linear, no VGPR destination), are issued once the platform rows have arrived,
+//     stay in flight under the whole Newton-Raphson stage, and are read back with ds_read_b128 for the PID;
+//   * the stage order is IK -> early observables -> Newton FK -> [wait for the DMA] PID -> TD -> world step, so the
+//     only memory wait on the critical path is the first round trip of the 5 platform rows;
+//   * the observables that are final after the IK (pose, twist, joint position, joint velocity: 7 of 10 rows) are
+//     stored before the Newton stage: the stores drain under compute instead of forming a tail;
+//   * nothing of the true-state IK but the measured lengths L* lives through the Newton stage: the structure
+//     matrix is rebuilt afterwards (one more IK evaluation, ~4 % more instructions) instead of holding 64 VGPRs.
+//
+// LDS per wave: 16 floats x cable pairs of geometry + (controller rows + command rows) x 1 KiB = 24.25 KiB at n = 8;
+// 4 waves per CU (one per SIMD) use 97 KiB of the CU's 160 KiB.
+#pragma once
+#include "cdpr_step_kernel.hpp"
+
+namespace cdpr {
+
+// One controller / command row of the calling wave, global -> LDS without a register destination: lane l copies the
+// 16 bytes at src to dst_row + 16 l (the LDS side of an LDS-DMA is always wave-base + lane * size).
+CDPR_DEV void row_to_lds(const float4* src, float4* dst_row) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst_row, 16, 0, 0);
+}
+
+// Pid::update for every cable pair (Pid.cpp:122-191; the same statements as in cdpr_step_kernel).
+template <int NP>
+CDPR_DEV void pid_pairs(const StepArgs& a, int calls, const v2f (&desired)[NP], const v2f (&actual)[NP], const v2f (&win)[NP][kWin],
+                        v2f (&ierr)[NP], v2f (&f)[NP], v2f (&e_new)[NP], int& ring_slot, float& dbg_p, float& dbg_i, float& dbg_d) {
+  const bool full = calls >= a.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
+  ring_slot = (calls - 1) % kWin;     // the oldest sample sits there and is overwritten by the caller
+  const float (&wt)[kWin + 2] = a.wrow;  // the host put the weights of this ring position into the arguments
+  v2f error[NP], acc[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    error[k] = desired[k] - actual[k];
+    acc[k] = splat(wt[kWin]) * error[k];
+  }
+#pragma unroll
+  for (int j = 0; j < kWin; ++j) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) acc[k] = fma2(wt[j], win[k][j], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const v2f p_term = splat(a.kp) * error[k];
+    const v2f prev_ierr = ierr[k];
+    v2f ie = fma2(a.dt, error[k], prev_ierr);
+    const v2f i_term = splat(a.ki) * ie;
+    const v2f i_cl = max2(min2(i_term, splat(a.imax)), splat(a.imin));  // Pid.cpp:143-152
+    const v2f ie_cl = i_cl * splat(a.inv_ki);
+    ie.x = (i_cl.x != i_term.x) ? ie_cl.x : ie.x;
+    ie.y = (i_cl.y != i_term.y) ? ie_cl.y : ie.y;
+    const v2f derived = full ? acc[k] * splat(a.inv_dt) : splat(0.f);
+    const v2f d_term = splat(a.kd) * derived;
+    const v2f cmd = fma2(a.kf, desired[k], p_term) + i_cl + d_term;
+    v2f out = a.clamp_cmd ? max2(min2(cmd, splat(a.cmax)), splat(a.cmin)) : cmd;  // Pid.cpp:175-177
+    const v2f bumped = fma2(splat(a.dt) * error[k], splat(a.ki), out);             // Pid.cpp:181-184
+    ie.x = (out.x != cmd.x) ? prev_ierr.x : ie.x;
+    ie.y = (out.y != cmd.y) ? prev_ierr.y : ie.y;
+    out.x = (out.x != cmd.x) ? bumped.x : out.x;
+    out.y = (out.y != cmd.y) ? bumped.y : out.y;
+    ierr[k] = ie;
+    f[k] = out;
+    e_new[k] = error[k];
+    if (k == 0) {
+      dbg_p = p_term.x;
+      dbg_i = i_term.x;
+      dbg_d = d_term.x;
+    }
+  }
+}
+
+template <int N, bool FK, bool TD>
+__global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
+  constexpr int NP = cable_pairs(N);
+  constexpr int P = plat_slots(FK);
+  constexpr int G = joint_groups(N);
+  constexpr int NH = (NP + 1) / 2;           // integral ("hot") rows
+  constexpr int kCtrl = 5 * NP + NH;         // controller rows of one robot
+  constexpr bool kCmdLds = (N % 4) == 0;     // Joy rows are float4-addressable: stage them through LDS as well
+  constexpr int kCmdRows = kCmdLds ? N / 4 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[NP * kGeomFloatsPerPair];
+  __shared__ float4 stage[kCtrl + (kCmdRows ? kCmdRows : 1)][64];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t r = blockIdx.x * 64u + lane;
+  const uint32_t rr = (r < a.batch) ? r : (a.batch - 1u);  // tail lanes shadow the last robot, stores are masked
+  const bool live = r < a.batch;
+  const size_t st = a.stride;
+  const uint32_t off = rr * 16u, woff = r * 16u;
+
+  // ---- loads that the first stages need: geometry (oldest), platform rows, and the Joy when it is not LDS-staged
+  CDPR_STAMP(0);
+  const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
+  const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
+               p3 = load_slot(a.state, st, 3, off);
+  float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
+  if (FK) p4 = load_slot(a.state, st, 4, off);
+  v2f desired[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
+  const float* cp = a.cmd + (size_t)rr * N;  // never null: before the first Joy the latched buffer holds zeros
+  if (!kCmdLds) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i & 1)
+        desired[i / 2].y = cp[i];
+      else
+        desired[i / 2].x = cp[i];
+    }
+  }
+  if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
+  // single-wave workgroup: LDS operations of one wave execute in order (see cdpr_step_kernel)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  Platform s;
+  s.px = p0.x; s.py = p0.y; s.pz = p0.z; s.qx = p0.w;
+  s.qy = p1.x; s.qz = p1.y; s.qw = p1.z; s.vx = p1.w;
+  s.vy = p2.x; s.vz = p2.y; s.wx = p2.z; s.wy = p2.w;
+  s.wz = p3.x;
+  float fkx = p3.y, fky = p3.z, fkz = p3.w, fkqx = p4.x, fkqy = p4.y, fkqz = p4.z, fkqw = p4.w;
+
+  // ---- controller rows and the Joy: global -> LDS, in flight until the PID stage.  Issued AFTER the platform rows
+  //      are in registers: hipcc drains every outstanding VMEM operation (vmcnt(0)) at the first use of an ordinary
+  //      load's result while an LDS-DMA is pending, so the DMA must not be pending yet when the platform rows are used.
+  const bool first_world = (a.flags & kFlagFirstWorldStep) != 0u;
+  const bool run_pid = !first_world && a.pid_calls != 0;  // wave-uniform (Pid.cpp:123-126: the first call returns 0)
+  {
+    // every ordinary load issued so far is consumed here (data dependence: no use of one can sink below the DMA issue)
+    float keep = (s.px + s.qy) + (s.vy + s.wz) + fkqw;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) keep += desired[k].x + desired[k].y;
+    asm volatile("" ::"v"(keep));
+    if (run_pid) {
+#pragma unroll
+      for (int j = 0; j < kCtrl; ++j)
+        row_to_lds(reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.state + (size_t)(P + j) * st) + off), &stage[j][0]);
+      if (kCmdLds) {
+#pragma unroll
+        for (int g = 0; g < kCmdRows; ++g) row_to_lds(reinterpret_cast<const float4*>(cp) + g, &stage[kCtrl + g][0]);
+      }
+    }
+  }
+
+  CDPR_STAMP(1);
+  // ---- IK on the state at t_k: joint positions and rates (observables), measured lengths L* for the estimator
+  v2f len[NP], q[NP], qd[NP], jac[NP][6];
+  {
+    v2f l0[NP];
+    ik_pairs<N, true>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      q[k] = l0[k] - len[k];
+      qd[k] = -fma2(s.wz, jac[k][5], fma2(s.wy, jac[k][4], fma2(s.wx, jac[k][3],
+                    fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
+    }
+  }
+  const bool publish = (a.publish_mask & 1ull) != 0ull;
+  if (publish && live) {  // the part of the observables that is final already (PLG.cpp:248-280)
+    store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+      const bool has = (2 * g + 1 < NP);
+      store_slot(a.obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
+      store_slot(a.obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
+    }
+  }
+
+  CDPR_STAMP(2);
+  // ---- Newton-Raphson forward kinematics ([NEW] SURVEY 8(a) row 14); only len lives in from the true state
+  float fk_res = 0.f;
+  int fk_it = 0;
+  v2f jest[NP][6];
+  if (FK) {
+    v2f elen[NP], unused[NP];
+    bool active = true;
+    for (int it = 0; it < a.fk_iters; ++it) {
+      ik_pairs<N, false>(lds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+      v2f res[NP];
+      v2f rm = splat(0.f);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        res[k] = len[k] - elen[k];
+        rm = max2(rm, abs2(res[k]));
+      }
+      active = active && !(fmaxf(rm.x, rm.y) < a.fk_tol);
+      float g[6];
+      jt_times<NP>(jest, res, g);
+      normal_solve<NP>(jest, a.fk_lambda, g);
+      if (active) {
+        fkx += g[0];
+        fky += g[1];
+        fkz += g[2];
+        quat_apply_rotvec(fkqx, fkqy, fkqz, fkqw, g[3], g[4], g[5]);
+        ++fk_it;
+      }
+    }
+    ik_pairs<N, false>(lds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+    v2f rm = splat(0.f);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
+    fk_res = fmaxf(rm.x, rm.y);
+  }
+
+  CDPR_STAMP(3);
+  // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191) on the controller rows from LDS
+  v2f f[NP], e_new[NP], ierr[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    f[k] = splat(0.f);
+    e_new[k] = splat(0.f);
+    ierr[k] = splat(0.f);
+  }
+  float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
+  bool dbg_wrote = false;
+  if (run_pid) {
+    // the DMA has landed once vmcnt reaches 0 (its LDS writes are counted there).  hipcc tracks an LDS-DMA against the
+    // ds_reads of the same LDS object and places this wait by itself; it is spelled out anyway.  No "memory" clobber:
+    // that would stop the derivative weights below from being scalar loads.  0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    CDPR_STAMP(4);
+    if (kCmdLds) {
+#pragma unroll
+      for (int g = 0; g < kCmdRows; ++g) {
+        const float4 v = stage[kCtrl + g][lane];
+        desired[2 * g] = (v2f){v.x, v.y};
+        desired[2 * g + 1] = (v2f){v.z, v.w};
+      }
+    }
+    v2f win[NP][kWin];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        const float4 w = stage[5 * k + m][lane];
+        win[k][2 * m] = (v2f){w.x, w.y};
+        win[k][2 * m + 1] = (v2f){w.z, w.w};
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NH; ++g) {
+      const float4 h = stage[5 * NP + g][lane];
+      ierr[2 * g] = (v2f){h.x, h.y};
+      if (2 * g + 1 < NP) ierr[2 * g + 1] = (v2f){h.z, h.w};
+    }
+    const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
+    v2f actual[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) actual[k] = actual_is_vel ? qd[k] : q[k];
+    int ring_slot;
+    pid_pairs<NP>(a, a.pid_calls, desired, actual, win, ierr, f, e_new, ring_slot, dbg_p, dbg_i, dbg_d);
+    dbg_wrote = true;
+    if (live) {  // one ring row per cable pair (the one that takes the new error) + the integral rows
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        if (m == (ring_slot >> 1)) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) CDPR_STORE_STATE(a.state, st, P + 5 * k + m, woff, ring_row(win[k], m, e_new[k], ring_slot));
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < NH; ++g) {
+        const int k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+        CDPR_STORE_STATE(a.state, st, P + 5 * NP + g, woff, make_float4(ierr[2 * g].x, ierr[2 * g].y, ierr[k1].x, ierr[k1].y));
+      }
+    }
+  }
+
+  CDPR_STAMP(5);
+  // ---- tension distribution ([NEW] SURVEY 8(a) row 15), SetForce limits
+  v2f applied[NP];
+  int td_flag = 0;
+  if (TD) {
+    v2f df[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) df[k] = f[k] - splat(a.td_mid);
+    float g[6];
+    if (FK) {
+      jt_times<NP>(jest, df, g);
+      normal_solve<NP, false>(jest, 0.f, g);
+    } else {
+      jt_times<NP>(jac, df, g);
+      normal_solve<NP, false>(jac, 0.f, g);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      v2f t = splat(a.td_mid);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) t = fma2(g[c], FK ? jest[k][c] : jac[k][c], t);
+      const v2f tc = max2(min2(t, splat(a.td_max)), splat(a.td_min));
+      td_flag |= (tc.x != t.x) ? 1 : 0;
+      if (2 * k + 1 < N) td_flag |= (tc.y != t.y) ? 1 : 0;
+      applied[k] = tc;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) applied[k] = f[k];
+  }
+  if (a.vel_limit > 0.f) {  // Joint::SetForce velocity truncation [EXT]
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      applied[k].x = (qd[k].x > a.vel_limit && applied[k].x > 0.f) || (qd[k].x < -a.vel_limit && applied[k].x < 0.f) ? 0.f : applied[k].x;
+      applied[k].y = (qd[k].y > a.vel_limit && applied[k].y > 0.f) || (qd[k].y < -a.vel_limit && applied[k].y < 0.f) ? 0.f : applied[k].y;
+    }
+  }
+  if (a.effort >= 0.f) {  // Joint::SetForce clamp (cube.sdf:438)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) applied[k] = max2(min2(applied[k], splat(a.effort)), splat(-a.effort));
+  }
+
+  if (a.dbg && live) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
+    float* d = a.dbg + (size_t)r * 9;
+    if (dbg_wrote) {
+      d[0] = dbg_p;
+      d[1] = dbg_i;
+      d[2] = dbg_d;
+      d[3] = desired[0].x;
+    }
+    d[4] = applied[0].x;
+  }
+  if (publish && live) {  // the rest of the observables
+    store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+      const bool has = (2 * g + 1 < NP);
+      store_slot(a.obs, st, 4 + 2 * G + g, woff,
+                 make_float4(applied[k0].x, applied[k0].y, has ? applied[k1].x : 0.f, has ? applied[k1].y : 0.f));
+    }
+  }
+
+  CDPR_STAMP(6);
+  // ---- world step to t_{k+1}: wrench = -J^T (applied - d qdot) + m g
+  {
+    v2f tens[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      tens[k] = fma2(-a.damping, qd[k], applied[k]);
+      if (a.unilateral) tens[k] = max2(tens[k], splat(0.f));
+    }
+    if (FK) {
+      // the true structure matrix did not live through the Newton stage: rebuild it (same inputs, same instructions,
+      // same bits).  The geometry pointer is made opaque so the compiler cannot keep the first evaluation alive instead.
+      uint32_t again = 0;  // an opaque zero OFFSET (an opaque pointer would lose the LDS address space: flat loads)
+      asm volatile("" : "+v"(again));
+      v2f len2[NP], l02[NP];
+      ik_pairs<N, false>(lds + again, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len2, jac, l02);
+    }
+    float w[6];
+    jt_times<NP>(jac, tens, w);
+    w[0] = a.fgx - w[0];
+    w[1] = a.fgy - w[1];
+    w[2] = a.fgz - w[2];
+    w[3] = -w[3];
+    w[4] = -w[4];
+    w[5] = -w[5];
+    integrate(a, s, w);
+  }
+  if (live) {
+    CDPR_STORE_STATE(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    CDPR_STORE_STATE(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    CDPR_STORE_STATE(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+    CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
+    if (FK) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+  }
+  CDPR_STAMP(7);
+}
+
+}  // namespace cdpr

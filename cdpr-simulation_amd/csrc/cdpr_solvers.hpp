@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) void cdpr_solver_kernel(const SolveArgs a) {
     jt_times<NP>(jac, ones, g);
 #pragma unroll
     for (int c = 0; c < 6; ++c) g[c] += a.wrench6[(size_t)r * 6 + c];
-    normal_solve<NP>(jac, 0.f, g);
+    normal_solve<NP, false>(jac, 0.f, g);
     int flag = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {

@@ -91,6 +91,9 @@ struct StepArgs {
   // wtab[ws*12 + 10]: weight of the new error itself (closed form of Pid::derive, Pid.cpp:193-247).  A device
   // buffer, not a kernel-argument array: indexing a by-value argument with a run-time slot sends it to scratch.
   const float* wtab;
+  // one-step launches (cdpr_onestep_kernel): the row of wtab for THIS launch's ring position, by value, so the
+  // weights are kernel-argument scalar loads whatever the kernel has done to memory before the PID stage
+  float wrow[kWin + 2];
   int nbuf, clamp_cmd;
 };
 
@@ -291,18 +294,84 @@ CDPR_DEV void chol_solve(float (&m)[6][6], float (&g)[6]) {
   }
 }
 
-// Solve (J^T J + lambda I) x = g in place (g -> x); J held as cable pairs.
-template <int NP>
+#ifndef CDPR_CHOL_PACKED
+#define CDPR_CHOL_PACKED 1  // 1: normal_solve uses the row-pair packed, right-looking factorization below; 0: chol_solve
+#endif
+
+// The same SPD 6x6 solve with the matrix held as ROW PAIRS: mp[c][p] = (m[2p][c], m[2p+1][c]), column c, only rows >= c
+// meaningful.  Right-looking (outer-product) order: once column j is scaled, every remaining entry takes its
+// -L[i][j] L[c][j] update at once, so (a) rows 2p, 2p+1 of a column update in ONE v_pk_fma_f32 with L[c][j] broadcast
+// through op_sel (22 packed fmas instead of 35 plain ones, 12 packed scalings instead of 15, and the diagonal needs no
+// chain of its own: it is the row-c half of the pair that holds it), and (b) the updates of one step are independent
+// of each other: a single wave per SIMD pays every dependent-issue stall in full, and the left-looking form is one
+// long chain per column.  Every entry still receives the same fmas in the same k order as chol_solve, so the
+// results are bit-identical to it.
+CDPR_DEV void chol_solve_pk(v2f (&mp)[6][3], float (&g)[6]) {
+  float invd[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int p0 = j / 2;
+    invd[j] = __frsqrt_rn((j & 1) ? mp[j][p0].y : mp[j][p0].x);
+#pragma unroll
+    for (int p = p0; p < 3; ++p) mp[j][p] = mp[j][p] * splat(invd[j]);  // L[.][j] (the diagonal half becomes sqrt(d): unused)
+#pragma unroll
+    for (int c = j + 1; c < 6; ++c) {
+      const float lcj = (c & 1) ? mp[j][c / 2].y : mp[j][c / 2].x;  // L[c][j]
+#pragma unroll
+      for (int p = c / 2; p < 3; ++p) mp[c][p] = fma2(-lcj, mp[j][p], mp[c][p]);
+    }
+  }
+  // forward substitution, column oriented: y_j leaves as a scalar, the rows below take their update in pairs
+  v2f gp[3] = {(v2f){g[0], g[1]}, (v2f){g[2], g[3]}, (v2f){g[4], g[5]}};
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    g[j] = ((j & 1) ? gp[j / 2].y : gp[j / 2].x) * invd[j];
+#pragma unroll
+    for (int p = (j + 1) / 2; p < 3; ++p) gp[p] = fma2(-g[j], mp[j][p], gp[p]);
+  }
+  // back substitution (L^T x = y): dot products along the columns of L, scalar
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    float s = g[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s = fmaf(-((k & 1) ? mp[i][k / 2].y : mp[i][k / 2].x), g[k], s);
+    g[i] = s * invd[i];
+  }
+}
+
+// Solve (J^T J + lambda I) x = g in place (g -> x); J held as cable pairs.  LAMBDA = false: no damping term (the
+// tension distribution), nothing is added to the diagonal.
+template <int NP, bool LAMBDA = true>
 CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6]) {
   v2f acc[21];
   gram_partial<NP>(jac, acc);
+#if CDPR_CHOL_PACKED
+  v2f mp[6][3];
+#pragma unroll
+  for (int a = 0, e = 0; a < 6; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b, ++e) {
+      const float v = (LAMBDA && a == b) ? hsum(acc[e]) + lambda : hsum(acc[e]);
+      if (a & 1)
+        mp[b][a / 2].y = v;
+      else
+        mp[b][a / 2].x = v;
+    }
+  }
+  // the halves above the diagonal (row 2p < column 2p+1) are never read for a result; give them a value
+  mp[1][0].x = 0.f;
+  mp[3][1].x = 0.f;
+  mp[5][2].x = 0.f;
+  chol_solve_pk(mp, g);
+#else
   float m[6][6];
 #pragma unroll
   for (int a = 0, e = 0; a < 6; ++a) {
 #pragma unroll
-    for (int b = 0; b <= a; ++b, ++e) m[a][b] = hsum(acc[e]) + ((a == b) ? lambda : 0.f);
+    for (int b = 0; b <= a; ++b, ++e) m[a][b] = (LAMBDA && a == b) ? hsum(acc[e]) + lambda : hsum(acc[e]);
   }
   chol_solve(m, g);
+#endif
 }
 
 struct Platform {
@@ -652,8 +721,9 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       v2f elen[NP], unused[NP];
       bool active = true;
       for (int it = 0; it < a.fk_iters; ++it) {
-        const float* lds_it = lds;
-        if (LOWREG) asm volatile("" : "+v"(lds_it));  // opaque per iteration: the geometry reads stay inside the loop
+        uint32_t lds_off = 0;  // opaque zero offset per iteration: the geometry reads stay inside the loop (an opaque
+        if (LOWREG) asm volatile("" : "+v"(lds_off));  // POINTER would lose the LDS address space and turn them into flat loads)
+        const float* lds_it = lds + lds_off;
         ik_pairs<N, false>(lds_it, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
         v2f res[NP];
         v2f rm = splat(0.f);
@@ -691,10 +761,10 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       float g[6];
       if (FK) {
         jt_times<NP>(jest, df, g);
-        normal_solve<NP>(jest, 0.f, g);
+        normal_solve<NP, false>(jest, 0.f, g);
       } else {
         jt_times<NP>(jac, df, g);
-        normal_solve<NP>(jac, 0.f, g);
+        normal_solve<NP, false>(jac, 0.f, g);
       }
 #pragma unroll
       for (int k = 0; k < NP; ++k) {

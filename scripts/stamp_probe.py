@@ -20,7 +20,8 @@ for stages in (3, 0):
     L.cdpr_device_download(eng._h, buf.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), buf.nbytes)
     t = buf.astype(np.float64) * 0.01  # us (100 MHz)
     t0 = t[:, 0].min()
-    names = ["entry", "data arrived / IK", "PID", "FK", "TD", "obs store", "final store", "end"]
+    names = (["entry", "data arrived / IK", "PID", "FK", "TD", "obs store", "final store", "end"] if os.environ.get("CDPR_ONESTEP") == "1" else
+             ["entry", "platform rows in, DMA issued", "IK + early obs", "Newton FK done", "DMA landed", "PID done", "TD + obs done", "end"])
     print(f"stages={stages}: kernel span {t[:,7].max()-t0:.2f} us; per-phase (median / min / max over waves), us since first wave entry:")
     for i, nm in enumerate(names):
         col = t[:, i] - t0

@@ -222,19 +222,21 @@ def test_pid_call_counter_never_saturates(pkg, oracle, monkeypatch):
     steps on a tiny batch (hipGraph replays) and stay on the oracle."""
     monkeypatch.setenv("CDPR_MAPPING", "1")
     B = 2
-    # the 8-cable robot is fully constrained (rank-6 structure matrix): position hold is an asymptotically stable
-    # equilibrium, so fp32 and fp64 do not drift apart over 10^6 steps (the 4-cable robot's free DoF would)
+    # the 8-cable robot is fully constrained (rank-6 structure matrix); the 4-cable robot's free DoF would wander
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B)
     rng = np.random.default_rng(3)
     pose = perturbed_poses(cfg.model, B, rng, 0.02, 0.03).astype(np.float32)
     eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
     eng.set_platform_state(pose7=pose), ora.set_platform_state(pose7=pose.astype(np.float64))
-    cmd = 1e-3 * rng.uniform(-1.0, 1.0, (B, 8)).astype(np.float32)  # joint position targets, metres
+    # Velocity mode with a zero command brings the platform to rest (the velocity Pids regulate every cable rate to 0 and
+    # their integrators end up holding gravity): a fixed point both precisions converge to, so 10^6 steps do not let
+    # fp32 and fp64 drift apart; then a velocity step right after the old saturation point: the D term must see it.
+    step_cmd = rng.uniform(-0.01, 0.01, (B, 8)).astype(np.float32)
     for e in (eng, ora):
         e.update(7)
-        e.set_position_command(cmd)  # Position mode from Load: no Pid reset, the counter keeps running
+        e.set_velocity_command(np.zeros((B, 8), dtype=np.float32))
         e.update((1 << 20) + 12345)
-        e.set_position_command(-cmd)  # a fresh error step right after the old saturation point: the D term must see it
+        e.set_velocity_command(step_cmd)  # same mode: no Pid reset, the call counter keeps running
         e.update(25)
     gq, gqd, ge = eng.joint_states()
     oq, oqd, oe = ora.joint_states()

@@ -826,3 +826,40 @@ def test_low_register_build_is_bit_identical(pkg, monkeypatch, mapping):
         out.append(e.raw_state() + e.joint_states() + e.fk_state())
     for x, y in zip(*out):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n_cables,stages", [(8, 3), (8, 1), (8, 2), (8, 0), (4, 0), (5, 0), (7, 3)])
+def test_second_generation_onestep_kernel_is_bit_identical(pkg, monkeypatch, mapping, n_cables, stages):
+    """cdpr_onestep_kernel (controller rows staged through LDS by LDS-DMA, Newton stage before the PID, structure matrix
+    rebuilt) performs the same arithmetic as the first-generation one-step kernel (CDPR_ONESTEP=1): bit-identical state,
+    observables, FK estimate and `pid` topic through Load -> position hold -> velocity Joy -> position Joy."""
+    once(mapping)
+    B = 200
+    rng = np.random.default_rng(23)
+    model = pkg.eight_cable_model() if n_cables == 8 else pkg.cube_model()
+    if n_cables not in (4, 8):
+        base = pkg.eight_cable_model()
+        from dataclasses import replace
+
+        model = replace(base, frame_anchors=base.frame_anchors[:n_cables], platform_anchors=base.platform_anchors[:n_cables])
+    cfg = pkg.Config(model=model, batch=B, stages=stages | pkg._abi.STAGE_PID_DEBUG)
+    pose = perturbed_poses(cfg.model, B, rng, 0.03, 0.05).astype(np.float32)
+    vel = rng.uniform(-0.04, 0.04, (B, n_cables)).astype(np.float32)
+    pos = rng.uniform(-0.002, 0.002, (B, n_cables)).astype(np.float32)
+    out = []
+    for gen in ("1", "2"):
+        monkeypatch.setenv("CDPR_ONESTEP", gen)
+        e = pkg.Engine(cfg, 0)
+        e.set_platform_state(pose7=pose)
+        snaps = []
+        for script in ((3, None), (14, ("v", vel)), (23, ("p", pos)), (12, ("v", -vel))):
+            if script[1] is not None:
+                (e.set_velocity_command if script[1][0] == "v" else e.set_position_command)(script[1][1])
+            for _ in range(script[0]):
+                e.update(1)
+            snaps.append(e.raw_state() + e.joint_states() + e.platform_state() + (e.pid_debug(),) + (e.fk_state() if stages & 1 else ()))
+        out.append(snaps)
+        e.close()
+    for sa, sb in zip(*out):
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x, y)
