@@ -24,6 +24,21 @@ for (B, n, stages) in cases:
             eng.profile_begin(); eng.update(300, spl); ms, nl = eng.profile_end(); ts.append(ms / 300 * 1e3)
         print(os.environ.get("AB_LABEL"), f"B={B} n={n} stages={stages} spl={spl}: {np.median(ts):.2f} us/step (min {min(ts):.2f})", flush=True)
     eng.close()
+if os.environ.get("AB_ROLLOUT", "1") == "1":
+    Br, S, H = bench.ROLLOUT_SHAPE
+    model, pose, command, _ = bench.make_workload(pkg, Br, 8, 1235, 10)
+    er = pkg.Engine(pkg.Config(model=model, batch=Br, stages=3), 0)
+    er.set_platform_state(pose7=pose); er.update(20)
+    dptr = er.device_upload(bench.make_rollout_commands(Br, H, S, 8))
+    d_ref, d_cost = er.device_upload(pose[:, :3].copy()), er.device_alloc(Br * S * 4)
+    er.rollout_velocity_device(dptr, S, H, d_ref, d_cost); er.synchronize()
+    ts = []
+    for rnd in range(7):
+        er.profile_begin()
+        for _ in range(5): er.rollout_velocity_device(dptr, S, H, d_ref, d_cost)
+        ms, nl = er.profile_end(); ts.append(ms / 5 * 1e3)
+    print(os.environ.get("AB_LABEL"), f"rollout {Br}x{S}x{H}: {np.median(ts):.1f} us (min {min(ts):.1f}) = {np.median(ts) / H:.2f} us/step", flush=True)
+    er.close()
 ''' % ROOT
 for rep in range(2):
     for label, env in variants:
