@@ -253,8 +253,8 @@ def main():
         done = 0
         while done < nsteps:
             s = first_step + done
-            if s % refresh == 0:
-                eng.set_velocity_command_device(sched[s // refresh], count)
+            if s % refresh == 0:  # the schedule lives in HBM: the engine reads the Joy batch in place (zero copy)
+                eng.bind_velocity_command_device(sched[s // refresh], count)
             k = min(refresh - s % refresh, nsteps - done)
             eng.update(k, args.steps_per_launch)
             done += k
@@ -291,7 +291,7 @@ def main():
         eng.profile_begin()
         t0 = time.perf_counter()
         for j in range(steps2 // refresh):
-            eng.set_velocity_command_device(sched2[j], count)
+            eng.bind_velocity_command_device(sched2[j], count)
             eng.update_record_device(refresh, spl, d_rec, image * refresh)  # every step's observables stay in HBM
         ms2, launches2 = eng.profile_end()
         barrier()

@@ -5,7 +5,7 @@ loader and the function prototypes are in `_native.py`.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_CABLES = 8
 MAX_D_BUFFER = 32
 MAX_D_DEGREE = 4
@@ -72,7 +72,7 @@ class ConfigStruct(C.Structure):
         ("stages", C.c_uint32),
         ("mapping", C.c_uint32),
         ("fk_max_iterations", C.c_uint32),
-        ("reserved_", C.c_uint32),
+        ("per_robot_commands", C.c_uint32),
         ("fk_lambda", C.c_double),
         ("fk_tolerance", C.c_double),
         ("td_f_min", C.c_double),

@@ -135,6 +135,7 @@ class Config:
     fkMaxIterations: int = 4
     fkLambda: float = 1e-9
     fkTolerance: float = 0.0
+    perRobotCommands: bool = False  # every robot has its own mode / Pid history: a Joy may reach some robots only ([NEW]: B plugin instances)
     tdFMin: float | None = None  # default: model.f_min
     tdFMax: float | None = None
 
@@ -256,6 +257,7 @@ class Config:
         s.stages = int(self.stages)
         s.mapping = int(self.mapping)
         s.fk_max_iterations = int(self.fkMaxIterations)
+        s.per_robot_commands = 1 if self.perRobotCommands else 0
         s.fk_lambda = float(self.fkLambda)
         s.fk_tolerance = float(self.fkTolerance)
         s.td_f_min = float(m.f_min if self.tdFMin is None else self.tdFMin)

@@ -75,6 +75,14 @@ struct cdpr_engine {
   bool use_graphs = true;
   float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
   float* d_pos[2] = {nullptr, nullptr};
+  // zero-copy commands (cdpr_bind_*_command_device): a caller-owned device buffer takes the place of d_*[0] / d_*[1]
+  const float* ext_vel[2] = {nullptr, nullptr};
+  const float* ext_pos[2] = {nullptr, nullptr};
+  // per-robot command arrival (cfg.per_robot_commands): every robot has its own mode; general controller path only
+  bool per_robot = false;
+  uint8_t* d_mode = nullptr;        // uint8[B]: 1 = Position, 2 = Velocity
+  uint8_t* d_mask[2] = {nullptr, nullptr};  // pending masks of the velocity / position command, uint8[B]
+  bool vel_masked = false, pos_masked = false;  // the pending command came with a mask
   bool vel_pending = false, pos_pending = false;
   bool have_vel = false, have_pos = false;  // a command of that kind has been latched since Load
   int mode = kModePosition;
@@ -510,6 +518,7 @@ int upload_home(cdpr_engine* h) {
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   }
   if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows() * h->tstride * sizeof(float), h->stream));
+  if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return CDPR_OK;
 }
@@ -525,6 +534,9 @@ void free_all(cdpr_engine* h) {
   if (h->d_rec) (void)hipFree(h->d_rec);
   if (h->d_force) (void)hipFree(h->d_force);
   if (h->d_cable) (void)hipFree(h->d_cable);
+  if (h->d_mode) (void)hipFree(h->d_mode);
+  for (int i = 0; i < 2; ++i)
+    if (h->d_mask[i]) (void)hipFree(h->d_mask[i]);
   if (h->d_roll_ref) (void)hipFree(h->d_roll_ref);
   if (h->d_roll_cost) (void)hipFree(h->d_roll_cost);
   for (int i = 0; i < 2; ++i) {
@@ -543,6 +555,8 @@ void free_all(cdpr_engine* h) {
 
 void engine_reset_host(cdpr_engine* h) {
   h->vel_pending = h->pos_pending = false;
+  h->vel_masked = h->pos_masked = false;
+  h->ext_vel[0] = h->ext_vel[1] = h->ext_pos[0] = h->ext_pos[1] = nullptr;
   h->have_vel = h->have_pos = false;
   h->mode = kModePosition;  // PLG.cpp:153-157: Position mode, target 0 after operator= -> reset()
   h->step = 0;
@@ -609,8 +623,9 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
   g.batch = h->batch;
   g.n = h->n;
   g.cable = h->d_cable;
-  g.vel_cmd = h->have_vel ? h->d_vel[0] : nullptr;
-  g.pos_cmd = h->have_pos ? h->d_pos[0] : nullptr;
+  g.vel_cmd = h->have_vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : nullptr;
+  g.pos_cmd = h->have_pos ? (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]) : nullptr;
+  g.mode_arr = h->per_robot ? h->d_mode : nullptr;
   g.rec = h->d_rec;
   g.tstride = h->tstride;
   g.force = h->d_force;
@@ -656,8 +671,45 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path)
     return hipMemsetAsync(h->d_rec + h->tstride * (1 + (size_t)which * kGfRows), 0, (size_t)kGfRows * h->tstride * sizeof(float), h->stream);
   };
+  if (h->per_robot) {
+    // every robot has its own mode: commands (masked or not) are latched on the device, robot by robot
+    auto latch = [&](float* pending, float* latched, const uint8_t* mask, int which, int new_mode) -> int {
+      LatchArgs la{};
+      la.mask = mask;
+      la.mode = h->d_mode;
+      la.pending = pending;
+      la.latched = latched;
+      la.pid_block = h->d_rec + h->tstride * (1 + (size_t)which * kGfRows);
+      la.tstride = h->tstride;
+      la.batch = h->batch;
+      la.n = h->n;
+      la.new_mode = new_mode;
+      const uint32_t total = h->batch * h->n;
+      hipLaunchKernelGGL(cdpr_latch_masked_kernel, dim3((total + 255u) / 256u), dim3(256), 0, h->stream, la);
+      hipLaunchKernelGGL(cdpr_set_mode_masked_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, mask, h->d_mode, h->batch, new_mode);
+      HIP_TRY(h, hipGetLastError());
+      return CDPR_OK;
+    };
+    if (h->vel_pending) {
+      if (int rc = latch(h->d_vel[1], h->d_vel[0], h->vel_masked ? h->d_mask[0] : nullptr, 1, kModeVelocity)) return rc;
+      h->vel_pending = h->vel_masked = false;
+      h->have_vel = true;
+    }
+    if (h->pos_pending) {
+      if (int rc = latch(h->d_pos[1], h->d_pos[0], h->pos_masked ? h->d_mask[1] : nullptr, 0, kModePosition)) return rc;
+      h->pos_pending = h->pos_masked = false;
+      h->have_pos = true;
+    }
+    return run_steps_general(h, nsteps);
+  }
   if (h->vel_pending) {
-    std::swap(h->d_vel[0], h->d_vel[1]);
+    if (h->ext_vel[1]) {  // bound caller buffer: latched by pointer, nothing copied
+      h->ext_vel[0] = h->ext_vel[1];
+      h->ext_vel[1] = nullptr;
+    } else {
+      std::swap(h->d_vel[0], h->d_vel[1]);
+      h->ext_vel[0] = nullptr;
+    }
     h->vel_pending = false;
     h->have_vel = true;
     reset_pid = (h->mode != kModeVelocity);  // JFC.cpp:113-115
@@ -665,7 +717,13 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     h->mode = kModeVelocity;
   }
   if (h->pos_pending) {
-    std::swap(h->d_pos[0], h->d_pos[1]);
+    if (h->ext_pos[1]) {
+      h->ext_pos[0] = h->ext_pos[1];
+      h->ext_pos[1] = nullptr;
+    } else {
+      std::swap(h->d_pos[0], h->d_pos[1]);
+      h->ext_pos[0] = nullptr;
+    }
     h->pos_pending = false;
     h->have_pos = true;
     reset_pid = (h->mode != kModePosition);  // JFC.cpp:101-103 (fast path: the single record now belongs to the position Pid)
@@ -691,10 +749,10 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   a.obs_step_stride = record ? image : 0;
   if (h->mode == kModeVelocity) {
     copy_pid(h->pid_vel, a);
-    a.cmd = h->d_vel[0];
+    a.cmd = h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0];
   } else {
     copy_pid(h->pid_pos, a);
-    a.cmd = h->d_pos[0];  // all zeros until the first jointPositions message: target 0 (PLG.cpp:153-157)
+    a.cmd = h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0];  // all zeros until the first jointPositions message: target 0 (PLG.cpp:153-157)
   }
   const uint32_t robots_per_block = h->lane_pair ? 32u : 64u;
   const dim3 grid((h->batch + robots_per_block - 1u) / robots_per_block), block(64);
@@ -856,7 +914,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     g_create_error = why;
     return CDPR_ERR_INVALID;
   }
-  const bool general = !fast_path_obstacle(*cfg).empty();
+  const bool general = cfg->per_robot_commands != 0 || !fast_path_obstacle(*cfg).empty();
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -877,6 +935,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
   h->general = general;
+  h->per_robot = cfg->per_robot_commands != 0;
   {
     // Mapping: measured on MI355X (scripts/ab_bench.py), two lanes per robot win while the batch leaves SIMDs
     // under-filled (16 384 x 8 cables: 9.0 vs 10.2 us/step; 4 096 x 4: 3.0 vs 3.4) and lose from 65 536 robots on
@@ -957,6 +1016,11 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     fill_gen_pid(cfg->position_pid, h->gpid[0]);
     fill_gen_pid(cfg->velocity_pid, h->gpid[1]);
   }
+  if (h->per_robot) {
+    if ((e = hipMalloc(&h->d_mode, h->batch)) != hipSuccess) return fail("hipMalloc(mode)", e);
+    for (int i = 0; i < 2; ++i)
+      if ((e = hipMalloc(&h->d_mask[i], h->batch)) != hipSuccess) return fail("hipMalloc(mask)", e);
+  }
   if (h->dbg)
     if ((e = hipMalloc(&h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float))) != hipSuccess)
       return fail("hipMalloc(dbg)", e);
@@ -1011,32 +1075,138 @@ int cdpr_set_platform_state(cdpr_handle_t h, const float* pose7, const float* tw
   return CDPR_OK;
 }
 
+// A pending command replaces the one before it (PLG.cpp:69,78: the callback overwrites the stored message); on a
+// per-robot handle an UNMASKED command after a masked one would have to merge with it, which the callbacks of
+// independent plugins never need: the later call wins for the robots it addresses, the earlier one keeps the rest.
+static int stage_masked(cdpr_engine* h, int which, const float* axes, size_t count, const uint8_t* robot_mask) {
+  if (!h->per_robot) {
+    h->err = "masked commands need a handle created with per_robot_commands = 1";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (!robot_mask) {
+    h->err = "null robot mask";
+    return CDPR_ERR_INVALID;
+  }
+  const size_t n = h->n, B = h->batch;
+  if (count != n * B && count != n) return CDPR_IGNORED;  // PLG.cpp:68-73,77-82
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  float* pending = which == 0 ? h->d_vel[1] : h->d_pos[1];
+  bool& is_pending = which == 0 ? h->vel_pending : h->pos_pending;
+  bool& masked = which == 0 ? h->vel_masked : h->pos_masked;
+  // merge with a command of the same kind that is already pending: rows and mask bits of the robots addressed now
+  std::vector<float> rows(n * B);
+  std::vector<uint8_t> mask(B, 0);
+  if (is_pending) {
+    HIP_TRY(h, hipMemcpyAsync(rows.data(), pending, n * B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (masked)
+      HIP_TRY(h, hipMemcpyAsync(mask.data(), h->d_mask[which], B, hipMemcpyDeviceToHost, h->stream));
+    else
+      std::fill(mask.begin(), mask.end(), (uint8_t)1);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+  }
+  for (size_t b = 0; b < B; ++b) {
+    if (!robot_mask[b]) continue;
+    mask[b] = 1;
+    memcpy(&rows[b * n], count == n ? axes : axes + b * n, n * sizeof(float));
+  }
+  HIP_TRY(h, hipMemcpyAsync(pending, rows.data(), n * B * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_mask[which], mask.data(), B, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  is_pending = true;
+  masked = true;
+  return CDPR_OK;
+}
+
 int cdpr_set_velocity_command(cdpr_handle_t h, const float* axes, size_t count) {
   if (!h) return CDPR_ERR_INVALID;
   int rc = stage_command(h, h->d_vel[1], axes, count, false);
-  if (rc == CDPR_OK) h->vel_pending = true;
+  if (rc == CDPR_OK) {
+    h->vel_pending = true;
+    h->vel_masked = false;
+    h->ext_vel[1] = nullptr;
+  }
   return rc;
 }
 
 int cdpr_set_position_command(cdpr_handle_t h, const float* axes, size_t count) {
   if (!h) return CDPR_ERR_INVALID;
   int rc = stage_command(h, h->d_pos[1], axes, count, false);
-  if (rc == CDPR_OK) h->pos_pending = true;
+  if (rc == CDPR_OK) {
+    h->pos_pending = true;
+    h->pos_masked = false;
+    h->ext_pos[1] = nullptr;
+  }
   return rc;
+}
+
+int cdpr_set_velocity_command_masked(cdpr_handle_t h, const float* axes, size_t count, const uint8_t* robot_mask) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (!axes) {
+    h->err = "null command buffer";
+    return CDPR_ERR_INVALID;
+  }
+  return stage_masked(h, 0, axes, count, robot_mask);
+}
+
+int cdpr_set_position_command_masked(cdpr_handle_t h, const float* axes, size_t count, const uint8_t* robot_mask) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (!axes) {
+    h->err = "null command buffer";
+    return CDPR_ERR_INVALID;
+  }
+  return stage_masked(h, 1, axes, count, robot_mask);
 }
 
 int cdpr_set_velocity_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
   if (!h) return CDPR_ERR_INVALID;
   int rc = stage_command(h, h->d_vel[1], d_axes, count, true);
-  if (rc == CDPR_OK) h->vel_pending = true;
+  if (rc == CDPR_OK) {
+    h->vel_pending = true;
+    h->vel_masked = false;
+    h->ext_vel[1] = nullptr;
+  }
   return rc;
 }
 
 int cdpr_set_position_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
   if (!h) return CDPR_ERR_INVALID;
   int rc = stage_command(h, h->d_pos[1], d_axes, count, true);
-  if (rc == CDPR_OK) h->pos_pending = true;
+  if (rc == CDPR_OK) {
+    h->pos_pending = true;
+    h->pos_masked = false;
+    h->ext_pos[1] = nullptr;
+  }
   return rc;
+}
+
+// Zero-copy form: the caller's device buffer float[B][n] IS the latched Joy batch from the next update on (no copy, no
+// synchronisation); it must stay valid and unchanged until another command of the same kind has been latched.
+static int bind_command(cdpr_engine* h, int which, const float* d_axes, size_t count) {
+  if (!d_axes) {
+    h->err = "null command buffer";
+    return CDPR_ERR_INVALID;
+  }
+  if (count != (size_t)h->n * h->batch) return CDPR_IGNORED;  // one Joy per robot; no broadcast without a copy
+  if (h->per_robot) {
+    h->err = "cdpr_bind_*_command_device: not available on a per_robot_commands handle (commands are latched robot by robot)";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (which == 0) {
+    h->ext_vel[1] = d_axes;
+    h->vel_pending = true;
+  } else {
+    h->ext_pos[1] = d_axes;
+    h->pos_pending = true;
+  }
+  return CDPR_OK;
+}
+
+int cdpr_bind_velocity_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
+  return h ? bind_command(h, 0, d_axes, count) : CDPR_ERR_INVALID;
+}
+
+int cdpr_bind_position_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
+  return h ? bind_command(h, 1, d_axes, count) : CDPR_ERR_INVALID;
 }
 
 int cdpr_update(cdpr_handle_t h, int nsteps) { return run_steps(h, nsteps, 1); }

@@ -56,7 +56,8 @@ struct GenArgs {
   size_t tstride;
   float* force;         // out: raw force per cable, float[B][n]
   float* dbg;           // `pid` topic (cable 0), float[B][9], or nullptr
-  int mode;             // 1 = Position, 2 = Velocity (JFC.h:35-37)
+  int mode;             // 1 = Position, 2 = Velocity (JFC.h:35-37): the whole batch, when mode_arr is null
+  const uint8_t* mode_arr;  // per-robot mode (handles created with per_robot_commands), uint8[B], or nullptr
   int first_world;      // t = 0: stepTime <= 0 -> force 0, nothing else (JFC.cpp:61-66)
   int now_step;
   float eps, dt;
@@ -265,7 +266,8 @@ __global__ __launch_bounds__(256) void cdpr_general_ctrl_kernel(const GenArgs a)
   GenTerms terms;
   terms.pi_written = terms.d_written = terms.desired_written = false;
   float force = 0.f;
-  if (a.mode == 2) {  // Velocity (JFC.cpp:71-83)
+  const int mode = a.mode_arr ? (int)a.mode_arr[r] : a.mode;
+  if (mode == 2) {  // Velocity (JFC.cpp:71-83)
     const float vt = a.vel_cmd ? a.vel_cmd[t] : 0.f;
     if (fabsf(vt) > a.eps) {
       *last_pos = q;
@@ -288,6 +290,39 @@ __global__ __launch_bounds__(256) void cdpr_general_ctrl_kernel(const GenArgs a)
     if (terms.d_written) d[2] = terms.d;
     if (terms.desired_written) d[3] = terms.desired;
   }
+}
+
+// Per-robot command arrival (cdpr_set_*_command_masked): what B independent plugin instances do when only some of
+// them receive a Joy before the next update() (PLG.cpp:206-219 per model).  One thread per (robot, cable):
+// robots in the mask latch their new target; entering the mode from the other one resets that mode's Pid
+// (JFC.cpp:101-103,113-115) = zero this thread's column of the Pid's record block.  The mode itself is written by
+// cdpr_set_mode_masked_kernel afterwards (the threads of one robot may sit in different waves).
+struct LatchArgs {
+  const uint8_t* mask;   // uint8[B], or nullptr = every robot
+  const uint8_t* mode;   // current per-robot mode
+  const float* pending;  // float[B][n]
+  float* latched;        // float[B][n]
+  float* pid_block;      // first row of the Pid block this command's mode owns (position or velocity)
+  size_t tstride;
+  uint32_t batch, n;
+  int new_mode;
+};
+
+__global__ __launch_bounds__(256) void cdpr_latch_masked_kernel(const LatchArgs a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= a.batch * a.n) return;
+  const uint32_t r = t / a.n;
+  if (a.mask && !a.mask[r]) return;
+  a.latched[t] = a.pending[t];
+  if ((int)a.mode[r] != a.new_mode) {
+    for (int row = 0; row < kGfRows; ++row) a.pid_block[(size_t)row * a.tstride + t] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void cdpr_set_mode_masked_kernel(const uint8_t* mask, uint8_t* mode, uint32_t batch, int new_mode) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= batch) return;
+  if (!mask || mask[r]) mode[r] = (uint8_t)new_mode;
 }
 
 }  // namespace cdpr

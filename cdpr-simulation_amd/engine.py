@@ -80,13 +80,28 @@ class Engine:
         t = None if twist6 is None else np.ascontiguousarray(twist6, dtype=np.float32).reshape(self.B, 6)
         self._check(lib().cdpr_set_platform_state(self._h, _fp(p), _fp(t)))
 
-    def set_velocity_command(self, axes) -> int:
+    def _command(self, fn, fn_masked, axes, mask) -> int:
         a = np.ascontiguousarray(axes, dtype=np.float32).ravel()
-        return self._check(lib().cdpr_set_velocity_command(self._h, _fp(a), a.size))
+        if mask is None:
+            return self._check(fn(self._h, _fp(a), a.size))
+        m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        return self._check(fn_masked(self._h, _fp(a), a.size, m.ctypes.data_as(C.POINTER(C.c_uint8))))
 
-    def set_position_command(self, axes) -> int:
-        a = np.ascontiguousarray(axes, dtype=np.float32).ravel()
-        return self._check(lib().cdpr_set_position_command(self._h, _fp(a), a.size))
+    def set_velocity_command(self, axes, mask=None) -> int:
+        """Joy on `jointVelocities`.  mask[B] (Config.perRobotCommands): only these robots receive it, the others keep
+        their target, mode and Pid state (what independent plugin instances do, PLG.cpp:206-219)."""
+        return self._command(lib().cdpr_set_velocity_command, lib().cdpr_set_velocity_command_masked, axes, mask)
+
+    def set_position_command(self, axes, mask=None) -> int:
+        return self._command(lib().cdpr_set_position_command, lib().cdpr_set_position_command_masked, axes, mask)
+
+    def bind_velocity_command_device(self, dptr: int, count: int) -> int:
+        """Zero-copy: the device buffer float[B][n] at dptr is the latched Joy batch from the next update on; it must stay
+        valid and unchanged until another velocity command has been latched."""
+        return self._check(lib().cdpr_bind_velocity_command_device(self._h, C.c_void_p(dptr), count))
+
+    def bind_position_command_device(self, dptr: int, count: int) -> int:
+        return self._check(lib().cdpr_bind_position_command_device(self._h, C.c_void_p(dptr), count))
 
     def set_velocity_command_device(self, dptr: int, count: int) -> int:
         return self._check(lib().cdpr_set_velocity_command_device(self._h, C.c_void_p(dptr), count))

@@ -60,21 +60,20 @@ class ShardedEngine:
         for e, p, t in zip(self.engines, ps, ts):
             e.set_platform_state(p, t)
 
-    def set_velocity_command(self, axes):
+    def _command(self, name, axes, mask):
         import numpy as np
 
         a = np.asarray(axes, dtype=np.float32)
         if a.size not in (self.n, self.n * self.B):
             return 1  # CDPR_IGNORED, as every shard would answer (PLG.cpp:68-73)
-        return max(e.set_velocity_command(x) for e, x in zip(self.engines, self._split(a, self.n)))
+        masks = [None] * len(self.engines) if mask is None else [np.asarray(mask, dtype=np.uint8).reshape(self.B)[lo:hi] for lo, hi in self.spans]
+        return max(getattr(e, name)(x, m) for e, x, m in zip(self.engines, self._split(a, self.n), masks))
 
-    def set_position_command(self, axes):
-        import numpy as np
+    def set_velocity_command(self, axes, mask=None):
+        return self._command("set_velocity_command", axes, mask)
 
-        a = np.asarray(axes, dtype=np.float32)
-        if a.size not in (self.n, self.n * self.B):
-            return 1
-        return max(e.set_position_command(x) for e, x in zip(self.engines, self._split(a, self.n)))
+    def set_position_command(self, axes, mask=None):
+        return self._command("set_position_command", axes, mask)
 
     def update(self, nsteps=1, steps_per_launch=1):
         for e in self.engines:  # asynchronous: all devices run concurrently

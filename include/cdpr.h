@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CDPR_ABI_VERSION 1u
+#define CDPR_ABI_VERSION 2u
 #define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
 #define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
 #define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
@@ -120,7 +120,10 @@ typedef struct cdpr_config {
   uint32_t stages;                  /* CDPR_STAGE_* */
   uint32_t mapping;                 /* CDPR_MAP_*   */
   uint32_t fk_max_iterations;       /* Newton-Raphson iteration cap */
-  uint32_t reserved_;
+  uint32_t per_robot_commands;      /* 1: every robot has its own JointForceCalculator mode and Pid call history, as B
+                                       independent plugin instances have (PLG.cpp:206-219 runs per model): a Joy may reach
+                                       some robots only (cdpr_set_*_command_masked).  Selects the general controller path.
+                                       0: a Joy batch always addresses every robot (mode uniform over the batch) */
   double fk_lambda;                 /* Levenberg damping added to the diagonal of J^T J */
   double fk_tolerance;              /* stop when max_i |L*_i - L_i| < tol; 0 = always run the cap */
   double td_f_min;                  /* cube.yaml:9 `min: 5`   */
@@ -164,9 +167,21 @@ int cdpr_set_platform_state(cdpr_handle_t h, const float *pose7, const float *tw
  * cdpr_update and zero-order-held until replaced (PLG.cpp:206-219). */
 int cdpr_set_velocity_command(cdpr_handle_t h, const float *axes, size_t count);
 int cdpr_set_position_command(cdpr_handle_t h, const float *axes, size_t count);
-/* Same, from a device buffer already resident in HBM (float[B][n]). */
+/* Same, from a device buffer already resident in HBM (float[B][n]); the batch is copied (device to device). */
 int cdpr_set_velocity_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
 int cdpr_set_position_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
+/* Zero-copy form for command schedules that live in HBM: the caller's device buffer float[B][n] (count = n*B) IS the
+ * latched Joy batch from the next cdpr_update on; nothing is copied or synchronised.  The buffer must stay valid and
+ * unchanged until another command of the same kind has been latched.  (The one exception to "no caller pointer is
+ * retained": that is its point.) */
+int cdpr_bind_velocity_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
+int cdpr_bind_position_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
+/* Per-robot arrival: the Joy batch reaches only the robots with robot_mask[b] != 0 (uint8[B], host); the others keep
+ * their target, their mode and their Pid state, exactly as plugin instances that received nothing before this
+ * update() (PLG.cpp:206-219 is per model).  axes: float[B][n] (rows of unmasked robots are ignored) or float[n]
+ * broadcast to the masked robots.  Needs cdpr_config_t.per_robot_commands = 1, else CDPR_ERR_UNSUPPORTED. */
+int cdpr_set_velocity_command_masked(cdpr_handle_t h, const float *axes, size_t count, const uint8_t *robot_mask);
+int cdpr_set_position_command_masked(cdpr_handle_t h, const float *axes, size_t count, const uint8_t *robot_mask);
 
 /* Replaces nsteps x { CdprGazeboPlugin::update (PLG.cpp:202-246) followed by
  * the Gazebo/ODE world step }.  Asynchronous: returns once the work is queued

@@ -579,7 +579,7 @@ struct orc_sim {
   double prev_publish;
   orc_robot *rob;
   float *vel_cmd, *pos_cmd; /* latched Joy.axes, float32 on the wire */
-  int vel_received, pos_received;
+  unsigned char *vel_received, *pos_received; /* per robot: a Joy arrived since the last update() (PLG.cpp:206,213) */
   double ib[9], ib_inv[9]; /* body inertia and its inverse */
 };
 
@@ -616,7 +616,9 @@ orc_sim *orc_create(const cdpr_config_t *cfg, int deriv_mode) {
   s->rob = (orc_robot *)malloc(sizeof(orc_robot) * cfg->batch);
   s->vel_cmd = (float *)calloc(cfg->batch * cfg->n_cables, sizeof(float));
   s->pos_cmd = (float *)calloc(cfg->batch * cfg->n_cables, sizeof(float));
-  if (!s->rob || !s->vel_cmd || !s->pos_cmd) {
+  s->vel_received = (unsigned char *)calloc(cfg->batch, 1);
+  s->pos_received = (unsigned char *)calloc(cfg->batch, 1);
+  if (!s->rob || !s->vel_cmd || !s->pos_cmd || !s->vel_received || !s->pos_received) {
     orc_destroy(s);
     return NULL;
   }
@@ -633,13 +635,16 @@ void orc_destroy(orc_sim *s) {
   free(s->rob);
   free(s->vel_cmd);
   free(s->pos_cmd);
+  free(s->vel_received);
+  free(s->pos_received);
   free(s);
 }
 
 void orc_reset(orc_sim *s) {
   s->step = 0;
   s->prev_publish = 0.0; /* PLG.cpp:59 */
-  s->vel_received = s->pos_received = 0;
+  memset(s->vel_received, 0, s->cfg.batch);
+  memset(s->pos_received, 0, s->cfg.batch);
   for (uint64_t b = 0; b < s->cfg.batch; ++b) robot_reset(s, &s->rob[b]);
 }
 
@@ -654,25 +659,31 @@ int orc_set_platform_state(orc_sim *s, const double *pose7, const double *twist6
   return CDPR_OK;
 }
 
-static int latch(orc_sim *s, float *dst, const float *axes, size_t count, int *flag) {
-  /* PLG.cpp:67-83: accept iff axes.size() == cWireCount, else silently ignore */
+static int latch(orc_sim *s, float *dst, const float *axes, size_t count, unsigned char *flag, const unsigned char *mask) {
+  /* PLG.cpp:67-83: accept iff axes.size() == cWireCount, else silently ignore.  mask (per-robot arrival, one plugin
+   * instance per robot): only the robots with mask[b] != 0 receive the message; NULL = every robot */
   size_t n = s->cfg.n_cables, B = s->cfg.batch;
-  if (count == n * B && B != 1) {
-    memcpy(dst, axes, sizeof(float) * n * B);
-  } else if (count == n) {
-    for (size_t b = 0; b < B; ++b) memcpy(dst + b * n, axes, sizeof(float) * n);
-  } else {
-    return CDPR_IGNORED;
+  int per_robot = (count == n * B && B != 1);
+  if (!per_robot && count != n) return CDPR_IGNORED;
+  for (size_t b = 0; b < B; ++b) {
+    if (mask && !mask[b]) continue;
+    memcpy(dst + b * n, per_robot ? axes + b * n : axes, sizeof(float) * n);
+    flag[b] = 1;
   }
-  *flag = 1;
   return CDPR_OK;
 }
 
 int orc_set_velocity_command(orc_sim *s, const float *axes, size_t count) {
-  return latch(s, s->vel_cmd, axes, count, &s->vel_received);
+  return latch(s, s->vel_cmd, axes, count, s->vel_received, NULL);
 }
 int orc_set_position_command(orc_sim *s, const float *axes, size_t count) {
-  return latch(s, s->pos_cmd, axes, count, &s->pos_received);
+  return latch(s, s->pos_cmd, axes, count, s->pos_received, NULL);
+}
+int orc_set_velocity_command_masked(orc_sim *s, const float *axes, size_t count, const unsigned char *mask) {
+  return latch(s, s->vel_cmd, axes, count, s->vel_received, mask);
+}
+int orc_set_position_command_masked(orc_sim *s, const float *axes, size_t count, const unsigned char *mask) {
+  return latch(s, s->pos_cmd, axes, count, s->pos_received, mask);
 }
 
 /* One world iteration for one robot at step index k:
@@ -796,8 +807,6 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
 int orc_update(orc_sim *s, int nsteps, int nthreads) {
   if (nsteps <= 0) return CDPR_OK;
   const unsigned n = s->cfg.n_cables;
-  const int vel_rx = s->vel_received, pos_rx = s->pos_received;
-  s->vel_received = s->pos_received = 0;
   /* publish schedule (PLG.cpp:236-242): strict '>' against the last published stamp */
   unsigned char *pub = (unsigned char *)malloc((size_t)nsteps);
   if (!pub) return CDPR_ERR_NOMEM;
@@ -821,10 +830,11 @@ int orc_update(orc_sim *s, int nsteps, int nthreads) {
   for (int64_t b = 0; b < B; ++b) {
     orc_robot *r = &s->rob[b];
     /* PLG.cpp:206-219: velocity command first, then position command */
-    if (vel_rx)
+    if (s->vel_received[b])
       for (unsigned i = 0; i < n; ++i) jfc_set_velocity_target(&r->jfc[i], (double)s->vel_cmd[b * n + i]);
-    if (pos_rx)
+    if (s->pos_received[b])
       for (unsigned i = 0; i < n; ++i) jfc_set_position_target(&r->jfc[i], (double)s->pos_cmd[b * n + i]);
+    s->vel_received[b] = s->pos_received[b] = 0;
     for (int k = 0; k < nsteps; ++k) robot_step(s, r, step0 + (uint64_t)k, pub[k]);
   }
   (void)nthreads;

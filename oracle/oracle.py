@@ -41,6 +41,8 @@ def lib():
         L.orc_set_platform_state.argtypes = [C.c_void_p, dp, dp]
         L.orc_set_velocity_command.argtypes = [C.c_void_p, fp, C.c_size_t]
         L.orc_set_position_command.argtypes = [C.c_void_p, fp, C.c_size_t]
+        L.orc_set_velocity_command_masked.argtypes = [C.c_void_p, fp, C.c_size_t, C.POINTER(C.c_uint8)]
+        L.orc_set_position_command_masked.argtypes = [C.c_void_p, fp, C.c_size_t, C.POINTER(C.c_uint8)]
         L.orc_update.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_rollout_velocity.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, dp, dp, C.c_int]
         L.orc_step_count.restype = C.c_uint64
@@ -111,15 +113,19 @@ class OracleSim:
         t = _as_f64(twist6, (self.B, 6))
         lib().orc_set_platform_state(self._h, _dp(p), _dp(t))
 
-    def _cmd(self, fn, axes):
+    def _cmd(self, fn, fn_masked, axes, mask):
         a = np.ascontiguousarray(axes, dtype=np.float32).ravel()
-        return fn(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
+        if mask is None:
+            return fn(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size)
+        m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(self.B)
+        return fn_masked(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size, m.ctypes.data_as(C.POINTER(C.c_uint8)))
 
-    def set_velocity_command(self, axes):
-        return self._cmd(lib().orc_set_velocity_command, axes)
+    def set_velocity_command(self, axes, mask=None):
+        """mask[B]: only these robots receive the Joy (per-robot arrival); None = every robot."""
+        return self._cmd(lib().orc_set_velocity_command, lib().orc_set_velocity_command_masked, axes, mask)
 
-    def set_position_command(self, axes):
-        return self._cmd(lib().orc_set_position_command, axes)
+    def set_position_command(self, axes, mask=None):
+        return self._cmd(lib().orc_set_position_command, lib().orc_set_position_command_masked, axes, mask)
 
     def update(self, nsteps=1, nthreads=0):
         return lib().orc_update(self._h, int(nsteps), int(nthreads))

@@ -863,3 +863,66 @@ def test_second_generation_onestep_kernel_is_bit_identical(pkg, monkeypatch, map
     for sa, sb in zip(*out):
         for x, y in zip(sa, sb):
             assert np.array_equal(x, y)
+
+
+def test_per_robot_command_arrival(pkg, oracle, mapping):
+    """cdpr_set_*_command_masked on a handle created with per_robot_commands: half the batch gets a position Joy in
+    mid-run while the other half stays in Velocity mode, some robots never hear anything, one group gets both kinds
+    before the same update; against the oracle (which is B independent JointForceCalculator sets by construction)."""
+    once(mapping)
+    B = 300
+    rng = np.random.default_rng(31)
+    for model, stages in ((pkg.eight_cable_model(), 3), (pkg.cube_model(), 0)):
+        n = model.n_cables
+        cfg = pkg.Config(model=model, batch=B, stages=stages, perRobotCommands=True)
+        eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.03, 0.05))
+        groups = rng.integers(0, 4, B)  # 0: silent, 1: velocity only, 2: velocity then position, 3: both at once later
+        v1 = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+        p1 = rng.uniform(-0.002, 0.002, (B, n)).astype(np.float32)
+        for e in (eng, ora):
+            e.update(15)
+            assert e.set_velocity_command(v1, mask=(groups == 1) | (groups == 2)) == 0
+            e.update(40)
+        compare(eng, ora, where="after the masked velocity Joy")
+        for e in (eng, ora):
+            assert e.set_position_command(p1, mask=(groups == 2)) == 0  # group 2: Velocity -> Position, position Pid reset
+            assert e.set_velocity_command(-v1, mask=(groups == 3)) == 0
+            assert e.set_position_command(p1[0], mask=(groups == 3)) == 0  # broadcast row; both kinds in one update
+            assert e.set_velocity_command(np.zeros(n + 1, np.float32), mask=np.ones(B)) == 1  # wrong length: dropped
+            e.update(60)
+        compare(eng, ora, where="after the mixed Joys")
+        for e in (eng, ora):
+            e.set_velocity_command(v1)  # an unmasked Joy addresses every robot
+            e.update(30)
+        compare(eng, ora, where="after the unmasked Joy")
+        eng.close()
+    plain = pkg.Engine(pkg.Config(batch=4), 0)
+    with pytest.raises(pkg.CdprError):  # a handle without per_robot_commands refuses masks instead of guessing
+        plain.set_velocity_command(np.zeros((4, 4), np.float32), mask=np.ones(4))
+
+
+def test_bound_command_buffers_are_used_in_place(pkg, oracle, mapping):
+    """cdpr_bind_*_command_device: the caller's HBM buffer is the latched Joy batch (no copy) on every path that reads a
+    command: one-step and fused launches, graph replays, both kinds, switching between bound and copied commands."""
+    B = 130
+    rng = np.random.default_rng(41)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng, 0.03, 0.05))
+    v = [rng.uniform(-0.03, 0.03, (B, 8)).astype(np.float32) for _ in range(3)]
+    p = rng.uniform(-0.002, 0.002, (B, 8)).astype(np.float32)
+    dv = [eng.device_upload(x) for x in v]
+    dp_ = eng.device_upload(p)
+    eng.update(11), ora.update(11)
+    assert eng.bind_velocity_command_device(dv[0], B * 8) == 0 and eng.bind_velocity_command_device(dv[0], 8) == 1
+    ora.set_velocity_command(v[0])
+    eng.update(30), ora.update(30)
+    eng.bind_velocity_command_device(dv[1], B * 8), ora.set_velocity_command(v[1])
+    eng.update(60, 10), ora.update(60)  # fused launches read the bound buffer too
+    compare(eng, ora, where="bound velocity commands")
+    eng.bind_position_command_device(dp_, B * 8), ora.set_position_command(p)
+    eng.update(25), ora.update(25)
+    eng.set_velocity_command(v[2]), ora.set_velocity_command(v[2])  # a copied command replaces the bound one
+    eng.update(25), ora.update(25)
+    compare(eng, ora, where="bound position command, then a copied velocity command")
+    for d in dv + [dp_]:
+        eng.device_free(d)

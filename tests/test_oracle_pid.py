@@ -181,3 +181,40 @@ def test_publish_period_decimates_observables(pkg, oracle):
         seen.append(sim.platform_state()[0][0, 2])
     changes = [k for k in range(1, 12) if seen[k] != seen[k - 1]]
     assert changes == [5, 10]  # published when now - prev > 0.0045: t = 0.005, 0.010
+
+
+def test_masked_commands_equal_independent_plugin_instances(pkg, oracle):
+    """Per-robot arrival: a batch in which only some robots receive a Joy before an update() must equal B separate
+    one-robot simulators (= B instances of CdprGazeboPlugin, PLG.cpp:206-219 runs per model), each of which got only
+    its own messages: unaddressed robots keep target, mode and Pid state."""
+    B, n = 5, 4
+    cfg = pkg.Config(batch=B)
+    rng = np.random.default_rng(77)
+    pose = np.tile(cfg.model.home_pose(), (B, 1))
+    pose[:, :3] += rng.uniform(-0.02, 0.02, (B, 3))
+    whole = oracle.OracleSim(cfg.to_struct())
+    solo = [oracle.OracleSim(pkg.Config(batch=1).to_struct()) for _ in range(B)]
+    whole.set_platform_state(pose7=pose)
+    for b, s_ in enumerate(solo):
+        s_.set_platform_state(pose7=pose[b:b + 1])
+    script = [("run", 12), ("vel", [1, 0, 1, 0, 0]), ("run", 20), ("pos", [0, 1, 1, 0, 0]), ("run", 15), ("vel", [1, 1, 0, 0, 1]),
+              ("pos", [0, 0, 0, 0, 1]), ("run", 25)]  # robot 3 never hears anything; robot 4 gets both kinds in one update
+    for kind, arg in script:
+        if kind == "run":
+            whole.update(arg)
+            for s_ in solo:
+                s_.update(arg)
+            continue
+        axes = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32) * (1.0 if kind == "vel" else 0.1)
+        mask = np.array(arg, dtype=np.uint8)
+        assert (whole.set_velocity_command if kind == "vel" else whole.set_position_command)(axes, mask) == 0
+        for b, s_ in enumerate(solo):
+            if mask[b]:
+                (s_.set_velocity_command if kind == "vel" else s_.set_position_command)(axes[b])
+    wp, wt = whole.raw_state()
+    wq, wqd, we = whole.joint_states()
+    for b, s_ in enumerate(solo):
+        sp, st_ = s_.raw_state()
+        sq, sqd, se = s_.joint_states()
+        assert np.array_equal(wp[b], sp[0]) and np.array_equal(wt[b], st_[0]) and np.array_equal(we[b], se[0])
+    assert whole.set_velocity_command(np.zeros((B, 3), np.float32), np.ones(B, np.uint8)) == 1  # wrong length: still dropped
