@@ -3,7 +3,8 @@
 Field names follow the ROS message definitions the reference uses:
 sensor_msgs/Joy (`axes: float32[]`), sensor_msgs/JointState (`name`, `position`,
 `velocity`, `effort`), cdpr_gazebo/PlatformState (msg/PlatformState.msg:1-3 =
-Header + geometry_msgs/Pose + geometry_msgs/Twist).
+Header + geometry_msgs/Pose + geometry_msgs/Twist), cdpr_gazebo/WireStates
+(msg/WireStates.msg:1-2 = Header + diagnostic_msgs/KeyValue stateChange).
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ class Header:
 class Joy:  # sensor_msgs/Joy; axes are float32 on the wire
     axes: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float32))
     header: Header = field(default_factory=Header)
+    robots: "np.ndarray | None" = None  # batched facade only: mask[B] of the robots this Joy reaches (None = all)
 
     def __post_init__(self):
         self.axes = np.asarray(self.axes, dtype=np.float32)
@@ -55,3 +57,16 @@ class PlatformState:  # cdpr_gazebo/PlatformState, PLG.cpp:258-280
     pose: Pose
     velocity: Twist
     header: Header = field(default_factory=Header)
+
+
+@dataclass
+class KeyValue:  # diagnostic_msgs/KeyValue
+    key: str = ""
+    value: str = ""
+
+
+@dataclass
+class WireStates:  # cdpr_gazebo/WireStates, msg/WireStates.msg:1-2; advertised at PLG.cpp:196, publishing is the TODO of PLG.cpp:230-231
+    stateChange: KeyValue = field(default_factory=KeyValue)
+    header: Header = field(default_factory=Header)
+    robot: int = 0  # batched facade only: which robot of the batch the event belongs to

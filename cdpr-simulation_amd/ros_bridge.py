@@ -1,0 +1,160 @@
+"""ROS 1 bridge: puts the facade (`CdprGazeboPlugin`, the plugin-callback surface of the reference) on real ROS topics.
+
+SURVEY.md 8(f) rank 4.  The reference's plugin talks roscpp directly (CdprGazeboPlugin.cpp:176-198); here a `rospy`
+node does the same wiring around the in-process TopicBus, with the same topic names and message types, so external
+tools (`rqt_plot`, the reference's own `sinevelocitytest` / `squarepositiontest` / `squarevelocitytest` publishers) work
+unchanged:
+
+    subscribe   jointVelocities, jointPositions   sensor_msgs/Joy            queue 256   (PLG.cpp:177-185)
+    publish     jointStates                        sensor_msgs/JointState     queue 256   (PLG.cpp:188-192, 248-256)
+                platformPose                       cdpr_gazebo/PlatformState              (PLG.cpp:197, 258-280)
+                wireStates                         cdpr_gazebo/WireStates                 (PLG.cpp:196; logic: plugin.publishWireStates)
+                pid                                sensor_msgs/Joy (9 axes)               (PLG.cpp:193-194, 233-235)
+
+ROS is absent from the build image and the GPU box, so `rospy` and the message packages are imported lazily, inside
+`CdprRosBridge.__init__`; the module itself imports anywhere.  A batch of B > 1 robots appears as B namespaces
+`<ns>/robot<b>/...`, each carrying ordinary single-robot messages; B = 1 uses the bare topic names of the reference.
+Sim time: the node publishes `/clock` (rosgraph_msgs/Clock) from the engine's step counter when `publish_clock` is set,
+which is what `use_sim_time` (cdpr_gazebo.launch:5) makes `ros::Time::now()` read in the reference.
+"""
+from __future__ import annotations
+
+import importlib
+from typing import List, Optional
+
+import numpy as np
+
+from . import plugin as _plugin
+from .messages import JointState, Joy, PlatformState, WireStates
+
+
+class CdprRosBridge:
+    def __init__(self, facade: "_plugin.CdprGazeboPlugin", node_name: str = "cdpr_gazebo_simulator", namespace: str = "",
+                 publish_clock: bool = False, init_node: bool = True):
+        self._rospy = importlib.import_module("rospy")
+        sensor = importlib.import_module("sensor_msgs.msg")
+        self._RosJoy, self._RosJointState = sensor.Joy, sensor.JointState
+        cdpr_msgs = importlib.import_module("cdpr_gazebo.msg")
+        self._RosPlatformState, self._RosWireStates = cdpr_msgs.PlatformState, cdpr_msgs.WireStates
+        self._RosKeyValue = importlib.import_module("diagnostic_msgs.msg").KeyValue
+        rospy = self._rospy
+        if init_node:
+            rospy.init_node(node_name)
+        self.facade = facade
+        self.B = int(facade.config.batch)
+        self.n = int(facade.config.n_cables)
+        ns = namespace.rstrip("/")
+        self._prefix = [f"{ns}/robot{b}/" if self.B > 1 else (f"{ns}/" if ns else "") for b in range(self.B)]
+        q = _plugin.cPublisherQueueSize
+        mk = lambda topic, typ: [rospy.Publisher(p + topic, typ, queue_size=q) for p in self._prefix]  # noqa: E731
+        self._pub_joint = mk(_plugin.cCableStatesTopic, self._RosJointState)
+        self._pub_platform = mk(_plugin.cPlatformPoseTopic, self._RosPlatformState)
+        self._pub_wire = mk(_plugin.cWireStatesTopic, self._RosWireStates)
+        self._pub_pid = mk(_plugin.cPidTopic, self._RosJoy)
+        self._clock = None
+        if publish_clock:
+            Clock = importlib.import_module("rosgraph_msgs.msg").Clock
+            self._Clock = Clock
+            self._clock = rospy.Publisher("/clock", Clock, queue_size=10)
+        # commands: one subscriber per robot; a robot's Joy is held until every update() and merged into one batch
+        self._pending = {_plugin.cVelocityTopic: {}, _plugin.cPositionTopic: {}}
+        self._last = {}
+        self._subs = []
+        for b, p in enumerate(self._prefix):
+            for topic in (_plugin.cVelocityTopic, _plugin.cPositionTopic):
+                self._subs.append(rospy.Subscriber(p + topic, self._RosJoy, self._on_joy, callback_args=(topic, b),
+                                                   queue_size=_plugin.cSubscriberQueueSize))
+        bus = facade.bus
+        bus.subscribe(_plugin.cCableStatesTopic, self._forward_joint_states)
+        bus.subscribe(_plugin.cPlatformPoseTopic, self._forward_platform_state)
+        bus.subscribe(_plugin.cWireStatesTopic, self._forward_wire_states)
+        bus.subscribe(_plugin.cPidTopic, self._forward_pid)
+
+    # ---- ROS -> facade
+    def _on_joy(self, msg, args) -> None:
+        topic, b = args
+        axes = np.asarray(msg.axes, dtype=np.float32)
+        if axes.size == self.n:  # anything else is dropped, as the plugin's callbacks do (PLG.cpp:68-73, 77-82)
+            self._pending[topic][b] = axes
+
+    def _flush_commands(self) -> None:
+        """Hand the Joys received since the last update to the facade's own subscriptions (its callback queues are drained
+        at the top of update(), PLG.cpp:203-204).  With per-robot arrival (Config.perRobotCommands) only the robots that
+        got a Joy are addressed; otherwise the batch-uniform engine latches all robots together, so robots that sent
+        none repeat their last Joy."""
+        for topic in (_plugin.cVelocityTopic, _plugin.cPositionTopic):
+            got = self._pending[topic]
+            if not got:
+                continue
+            last = self._last.setdefault(topic, np.zeros((self.B, self.n), dtype=np.float32))
+            mask = np.zeros(self.B, dtype=np.uint8)
+            for b, axes in got.items():
+                last[b] = axes
+                mask[b] = 1
+            got.clear()
+            partial = self.B > 1 and not mask.all() and self.facade.config.perRobotCommands
+            self.facade.bus.publish(topic, Joy(axes=last.copy(), robots=mask if partial else None))
+
+    # ---- facade -> ROS
+    def _stamp(self, t: float):
+        return self._rospy.Time.from_sec(float(t))
+
+    def _forward_joint_states(self, m: JointState) -> None:
+        for b, pub in enumerate(self._pub_joint):
+            out = self._RosJointState()
+            out.header.stamp = self._stamp(m.header.stamp)
+            out.name = list(m.name)
+            out.position = [float(v) for v in np.asarray(m.position)[b]]
+            out.velocity = [float(v) for v in np.asarray(m.velocity)[b]]
+            out.effort = [float(v) for v in np.asarray(m.effort)[b]]
+            pub.publish(out)
+
+    def _forward_platform_state(self, m: PlatformState) -> None:
+        for b, pub in enumerate(self._pub_platform):
+            out = self._RosPlatformState()
+            out.header.stamp = self._stamp(m.header.stamp)
+            p, o = np.asarray(m.pose.position)[b], np.asarray(m.pose.orientation)[b]
+            out.pose.position.x, out.pose.position.y, out.pose.position.z = (float(v) for v in p)
+            out.pose.orientation.x, out.pose.orientation.y, out.pose.orientation.z, out.pose.orientation.w = (float(v) for v in o)  # PLG.cpp:266-269
+            lin, ang = np.asarray(m.velocity.linear)[b], np.asarray(m.velocity.angular)[b]
+            out.velocity.linear.x, out.velocity.linear.y, out.velocity.linear.z = (float(v) for v in lin)
+            out.velocity.angular.x, out.velocity.angular.y, out.velocity.angular.z = (float(v) for v in ang)
+            pub.publish(out)
+
+    def _forward_wire_states(self, m: WireStates) -> None:
+        out = self._RosWireStates()
+        out.header.stamp = self._stamp(m.header.stamp)
+        out.stateChange = self._RosKeyValue(key=m.stateChange.key, value=m.stateChange.value)
+        self._pub_wire[m.robot].publish(out)
+
+    def _forward_pid(self, m: Joy) -> None:
+        axes = np.asarray(m.axes).reshape(self.B, -1)
+        for b, pub in enumerate(self._pub_pid):
+            out = self._RosJoy()
+            out.header.stamp = self._stamp(m.header.stamp)
+            out.axes = [float(v) for v in axes[b]]
+            pub.publish(out)
+
+    # ---- the loop Gazebo's world thread runs in the reference
+    def step(self, nsteps: int = 1) -> None:
+        self._flush_commands()
+        self.facade.update(nsteps)
+        if self._clock is not None:
+            c = self._Clock()
+            c.clock = self._stamp(self.facade.engine.sim_time)
+            self._clock.publish(c)
+
+    def spin(self, steps_per_cycle: int = 1, real_time_factor: Optional[float] = 1.0) -> None:
+        """Advance until shutdown.  real_time_factor = None runs as fast as the GPU goes; 1.0 paces sim time to wall time."""
+        rospy = self._rospy
+        rate = None
+        if real_time_factor:
+            rate = rospy.Rate(real_time_factor / (self.facade.config.dt * steps_per_cycle))
+        while not rospy.is_shutdown():
+            self.step(steps_per_cycle)
+            if rate is not None:
+                rate.sleep()
+
+    def topics(self) -> List[str]:
+        return [p + t for p in self._prefix for t in (_plugin.cVelocityTopic, _plugin.cPositionTopic, _plugin.cCableStatesTopic,
+                                                      _plugin.cPlatformPoseTopic, _plugin.cWireStatesTopic, _plugin.cPidTopic)]
