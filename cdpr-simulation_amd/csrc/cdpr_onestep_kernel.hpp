@@ -34,7 +34,7 @@ CDPR_DEV void row_to_lds(const float4* src, float4* dst_row) {
 #define CDPR_V2_ROWSTORE 0  // 0: one buffer descriptor per row (store_slot).  1: one descriptor per buffer + the row as scalar
 #endif                      // offset: 100 fewer scalar instructions and 14 -> 6 spilled SGPRs, same time within noise
                             // (profiles/r02f_onestep_v2_variants_ab.txt) - but the FK instantiations at n = 8 then fail
-                            // the bit-identity and oracle tests on MI355X (cause not found in the ISA; the per-row form
+                            // the bit-identity and parity tests on MI355X (cause not found in the ISA; the per-row form
                             // passes the whole suite), so it stays off.  Also measured, neither faster: weights staged
                             // in LDS instead of kernel arguments, cable constants re-read per Newton iteration.
 // Row stores: ONE buffer descriptor per buffer (4 SGPRs) and the row as the scalar offset operand (1 SGPR) instead of
