@@ -77,4 +77,9 @@ class ConfigStruct(C.Structure):
         ("fk_tolerance", C.c_double),
         ("td_f_min", C.c_double),
         ("td_f_max", C.c_double),
+        ("passive_damping", C.c_double),
+        ("leg_inertia", C.c_double),
+        ("cable_axial_mass", C.c_double),
+        ("anchor_point_mass", C.c_double),
+        ("anchor_inertia", C.c_double),
     ]

@@ -62,6 +62,12 @@ class Model:
     effort_limit: float = 100.0  # cube.sdf:438 / cube.yaml:9
     velocity_limit: float = -1.0  # cube.sdf:439 has 10; < 0 = not modelled (the contract's reduced model)
     unilateral_cables: bool = False  # [NEW] option: cables cannot push
+    # lumped terms for what the massless-cable reduction drops of the 22-link SDF model (all 0: the reduced model)
+    passive_damping: float = 0.0    # every passive revolute joint of a leg, cube.sdf:396,425,471,500,515 (0.01)
+    leg_inertia: float = 0.0        # virt_X + virt_Y + cable link + virt_Ypf turning about the frame anchor (4 x 0.001)
+    cable_axial_mass: float = 0.0   # cable link sliding along the cable axis, cube.sdf:368 (0.001)
+    anchor_point_mass: float = 0.0  # virt_Xpf + virt_Ypf at each platform anchor (2 x 0.001)
+    anchor_inertia: float = 0.0     # virt_Xpf turning with the platform (0.001)
     f_min: float = 5.0  # cube.yaml:9 `min`
     f_max: float = 100.0  # cube.yaml:9 `effort`
 
@@ -250,6 +256,11 @@ class Config:
         s.effort_limit = float(m.effort_limit)
         s.velocity_limit = float(m.velocity_limit)
         s.unilateral_cables = 1 if m.unilateral_cables else 0
+        s.passive_damping = float(m.passive_damping)
+        s.leg_inertia = float(m.leg_inertia)
+        s.cable_axial_mass = float(m.cable_axial_mass)
+        s.anchor_point_mass = float(m.anchor_point_mass)
+        s.anchor_inertia = float(m.anchor_inertia)
         _fill_pid(s.velocity_pid, self.velocityController)
         _fill_pid(s.position_pid, self.effective_position_pid())
         s.velocity_epsilon = float(self.velocityEpsilon)

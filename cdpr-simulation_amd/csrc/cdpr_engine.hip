@@ -53,6 +53,7 @@ struct cdpr_engine {
   float* d_geom = nullptr;  // pair-interleaved cable geometry, staged in LDS by the kernel
   int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
   bool lane_pair = false;   // two lanes per robot (cdpr_step_kernel_pair.hpp) instead of one
+  bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
   bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
   // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
@@ -177,6 +178,8 @@ std::string validate(const cdpr_config_t& c) {
   if (c.batch < 1 || c.batch > (1ull << 27)) return "batch out of range (1 .. 2^27 robots per handle)";
   if (!(c.dt > 0.0)) return "dt must be > 0";
   if (!(c.mass > 0.0)) return "mass must be > 0";
+  if (c.passive_damping < 0.0 || c.leg_inertia < 0.0 || c.cable_axial_mass < 0.0 || c.anchor_point_mass < 0.0 || c.anchor_inertia < 0.0)
+    return "lumped-leg terms (passive_damping, leg_inertia, cable_axial_mass, anchor_point_mass, anchor_inertia) must be >= 0";
   double inv[6];
   if (!mat3_inverse_sym(c.inertia, inv)) return "inertia is singular";
   for (uint32_t i = 0; i < c.n_cables; ++i)
@@ -265,6 +268,15 @@ void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   k.effort = (float)c.effort_limit;
   k.vel_limit = (float)c.velocity_limit;
   k.unilateral = c.unilateral_cables ? 1 : 0;
+  k.ph_c = (float)c.passive_damping;
+  k.ph_jleg = (float)c.leg_inertia;
+  k.ph_max = (float)c.cable_axial_mass;
+  k.ph_mpt = (float)c.anchor_point_mass;
+  k.ph_iadd_total = (float)(c.anchor_inertia * (double)c.n_cables);
+  k.ph_mass = (float)c.mass;
+  k.gx = (float)c.gravity[0];
+  k.gy = (float)c.gravity[1];
+  k.gz = (float)c.gravity[2];
   k.fk_lambda = (float)c.fk_lambda;
   k.fk_tol = (float)c.fk_tolerance;
   k.fk_iters = (int)c.fk_max_iterations;
@@ -404,6 +416,38 @@ StepKernel pick_onestep_kernel(uint32_t n, bool fk, bool td) {
     case 6: return pick_onestep_stage<6>(fk, td);
     case 7: return pick_onestep_stage<7>(fk, td);
     case 8: return pick_onestep_stage<8>(fk, td);
+  }
+  return nullptr;
+}
+
+// lumped-leg physics (PHYS = true): one generic stepping kernel (any steps per launch), the platform kernel of the
+// general controller path, the MPC rollout
+enum PhysKind { kPhysStep, kPhysExt, kPhysRollout };
+template <int N, bool FK, bool TD>
+StepKernel phys_variant(int kind) {
+  if (kind == kPhysExt) return cdpr_step_kernel<N, FK, TD, true, true, false, false, true>;
+  if (kind == kPhysRollout) return cdpr_step_kernel<N, FK, TD, false, false, true, false, true>;
+  return cdpr_step_kernel<N, FK, TD, false, false, false, false, true>;
+}
+template <int N>
+StepKernel pick_phys_stage(bool fk, bool td, int kind) {
+  if constexpr (N >= 6) {
+    if (fk && td) return phys_variant<N, true, true>(kind);
+    if (fk) return phys_variant<N, true, false>(kind);
+    if (td) return phys_variant<N, false, true>(kind);
+  }
+  return phys_variant<N, false, false>(kind);
+}
+StepKernel pick_phys_kernel(uint32_t n, bool fk, bool td, int kind) {
+  switch (n) {
+    case 1: return pick_phys_stage<1>(fk, td, kind);
+    case 2: return pick_phys_stage<2>(fk, td, kind);
+    case 3: return pick_phys_stage<3>(fk, td, kind);
+    case 4: return pick_phys_stage<4>(fk, td, kind);
+    case 5: return pick_phys_stage<5>(fk, td, kind);
+    case 6: return pick_phys_stage<6>(fk, td, kind);
+    case 7: return pick_phys_stage<7>(fk, td, kind);
+    case 8: return pick_phys_stage<8>(fk, td, kind);
   }
   return nullptr;
 }
@@ -635,7 +679,7 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
   g.dt = (float)h->cfg.dt;
   g.pid[0] = h->gpid[0];
   g.pid[1] = h->gpid[1];
-  StepKernel plat = pick_ext_kernel(h->n, h->fk, h->td);
+  StepKernel plat = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysExt) : pick_ext_kernel(h->n, h->fk, h->td);
   const uint32_t total = h->batch * h->n;
   for (int k = 0; k < nsteps; ++k) {
     const bool first_world = (h->step == 0);
@@ -769,7 +813,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // into [60, 70) so they stay small and steady-state launch sequences repeat with period 10
     a.pid_calls = fold_pid_calls(h->pid_calls);
     set_weight_row(h, a);
-    StepKernel kern = h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
+    StepKernel kern = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
+                      : h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
                                    : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
                                                             : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_kernel<true>(h->n, h->fk, h->td)))
                                                : pick_kernel<false>(h->n, h->fk, h->td));
@@ -936,13 +981,15 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
   h->general = general;
   h->per_robot = cfg->per_robot_commands != 0;
+  h->phys = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 ||
+            cfg->anchor_inertia != 0.0;
   {
     // Mapping: measured on MI355X (scripts/ab_bench.py), two lanes per robot win while the batch leaves SIMDs
     // under-filled (16 384 x 8 cables: 9.0 vs 10.2 us/step; 4 096 x 4: 3.0 vs 3.4) and lose from 65 536 robots on
     // (16.4 vs 15.7 us/step: the duplicated 6x6 solves cost more than the second wave per SIMD hides), so AUTO
     // takes the pair mapping up to 32 768 robots at n = 8 (32 768: 9.5 vs 10.5 us/step; 49 152: 13.6 vs 11.2) and up
     // to 65 536 at n = 4 (65 536: 4.9 vs 5.2; 131 072: 8.5 vs 8.1).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
-    const bool can_pair = !general && (cfg->n_cables == 4 || cfg->n_cables == 8);
+    const bool can_pair = !general && !h->phys && (cfg->n_cables == 4 || cfg->n_cables == 8);
     uint32_t mapping = cfg->mapping;
     if (mapping == CDPR_MAP_AUTO) {
       const char* mv = std::getenv("CDPR_MAPPING");
@@ -953,8 +1000,9 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
     // Measured (scripts/ab_bench.py with CDPR_LOWREG=0|1, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
     // 131 072: 29.9 -> 27.0; 196 608: 41.2 -> 36.3; 524 288: 89.9 -> 79.0 (6.6e9 state-steps/s)
-    h->lowreg = !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
-    if (const char* lr = std::getenv("CDPR_LOWREG")) h->lowreg = (lr[0] == '1') && !general && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
+    h->lowreg = !general && !h->phys && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
+    if (const char* lr = std::getenv("CDPR_LOWREG"))
+      h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
   }
   if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
@@ -1391,7 +1439,7 @@ static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float
   a.roll_cost = d_cost;
   a.roll_samples = (uint32_t)samples;
   const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  StepKernel kern = pick_rollout_kernel(h->n, h->fk, h->td);
+  StepKernel kern = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysRollout) : pick_rollout_kernel(h->n, h->fk, h->td);
   hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   ++h->launches;

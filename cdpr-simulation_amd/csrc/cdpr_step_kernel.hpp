@@ -81,6 +81,10 @@ struct StepArgs {
   float damping, effort;                           // joint damping; SetForce clamp (effort < 0: none)
   float vel_limit;                                 // SetForce velocity truncation (<= 0: none)
   int unilateral;                                  // cables cannot push
+  // lumped legs (PHYS instantiations only; cdpr_config_t.passive_damping ...): joint damping c of the passive
+  // revolutes, inertia turning with a leg, mass sliding along the cable, point mass at each platform anchor,
+  // n x the inertia each leg adds to the platform, gravity (for the point masses' weight)
+  float ph_c, ph_jleg, ph_max, ph_mpt, ph_iadd_total, ph_mass, gx, gy, gz;
   // FK / TD ([NEW] stages)
   float fk_lambda, fk_tol;
   int fk_iters;
@@ -420,6 +424,140 @@ CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
   s.qw = nw * inv;
 }
 
+// World step with the lumped legs ([EXT] -> reduced; closed forms in DESIGN.md section 1).  Leg i turns about its frame anchor with angular velocity (u x vP)/L, vP = v + omega x rb.  The
+// passive joint dampers (universal pair at the frame, spherical triple at the platform, c each) act on the platform
+// through a transverse force at the anchor, Fd = -(c/L)(2 vt/L - omega x u) (massless-leg torque balance), plus the
+// spherical joint's torque c((u x vP)/L - omega); the links' inertia appears at the anchor as the apparent mass
+// A = alpha I + beta u u^T (alpha = J_leg/L^2 + m_pt, beta = m_ax - J_leg/L^2), so the 6x6 mass matrix is
+// M0 + sum alpha_i [[I, -[rb]x], [[rb]x, |rb|^2 I - rb rb^T]] + sum beta_i J_i J_i^T (J_i = [u, rb x u], the structure
+// matrix row).  w comes in as the cable + gravity wrench and leaves untouched; velocity-product terms of the legs are
+// neglected.  Two cables per instruction, like everything per-cable here.
+template <int N>
+CDPR_DEV void integrate_lumped(const StepArgs& a, const float* lds, Platform& s, const v2f (&jac)[cable_pairs(N)][6],
+                               const v2f (&len)[cable_pairs(N)], float (&w)[6]) {
+  constexpr int NP = cable_pairs(N);
+  const Rot r = quat_to_rot(s.qx, s.qy, s.qz, s.qw);
+  v2f fx = splat(0.f), fy = splat(0.f), fz = splat(0.f), tx = splat(0.f), ty = splat(0.f), tz = splat(0.f);
+  v2f sa = splat(0.f), sax = splat(0.f), say = splat(0.f), saz = splat(0.f);      // sum alpha, sum alpha rb
+  v2f ixx = splat(0.f), iyy = splat(0.f), izz = splat(0.f), ixy = splat(0.f), ixz = splat(0.f), iyz = splat(0.f);  // sum alpha (|rb|^2 I - rb rb^T)
+  v2f gram[21];
+#pragma unroll
+  for (int e = 0; e < 21; ++e) gram[e] = splat(0.f);
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const float4 g1 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair + 4);
+    const float4 g2 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair + 8);
+    const float4 g3 = *reinterpret_cast<const float4*>(lds + k * kGeomFloatsPerPair + 12);
+    const v2f mask = ((N & 1) && k == NP - 1) ? (v2f){g3.z, g3.w} : splat(1.f);  // the padding cable of an odd count
+    const v2f bx = {g1.z, g1.w}, by = {g2.x, g2.y}, bz = {g2.z, g2.w};
+    const v2f rbx = fma2(r.r02, bz, fma2(r.r01, by, splat(r.r00) * bx));
+    const v2f rby = fma2(r.r12, bz, fma2(r.r11, by, splat(r.r10) * bx));
+    const v2f rbz = fma2(r.r22, bz, fma2(r.r21, by, splat(r.r20) * bx));
+    const v2f ux = jac[k][0], uy = jac[k][1], uz = jac[k][2];
+    const v2f l = (mask.x == 0.f || mask.y == 0.f) ? (v2f){len[k].x + (1.f - mask.x), len[k].y + (1.f - mask.y)} : len[k];  // padded lane: L = 1
+    const v2f il = (v2f){__frcp_rn(l.x), __frcp_rn(l.y)};
+    // anchor velocity vP = v + omega x rb, its part across the cable, omega x u, u x vP
+    const v2f vpx = fma2(s.wy, rbz, fma2(-s.wz, rby, splat(s.vx)));
+    const v2f vpy = fma2(s.wz, rbx, fma2(-s.wx, rbz, splat(s.vy)));
+    const v2f vpz = fma2(s.wx, rby, fma2(-s.wy, rbx, splat(s.vz)));
+    const v2f along = fma2(uz, vpz, fma2(uy, vpy, ux * vpx));
+    const v2f vtx = fma2(-along, ux, vpx), vty = fma2(-along, uy, vpy), vtz = fma2(-along, uz, vpz);
+    const v2f oux = fma2(s.wy, uz, -(splat(s.wz) * uy)), ouy = fma2(s.wz, ux, -(splat(s.wx) * uz)), ouz = fma2(s.wx, uy, -(splat(s.wy) * ux));
+    const v2f uvx = fma2(uy, vpz, -(uz * vpy)), uvy = fma2(uz, vpx, -(ux * vpz)), uvz = fma2(ux, vpy, -(uy * vpx));
+    const v2f cl = splat(-a.ph_c) * il * mask;  // -(c / L)
+    const v2f two_il = il + il;
+    const v2f fdx = cl * fma2(two_il, vtx, -oux), fdy = cl * fma2(two_il, vty, -ouy), fdz = cl * fma2(two_il, vtz, -ouz);
+    // weight of the point masses at the anchor
+    const v2f pm = splat(a.ph_mpt) * mask;
+    const v2f fax = fma2(a.gx, pm, fdx), fay = fma2(a.gy, pm, fdy), faz = fma2(a.gz, pm, fdz);
+    fx += fax;
+    fy += fay;
+    fz += faz;
+    const v2f cm = splat(a.ph_c) * mask;
+    tx += fma2(rby, faz, -(rbz * fay)) + cm * fma2(uvx, il, splat(-s.wx));
+    ty += fma2(rbz, fax, -(rbx * faz)) + cm * fma2(uvy, il, splat(-s.wy));
+    tz += fma2(rbx, fay, -(rby * fax)) + cm * fma2(uvz, il, splat(-s.wz));
+    // apparent mass of the leg at the anchor
+    const v2f mu = splat(a.ph_jleg) * il * il;
+    const v2f alpha = (mu + splat(a.ph_mpt)) * mask, beta = (splat(a.ph_max) - mu) * mask;
+    sa += alpha;
+    sax = fma2(alpha, rbx, sax);
+    say = fma2(alpha, rby, say);
+    saz = fma2(alpha, rbz, saz);
+    const v2f rb2 = fma2(rbz, rbz, fma2(rby, rby, rbx * rbx));
+    ixx = fma2(alpha, fma2(-rbx, rbx, rb2), ixx);
+    iyy = fma2(alpha, fma2(-rby, rby, rb2), iyy);
+    izz = fma2(alpha, fma2(-rbz, rbz, rb2), izz);
+    ixy = fma2(-alpha, rbx * rby, ixy);
+    ixz = fma2(-alpha, rbx * rbz, ixz);
+    iyz = fma2(-alpha, rby * rbz, iyz);
+    v2f bj[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) bj[c] = beta * jac[k][c];
+#pragma unroll
+    for (int p = 0, e = 0; p < 6; ++p) {
+#pragma unroll
+      for (int q = 0; q <= p; ++q, ++e) gram[e] = fma2(bj[p], jac[k][q], gram[e]);
+    }
+  }
+  // world inertia R Ib R^T (+ the share of every leg that turns with the platform), gyroscopic torque
+  const float b00 = a.ib[0], b11 = a.ib[1], b22 = a.ib[2], b01 = a.ib[3], b02 = a.ib[4], b12 = a.ib[5];
+  const float c00 = fmaf(r.r02, b02, fmaf(r.r01, b01, r.r00 * b00)), c01 = fmaf(r.r02, b12, fmaf(r.r01, b11, r.r00 * b01)), c02 = fmaf(r.r02, b22, fmaf(r.r01, b12, r.r00 * b02));
+  const float c10 = fmaf(r.r12, b02, fmaf(r.r11, b01, r.r10 * b00)), c11 = fmaf(r.r12, b12, fmaf(r.r11, b11, r.r10 * b01)), c12 = fmaf(r.r12, b22, fmaf(r.r11, b12, r.r10 * b02));
+  const float c20 = fmaf(r.r22, b02, fmaf(r.r21, b01, r.r20 * b00)), c21 = fmaf(r.r22, b12, fmaf(r.r21, b11, r.r20 * b01)), c22 = fmaf(r.r22, b22, fmaf(r.r21, b12, r.r20 * b02));
+  const float w00 = fmaf(c02, r.r02, fmaf(c01, r.r01, c00 * r.r00)) + a.ph_iadd_total, w11 = fmaf(c12, r.r12, fmaf(c11, r.r11, c10 * r.r10)) + a.ph_iadd_total,
+              w22 = fmaf(c22, r.r22, fmaf(c21, r.r21, c20 * r.r20)) + a.ph_iadd_total;
+  const float w01 = fmaf(c02, r.r12, fmaf(c01, r.r11, c00 * r.r10)), w02 = fmaf(c02, r.r22, fmaf(c01, r.r21, c00 * r.r20)),
+              w12 = fmaf(c12, r.r22, fmaf(c11, r.r21, c10 * r.r20));
+  const float iox = fmaf(w02, s.wz, fmaf(w01, s.wy, w00 * s.wx)), ioy = fmaf(w12, s.wz, fmaf(w11, s.wy, w01 * s.wx)), ioz = fmaf(w22, s.wz, fmaf(w12, s.wy, w02 * s.wx));
+  float rhs[6] = {w[0] + hsum(fx), w[1] + hsum(fy), w[2] + hsum(fz), w[3] + hsum(tx) - fmaf(s.wy, ioz, -(s.wz * ioy)),
+                  w[4] + hsum(ty) - fmaf(s.wz, iox, -(s.wx * ioz)), w[5] + hsum(tz) - fmaf(s.wx, ioy, -(s.wy * iox))};
+  // mass matrix, lower triangle; [[rb]x]: rows (0,-z,y), (z,0,-x), (-y,x,0): lower-left block = +alpha [rb]x
+  const float A = hsum(sa), ax = hsum(sax), ay = hsum(say), az = hsum(saz);
+  const float mass = a.ph_mass;
+  float m[6][6];
+#pragma unroll
+  for (int p = 0, e = 0; p < 6; ++p) {
+#pragma unroll
+    for (int q = 0; q <= p; ++q, ++e) m[p][q] = hsum(gram[e]);
+  }
+  m[0][0] += mass + A;
+  m[1][1] += mass + A;
+  m[2][2] += mass + A;
+  m[3][1] += -az;  // row 3 of [rb]x summed: (0, -z, y)
+  m[3][2] += ay;
+  m[4][0] += az;   // (z, 0, -x)
+  m[4][2] += -ax;
+  m[5][0] += -ay;  // (-y, x, 0)
+  m[5][1] += ax;
+  m[3][3] += w00 + hsum(ixx);
+  m[4][4] += w11 + hsum(iyy);
+  m[5][5] += w22 + hsum(izz);
+  m[4][3] += w01 + hsum(ixy);
+  m[5][3] += w02 + hsum(ixz);
+  m[5][4] += w12 + hsum(iyz);
+  chol_solve(m, rhs);
+  s.vx = fmaf(a.dt, rhs[0], s.vx);
+  s.vy = fmaf(a.dt, rhs[1], s.vy);
+  s.vz = fmaf(a.dt, rhs[2], s.vz);
+  s.wx = fmaf(a.dt, rhs[3], s.wx);
+  s.wy = fmaf(a.dt, rhs[4], s.wy);
+  s.wz = fmaf(a.dt, rhs[5], s.wz);
+  s.px = fmaf(a.dt, s.vx, s.px);
+  s.py = fmaf(a.dt, s.vy, s.py);
+  s.pz = fmaf(a.dt, s.vz, s.pz);
+  const float h = a.half_dt;
+  const float nx = fmaf(h, fmaf(-s.wz, s.qy, fmaf(s.wy, s.qz, s.qw * s.wx)), s.qx);
+  const float ny = fmaf(h, fmaf(-s.wx, s.qz, fmaf(s.wz, s.qx, s.qw * s.wy)), s.qy);
+  const float nz = fmaf(h, fmaf(-s.wy, s.qx, fmaf(s.wx, s.qy, s.qw * s.wz)), s.qz);
+  const float nw = fmaf(-h, fmaf(s.wz, s.qz, fmaf(s.wy, s.qy, s.wx * s.qx)), s.qw);
+  const float inv = __frsqrt_rn(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
+  s.qx = nx * inv;
+  s.qy = ny * inv;
+  s.qz = nz * inv;
+  s.qw = nw * inv;
+}
+
 // Slot row `slot` of robot at byte offset `off` (= 16 * robot, 32-bit): SGPR row base + one shared VGPR
 // offset, so 30 rows cost one address register instead of 30 64-bit pointers.
 CDPR_DEV float4 load_slot(const float4* base, size_t stride, int slot, uint32_t off) {
@@ -491,7 +629,9 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
 // LOWREG = true (one-step kernel, large batches): fit two waves per SIMD (<= 256 registers) by NOT keeping what can be
 // recomputed: the cable constants are re-read from LDS in every Newton iteration instead of being hoisted into 48
 // registers, and the true structure matrix is rebuilt after the Newton stage instead of living through it.
-template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false, bool LOWREG = false>
+// PHYS = true: the world step carries the lumped legs (integrate_lumped): handles created with any of
+// cdpr_config_t.passive_damping / leg_inertia / cable_axial_mass / anchor_point_mass / anchor_inertia.
+template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false, bool LOWREG = false, bool PHYS = false>
 __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
@@ -842,7 +982,10 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       w[3] = -w[3];
       w[4] = -w[4];
       w[5] = -w[5];
-      integrate(a, s, w);
+      if (PHYS)
+        integrate_lumped<N>(a, lds, s, jac, len, w);
+      else
+        integrate(a, s, w);
     }
     if (ROLLOUT) {
       const float ex = s.px - refx, ey = s.py - refy, ez = s.pz - refz;

@@ -63,7 +63,13 @@ def _pose(elem) -> np.ndarray:
     return np.array([float(v) for v in p.text.split()]) if p is not None else np.zeros(6)
 
 
-def load_sdf(path_or_text: str, f_min: float = 5.0) -> Model:
+def load_sdf(path_or_text: str, f_min: float = 5.0, lumped_links: bool = False) -> Model:
+    """`lumped_links=True` also reads what the massless-cable reduction drops into the model's lumped
+    leg terms: the damping of the passive revolute joints (`rev_X<i>`, cube.sdf:396) and the masses / inertias of the
+    five small links of every leg (cube.sdf:359-369, 372-382, ...): virt_X + virt_Y + cable + virt_Ypf turn with the leg
+    (leg_inertia), the cable link slides along the axis (cable_axial_mass), virt_Xpf + virt_Ypf ride on the platform
+    anchor (anchor_point_mass), virt_Xpf turns with the platform (anchor_inertia).  Off by default: the contract's
+    reduced model."""
     text = open(path_or_text).read() if "<" not in path_or_text else path_or_text
     root = ET.fromstring(text)
     model = root.find("model") if root.tag == "sdf" else root
@@ -94,6 +100,24 @@ def load_sdf(path_or_text: str, f_min: float = 5.0) -> Model:
         axis = joints[f"cable{i}"].find("axis")
         damping = float(axis.find("dynamics/damping").text)
         effort = float(axis.find("limit/effort").text)
+    lumped = {}
+    if lumped_links:
+        def inertial(name):
+            el = links[name].find("inertial") if name in links else None
+            if el is None:
+                return 0.0, 0.0
+            return float(el.find("mass").text), float(el.find("inertia/ixx").text)
+
+        m_c, i_c = inertial("cable0")
+        (m_x, i_x), (m_y, i_y), (m_xp, i_xp), (m_yp, i_yp) = (inertial(f"{k}0") for k in ("virt_X", "virt_Y", "virt_Xpf", "virt_Ypf"))
+        passive = joints.get("rev_X0")
+        lumped = dict(
+            passive_damping=float(passive.find("axis/dynamics/damping").text) if passive is not None else 0.0,
+            leg_inertia=i_x + i_y + i_c + i_yp,
+            cable_axial_mass=m_c,
+            anchor_point_mass=m_xp + m_yp,
+            anchor_inertia=i_xp,
+        )
     return Model(
         frame_anchors=np.array(fa),
         platform_anchors=np.array(pa),
@@ -105,4 +129,5 @@ def load_sdf(path_or_text: str, f_min: float = 5.0) -> Model:
         effort_limit=effort,
         f_min=f_min,
         f_max=effort,
+        **lumped,
     )

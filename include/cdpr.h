@@ -128,6 +128,18 @@ typedef struct cdpr_config {
   double fk_tolerance;              /* stop when max_i |L*_i - L_i| < tol; 0 = always run the cap */
   double td_f_min;                  /* cube.yaml:9 `min: 5`   */
   double td_f_max;                  /* cube.yaml:9 `effort`   */
+
+  /* What the massless-cable reduction drops of the 22-link SDF model, as lumped first-order terms ([EXT] Gazebo/ODE
+   * integrates these bodies and joints; closed forms: DESIGN.md section 1).  All 0 = the contract's reduced model. */
+  double passive_damping;           /* damping of EVERY passive revolute joint of a leg: the frame-side universal pair
+                                       rev_X / rev_Y and the platform-side spherical triple rev_Xpf / rev_Ypf / rev_Zpf
+                                       (cube.sdf:396,425,471,500,515: 0.01) */
+  double leg_inertia;               /* inertia of the links that turn with a cable about its frame anchor: virt_X, virt_Y,
+                                       the cable link, virt_Ypf (cube.sdf:359-366,...: 4 x 0.001 kg m^2) */
+  double cable_axial_mass;          /* mass that slides along the cable axis with the prismatic joint: the cable link
+                                       (cube.sdf:368: 0.001 kg) */
+  double anchor_point_mass;         /* mass carried at each platform anchor: virt_Xpf, virt_Ypf (cube.sdf:456,485: 2 x 0.001 kg) */
+  double anchor_inertia;            /* inertia each leg adds to the platform: virt_Xpf (cube.sdf:448-455: 0.001 kg m^2) */
 } cdpr_config_t;
 
 typedef struct cdpr_engine *cdpr_handle_t;

@@ -777,18 +777,111 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
   double rm[9];
   quat_to_rot(r->pose + 3, rm);
   double *v = r->twist, *om = r->twist + 3;
-  for (int a = 0; a < 3; ++a) v[a] += cfg->dt * w[a] / cfg->mass;
-  double tb[3], ob[3], iob[3], gyro[3], ab[3], aw[3];
-  for (int a = 0; a < 3; ++a) {
-    tb[a] = rm[0 + a] * w[3] + rm[3 + a] * w[4] + rm[6 + a] * w[5]; /* R^T tau */
-    ob[a] = rm[0 + a] * om[0] + rm[3 + a] * om[1] + rm[6 + a] * om[2];
+  const int lumped = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 ||
+                     cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
+  if (!lumped) {
+    for (int a = 0; a < 3; ++a) v[a] += cfg->dt * w[a] / cfg->mass;
+    double tb[3], ob[3], iob[3], gyro[3], ab[3], aw[3];
+    for (int a = 0; a < 3; ++a) {
+      tb[a] = rm[0 + a] * w[3] + rm[3 + a] * w[4] + rm[6 + a] * w[5]; /* R^T tau */
+      ob[a] = rm[0 + a] * om[0] + rm[3 + a] * om[1] + rm[6 + a] * om[2];
+    }
+    for (int a = 0; a < 3; ++a) iob[a] = s->ib[3 * a] * ob[0] + s->ib[3 * a + 1] * ob[1] + s->ib[3 * a + 2] * ob[2];
+    cross3(ob, iob, gyro);
+    for (int a = 0; a < 3; ++a) tb[a] -= gyro[a];
+    for (int a = 0; a < 3; ++a) ab[a] = s->ib_inv[3 * a] * tb[0] + s->ib_inv[3 * a + 1] * tb[1] + s->ib_inv[3 * a + 2] * tb[2];
+    for (int a = 0; a < 3; ++a) aw[a] = rm[3 * a] * ab[0] + rm[3 * a + 1] * ab[1] + rm[3 * a + 2] * ab[2];
+    for (int a = 0; a < 3; ++a) om[a] += cfg->dt * aw[a];
+  } else {
+    /* Lumped legs ([EXT] -> reduced).  Leg i turns about its frame anchor with angular velocity
+     * (u x vP)/L, vP = v + omega x rb the velocity of its platform anchor.  Massless-leg torque balance gives the force
+     * the passive joint dampers put on the platform at the anchor, Fd = -(c/L) (2 vt/L - omega x u), vt the part of vP
+     * across the cable, plus the spherical joint's torque c ((u x vP)/L - omega).  The links' inertia appears at the
+     * anchor as the apparent mass A = alpha I + beta u u^T, alpha = J_leg/L^2 + m_pt, beta = m_ax - J_leg/L^2, so the
+     * platform's 6x6 mass matrix becomes M0 + sum_i G_i^T A_i G_i with G_i = [I, -[rb_i]x]; velocity-product terms of
+     * the legs are neglected (first order). */
+    double M[6][6] = {{0}};
+    double iw[9]; /* world inertia R Ib R^T, plus the per-leg share that turns with the platform */
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double acc = 0;
+        for (int c = 0; c < 3; ++c)
+          for (int d = 0; d < 3; ++d) acc += rm[3 * a + c] * s->ib[3 * c + d] * rm[3 * b + d];
+        iw[3 * a + b] = acc + (a == b ? (double)n * cfg->anchor_inertia : 0.0);
+      }
+    for (int a = 0; a < 3; ++a) {
+      M[a][a] = cfg->mass;
+      for (int b = 0; b < 3; ++b) M[3 + a][3 + b] = iw[3 * a + b];
+    }
+    double iom[3] = {iw[0] * om[0] + iw[1] * om[1] + iw[2] * om[2], iw[3] * om[0] + iw[4] * om[1] + iw[5] * om[2],
+                     iw[6] * om[0] + iw[7] * om[1] + iw[8] * om[2]};
+    double gyro[3];
+    cross3(om, iom, gyro);
+    for (int a = 0; a < 3; ++a) w[3 + a] -= gyro[a];
+    for (unsigned i = 0; i < n; ++i) {
+      const double *u = jac + i * 6;
+      double rb[3], b3[3] = {cfg->platform_anchor[i][0], cfg->platform_anchor[i][1], cfg->platform_anchor[i][2]};
+      for (int a = 0; a < 3; ++a) rb[a] = rm[3 * a] * b3[0] + rm[3 * a + 1] * b3[1] + rm[3 * a + 2] * b3[2];
+      const double L = cfg->cable_ref_length[i] - q[i];
+      double orb[3], vp[3], vt[3], ou[3], uvp[3], fd[3], td_[3], rbf[3];
+      cross3(om, rb, orb);
+      for (int a = 0; a < 3; ++a) vp[a] = v[a] + orb[a];
+      const double along = u[0] * vp[0] + u[1] * vp[1] + u[2] * vp[2];
+      for (int a = 0; a < 3; ++a) vt[a] = vp[a] - u[a] * along;
+      cross3(om, u, ou);
+      cross3(u, vp, uvp);
+      const double c = cfg->passive_damping;
+      for (int a = 0; a < 3; ++a) fd[a] = -(c / L) * (2.0 * vt[a] / L - ou[a]);
+      cross3(rb, fd, rbf);
+      for (int a = 0; a < 3; ++a) td_[a] = rbf[a] + c * (uvp[a] / L - om[a]);
+      /* weight of the point masses at the anchor */
+      double fg[3] = {cfg->anchor_point_mass * cfg->gravity[0], cfg->anchor_point_mass * cfg->gravity[1], cfg->anchor_point_mass * cfg->gravity[2]};
+      double rbg[3];
+      cross3(rb, fg, rbg);
+      for (int a = 0; a < 3; ++a) {
+        w[a] += fd[a] + fg[a];
+        w[3 + a] += td_[a] + rbg[a];
+      }
+      const double mu = cfg->leg_inertia / (L * L);
+      const double alpha = mu + cfg->anchor_point_mass, beta = cfg->cable_axial_mass - mu;
+      const double rb2 = rb[0] * rb[0] + rb[1] * rb[1] + rb[2] * rb[2];
+      const double X[9] = {0, -rb[2], rb[1], rb[2], 0, -rb[0], -rb[1], rb[0], 0}; /* [rb]x */
+      for (int a = 0; a < 3; ++a) {
+        M[a][a] += alpha;
+        for (int b = 0; b < 3; ++b) {
+          M[a][3 + b] -= alpha * X[3 * a + b];
+          M[3 + a][b] += alpha * X[3 * a + b];
+          M[3 + a][3 + b] += alpha * ((a == b ? rb2 : 0.0) - rb[a] * rb[b]);
+        }
+      }
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) M[a][b] += beta * u[a] * u[b]; /* u[0..5] is the structure-matrix row [u, rb x u] = G^T u */
+    }
+    /* solve M acc = w (SPD): Cholesky */
+    double acc6[6];
+    for (int j = 0; j < 6; ++j) {
+      for (int k = 0; k < j; ++k) M[j][j] -= M[j][k] * M[j][k];
+      M[j][j] = sqrt(M[j][j]);
+      for (int i2 = j + 1; i2 < 6; ++i2) {
+        for (int k = 0; k < j; ++k) M[i2][j] -= M[i2][k] * M[j][k];
+        M[i2][j] /= M[j][j];
+      }
+    }
+    for (int i2 = 0; i2 < 6; ++i2) {
+      double sum = w[i2];
+      for (int k = 0; k < i2; ++k) sum -= M[i2][k] * acc6[k];
+      acc6[i2] = sum / M[i2][i2];
+    }
+    for (int i2 = 5; i2 >= 0; --i2) {
+      double sum = acc6[i2];
+      for (int k = i2 + 1; k < 6; ++k) sum -= M[k][i2] * acc6[k];
+      acc6[i2] = sum / M[i2][i2];
+    }
+    for (int a = 0; a < 3; ++a) {
+      v[a] += cfg->dt * acc6[a];
+      om[a] += cfg->dt * acc6[3 + a];
+    }
   }
-  for (int a = 0; a < 3; ++a) iob[a] = s->ib[3 * a] * ob[0] + s->ib[3 * a + 1] * ob[1] + s->ib[3 * a + 2] * ob[2];
-  cross3(ob, iob, gyro);
-  for (int a = 0; a < 3; ++a) tb[a] -= gyro[a];
-  for (int a = 0; a < 3; ++a) ab[a] = s->ib_inv[3 * a] * tb[0] + s->ib_inv[3 * a + 1] * tb[1] + s->ib_inv[3 * a + 2] * tb[2];
-  for (int a = 0; a < 3; ++a) aw[a] = rm[3 * a] * ab[0] + rm[3 * a + 1] * ab[1] + rm[3 * a + 2] * ab[2];
-  for (int a = 0; a < 3; ++a) om[a] += cfg->dt * aw[a];
   for (int a = 0; a < 3; ++a) r->pose[a] += cfg->dt * v[a];
   {
     double *qq = r->pose + 3;

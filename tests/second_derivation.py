@@ -172,6 +172,69 @@ def world_step(model, dt, gravity, p, rot, v, w, tension_axial, u, rb):
     return p2, rot2, v2, w2
 
 
+def lumped_leg_terms(model, p, rot, v, w, frame_anchors, platform_anchors):
+    """The lumped legs from ENERGY functions instead of force balances (the oracle and the kernels use closed-form
+    forces and a closed-form mass matrix): kinetic energy T(xi) and Rayleigh dissipation D(xi) of
+    the leg links and passive joint dampers as quadratic functions of the platform twist xi = [v; omega] at the current
+    pose; the added mass matrix is the Hessian of T, the damper wrench is -grad D, both by central differences (exact
+    for quadratics).  Leg i turns about its frame anchor with angular velocity (u x vP)/L, vP = v + omega x rb."""
+    rb = rot.apply(platform_anchors)
+    l = p + rb - frame_anchors
+    L = np.linalg.norm(l, axis=1)
+    u = l / L[:, None]
+    n = len(L)
+
+    def rates(xi):
+        vp = xi[:3] + np.cross(xi[3:], rb)
+        w_leg = np.cross(u, vp) / L[:, None]
+        return vp, w_leg
+
+    def kinetic(xi):
+        vp, w_leg = rates(xi)
+        t = 0.5 * model.leg_inertia * (w_leg**2).sum()                       # virt_X, virt_Y, cable, virt_Ypf turn with the leg
+        t += 0.5 * model.cable_axial_mass * (np.einsum("ij,ij->i", u, vp) ** 2).sum()   # cable link slides along the axis
+        t += 0.5 * model.anchor_point_mass * (vp**2).sum()                   # virt_Xpf, virt_Ypf ride on the anchor
+        t += 0.5 * n * model.anchor_inertia * (xi[3:] ** 2).sum()            # virt_Xpf turns with the platform
+        return t
+
+    def dissipation(xi):
+        _, w_leg = rates(xi)
+        # universal pair at the frame: the leg's own rate; spherical triple at the platform: leg relative to platform
+        return 0.5 * model.passive_damping * ((w_leg**2).sum() + ((w_leg - xi[3:]) ** 2).sum())
+
+    xi0 = np.concatenate([v, w])
+    eye = np.eye(6)
+    grad_d = np.array([(dissipation(xi0 + eye[k]) - dissipation(xi0 - eye[k])) / 2.0 for k in range(6)])
+    hess_t = np.empty((6, 6))
+    for a in range(6):
+        for b in range(6):
+            hess_t[a, b] = (kinetic(eye[a] + eye[b]) - kinetic(eye[a] - eye[b]) - kinetic(-eye[a] + eye[b]) + kinetic(-eye[a] - eye[b])) / 4.0
+    return hess_t, -grad_d, rb
+
+
+def world_step_lumped(model, dt, gravity, p, rot, v, w, tension_axial, u, rb, frame_anchors, platform_anchors):
+    """world_step with the lumped legs: M(q) xi_dot = wrench, semi-implicit Euler, exact rotation update."""
+    m = model.mass
+    ixx, iyy, izz, ixy, ixz, iyz = model.inertia
+    ib = np.array([[ixx, ixy, ixz], [ixy, iyy, iyz], [ixz, iyz, izz]])
+    r = rot.as_matrix()
+    iw = r @ ib @ r.T
+    added, damper, _ = lumped_leg_terms(model, p, rot, v, w, frame_anchors, platform_anchors)
+    mass = np.zeros((6, 6))
+    mass[:3, :3] = m * np.eye(3)
+    mass[3:, 3:] = iw
+    mass += added
+    forces = -tension_axial[:, None] * u
+    g = np.asarray(gravity, dtype=np.float64)
+    f = forces.sum(axis=0) + m * g + len(u) * model.anchor_point_mass * g
+    tau = np.cross(rb, forces).sum(axis=0) + np.cross(rb, model.anchor_point_mass * g).sum(axis=0)
+    i_tot = iw + len(u) * model.anchor_inertia * np.eye(3)
+    rhs = np.concatenate([f, tau - np.cross(w, i_tot @ w)]) + damper
+    acc = np.linalg.solve(mass, rhs)
+    v2, w2 = v + dt * acc[:3], w + dt * acc[3:]
+    return p + dt * v2, Rotation.from_rotvec(dt * w2) * rot, v2, w2
+
+
 class SecondRobot:
     """One robot advanced the way CdprGazeboPlugin::update + the world step do it, on the pieces above."""
 
@@ -223,7 +286,12 @@ class SecondRobot:
             self.obs = dict(q=q, qd=qd, effort=applied, pose=np.concatenate([self.p, self.rot.as_quat()]),
                             twist=np.concatenate([self.v, self.w]))
             axial = applied - self.damping * qd  # explicit joint damping (cube.sdf:442)
-            self.p, self.rot, self.v, self.w = world_step(self.model, self.dt, self.gravity, self.p, self.rot, self.v, self.w, axial, u, rb)
+            m = self.model
+            if m.passive_damping or m.leg_inertia or m.cable_axial_mass or m.anchor_point_mass or m.anchor_inertia:
+                self.p, self.rot, self.v, self.w = world_step_lumped(m, self.dt, self.gravity, self.p, self.rot, self.v, self.w, axial, u, rb,
+                                                                     self.fa, self.pb)
+            else:
+                self.p, self.rot, self.v, self.w = world_step(m, self.dt, self.gravity, self.p, self.rot, self.v, self.w, axial, u, rb)
             self.step += 1
 
 

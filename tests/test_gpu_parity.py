@@ -1022,3 +1022,48 @@ def test_ros_bridge_end_to_end_with_a_fake_rospy(pkg, oracle, monkeypatch, mappi
     ps = log["pubs"]["platformPose"].sent[-1]
     op = ora.platform_state()[0][0]
     assert abs(ps.pose.position.z - op[2]) < TOL["pose"] and abs(ps.pose.orientation.w - op[6]) < TOL["pose"]
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0])
+def test_lumped_leg_physics_terms(pkg, oracle, mapping, scale):
+    """passive joint damping (cube.sdf:396) and the leg links' masses / inertias (cube.sdf:359-382)
+    as lumped terms in the world step (PHYS kernels): one-step and fused launches, the general controller path, the MPC
+    rollout, 4 / 7 / 8 cables, at the shipped link values and 30x exaggerated, against the oracle."""
+    once(mapping)
+    from dataclasses import replace
+
+    rng = np.random.default_rng(5)
+    lumped = dict(passive_damping=0.01 * scale, leg_inertia=0.004 * scale, cable_axial_mass=0.001 * scale, anchor_point_mass=0.002 * scale,
+                  anchor_inertia=0.001 * scale)
+    eight = pkg.eight_cable_model()
+    seven = replace(eight, frame_anchors=eight.frame_anchors[:7], platform_anchors=eight.platform_anchors[:7])
+    for base, stages, eps in ((eight, 3, -0.001), (pkg.cube_model(), 0, -0.001), (seven, 3, -0.001), (eight, 3, 0.002)):
+        n = base.n_cables
+        model = replace(base, inertia=(0.9, 1.1, 1.0, 0.05, -0.03, 0.02), **lumped)
+        B = 150
+        cfg = pkg.Config(model=model, batch=B, stages=stages, velocityEpsilon=eps, gravity=(0.3, -0.2, -9.7))
+        eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.03, 0.05))
+        cmd = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+        eng.update(20), ora.update(20)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        eng.update(45), ora.update(45)
+        compare(eng, ora, where=f"one-step launches, n={n}, eps={eps}")
+        if eps < 0:
+            eng.update(40, 10), ora.update(40)
+            compare(eng, ora, where=f"fused launches, n={n}")
+            if stages == 3 and n == 8:
+                cmds = rng.uniform(-0.03, 0.03, (B, 10, 4, n)).astype(np.float32)
+                ref = eng.raw_state()[0][:, :3].astype(np.float64) + [0.0, 0.0, 0.01]
+                gc, oc = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref)
+                assert np.abs(gc - oc).max() < 1e-6 + 2e-4 * np.abs(oc).max()
+        eng.close()
+    # the terms change the motion measurably (the test is not vacuous) ...
+    a = pkg.Engine(pkg.Config(model=replace(eight, **lumped), batch=4, stages=3), 0)
+    b = pkg.Engine(pkg.Config(model=eight, batch=4, stages=3), 0)
+    for e in (a, b):
+        e.set_velocity_command(np.full((4, 8), 0.03, np.float32))
+        e.update(200)
+    assert np.abs(a.raw_state()[1] - b.raw_state()[1]).max() > 1e-5 * scale
+    # ... and a negative one is refused at create
+    with pytest.raises(ValueError):
+        pkg.Engine(pkg.Config(model=replace(eight, leg_inertia=-1.0), batch=1), 0)

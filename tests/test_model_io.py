@@ -93,3 +93,15 @@ def test_reference_files_load_to_the_transcribed_model(pkg):
         assert (m.mass, tuple(m.inertia), m.joint_damping, m.effort_limit) == (ref.mass, tuple(ref.inertia), ref.joint_damping, ref.effort_limit)
         assert np.allclose(m.reference_lengths(), 0.485592422, atol=1e-6)
     assert pkg.load_yaml(os.path.join(REF, "cube.yaml")).home_position == (0.0, 0.0, 2.0)  # what the yaml itself says (cube.yaml:17)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_sdf_lumped_link_terms(pkg):
+    """The five 0.001 kg / 0.001 kg m^2 links and the 0.01 passive damping of every leg of cube.sdf, as lumped terms."""
+    m = pkg.load_sdf(os.path.join(REF, "cube.sdf"), lumped_links=True)
+    assert (m.passive_damping, m.cable_axial_mass) == (0.01, 0.001)
+    assert abs(m.leg_inertia - 0.004) < 1e-15 and abs(m.anchor_point_mass - 0.002) < 1e-15 and m.anchor_inertia == 0.001
+    plain = pkg.load_sdf(os.path.join(REF, "cube.sdf"))
+    assert plain.passive_damping == plain.leg_inertia == plain.anchor_point_mass == 0.0  # off by default: the contract's reduced model
+    s = pkg.Config(model=m).to_struct()
+    assert (s.passive_damping, s.leg_inertia, s.cable_axial_mass, s.anchor_point_mass, s.anchor_inertia) == (0.01, m.leg_inertia, 0.001, m.anchor_point_mass, 0.001)
