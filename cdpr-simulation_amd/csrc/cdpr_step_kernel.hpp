@@ -971,6 +971,8 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
         if (a.unilateral) tens[k] = max2(tens[k], splat(0.f));  // [NEW] option: a cable cannot push
       }
       if (LOWREG && FK) {  // rebuild the true structure matrix (it was not kept alive through the Newton stage)
+        // (measured for multi-step and rollout launches too, with and without per-iteration geometry reads: 330 -> 33
+        //  v_accvgpr moves per step, yet 3-9 % slower: profiles/r02l_multistep_register_pressure_ab.txt)
         v2f len2[NP], l02[NP];
         ik_pairs<N, false>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len2, jac, l02);
       }
