@@ -55,6 +55,7 @@ struct cdpr_engine {
   bool lane_pair = false;   // two lanes per robot (cdpr_step_kernel_pair.hpp) instead of one
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
+  bool split = false;       // FK + TD one-step launches use cdpr_split_kernel (estimator wave + controller wave per 64 robots)
   bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
   // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
   bool general = false;
@@ -277,6 +278,9 @@ void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   k.gx = (float)c.gravity[0];
   k.gy = (float)c.gravity[1];
   k.gz = (float)c.gravity[2];
+  k.split_swap = 0x9;  // measured on MI355X (65 536 x 8): masks 0 .. 0xf8 give 10.8-11.3 us/step, 0x9 the best; bits 8-9 (the
+                       // workgroups that share a CU) make it 12.8: the dispatcher already alternates the SIMD pairs there
+  if (const char* sw = std::getenv("CDPR_SPLIT_SWAP")) k.split_swap = (uint32_t)strtoul(sw, nullptr, 0);
   k.fk_lambda = (float)c.fk_lambda;
   k.fk_tol = (float)c.fk_tolerance;
   k.fk_iters = (int)c.fk_max_iterations;
@@ -448,6 +452,15 @@ StepKernel pick_phys_kernel(uint32_t n, bool fk, bool td, int kind) {
     case 6: return pick_phys_stage<6>(fk, td, kind);
     case 7: return pick_phys_stage<7>(fk, td, kind);
     case 8: return pick_phys_stage<8>(fk, td, kind);
+  }
+  return nullptr;
+}
+
+StepKernel pick_split_kernel(uint32_t n) {
+  switch (n) {
+    case 6: return cdpr_split_kernel<6>;
+    case 7: return cdpr_split_kernel<7>;
+    case 8: return cdpr_split_kernel<8>;
   }
   return nullptr;
 }
@@ -799,7 +812,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     a.cmd = h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0];  // all zeros until the first jointPositions message: target 0 (PLG.cpp:153-157)
   }
   const uint32_t robots_per_block = h->lane_pair ? 32u : 64u;
-  const dim3 grid((h->batch + robots_per_block - 1u) / robots_per_block), block(64);
+  const dim3 grid((h->batch + robots_per_block - 1u) / robots_per_block);
 
   constexpr int kGraphChunk = 20;  // launches per captured graph (a multiple of the ring period 10)
   int done = 0;
@@ -816,8 +829,12 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     StepKernel kern = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
                       : h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
                                    : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
+                                                            : h->split ? pick_split_kernel(h->n)
                                                             : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_kernel<true>(h->n, h->fk, h->td)))
                                                : pick_kernel<false>(h->n, h->fk, h->td));
+
+    // the role-split kernel runs two waves (estimator, controller) per 64 robots
+    const dim3 block((k == 1 && h->split && !h->phys && !h->lane_pair && !h->lowreg) ? 128 : 64);
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
@@ -995,7 +1012,13 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
       const char* mv = std::getenv("CDPR_MAPPING");
       if (mv && (mv[0] == '1' || mv[0] == '2')) mapping = (uint32_t)(mv[0] - '0');
     }
-    if (mapping == CDPR_MAP_AUTO) mapping = (can_pair && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
+    // FK + TD handles: the role-split kernel (cdpr_split_kernel: two waves per 64 robots with different roles) beats both
+    // mappings up to one robot per hardware lane (profiles/r02o_split_kernel_batch_scan.txt, us/step pair or one-wave ->
+    // split: 4 096: 7.6 -> 7.2; 16 384: 8.4 -> 7.7; 32 768: 9.7 -> 9.1; 49 152: 10.8 -> 9.7; 65 536: 11.9 -> 10.9), so AUTO
+    // keeps those on the lane-per-robot mapping; above ~82 000 robots the low-register kernel takes over (below)
+    const bool split_case = !general && !h->phys && (cfg->stages & CDPR_STAGE_FK) && (cfg->stages & CDPR_STAGE_TD) && cfg->n_cables >= 6;
+    if (mapping == CDPR_MAP_AUTO)
+      mapping = (can_pair && !split_case && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
     h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
     // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
     // Measured (scripts/ab_bench.py with CDPR_LOWREG=0|1, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
@@ -1005,6 +1028,8 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
       h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
   }
   if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
+  h->split = h->onestep_v2 && !general && !h->phys && !h->lane_pair && !h->lowreg && h->fk && h->td && cfg->n_cables >= 6;
+  if (const char* sp = std::getenv("CDPR_SPLIT")) h->split = h->split && sp[0] != '0';
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
   memset(&h->base, 0, sizeof h->base);

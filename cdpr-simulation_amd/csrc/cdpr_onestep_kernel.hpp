@@ -403,4 +403,313 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
   CDPR_STAMP(7);
 }
 
+// =====================================================================================================================
+// cdpr_split_kernel — the one-step launch for FK + TD handles with TWO waves per 64 robots (a 128-thread workgroup), each
+// with its own role, so that every SIMD hosts two waves although 65 536 robots are only 1 024 wavefronts of lanes:
+//
+//   estimator wave (wave 0)   platform rows -> measured lengths -> Newton-Raphson FK (4 iterations + closing evaluation)
+//                             -> [forces from the controller wave] tension distribution -> tensions back
+//   controller wave (wave 1)  platform + controller rows -> IK (structure matrix, joint positions / rates) -> early
+//                             observables -> per-cable PID -> forces out -> [tensions from the estimator wave] SetForce
+//                             limits -> remaining observables -> world step -> state
+//
+// Why: one wave alone issues a vector instruction every 4 cycles at best, which wastes half of the SIMD on every
+// non-packed instruction (v_fma_f32 occupies the pipe 2 cycles, v_pk_fma_f32 4) and exposes every dependent-issue stall;
+// two co-resident waves interleave.  The lane-pair mapping gets its second wave by giving every robot two lanes, which
+// duplicates the serial 6x6 solves (+46 % instructions: measured slower from 65 536 robots on).  Splitting by ROLE
+// duplicates only the platform-row loads and one length evaluation (~3 %), and it takes the PID, the observable stores
+// and all controller-row traffic off the Newton stage's critical path.  The hand-offs are 8 forces one way and 8
+// tensions + 6 estimator scalars the other way, through LDS, with two workgroup barriers.  Same arithmetic as the
+// one-wave kernels (shared device functions, -ffp-contract=off): bit-identical, tested.
+// Registers: __launch_bounds__(128, 2) = at most 256 per wave, VGPR + AGPR together.
+template <int N>
+__global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
+  constexpr int NP = cable_pairs(N);
+  constexpr int P = plat_slots(true);
+  constexpr int G = joint_groups(N);
+  constexpr int NH = (NP + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float lds[2][NP * kGeomFloatsPerPair];  // one geometry copy per wave: no barrier before first use
+  __shared__ v2f x_force[NP][64];      // controller -> estimator: raw per-cable forces
+  __shared__ v2f x_tension[NP][64];    // estimator -> controller: distributed tensions (before the SetForce limits)
+  __shared__ float x_est[6][64];       // estimator -> controller: fk x y z, residual, iterations, infeasible flag
+
+  // which of the two waves estimates: swapped from workgroup to workgroup (bits of the workgroup index chosen by the
+  // host, StepArgs::split_swap) so that the two waves a SIMD hosts tend to be one of each role
+  const uint32_t swap = __builtin_popcount(blockIdx.x & a.split_swap) & 1u;
+  const uint32_t wave = (threadIdx.x >> 6) ^ swap, lane = threadIdx.x & 63u;
+  const uint32_t r = blockIdx.x * 64u + lane;
+  const uint32_t rr = (r < a.batch) ? r : (a.batch - 1u);  // tail lanes shadow the last robot, stores are masked
+  const bool live = r < a.batch;
+  const size_t st = a.stride;
+  const uint32_t off = rr * 16u, woff = r * 16u;
+  float* const geo = lds[wave];
+
+  const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
+  const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
+               p3 = load_slot(a.state, st, 3, off);
+  if (wave == 0) {
+    // ------------------------------------------------------------------------------------------------ estimator wave
+    const float4 p4 = load_slot(a.state, st, 4, off);
+    if (lane < NP * kGeomFloatsPerPair) geo[lane] = gval;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float fkx = p3.y, fky = p3.z, fkz = p3.w, fkqx = p4.x, fkqy = p4.y, fkqz = p4.z, fkqw = p4.w;
+    v2f len[NP];
+    {
+      v2f jac[NP][6], l0[NP];  // only the measured lengths L* are kept of the true-state evaluation
+      ik_pairs<N, false>(geo, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, len, jac, l0);
+    }
+    float fk_res = 0.f;
+    int fk_it = 0;
+    v2f jest[NP][6];
+    {
+      v2f elen[NP], unused[NP];
+      bool active = true;
+      for (int it = 0; it < a.fk_iters; ++it) {
+        ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+        v2f res[NP];
+        v2f rm = splat(0.f);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          res[k] = len[k] - elen[k];
+          rm = max2(rm, abs2(res[k]));
+        }
+        active = active && !(fmaxf(rm.x, rm.y) < a.fk_tol);
+        float g[6];
+        jt_times<NP>(jest, res, g);
+        normal_solve<NP>(jest, a.fk_lambda, g);
+        if (active) {
+          fkx += g[0];
+          fky += g[1];
+          fkz += g[2];
+          quat_apply_rotvec(fkqx, fkqy, fkqz, fkqw, g[3], g[4], g[5]);
+          ++fk_it;
+        }
+      }
+      ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+      v2f rm = splat(0.f);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
+      fk_res = fmaxf(rm.x, rm.y);
+    }
+    if (live) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): nothing of this wave's LDS traffic is pending
+    __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in x_force
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    v2f f[NP], df[NP], t_out[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      f[k] = x_force[k][lane];
+      df[k] = f[k] - splat(a.td_mid);
+    }
+    int td_flag = 0;
+    {
+      float g[6];
+      jt_times<NP>(jest, df, g);
+      normal_solve<NP, false>(jest, 0.f, g);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        v2f t = splat(a.td_mid);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t = fma2(g[c], jest[k][c], t);
+        const v2f tc = max2(min2(t, splat(a.td_max)), splat(a.td_min));
+        td_flag |= (tc.x != t.x) ? 1 : 0;
+        if (2 * k + 1 < N) td_flag |= (tc.y != t.y) ? 1 : 0;
+        t_out[k] = tc;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) x_tension[k][lane] = t_out[k];
+    x_est[0][lane] = fkx;
+    x_est[1][lane] = fky;
+    x_est[2][lane] = fkz;
+    x_est[3][lane] = fk_res;
+    x_est[4][lane] = (float)fk_it;
+    x_est[5][lane] = (float)td_flag;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();  // #2: tensions and estimator results are out
+    return;
+  }
+  // ---------------------------------------------------------------------------------------------------- controller wave
+  constexpr int kCtrl = 5 * NP + NH;
+  float4 wraw[NP][5], hraw[NH];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+#pragma unroll
+    for (int m = 0; m < 5; ++m) wraw[k][m] = load_slot(a.state, st, P + 5 * k + m, off);
+  }
+#pragma unroll
+  for (int g = 0; g < NH; ++g) hraw[g] = load_slot(a.state, st, P + 5 * NP + g, off);
+  (void)kCtrl;
+  v2f desired[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
+  const float* cp = a.cmd + (size_t)rr * N;  // never null: before the first Joy the latched buffer holds zeros
+  if (N % 4 == 0) {
+#pragma unroll
+    for (int g = 0; g < N / 4; ++g) {
+      const float4 v = reinterpret_cast<const float4*>(cp)[g];
+      desired[2 * g] = (v2f){v.x, v.y};
+      desired[2 * g + 1] = (v2f){v.z, v.w};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i & 1)
+        desired[i / 2].y = cp[i];
+      else
+        desired[i / 2].x = cp[i];
+    }
+  }
+  if (lane < NP * kGeomFloatsPerPair) geo[lane] = gval;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  Platform s;
+  s.px = p0.x; s.py = p0.y; s.pz = p0.z; s.qx = p0.w;
+  s.qy = p1.x; s.qz = p1.y; s.qw = p1.z; s.vx = p1.w;
+  s.vy = p2.x; s.vz = p2.y; s.wx = p2.z; s.wy = p2.w;
+  s.wz = p3.x;
+
+  // ---- IK on the state at t_k; the structure matrix stays alive for the world step (this wave runs no Newton stage)
+  v2f len[NP], q[NP], qd[NP], jac[NP][6];
+  {
+    v2f l0[NP];
+    ik_pairs<N, true>(geo, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      q[k] = l0[k] - len[k];
+      qd[k] = -fma2(s.wz, jac[k][5], fma2(s.wy, jac[k][4], fma2(s.wx, jac[k][3],
+                    fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
+    }
+  }
+  const bool publish = (a.publish_mask & 1ull) != 0ull;
+  if (publish && live) {
+    store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+      const bool has = (2 * g + 1 < NP);
+      store_slot(a.obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
+      store_slot(a.obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
+    }
+  }
+
+  // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
+  v2f f[NP], e_new[NP], ierr[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    f[k] = splat(0.f);
+    e_new[k] = splat(0.f);
+    ierr[k] = (k & 1) ? (v2f){hraw[k / 2].z, hraw[k / 2].w} : (v2f){hraw[k / 2].x, hraw[k / 2].y};
+  }
+  float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
+  bool dbg_wrote = false;
+  const bool first_world = (a.flags & kFlagFirstWorldStep) != 0u;
+  if (!first_world && a.pid_calls != 0) {
+    v2f win[NP][kWin];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].y};
+        win[k][2 * m + 1] = (v2f){wraw[k][m].z, wraw[k][m].w};
+      }
+    }
+    const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
+    v2f actual[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) actual[k] = actual_is_vel ? qd[k] : q[k];
+    int ring_slot;
+    pid_pairs<NP>(a, a.pid_calls, desired, actual, win, ierr, f, e_new, ring_slot, dbg_p, dbg_i, dbg_d);
+    dbg_wrote = true;
+    if (live) {
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        if (m == (ring_slot >> 1)) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) CDPR_STORE_STATE(a.state, st, P + 5 * k + m, woff, ring_row(win[k], m, e_new[k], ring_slot));
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < NH; ++g) {
+        const int k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+        CDPR_STORE_STATE(a.state, st, P + 5 * NP + g, woff, make_float4(ierr[2 * g].x, ierr[2 * g].y, ierr[k1].x, ierr[k1].y));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) x_force[k][lane] = f[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the forces are in LDS (vector memory operations stay in flight)
+  __builtin_amdgcn_s_barrier();        // #1
+  __builtin_amdgcn_s_barrier();        // #2: the estimator wave has finished the tension distribution
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  v2f applied[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) applied[k] = x_tension[k][lane];
+  const float fkx = x_est[0][lane], fky = x_est[1][lane], fkz = x_est[2][lane], fk_res = x_est[3][lane], fk_it = x_est[4][lane],
+              td_flag = x_est[5][lane];
+  if (a.vel_limit > 0.f) {  // Joint::SetForce velocity truncation [EXT]
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      applied[k].x = (qd[k].x > a.vel_limit && applied[k].x > 0.f) || (qd[k].x < -a.vel_limit && applied[k].x < 0.f) ? 0.f : applied[k].x;
+      applied[k].y = (qd[k].y > a.vel_limit && applied[k].y > 0.f) || (qd[k].y < -a.vel_limit && applied[k].y < 0.f) ? 0.f : applied[k].y;
+    }
+  }
+  if (a.effort >= 0.f) {  // Joint::SetForce clamp (cube.sdf:438)
+#pragma unroll
+    for (int k = 0; k < NP; ++k) applied[k] = max2(min2(applied[k], splat(a.effort)), splat(-a.effort));
+  }
+  if (a.dbg && live) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
+    float* d = a.dbg + (size_t)r * 9;
+    if (dbg_wrote) {
+      d[0] = dbg_p;
+      d[1] = dbg_i;
+      d[2] = dbg_d;
+      d[3] = desired[0].x;
+    }
+    d[4] = applied[0].x;
+  }
+  if (publish && live) {
+    store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, fk_it, td_flag));
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+      const bool has = (2 * g + 1 < NP);
+      store_slot(a.obs, st, 4 + 2 * G + g, woff,
+                 make_float4(applied[k0].x, applied[k0].y, has ? applied[k1].x : 0.f, has ? applied[k1].y : 0.f));
+    }
+  }
+  // ---- world step to t_{k+1}: wrench = -J^T (applied - d qdot) + m g
+  {
+    v2f tens[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      tens[k] = fma2(-a.damping, qd[k], applied[k]);
+      if (a.unilateral) tens[k] = max2(tens[k], splat(0.f));
+    }
+    float w[6];
+    jt_times<NP>(jac, tens, w);
+    w[0] = a.fgx - w[0];
+    w[1] = a.fgy - w[1];
+    w[2] = a.fgz - w[2];
+    w[3] = -w[3];
+    w[4] = -w[4];
+    w[5] = -w[5];
+    integrate(a, s, w);
+  }
+  if (live) {
+    CDPR_STORE_STATE(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    CDPR_STORE_STATE(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    CDPR_STORE_STATE(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+    CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
+  }
+}
+
 }  // namespace cdpr

@@ -99,6 +99,7 @@ struct StepArgs {
   // weights are kernel-argument scalar loads whatever the kernel has done to memory before the PID stage
   float wrow[kWin + 2];
   int nbuf, clamp_cmd;
+  uint32_t split_swap;  // cdpr_split_kernel: workgroups whose index has odd parity under this mask swap the roles of their waves
 };
 
 __host__ __device__ constexpr int plat_slots(bool fk) { return fk ? 5 : 4; }

@@ -850,8 +850,11 @@ def test_second_generation_onestep_kernel_is_bit_identical(pkg, monkeypatch, map
     vel = rng.uniform(-0.04, 0.04, (B, n_cables)).astype(np.float32)
     pos = rng.uniform(-0.002, 0.002, (B, n_cables)).astype(np.float32)
     out = []
-    for gen in ("1", "2"):
+    # first generation; second generation with the role-split two-wave kernel where it applies (FK + TD); second
+    # generation with one wave per 64 robots everywhere
+    for gen, split in (("1", "1"), ("2", "1"), ("2", "0")):
         monkeypatch.setenv("CDPR_ONESTEP", gen)
+        monkeypatch.setenv("CDPR_SPLIT", split)
         e = pkg.Engine(cfg, 0)
         e.set_platform_state(pose7=pose)
         snaps = []
@@ -863,9 +866,10 @@ def test_second_generation_onestep_kernel_is_bit_identical(pkg, monkeypatch, map
             snaps.append(e.raw_state() + e.joint_states() + e.platform_state() + (e.pid_debug(),) + (e.fk_state() if stages & 1 else ()))
         out.append(snaps)
         e.close()
-    for sa, sb in zip(*out):
-        for x, y in zip(sa, sb):
-            assert np.array_equal(x, y)
+    for other in out[1:]:
+        for sa, sb in zip(out[0], other):
+            for x, y in zip(sa, sb):
+                assert np.array_equal(x, y)
 
 
 def test_per_robot_command_arrival(pkg, oracle, mapping):
