@@ -422,6 +422,20 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
 // tensions + 6 estimator scalars the other way, through LDS, with two workgroup barriers.  Same arithmetic as the
 // one-wave kernels (shared device functions, -ffp-contract=off): bit-identical, tested.
 // Registers: __launch_bounds__(128, 2) = at most 256 per wave, VGPR + AGPR together.
+#ifndef CDPR_SPLIT_PRIO
+#define CDPR_SPLIT_PRIO 1  // 1 = estimator wave at s_setprio 3 (measured 10.89 vs 11.05 us/step), 2 = controller wave at 3 (11.7), 0 = none
+#endif
+#ifdef CDPR_STAMPS
+#define CDPR_SPLIT_STAMP(i)                                                                                          \
+  do {                                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();           \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  } while (0)
+#else
+#define CDPR_SPLIT_STAMP(i) do { } while (0)
+#endif
+
 template <int N>
 __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
@@ -444,11 +458,20 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   const uint32_t off = rr * 16u, woff = r * 16u;
   float* const geo = lds[wave];
 
+  if (wave == 0) CDPR_SPLIT_STAMP(0);
+#ifdef CDPR_STAMPS
+  if (a.stamps && lane == 0)  // where this wave runs: HW_ID (wave, SIMD, CU, SH, SE) | XCC_ID << 16, per PHYSICAL wave of the workgroup
+    reinterpret_cast<uint32_t*>(&a.stamps[(size_t)blockIdx.x * 8 + 7])[threadIdx.x >> 6] =
+        (__builtin_amdgcn_s_getreg((16 - 1) << 11 | 4) & 0xffffu) | ((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 0xfu) << 16);
+#endif
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
   const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
                p3 = load_slot(a.state, st, 3, off);
   if (wave == 0) {
     // ------------------------------------------------------------------------------------------------ estimator wave
+#if CDPR_SPLIT_PRIO == 1
+    __builtin_amdgcn_s_setprio(3);  // the estimator is the critical path: it wins the SIMD's issue arbitration
+#endif
     const float4 p4 = load_slot(a.state, st, 4, off);
     if (lane < NP * kGeomFloatsPerPair) geo[lane] = gval;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -494,8 +517,10 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
       fk_res = fmaxf(rm.x, rm.y);
     }
     if (live) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+    CDPR_SPLIT_STAMP(1);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): nothing of this wave's LDS traffic is pending
     __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in x_force
+    CDPR_SPLIT_STAMP(2);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     v2f f[NP], df[NP], t_out[NP];
 #pragma unroll
@@ -529,10 +554,14 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     x_est[5][lane] = (float)td_flag;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0xC07F);
+    CDPR_SPLIT_STAMP(3);
     __builtin_amdgcn_s_barrier();  // #2: tensions and estimator results are out
     return;
   }
   // ---------------------------------------------------------------------------------------------------- controller wave
+#if CDPR_SPLIT_PRIO == 2
+  __builtin_amdgcn_s_setprio(3);
+#endif
   constexpr int kCtrl = 5 * NP + NH;
   float4 wraw[NP][5], hraw[NH];
 #pragma unroll
@@ -647,8 +676,10 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   for (int k = 0; k < NP; ++k) x_force[k][lane] = f[k];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the forces are in LDS (vector memory operations stay in flight)
+  CDPR_SPLIT_STAMP(4);
   __builtin_amdgcn_s_barrier();        // #1
   __builtin_amdgcn_s_barrier();        // #2: the estimator wave has finished the tension distribution
+  CDPR_SPLIT_STAMP(5);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   v2f applied[NP];
 #pragma unroll
@@ -710,6 +741,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     CDPR_STORE_STATE(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
     CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
   }
+  CDPR_SPLIT_STAMP(6);
 }
 
 }  // namespace cdpr

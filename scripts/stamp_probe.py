@@ -20,9 +20,11 @@ for stages in (3, 0):
     L.cdpr_device_download(eng._h, buf.ctypes.data_as(C.c_void_p), C.c_void_p(dptr), buf.nbytes)
     t = buf.astype(np.float64) * 0.01  # us (100 MHz)
     t0 = t[:, 0].min()
-    names = (["entry", "data arrived / IK", "PID", "FK", "TD", "obs store", "final store", "end"] if os.environ.get("CDPR_ONESTEP") == "1" else
+    split = os.environ.get("CDPR_ONESTEP") != "1" and os.environ.get("CDPR_SPLIT") != "0" and stages == 3
+    names = ["est: entry", "est: Newton done", "est: forces received", "est: TD done", "ctl: PID done, forces out", "ctl: tensions received", "ctl: end", "-"] if split else (["entry", "data arrived / IK", "PID", "FK", "TD", "obs store", "final store", "end"] if os.environ.get("CDPR_ONESTEP") == "1" else
              ["entry", "platform rows in, DMA issued", "IK + early obs", "Newton FK done", "DMA landed", "PID done", "TD + obs done", "end"])
-    print(f"stages={stages}: kernel span {t[:,7].max()-t0:.2f} us; per-phase (median / min / max over waves), us since first wave entry:")
+    last = 6 if split else 7
+    print(f"stages={stages}: kernel span {t[:,last].max()-t0:.2f} us; per-phase (median / min / max over waves), us since first wave entry:")
     for i, nm in enumerate(names):
         col = t[:, i] - t0
         print(f"  {i} {nm:20s} {np.median(col):7.2f} {col.min():7.2f} {col.max():7.2f}")
