@@ -1027,6 +1027,10 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     if (const char* lr = std::getenv("CDPR_LOWREG"))
       h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
   }
+  // second-generation one-step kernel: wins wherever there is a Newton stage to hide the controller rows under, and
+  // without one from ~32 768 robots on (65 536 x 8, no FK: 6.3 vs 7.0 us/step); small batches without FK are pure
+  // latency and the extra LDS round trip loses (4 096 x 4: 4.18 vs 3.99 us by rocprofv3)
+  h->onestep_v2 = h->fk || cfg->batch > 32768u;
   if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
   h->split = h->onestep_v2 && !general && !h->phys && !h->lane_pair && !h->lowreg && h->fk && h->td && cfg->n_cables >= 6;
   if (const char* sp = std::getenv("CDPR_SPLIT")) h->split = h->split && sp[0] != '0';
