@@ -219,9 +219,10 @@ def main():
 
     if args.dry_run:  # exercises exactly the rank plumbing (used by the CPU test suite; nothing is measured)
         ctx.barrier()
+        ctx.fast_barrier()
         t0 = time.perf_counter()
         time.sleep(0.01)
-        ctx.barrier()
+        ctx.fast_barrier()
         elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
@@ -263,13 +264,20 @@ def main():
         eng.synchronize()  # hipStreamSynchronize on the engine's stream (all of this process's GPU work)
         ctx.barrier()      # torch.cuda.synchronize() + dist.barrier() when N > 1
 
+    def edge():
+        """Edge of a timed region: this rank's GPU work done, then every rank here.  The cross-rank part is a shared-memory
+        spin barrier (microseconds): an RCCL / gloo barrier costs ~100 us, a third of a 20-step timed region."""
+        eng.synchronize()
+        ctx.fast_barrier()
+
     advance(0, args.warmup)
     barrier()
+    edge()
     eng.profile_begin()
     t0 = time.perf_counter()
     advance(args.warmup, args.steps)
     ev_ms, launches = eng.profile_end()
-    barrier()
+    edge()
     elapsed = time.perf_counter() - t0
     elapsed = ctx.max_over_ranks(elapsed)
 
@@ -288,13 +296,14 @@ def main():
         image = eng.observable_image_bytes()
         d_rec = eng.device_upload(np.zeros(image * refresh, dtype=np.uint8))  # trajectory record of one command hold
         barrier()
+        edge()
         eng.profile_begin()
         t0 = time.perf_counter()
         for j in range(steps2 // refresh):
             eng.bind_velocity_command_device(sched2[j], count)
             eng.update_record_device(refresh, spl, d_rec, image * refresh)  # every step's observables stay in HBM
         ms2, launches2 = eng.profile_end()
-        barrier()
+        edge()
         el2 = ctx.max_over_ranks(time.perf_counter() - t0)
         eng.device_free(d_rec)
         for p_ in sched2:
@@ -328,10 +337,11 @@ def main():
             reps = 10
             er.synchronize()
             ctx.barrier()
+            ctx.fast_barrier()
             t0 = time.perf_counter()
             for _ in range(reps):
                 cost = er.rollout_velocity((dptr, S, H), ref)  # ref upload + kernel + cost download, synchronous
-            ctx.barrier()
+            ctx.fast_barrier()
             elr = ctx.max_over_ranks(time.perf_counter() - t0) / reps
             # kernel alone: device-resident reference and costs, HIP events on the engine's stream
             d_ref = er.device_upload(ref)

@@ -32,6 +32,11 @@ t0 = time.perf_counter()
 sim.update(20); sim.set_velocity_command(cmd[lo:hi]); sim.update(50)
 ctx.barrier()
 elapsed = ctx.max_over_ranks(time.perf_counter() - t0 + 0.25 * ctx.rank)
+t1 = time.perf_counter()
+if ctx.rank == 1:
+    time.sleep(0.3)
+ctx.fast_barrier()  # shared-memory spin barrier: rank 0 must sit here until rank 1 arrives
+open(os.path.join({out!r}, f"wait{{ctx.rank}}.txt"), "w").write(repr((time.perf_counter() - t1, ctx._spin is not None, ctx._spin.path if ctx._spin else "")))
 np.save(os.path.join({out!r}, f"shard{{ctx.rank}}.npy"), sim.raw_state()[0])
 if ctx.rank == 0:
     open(os.path.join({out!r}, "elapsed.txt"), "w").write(repr(elapsed))
@@ -59,6 +64,10 @@ def test_two_rank_sharding_matches_unsharded(tmp_path, pkg, oracle):
     parts = np.concatenate([np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")])
     assert np.array_equal(parts, whole)
     assert float((tmp_path / "elapsed.txt").read_text()) >= 0.25  # MAX over ranks, not rank 0's own time
+    waited0, spin0, path0 = eval((tmp_path / "wait0.txt").read_text())
+    waited1, spin1, _ = eval((tmp_path / "wait1.txt").read_text())
+    assert spin0 and spin1 and waited0 >= 0.29 and waited1 < waited0 + 0.05  # the fast barrier really holds rank 0 back
+    assert not os.path.exists(path0)  # and its /dev/shm file is removed at close
 
 
 def test_shard_range_covers_everything(pkg):
