@@ -101,6 +101,8 @@ struct cdpr_engine {
   float* d_roll_cost = nullptr;  // float[B][samples]
   size_t roll_cost_cap = 0;      // trajectories d_roll_cost can hold
   uint64_t roll_pending = 0;     // trajectories of the launched, not yet fetched rollout
+  float* d_unpack = nullptr;     // read-out scratch (cdpr_get_*): robot-major copy of the requested fields, grow-only
+  size_t unpack_cap = 0;
   std::string err;
 };
 
@@ -594,6 +596,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_mode) (void)hipFree(h->d_mode);
   for (int i = 0; i < 2; ++i)
     if (h->d_mask[i]) (void)hipFree(h->d_mask[i]);
+  if (h->d_unpack) (void)hipFree(h->d_unpack);
   if (h->d_roll_ref) (void)hipFree(h->d_roll_ref);
   if (h->d_roll_cost) (void)hipFree(h->d_roll_cost);
   for (int i = 0; i < 2; ++i) {
@@ -918,22 +921,48 @@ int fetch_slots(cdpr_engine* h, const float4* dsrc, int nslots, std::vector<floa
   return CDPR_OK;
 }
 
-inline float comp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
-
-void unpack_platform(const cdpr_engine* h, const std::vector<float4>& s, float* pose7, float* twist6) {
-  const size_t st = h->stride;
-  for (uint32_t r = 0; r < h->batch; ++r) {
-    const float4 a = s[0 * st + r], b = s[1 * st + r], c = s[2 * st + r], d = s[3 * st + r];
-    if (pose7) {
-      float* p = pose7 + (size_t)r * 7;
-      p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z;
-    }
-    if (twist6) {
-      float* t = twist6 + (size_t)r * 6;
-      t[0] = b.w; t[1] = c.x; t[2] = c.y; t[3] = c.z; t[4] = c.w; t[5] = d.x;
-    }
+// One field group of every robot out of a slot-row buffer into a caller's robot-major host array: a device-side gather
+// into the read-out scratch, then one contiguous copy.  fields = (slot, component) per output column.
+int fetch_fields(cdpr_engine* h, const float4* rows, const std::vector<std::pair<int, int>>& fields, void* host_out, uint32_t as_int = 0) {
+  if (!host_out) return CDPR_OK;
+  const size_t count = (size_t)h->batch * fields.size();
+  if (h->unpack_cap < count) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->d_unpack) (void)hipFree(h->d_unpack);
+    h->d_unpack = nullptr;
+    h->unpack_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_unpack, count * sizeof(float)));
+    h->unpack_cap = count;
   }
+  UnpackArgs u{};
+  u.rows = rows;
+  u.out = h->d_unpack;
+  u.stride = h->stride;
+  u.batch = h->batch;
+  u.width = (uint32_t)fields.size();
+  u.as_int = as_int;
+  for (size_t j = 0; j < fields.size(); ++j) {
+    u.slot[j] = (uint8_t)fields[j].first;
+    u.comp[j] = (uint8_t)fields[j].second;
+  }
+  hipLaunchKernelGGL(cdpr_unpack_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, h->stream, u);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(host_out, h->d_unpack, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));  // the scratch is reused by the next call
+  return CDPR_OK;
 }
+
+// pose7 = slot 0 xyzw, slot 1 xyz; twist6 = slot 1 w, slot 2 xyzw, slot 3 x
+const std::vector<std::pair<int, int>> kPoseFields = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 0}, {1, 1}, {1, 2}};
+const std::vector<std::pair<int, int>> kTwistFields = {{1, 3}, {2, 0}, {2, 1}, {2, 2}, {2, 3}, {3, 0}};
+
+int fetch_platform(cdpr_engine* h, const float4* rows, float* pose7, float* twist6) {
+  int rc = fetch_fields(h, rows, kPoseFields, pose7);
+  if (rc != CDPR_OK) return rc;
+  return fetch_fields(h, rows, kTwistFields, twist6);
+}
+
+inline float comp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 
 }  // namespace
 
@@ -1354,16 +1383,13 @@ uint64_t cdpr_step_count(cdpr_handle_t h) { return h ? h->step : 0; }
 int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, float* effort) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  std::vector<float4> o;
-  int rc = fetch_slots(h, h->d_obs, h->n_obs, o);
-  if (rc != CDPR_OK) return rc;
-  const size_t st = h->stride;
   const int G = joint_groups((int)h->n);
   float* dst[3] = {position, velocity, effort};
   for (int f = 0; f < 3; ++f) {
-    if (!dst[f]) continue;
-    for (uint32_t r = 0; r < h->batch; ++r)
-      for (uint32_t i = 0; i < h->n; ++i) dst[f][(size_t)r * h->n + i] = comp(o[(size_t)(4 + f * G + i / 4) * st + r], i % 4);
+    std::vector<std::pair<int, int>> fields;
+    for (uint32_t i = 0; i < h->n; ++i) fields.push_back({4 + f * G + (int)(i / 4), (int)(i % 4)});
+    int rc = fetch_fields(h, h->d_obs, fields, dst[f]);
+    if (rc != CDPR_OK) return rc;
   }
   return CDPR_OK;
 }
@@ -1371,21 +1397,13 @@ int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, flo
 int cdpr_get_platform_state(cdpr_handle_t h, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  std::vector<float4> o;
-  int rc = fetch_slots(h, h->d_obs, 4, o);
-  if (rc != CDPR_OK) return rc;
-  unpack_platform(h, o, pose7, twist6);
-  return CDPR_OK;
+  return fetch_platform(h, h->d_obs, pose7, twist6);
 }
 
 int cdpr_get_raw_state(cdpr_handle_t h, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  std::vector<float4> s;
-  int rc = fetch_slots(h, h->d_state, 4, s);
-  if (rc != CDPR_OK) return rc;
-  unpack_platform(h, s, pose7, twist6);
-  return CDPR_OK;
+  return fetch_platform(h, h->d_state, pose7, twist6);
 }
 
 int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
@@ -1408,22 +1426,12 @@ int cdpr_get_fk_state(cdpr_handle_t h, float* pose7, float* residual, int32_t* i
     return CDPR_ERR_UNSUPPORTED;
   }
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  std::vector<float4> s, o;
-  int rc = fetch_slots(h, h->d_state, 5, s);
+  // estimate: state slot 3 yzw + slot 4 xyzw; residual / iteration count: observable slot 3 y, z
+  int rc = fetch_fields(h, h->d_state, {{3, 1}, {3, 2}, {3, 3}, {4, 0}, {4, 1}, {4, 2}, {4, 3}}, pose7);
   if (rc != CDPR_OK) return rc;
-  rc = fetch_slots(h, h->d_obs, 4, o);
+  rc = fetch_fields(h, h->d_obs, {{3, 1}}, residual);
   if (rc != CDPR_OK) return rc;
-  const size_t st = h->stride;
-  for (uint32_t r = 0; r < h->batch; ++r) {
-    if (pose7) {
-      float* p = pose7 + (size_t)r * 7;
-      const float4 d = s[3 * st + r], e = s[4 * st + r];
-      p[0] = d.y; p[1] = d.z; p[2] = d.w; p[3] = e.x; p[4] = e.y; p[5] = e.z; p[6] = e.w;
-    }
-    if (residual) residual[r] = o[3 * st + r].y;
-    if (iterations) iterations[r] = (int32_t)o[3 * st + r].z;
-  }
-  return CDPR_OK;
+  return fetch_fields(h, h->d_obs, {{3, 2}}, iterations, 1u);
 }
 
 int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
@@ -1434,13 +1442,7 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
   }
   int rc = cdpr_get_joint_states(h, nullptr, nullptr, tension);  // applied force == distributed tension
   if (rc != CDPR_OK) return rc;
-  if (infeasible) {
-    std::vector<float4> o;
-    rc = fetch_slots(h, h->d_obs, 4, o);
-    if (rc != CDPR_OK) return rc;
-    for (uint32_t r = 0; r < h->batch; ++r) infeasible[r] = (int32_t)o[3 * (size_t)h->stride + r].w;
-  }
-  return CDPR_OK;
+  return fetch_fields(h, h->d_obs, {{3, 3}}, infeasible, 1u);
 }
 
 // Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in

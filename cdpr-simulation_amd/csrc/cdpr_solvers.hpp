@@ -140,4 +140,23 @@ __global__ __launch_bounds__(64) void cdpr_solver_kernel(const SolveArgs a) {
   }
 }
 
+// Observable read-out: slot rows (float4 per robot per slot) -> robot-major float arrays as the C-ABI hands them out
+// ([B][W]), on the device, so the host gets one contiguous copy instead of transposing B x W values in a scalar loop
+// (at 524 288 robots: 50 MB of joint states).  Thread (r, j) picks component comp[j] of slot slot[j] of robot r.
+struct UnpackArgs {
+  const float4* rows;
+  float* out;
+  uint32_t stride, batch, width;
+  uint8_t slot[24], comp[24];
+  uint32_t as_int;  // bit j set: the value is converted to int32 (iteration counts, flags) before it is stored
+};
+
+__global__ __launch_bounds__(256) void cdpr_unpack_kernel(const UnpackArgs a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= a.batch * a.width) return;
+  const uint32_t r = t / a.width, j = t - r * a.width;
+  const float v = comp4(a.rows[(size_t)a.slot[j] * a.stride + r], a.comp[j]);
+  a.out[t] = ((a.as_int >> j) & 1u) ? __int_as_float((int)v) : v;
+}
+
 }  // namespace cdpr
