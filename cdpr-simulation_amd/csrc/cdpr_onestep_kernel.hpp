@@ -30,26 +30,11 @@ CDPR_DEV void row_to_lds(const float4* src, float4* dst_row) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst_row, 16, 0, 0);
 }
 
-#ifndef CDPR_V2_ROWSTORE
-#define CDPR_V2_ROWSTORE 0  // 0: one buffer descriptor per row (store_slot).  1: one descriptor per buffer + the row as scalar
-#endif                      // offset: 100 fewer scalar instructions and 14 -> 6 spilled SGPRs, same time within noise
-                            // (profiles/r02f_onestep_v2_variants_ab.txt) - but the FK instantiations at n = 8 then fail
-                            // the bit-identity and parity tests on MI355X (cause not found in the ISA; the per-row form
-                            // passes the whole suite), so it stays off.  Also measured, neither faster: weights staged
-                            // in LDS instead of kernel arguments, cable constants re-read per Newton iteration.
-// Row stores: ONE buffer descriptor per buffer (4 SGPRs) and the row as the scalar offset operand (1 SGPR) instead of
-// one descriptor per row.  Offsets are 32-bit: a buffer must stay below 4 GiB (524 288 robots x 27 rows x 16 B = 226 MB).
-CDPR_DEV auto whole_buffer(float4* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000); }
-template <typename R>
-CDPR_DEV void store_row(R rsrc, float4* base, size_t stride, int slot, uint32_t lane_bytes, const float4& v) {
-#if CDPR_V2_ROWSTORE
-  const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
-                   __builtin_bit_cast(unsigned, v.w)};
-  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, lane_bytes, (uint32_t)slot * (uint32_t)stride * 16u, CDPR_STORE_AUX);
-#else
-  store_slot(base, stride, slot, lane_bytes, v);
-#endif
-}
+// Row stores go through store_slot (one buffer descriptor per row).  One descriptor per BUFFER with the row as the scalar
+// offset operand was measured too: 100 fewer scalar instructions and 14 -> 6 spilled SGPRs, the same time within noise
+// (profiles/r02f_onestep_v2_variants_ab.txt) - and the FK instantiations at n = 8 then failed the bit-identity and
+// parity tests on MI355X (cause not found in the ISA), so that form is not in the tree.  Also measured, neither faster:
+// weights staged in LDS instead of kernel arguments, cable constants re-read per Newton iteration.
 
 // Pid::update for every cable pair (Pid.cpp:122-191; the same statements as in cdpr_step_kernel).
 template <int NP>
@@ -121,8 +106,6 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
   // ---- loads that the first stages need: geometry (oldest), platform rows, and the Joy when it is not LDS-staged
   CDPR_STAMP(0);
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
-  const auto state_rsrc = whole_buffer(a.state);
-  const auto obs_rsrc = whole_buffer(a.obs);
   const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
                p3 = load_slot(a.state, st, 3, off);
   float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
@@ -190,15 +173,15 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
   }
   const bool publish = (a.publish_mask & 1ull) != 0ull;
   if (publish && live) {  // the part of the observables that is final already (PLG.cpp:248-280)
-    store_row(obs_rsrc, a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
-    store_row(obs_rsrc, a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
-    store_row(obs_rsrc, a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+    store_slot(a.obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    store_slot(a.obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    store_slot(a.obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
       const bool has = (2 * g + 1 < NP);
-      store_row(obs_rsrc, a.obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
-      store_row(obs_rsrc, a.obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
+      store_slot(a.obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
+      store_slot(a.obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
     }
   }
 
@@ -292,13 +275,13 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
       for (int m = 0; m < 5; ++m) {
         if (m == (ring_slot >> 1)) {
 #pragma unroll
-          for (int k = 0; k < NP; ++k) store_row(state_rsrc, a.state, st, P + 5 * k + m, woff, ring_row(win[k], m, e_new[k], ring_slot));
+          for (int k = 0; k < NP; ++k) CDPR_STORE_STATE(a.state, st, P + 5 * k + m, woff, ring_row(win[k], m, e_new[k], ring_slot));
         }
       }
 #pragma unroll
       for (int g = 0; g < NH; ++g) {
         const int k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
-        store_row(state_rsrc, a.state, st, P + 5 * NP + g, woff, make_float4(ierr[2 * g].x, ierr[2 * g].y, ierr[k1].x, ierr[k1].y));
+        CDPR_STORE_STATE(a.state, st, P + 5 * NP + g, woff, make_float4(ierr[2 * g].x, ierr[2 * g].y, ierr[k1].x, ierr[k1].y));
       }
     }
   }
@@ -356,12 +339,12 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     d[4] = applied[0].x;
   }
   if (publish && live) {  // the rest of the observables
-    store_row(obs_rsrc, a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+    store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
       const bool has = (2 * g + 1 < NP);
-      store_row(obs_rsrc, a.obs, st, 4 + 2 * G + g, woff,
+      store_slot(a.obs, st, 4 + 2 * G + g, woff,
                 make_float4(applied[k0].x, applied[k0].y, has ? applied[k1].x : 0.f, has ? applied[k1].y : 0.f));
     }
   }
@@ -394,11 +377,11 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     integrate(a, s, w);
   }
   if (live) {
-    store_row(state_rsrc, a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
-    store_row(state_rsrc, a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
-    store_row(state_rsrc, a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
-    store_row(state_rsrc, a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
-    if (FK) store_row(state_rsrc, a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+    CDPR_STORE_STATE(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    CDPR_STORE_STATE(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    CDPR_STORE_STATE(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+    CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
+    if (FK) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
   }
   CDPR_STAMP(7);
 }
