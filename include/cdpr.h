@@ -228,11 +228,11 @@ int cdpr_get_platform_state(cdpr_handle_t h, float *pose7, float *twist6);
  * desired, applied force of cable 0, then four unused zeros.  Needs
  * CDPR_STAGE_PID_DEBUG. */
 int cdpr_get_pid_debug(cdpr_handle_t h, float *axes9);
-/* Forward-kinematics estimate of the last step (CDPR_STAGE_FK): pose7[B][7],
- * residual[B] = max_i |L*_i - L_i(estimate)|, iterations[B]. */
+/* Forward-kinematics estimator (CDPR_STAGE_FK): pose7[B][7] = the estimate after the last step; residual[B] =
+ * max_i |L*_i - L_i(estimate)| and iterations[B] travel with the observables: as of the last PUBLISHED step. */
 int cdpr_get_fk_state(cdpr_handle_t h, float *pose7, float *residual, int32_t *iterations);
-/* Tension distribution of the last step (CDPR_STAGE_TD): tension[B][n] after
- * bounds, infeasible[B] = 1 where a bound was active. */
+/* Tension distribution of the last PUBLISHED step (CDPR_STAGE_TD): tension[B][n] = the force applied to the joints
+ * (after the bounds and the SetForce limits: the `effort` observable), infeasible[B] = 1 where a bound was active. */
 int cdpr_get_td_state(cdpr_handle_t h, float *tension, int32_t *infeasible);
 /* Current platform state (not decimated by publish_period), for checkpoints
  * and tests: pose7[B][7], twist6[B][6]. */

@@ -569,6 +569,8 @@ typedef struct orc_robot {
   /* published observables */
   double pub_q[CDPR_MAX_CABLES], pub_qd[CDPR_MAX_CABLES], pub_eff[CDPR_MAX_CABLES];
   double pub_pose[7], pub_twist[6];
+  double pub_fk_res;            /* estimator residual / iteration count and the infeasibility flag travel with the */
+  int32_t pub_fk_iters, pub_td_flag; /* observables (they share a row with them on the device): as of the last PUBLISHED step */
   double dbg[CDPR_PID_DEBUG_AXES];
 } orc_robot;
 
@@ -765,6 +767,9 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
     }
     memcpy(r->pub_pose, r->pose, sizeof(r->pub_pose));
     memcpy(r->pub_twist, r->twist, sizeof(r->pub_twist));
+    r->pub_fk_res = r->fk_res;
+    r->pub_fk_iters = r->fk_iters;
+    r->pub_td_flag = r->td_flag;
   }
 
   /* world step: explicit joint damping, wrench = -J^T T + m g, semi-implicit Euler */
@@ -1000,16 +1005,16 @@ void orc_get_pid_debug(const orc_sim *s, double *axes9) {
 void orc_get_fk_state(const orc_sim *s, double *pose7, double *residual, int32_t *iterations) {
   for (uint64_t b = 0; b < s->cfg.batch; ++b) {
     if (pose7) memcpy(pose7 + 7 * b, s->rob[b].fk_pose, 7 * sizeof(double));
-    if (residual) residual[b] = s->rob[b].fk_res;
-    if (iterations) iterations[b] = s->rob[b].fk_iters;
+    if (residual) residual[b] = s->rob[b].pub_fk_res;
+    if (iterations) iterations[b] = s->rob[b].pub_fk_iters;
   }
 }
 
 void orc_get_td_state(const orc_sim *s, double *tension, int32_t *infeasible) {
   unsigned n = s->cfg.n_cables;
   for (uint64_t b = 0; b < s->cfg.batch; ++b) {
-    if (tension) memcpy(tension + n * b, s->rob[b].td_tension, n * sizeof(double));
-    if (infeasible) infeasible[b] = s->rob[b].td_flag;
+    if (tension) memcpy(tension + n * b, s->rob[b].pub_eff, n * sizeof(double)); /* the applied force of the published step */
+    if (infeasible) infeasible[b] = s->rob[b].pub_td_flag;
   }
 }
 

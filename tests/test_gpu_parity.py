@@ -1071,3 +1071,29 @@ def test_lumped_leg_physics_terms(pkg, oracle, mapping, scale):
     # ... and a negative one is refused at create
     with pytest.raises(ValueError):
         pkg.Engine(pkg.Config(model=replace(eight, leg_inertia=-1.0), batch=1), 0)
+
+
+def test_role_split_kernel_with_optional_terms_and_publish_decimation(pkg, oracle, mapping):
+    """The FK + TD one-step path (cdpr_split_kernel) with everything switched on that the headline run leaves off:
+    SetForce velocity truncation, unilateral cables, a publish period that decimates the observables, the `pid` topic,
+    a batch that is no multiple of 64; against the oracle."""
+    once(mapping)
+    from dataclasses import replace
+
+    B = 203
+    rng = np.random.default_rng(71)
+    model = replace(pkg.eight_cable_model(), velocity_limit=0.02, unilateral_cables=True)
+    cfg = pkg.Config(model=model, batch=B, stages=3 | pkg._abi.STAGE_PID_DEBUG, publishPeriod=0.0035)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.03, 0.06))
+    assert eng.mapping == "lane-per-robot"
+    for j in range(6):
+        cmd = rng.uniform(-0.08, 0.08, (B, 8)).astype(np.float32)  # fast enough to trip the velocity truncation
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        for _ in range(3):
+            eng.update(7), ora.update(7)
+            compare(eng, ora, tol=dict(TOL, eff=5e-2), where=f"command {j}")
+            assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 5e-2
+    assert np.abs(eng.raw_state()[0] - ora.raw_state()[0]).max() < TOL["pose"]  # the undecimated state as well
+    gt, gf = eng.td_state()
+    ot, of = ora.td_state()
+    assert np.array_equal(gf, of)
