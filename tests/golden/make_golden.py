@@ -137,6 +137,39 @@ int main(void) {
 """
 
 
+SQUARE_C = r"""
+/* the arithmetic of squarevelocitytest.cpp:20-34 and squarepositiontest.cpp:21-35 for the shipped constants (10 Hz,
+   double accumulation of 1/rate, float32 Joy axis); the velocity gate uses fabs (the reference writes an unqualified
+   abs: see DESIGN.md, quirks) */
+#include <math.h>
+#include <stdio.h>
+int main(void) {
+  double time = 0.0;
+  for (int k = 0; k <= 220; ++k) {
+    double sv = sin(time * 0.05 * 2 * M_PI), sp = sin(time * 0.1 * 2 * M_PI);
+    float vel = (float)(fabs(sv) >= sqrt(0.5) ? copysign(0.06, sv) : 0.0);
+    float pos = (float)(0.0 + copysign(0.05, sp));
+    printf("%d %.9g %.9g\n", k, (double)vel, (double)pos);
+    time += 1.0 / 10.0;
+  }
+  return 0;
+}
+"""
+
+
+def square_sequences():
+    """The first 221 samples (22 s, more than one period of either) of both square publishers, from a C program (gcc, libm)."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "sq.c"), os.path.join(d, "sq")
+        open(src, "w").write(SQUARE_C)
+        subprocess.run(["gcc", "-O0", "-o", exe, src, "-lm"], check=True)
+        rows = [ln.split() for ln in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines()]
+    return {"velocity": [float(r[1]) for r in rows], "position": [float(r[2]) for r in rows]}
+
+
 def sine_spot_values():
     """Five-plus spot values of the config-1 command stream, from a C program (gcc, libm) that repeats the
     publisher's arithmetic; not from numpy and not from cdpr_simulation_amd.stimulus."""
@@ -154,6 +187,7 @@ def sine_spot_values():
 def pid_kat():
     return {
         "sine_velocity_spot_values": sine_spot_values(),
+        "square_publishers_first_221_samples": square_sequences(),
         "source": "SURVEY.md Appendix A (survey-time probe; stand-in headers; not reproducible here)",
         "velocity_pid_toy_plant": {
             "plant": "qdd = F - qd, semi-implicit Euler, dt = 1e-3; Pid::update called from k = 0 with now = k*dt",

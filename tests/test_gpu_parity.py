@@ -1097,3 +1097,32 @@ def test_role_split_kernel_with_optional_terms_and_publish_decimation(pkg, oracl
     gt, gf = eng.td_state()
     ot, of = ora.td_state()
     assert np.array_equal(gf, of)
+
+
+def test_hip_path_against_the_second_derivation_directly(pkg, mapping):
+    """Closing the triangle: the HIP engine against tests/second_derivation.py (numpy / scipy, written from the
+    reference text, shares no code with the oracle) without the oracle in between.  Config 1's robot under
+    sinevelocitytest for 1 s, then a position Joy; and an 8-cable robot with FK + TD off (the second derivation has
+    neither).  Centred-time fit in the restatement (= the exact derivative the GPU's FIR computes)."""
+    once(mapping)
+    import second_derivation as sd
+
+    for model, n in ((pkg.cube_model(), 4), (pkg.eight_cable_model(), 8)):
+        cfg = pkg.Config(model=model, batch=1)
+        eng = pkg.Engine(cfg, 0)
+        bot = sd.SecondRobot(cfg, centred=True)
+        gen = pkg.stimulus.sine_velocity(n)
+        for k in range(60):
+            cmd = next(gen) if k < 45 else np.full(n, 0.002 * (-1) ** k, dtype=np.float32)
+            if k < 45:
+                eng.set_velocity_command(cmd), bot.set_velocity_command(cmd)
+            elif k % 5 == 0:
+                eng.set_position_command(cmd), bot.set_position_command(cmd)
+            eng.update(10), bot.update(10)
+            gp, gt = eng.platform_state()
+            gq, gqd, ge = eng.joint_states()
+            quat_gap = min(np.abs(gp[0, 3:] - bot.obs["pose"][3:]).max(), np.abs(gp[0, 3:] + bot.obs["pose"][3:]).max())
+            assert np.abs(gp[0, :3] - bot.obs["pose"][:3]).max() < TOL["pose"] and quat_gap < TOL["pose"], k
+            assert np.abs(gt[0] - bot.obs["twist"]).max() < TOL["twist"] and np.abs(gq[0] - bot.obs["q"]).max() < TOL["q"], k
+            assert np.abs(gqd[0] - bot.obs["qd"]).max() < TOL["qd"] and np.abs(ge[0] - bot.obs["effort"]).max() < TOL["eff"], k
+        eng.close()

@@ -293,3 +293,15 @@ def test_sine_velocity_spot_values(pkg):
         assert got.dtype == np.float32 and got.shape == (4,) and np.all(got == got[0])
         assert got[0] == np.float32(v), (k, float(got[0]), v)  # bit-exact float32 (the fixture holds 9 significant digits)
     assert abs(kat["1"] - 0.000314157194) < 1e-12  # the value the survey's probe observed
+
+
+def test_square_publishers_against_c_generated_sequences(pkg):
+    """squarevelocitytest / squarepositiontest: the first 22 s of both command streams, bit-exact
+    float32, against a C program that repeats the publishers' arithmetic (tests/golden/make_golden.py)."""
+    kat = json.load(open(os.path.join(GOLD, "pid_kat.json")))["square_publishers_first_221_samples"]
+    gv, gp = pkg.stimulus.square_velocity(4), pkg.stimulus.square_position(4)
+    vel = [next(gv) for _ in range(221)]
+    pos = [next(gp) for _ in range(221)]
+    assert all(v.dtype == np.float32 and v[0] == np.float32(k) and np.all(v == v[0]) for v, k in zip(vel, kat["velocity"]))
+    assert all(p[0] == np.float32(k) and np.all(p == p[0]) for p, k in zip(pos, kat["position"]))
+    assert {float(np.float32(x)) for x in kat["velocity"]} == {0.0, float(np.float32(0.06)), float(np.float32(-0.06))}
