@@ -276,8 +276,8 @@ def main():
     eng.profile_begin()
     t0 = time.perf_counter()
     advance(args.warmup, args.steps)
-    ev_ms, launches = eng.profile_end()
-    edge()
+    ev_ms, launches = eng.profile_end()  # records the closing event and synchronises the engine's stream: this rank is done
+    ctx.fast_barrier()                   # ... and so is every other rank
     elapsed = time.perf_counter() - t0
     elapsed = ctx.max_over_ranks(elapsed)
 
@@ -303,7 +303,7 @@ def main():
             eng.bind_velocity_command_device(sched2[j], count)
             eng.update_record_device(refresh, spl, d_rec, image * refresh)  # every step's observables stay in HBM
         ms2, launches2 = eng.profile_end()
-        edge()
+        ctx.fast_barrier()
         el2 = ctx.max_over_ranks(time.perf_counter() - t0)
         eng.device_free(d_rec)
         for p_ in sched2:

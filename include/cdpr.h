@@ -267,8 +267,9 @@ int cdpr_device_upload(cdpr_handle_t h, void *dst, const void *src, size_t bytes
 int cdpr_device_download(cdpr_handle_t h, void *dst, const void *src, size_t bytes);
 
 /* Timing of the step kernel on the handle's own stream with HIP events:
- * begin records an event, end records another, synchronises, and returns the
- * elapsed milliseconds and the number of step-kernel launches in between. */
+ * begin records an event, end records another, synchronises THE STREAM (on return
+ * everything queued on the handle has completed, as after cdpr_synchronize), and
+ * returns the elapsed milliseconds and the number of step-kernel launches in between. */
 int cdpr_profile_begin(cdpr_handle_t h);
 int cdpr_profile_end(cdpr_handle_t h, float *elapsed_ms, uint64_t *kernel_launches);
 
