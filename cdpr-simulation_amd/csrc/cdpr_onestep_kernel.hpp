@@ -418,6 +418,11 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
 #else
 #define CDPR_SPLIT_STAMP(i) do { } while (0)
 #endif
+#if defined(CDPR_STAMPS) && defined(CDPR_STAMPS_ITER)  // stamps 4..6 = end of Newton iterations 1..3 instead of the controller's
+#define CDPR_CTL_STAMP(i) do { } while (0)
+#else
+#define CDPR_CTL_STAMP(i) CDPR_SPLIT_STAMP(i)
+#endif
 
 template <int N>
 __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
@@ -492,6 +497,14 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
           quat_apply_rotvec(fkqx, fkqy, fkqz, fkqw, g[3], g[4], g[5]);
           ++fk_it;
         }
+#ifdef CDPR_STAMPS_ITER
+        if (it < 3) {
+          asm volatile("" ::"v"(fkqw));
+          __builtin_amdgcn_sched_barrier(0);
+          if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 4 + it] = __builtin_amdgcn_s_memrealtime();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
       ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
       v2f rm = splat(0.f);
@@ -501,6 +514,11 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     }
     if (live) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
     CDPR_SPLIT_STAMP(1);
+    // the tension distribution's matrix and its factor need no forces: done while the controller wave may still be busy
+    v2f td_l[6][3];
+    float td_invd[6];
+    normal_matrix_pk<NP, false>(jest, 0.f, td_l);
+    chol_factor_pk(td_l, td_invd);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): nothing of this wave's LDS traffic is pending
     __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in x_force
     CDPR_SPLIT_STAMP(2);
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     {
       float g[6];
       jt_times<NP>(jest, df, g);
-      normal_solve<NP, false>(jest, 0.f, g);
+      chol_apply_pk(td_l, td_invd, g);
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         v2f t = splat(a.td_mid);
@@ -659,10 +677,10 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   for (int k = 0; k < NP; ++k) x_force[k][lane] = f[k];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the forces are in LDS (vector memory operations stay in flight)
-  CDPR_SPLIT_STAMP(4);
+  CDPR_CTL_STAMP(4);
   __builtin_amdgcn_s_barrier();        // #1
   __builtin_amdgcn_s_barrier();        // #2: the estimator wave has finished the tension distribution
-  CDPR_SPLIT_STAMP(5);
+  CDPR_CTL_STAMP(5);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   v2f applied[NP];
 #pragma unroll
@@ -724,7 +742,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     CDPR_STORE_STATE(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
     CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
   }
-  CDPR_SPLIT_STAMP(6);
+  CDPR_CTL_STAMP(6);
 }
 
 }  // namespace cdpr

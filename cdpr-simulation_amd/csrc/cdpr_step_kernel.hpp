@@ -128,7 +128,13 @@ __host__ __device__ constexpr int obs_slots(int n) { return 4 + 3 * joint_groups
 CDPR_DEV v2f splat(float s) { return (v2f){s, s}; }
 CDPR_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 CDPR_DEV v2f fma2(float a, v2f b, v2f c) { return __builtin_elementwise_fma(splat(a), b, c); }
-CDPR_DEV float hsum(v2f v) { return v.x + v.y; }
+// x + y of a pair as ONE v_add_f32 on the two halves.  Written as `v.x + v.y` the backend pairs neighbouring sums up into
+// v_pk_add_f32 and pays three v_mov_b32 per pair to line the halves up (12 instructions for six sums instead of 6).
+CDPR_DEV float hsum(v2f v) {
+  float r;
+  asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y));
+  return r;
+}
 CDPR_DEV v2f rsq2(v2f v) { return (v2f){__frsqrt_rn(v.x), __frsqrt_rn(v.y)}; }
 CDPR_DEV v2f min2(v2f a, v2f b) { return (v2f){fminf(a.x, b.x), fminf(a.y, b.y)}; }
 CDPR_DEV v2f max2(v2f a, v2f b) { return (v2f){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
@@ -311,8 +317,7 @@ CDPR_DEV void chol_solve(float (&m)[6][6], float (&g)[6]) {
 // of each other: a single wave per SIMD pays every dependent-issue stall in full, and the left-looking form is one
 // long chain per column.  Every entry still receives the same fmas in the same k order as chol_solve, so the
 // results are bit-identical to it.
-CDPR_DEV void chol_solve_pk(v2f (&mp)[6][3], float (&g)[6]) {
-  float invd[6];
+CDPR_DEV void chol_factor_pk(v2f (&mp)[6][3], float (&invd)[6]) {
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int p0 = j / 2;
@@ -326,6 +331,10 @@ CDPR_DEV void chol_solve_pk(v2f (&mp)[6][3], float (&g)[6]) {
       for (int p = c / 2; p < 3; ++p) mp[c][p] = fma2(-lcj, mp[j][p], mp[c][p]);
     }
   }
+}
+
+// L L^T x = g with the factor of chol_factor_pk (g -> x)
+CDPR_DEV void chol_apply_pk(const v2f (&mp)[6][3], const float (&invd)[6], float (&g)[6]) {
   // forward substitution, column oriented: y_j leaves as a scalar, the rows below take their update in pairs
   v2f gp[3] = {(v2f){g[0], g[1]}, (v2f){g[2], g[3]}, (v2f){g[4], g[5]}};
 #pragma unroll
@@ -344,14 +353,17 @@ CDPR_DEV void chol_solve_pk(v2f (&mp)[6][3], float (&g)[6]) {
   }
 }
 
-// Solve (J^T J + lambda I) x = g in place (g -> x); J held as cable pairs.  LAMBDA = false: no damping term (the
-// tension distribution), nothing is added to the diagonal.
+CDPR_DEV void chol_solve_pk(v2f (&mp)[6][3], float (&g)[6]) {
+  float invd[6];
+  chol_factor_pk(mp, invd);
+  chol_apply_pk(mp, invd, g);
+}
+
+// J^T J (+ lambda I) of a structure matrix held as cable pairs, as the row pairs chol_factor_pk takes
 template <int NP, bool LAMBDA = true>
-CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6]) {
+CDPR_DEV void normal_matrix_pk(const v2f (&jac)[NP][6], float lambda, v2f (&mp)[6][3]) {
   v2f acc[21];
   gram_partial<NP>(jac, acc);
-#if CDPR_CHOL_PACKED
-  v2f mp[6][3];
 #pragma unroll
   for (int a = 0, e = 0; a < 6; ++a) {
 #pragma unroll
@@ -367,8 +379,19 @@ CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6])
   mp[1][0].x = 0.f;
   mp[3][1].x = 0.f;
   mp[5][2].x = 0.f;
+}
+
+// Solve (J^T J + lambda I) x = g in place (g -> x); J held as cable pairs.  LAMBDA = false: no damping term (the
+// tension distribution), nothing is added to the diagonal.
+template <int NP, bool LAMBDA = true>
+CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6]) {
+#if CDPR_CHOL_PACKED
+  v2f mp[6][3];
+  normal_matrix_pk<NP, LAMBDA>(jac, lambda, mp);
   chol_solve_pk(mp, g);
 #else
+  v2f acc[21];
+  gram_partial<NP>(jac, acc);
   float m[6][6];
 #pragma unroll
   for (int a = 0, e = 0; a < 6; ++a) {

@@ -1,6 +1,6 @@
 """Diagnostic: where does one launch of the one-step kernel spend its time? (s_memrealtime stamps per wave)"""
 import os, sys, ctypes as C
-os.environ["CDPR_LIB"] = "libcdpr_hip_stamps.so"; os.environ["CDPR_MAPPING"] = os.environ.get("MAPSEL", "1")
+os.environ["CDPR_LIB"] = os.environ.get("STAMP_LIB", "libcdpr_hip_stamps.so"); os.environ["CDPR_MAPPING"] = os.environ.get("MAPSEL", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -8,7 +8,7 @@ import cdpr_simulation_amd as pkg, bench
 from cdpr_simulation_amd._native import lib
 L = lib(); L.cdpr_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
 for stages in (3, 0):
-    B, n = 65536, 8
+    B, n = int(os.environ.get("STAMP_B", "65536")), 8
     model, pose, command, n_cmd = bench.make_workload(pkg, B, n, 1235, 10)
     eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=stages), 0)
     eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
