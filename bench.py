@@ -425,7 +425,7 @@ def main():
                 # rewrites 6 controller rows per step where the contract's accounting assumes 24
                 "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
                 "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "limiter": "latency of one robot's serial chain at one wave per SIMD (DESIGN.md section 4), not HBM bandwidth",
+                "limiter": "instruction issue of the one wave that carries a robot's serial chain (5 cycles per vector instruction, DESIGN.md section 4), not HBM bandwidth",
             },
         }
         out.update(secondary)

@@ -136,6 +136,7 @@ class LocalSpinBarrier:
         import mmap
 
         self.rank, self.world, self.epoch = rank, world, 0
+        self.timeout_s = 300.0
         self.path = f"/dev/shm/cdpr_bench_barrier_{key}"
         if rank == 0:
             with open(self.path, "wb") as f:
@@ -153,8 +154,18 @@ class LocalSpinBarrier:
         self._slots[self.rank] = self.epoch
         e = self.epoch
         s = self._slots
+        spins = 0
+        t_start = 0.0
         while int(s.min()) < e:
-            pass
+            spins += 1
+            if (spins & 0xFFFF) == 0:  # a rank that died must not leave the others spinning for ever
+                import time
+
+                now = time.monotonic()
+                if t_start == 0.0:
+                    t_start = now
+                elif now - t_start > self.timeout_s:
+                    raise RuntimeError(f"LocalSpinBarrier: rank {self.rank} waited {self.timeout_s:.0f} s at epoch {e} (slots {s.tolist()})")
 
     def close(self) -> None:
         self._slots = None
