@@ -209,6 +209,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 
+    # stdout carries the ONE JSON line and nothing else: native libraries (gloo's "[Gloo] Rank 0 is connected ...", RCCL
+    # notices) write to file descriptor 1 behind Python's back, so descriptor 1 points at stderr from here on and the
+    # line goes out through a private copy of the original descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(json_fd, (line + "\n").encode())
+
     from cdpr_simulation_amd.sharding import RankContext
 
     # torch.distributed (RCCL) only provides the rendezvous: barrier + max over ranks. No data-path collective.
@@ -225,10 +235,10 @@ def main():
         ctx.fast_barrier()
         elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
-            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
-                              "config": {"workload": "dry run: rank plumbing only, no GPU work"}}), flush=True)
+            emit(json.dumps({"metric": METRIC, "value": 0.0, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
+                             "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+                             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                             "config": {"workload": "dry run: rank plumbing only, no GPU work"}}))
         ctx.close()
         return
 
@@ -431,7 +441,7 @@ def main():
         out.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     for p in sched:
         eng.device_free(p)
     eng.close()

@@ -66,9 +66,9 @@ def _run_bench(extra, timeout=300):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0 only
-    return json.loads(lines[0])
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout  # stdout is the ONE JSON line of rank 0 and nothing else
+    return json.loads(lines[0])                                     # (gloo / RCCL notices go to stderr)
 
 
 def test_bench_gpus_2_spawns_its_own_ranks():
