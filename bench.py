@@ -416,6 +416,7 @@ def main():
                 "steps_per_launch": args.steps_per_launch,
                 "mapping": eng.mapping,
                 "state_finite": finite,
+                "rendezvous": ctx.backend_name(),  # "none" (one rank), "nccl" (= RCCL) or "gloo": barrier + max only, no data-path collective
             },
             "roofline": {
                 "bound": "hbm",

@@ -138,16 +138,23 @@ class LocalSpinBarrier:
         self.rank, self.world, self.epoch = rank, world, 0
         self.timeout_s = 300.0
         self.path = f"/dev/shm/cdpr_bench_barrier_{key}"
+        self.ok = True  # every rank runs the same sequence of process-group calls whatever fails locally (no rank may
+        self._f = self._mm = self._slots = None  # drop out of a collective); the caller agrees on `ok` across ranks
         if rank == 0:
-            with open(self.path, "wb") as f:
-                f.write(b"\0" * 8 * world)
+            try:
+                with open(self.path, "wb") as f:
+                    f.write(b"\0" * 8 * world)
+            except OSError:
+                self.ok = False
         dist.barrier()
-        self._f = open(self.path, "r+b")
-        self._mm = mmap.mmap(self._f.fileno(), 8 * world)
-        import numpy as np
+        try:
+            self._f = open(self.path, "r+b")
+            self._mm = mmap.mmap(self._f.fileno(), 8 * world)
+            import numpy as np
 
-        self._slots = np.frombuffer(self._mm, dtype=np.uint64, count=world)
-        dist.barrier()
+            self._slots = np.frombuffer(self._mm, dtype=np.uint64, count=world)
+        except (OSError, ValueError):
+            self.ok = False
 
     def wait(self) -> None:
         self.epoch += 1
@@ -169,11 +176,13 @@ class LocalSpinBarrier:
 
     def close(self) -> None:
         self._slots = None
-        try:
-            self._mm.close()
-            self._f.close()
-        except Exception:
-            pass
+        for h in (self._mm, self._f):
+            try:
+                if h is not None:
+                    h.close()
+            except Exception:
+                pass
+        self._mm = self._f = None
         if self.rank == 0:
             try:
                 os.unlink(self.path)
@@ -194,8 +203,8 @@ class RankContext:
         rank = int(os.environ.get("RANK", "0"))
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        if world == 1:
-            return cls(rank, local_rank, world, None)
+        if world == 1 and os.environ.get("CDPR_FORCE_RENDEZVOUS") != "1":  # (the override: a one-rank process group,
+            return cls(rank, local_rank, world, None)                          # to exercise the RCCL calls on one GPU)
         import torch
         import torch.distributed as dist
 
@@ -209,11 +218,16 @@ class RankContext:
             dist.init_process_group(backend="gloo")
         ctx = cls(rank, local_rank, world, dist)
         if int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world:  # every rank on this node (bench.py's contract: one node)
-            try:
-                ctx._spin = LocalSpinBarrier(rank, world, f"{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}", dist)
-            except Exception:
-                ctx._spin = None
+            spin = LocalSpinBarrier(rank, world, f"{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}", dist)
+            # all ranks or none: a rank on its own in the spin barrier (or out of it) would hang the others
+            if ctx.min_over_ranks(1.0 if spin.ok else 0.0) > 0.5:
+                ctx._spin = spin
+            else:
+                spin.close()
         return ctx
+
+    def backend_name(self) -> str:
+        return "none" if self._dist is None else str(self._dist.get_backend())
 
     def barrier(self) -> None:
         if self._dist is not None:
@@ -240,6 +254,9 @@ class RankContext:
         t = torch.tensor([value], dtype=torch.float64, device=dev)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())
+
+    def min_over_ranks(self, value: float) -> float:
+        return -self.max_over_ranks(-value)
 
     def close(self) -> None:
         if self._dist is not None:

@@ -216,6 +216,30 @@ def test_bench_gpus_2_is_its_own_launcher_on_the_gpu():
     assert out["rollout"]["cost_finite"] is True and "config5: 2 x 512" in out["rollout"]["workload"]
 
 
+def test_bench_rccl_rendezvous_on_one_rank():
+    """The process-group calls bench.py makes under `torch.distributed.run` with one GPU per rank (backend "nccl" = RCCL:
+    init with a device id, barrier, max over ranks on a device tensor, the shared-memory barrier's set-up) — forced on for
+    a world of ONE rank, the only way to run them on a 1-GPU lease."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               CDPR_FORCE_RENDEZVOUS="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("CDPR_MAPPING", "CDPR_LOWREG", "CDPR_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "10", "--batch", "8192", "--no-cpu-baseline",
+                        "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 1e7 and out["config"]["state_finite"] is True
+    assert out["config"].get("rendezvous") == "nccl"
+
+
 def test_pid_call_counter_never_saturates(pkg, oracle, monkeypatch):
     """the host-side Pid call counter used to clamp at 2^20, which froze the derivative ring (the
     D term went silently wrong after ~17.5 min of sim time).  It is folded with its phase kept now: run past 2^20
