@@ -6,6 +6,8 @@
 //   PLG.cpp = src/CdprGazeboPlugin.cpp, JFC.cpp = src/JointForceCalculator.cpp, Pid.cpp = src/Pid.cpp
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -105,6 +107,8 @@ struct cdpr_engine {
   size_t unpack_cap = 0;
   std::string err;
 };
+
+static hipError_t wait_stream(cdpr_engine* h);  // poll, then block (defined next to cdpr_synchronize)
 
 namespace {
 
@@ -578,7 +582,7 @@ int upload_home(cdpr_engine* h) {
   }
   if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows() * h->tstride * sizeof(float), h->stream));
   if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -635,7 +639,7 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
   if (count == n * B) {
     HIP_TRY(h, hipMemcpyAsync(dst, src, n * B * sizeof(float), from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                               h->stream));
-    if (!from_device) HIP_TRY(h, hipStreamSynchronize(h->stream));  // caller may reuse its buffer on return
+    if (!from_device) HIP_TRY(h, wait_stream(h));  // caller may reuse its buffer on return
   } else {
     std::vector<float> one(n);
     if (from_device)
@@ -645,7 +649,7 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
     std::vector<float> all(n * B);
     for (size_t b = 0; b < B; ++b) memcpy(&all[b * n], one.data(), n * sizeof(float));
     HIP_TRY(h, hipMemcpyAsync(dst, all.data(), n * B * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, wait_stream(h));
   }
   return CDPR_OK;
 }
@@ -917,7 +921,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
 int fetch_slots(cdpr_engine* h, const float4* dsrc, int nslots, std::vector<float4>& host) {
   host.resize((size_t)nslots * h->stride);
   HIP_TRY(h, hipMemcpyAsync(host.data(), dsrc, host.size() * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -927,7 +931,7 @@ int fetch_fields(cdpr_engine* h, const float4* rows, const std::vector<std::pair
   if (!host_out) return CDPR_OK;
   const size_t count = (size_t)h->batch * fields.size();
   if (h->unpack_cap < count) {
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, wait_stream(h));
     if (h->d_unpack) (void)hipFree(h->d_unpack);
     h->d_unpack = nullptr;
     h->unpack_cap = 0;
@@ -948,7 +952,7 @@ int fetch_fields(cdpr_engine* h, const float4* rows, const std::vector<std::pair
   hipLaunchKernelGGL(cdpr_unpack_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, h->stream, u);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(host_out, h->d_unpack, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));  // the scratch is reused by the next call
+  HIP_TRY(h, wait_stream(h));  // the scratch is reused by the next call
   return CDPR_OK;
 }
 
@@ -1149,7 +1153,7 @@ void cdpr_destroy(cdpr_handle_t h) {
 int cdpr_reset(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   engine_reset_host(h);
   return upload_home(h);
 }
@@ -1177,7 +1181,7 @@ int cdpr_set_platform_state(cdpr_handle_t h, const float* pose7, const float* tw
     }
   }
   HIP_TRY(h, hipMemcpyAsync(h->d_state, s.data(), s.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -1208,7 +1212,7 @@ static int stage_masked(cdpr_engine* h, int which, const float* axes, size_t cou
       HIP_TRY(h, hipMemcpyAsync(mask.data(), h->d_mask[which], B, hipMemcpyDeviceToHost, h->stream));
     else
       std::fill(mask.begin(), mask.end(), (uint8_t)1);
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, wait_stream(h));
   }
   for (size_t b = 0; b < B; ++b) {
     if (!robot_mask[b]) continue;
@@ -1217,7 +1221,7 @@ static int stage_masked(cdpr_engine* h, int which, const float* axes, size_t cou
   }
   HIP_TRY(h, hipMemcpyAsync(pending, rows.data(), n * B * sizeof(float), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_mask[which], mask.data(), B, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   is_pending = true;
   masked = true;
   return CDPR_OK;
@@ -1369,10 +1373,31 @@ int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position,
   return CDPR_OK;
 }
 
+// Wait for the handle's stream with the host in the loop in mind (update -> synchronize -> read observables, every
+// step): poll hipStreamQuery for the first kSpinUs microseconds (the blocking wait's wake-up costs 15-25 us, which is two
+// step kernels; measured by scripts/short_run_probe.py), then hand over to the blocking hipStreamSynchronize so that long
+// waits do not burn a core.  CDPR_SYNC_SPIN_US overrides (0 = always block).
+static hipError_t wait_stream(cdpr_engine* h) {
+  static const long spin_us = [] {
+    const char* v = std::getenv("CDPR_SYNC_SPIN_US");
+    return v ? std::atol(v) : 2000L;
+  }();
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) return hipSuccess;
+      if (q != hipErrorNotReady) return q;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
+    }
+  }
+  return hipStreamSynchronize(h->stream);
+}
+
 int cdpr_synchronize(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -1415,7 +1440,7 @@ int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   HIP_TRY(h, hipMemcpyAsync(axes9, h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float), hipMemcpyDeviceToHost,
                             h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -1516,7 +1541,7 @@ int cdpr_rollout_velocity_launch(cdpr_handle_t h, int samples, int horizon, cons
   const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
   if (!h->d_roll_ref) HIP_TRY(h, hipMalloc(&h->d_roll_ref, (size_t)h->batch * 3 * sizeof(float)));
   if (h->roll_cost_cap < traj) {  // grow-only; the stream may still be reading the old buffer
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, wait_stream(h));
     if (h->d_roll_cost) (void)hipFree(h->d_roll_cost);
     h->d_roll_cost = nullptr;
     h->roll_cost_cap = 0;
@@ -1538,7 +1563,7 @@ int cdpr_rollout_velocity_fetch(cdpr_handle_t h, float* cost) {
   }
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   HIP_TRY(h, hipMemcpyAsync(cost, h->d_roll_cost, (size_t)h->roll_pending * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   h->roll_pending = 0;
   return CDPR_OK;
 }
@@ -1582,7 +1607,7 @@ int cdpr_device_upload(cdpr_handle_t h, void* dst, const void* src, size_t bytes
   if (!h || !dst || !src) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -1590,7 +1615,7 @@ int cdpr_device_download(cdpr_handle_t h, void* dst, const void* src, size_t byt
   if (!h || !dst || !src) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -1608,7 +1633,7 @@ int cdpr_profile_end(cdpr_handle_t h, float* elapsed_ms, uint64_t* kernel_launch
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
   // ONE wait for everything queued on the stream, the closing event included.  (hipEventSynchronize followed by the
   // caller's hipStreamSynchronize costs two wake-ups: measured 28 us on a 20-launch timed region, scripts/short_run_probe.py.)
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   float ms = 0.f;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   if (elapsed_ms) *elapsed_ms = ms;
@@ -1665,7 +1690,7 @@ int cdpr_solve_ik(cdpr_handle_t h, const float* pose7, const float* twist6, floa
   DOWN(q, dq, B * n, float);
   DOWN(qdot, dqd, B * n, float);
   DOWN(jac, dj, B * n * 6, float);
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -1700,7 +1725,7 @@ int cdpr_solve_fk(cdpr_handle_t h, const float* lengths, const float* seed7, flo
   DOWN(pose7, dp, B * 7, float);
   DOWN(residual, dr, B, float);
   DOWN(iterations, di, B, int32_t);
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 
@@ -1736,7 +1761,7 @@ int cdpr_solve_td(cdpr_handle_t h, const float* pose7, const float* wrench6, flo
   HIP_TRY(h, hipGetLastError());
   DOWN(tension, dt, B * n, float);
   DOWN(infeasible, df, B, int32_t);
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
 #undef UP

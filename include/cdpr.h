@@ -211,6 +211,9 @@ int cdpr_observable_image_bytes(cdpr_handle_t h, size_t *bytes);
 int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void *d_record, size_t record_bytes);
 int cdpr_decode_observables(cdpr_handle_t h, const void *image, float *position, float *velocity, float *effort,
                             float *pose7, float *twist6);
+/* Waits until everything queued on the handle has completed.  Every wait of the library polls the stream for up to 2 ms
+ * before it blocks (a blocked host thread wakes up 15-25 us late, two step kernels; environment CDPR_SYNC_SPIN_US
+ * overrides, 0 = always block). */
 int cdpr_synchronize(cdpr_handle_t h);
 uint32_t cdpr_mapping(cdpr_handle_t h);              /* CDPR_MAP_* actually in use (what CDPR_MAP_AUTO resolved to) */
 uint64_t cdpr_step_count(cdpr_handle_t h);           /* world steps since create/reset; sim time = count * dt */
