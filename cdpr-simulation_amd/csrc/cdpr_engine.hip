@@ -6,6 +6,7 @@
 //   PLG.cpp = src/CdprGazeboPlugin.cpp, JFC.cpp = src/JointForceCalculator.cpp, Pid.cpp = src/Pid.cpp
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 
 #include <algorithm>
@@ -98,6 +99,11 @@ struct cdpr_engine {
   float wtab_host[2][kWin * (kWin + 2)]{};  // the same tables on the host: one-step launches take their row by value
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t launches = 0, launches_mark = 0;
+  // cdpr_get_observables: pinned, device-mapped host image of one published step + completion word
+  float* h_pub = nullptr;        // host pointer (hipHostMalloc)
+  uint64_t* h_pub_done = nullptr;
+  uint32_t* d_pub_arrivals = nullptr;
+  uint64_t pub_epoch = 0;
   // MPC rollout scratch, persistent and grow-only (no hipMalloc / hipFree inside a rollout)
   float* d_roll_ref = nullptr;   // float[B][3]
   float* d_roll_cost = nullptr;  // float[B][samples]
@@ -601,6 +607,9 @@ void free_all(cdpr_engine* h) {
   for (int i = 0; i < 2; ++i)
     if (h->d_mask[i]) (void)hipFree(h->d_mask[i]);
   if (h->d_unpack) (void)hipFree(h->d_unpack);
+  if (h->h_pub) (void)hipHostFree(h->h_pub);
+  if (h->h_pub_done) (void)hipHostFree(h->h_pub_done);
+  if (h->d_pub_arrivals) (void)hipFree(h->d_pub_arrivals);
   if (h->d_roll_ref) (void)hipFree(h->d_roll_ref);
   if (h->d_roll_cost) (void)hipFree(h->d_roll_cost);
   for (int i = 0; i < 2; ++i) {
@@ -1416,6 +1425,98 @@ int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, flo
     int rc = fetch_fields(h, h->d_obs, fields, dst[f]);
     if (rc != CDPR_OK) return rc;
   }
+  return CDPR_OK;
+}
+
+// JointState + PlatformState of the last published step in ONE device round trip (PLG.cpp:248-280 publishes both every
+// step): the gather kernel writes the five arrays into a pinned host image and then a completion word the host spins
+// on.  (cdpr_get_joint_states + cdpr_get_platform_state are five gathers, five copies and five waits.)
+int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, float* effort, float* pose7, float* twist6) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  const uint32_t n = h->n, width = 3u * n + 13u;
+  const size_t count = (size_t)h->batch * width;
+  if (!h->h_pub) {
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_pub, count * sizeof(float), hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_pub_done, sizeof(uint64_t), hipHostMallocMapped));
+    *h->h_pub_done = 0;
+    HIP_TRY(h, hipMalloc(&h->d_pub_arrivals, sizeof(uint32_t)));
+    HIP_TRY(h, hipMemsetAsync(h->d_pub_arrivals, 0, sizeof(uint32_t), h->stream));
+  }
+  // small images go straight to host memory from the gather kernel (a per-step caller of a few robots: ~5 us); large
+  // ones through device scratch and the copy engine (kernel stores over PCIe reach ~7 GB/s, the copy engine ~30)
+  const bool direct = count * sizeof(float) <= (256u << 10);
+  if (!direct && h->unpack_cap < count) {
+    HIP_TRY(h, wait_stream(h));
+    if (h->d_unpack) (void)hipFree(h->d_unpack);
+    h->d_unpack = nullptr;
+    h->unpack_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_unpack, count * sizeof(float)));
+    h->unpack_cap = count;
+  }
+  PublishArgs u{};
+  u.rows = h->d_obs;
+  if (direct) {
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&u.out, h->h_pub, 0));
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&u.done, h->h_pub_done, 0));
+  } else {
+    u.out = h->d_unpack;
+    u.done = nullptr;
+  }
+  u.arrivals = h->d_pub_arrivals;
+  u.epoch = ++h->pub_epoch;
+  u.stride = h->stride;
+  u.batch = h->batch;
+  u.n = n;
+  u.width = width;
+  const int G = joint_groups((int)n);
+  uint32_t j = 0;
+  for (int f = 0; f < 3; ++f)
+    for (uint32_t i = 0; i < n; ++i, ++j) {
+      u.slot[j] = (uint8_t)(4 + f * G + (int)(i / 4));
+      u.comp[j] = (uint8_t)(i % 4);
+    }
+  for (const auto& pc : kPoseFields) u.slot[j] = (uint8_t)pc.first, u.comp[j] = (uint8_t)pc.second, ++j;
+  for (const auto& pc : kTwistFields) u.slot[j] = (uint8_t)pc.first, u.comp[j] = (uint8_t)pc.second, ++j;
+  hipLaunchKernelGGL(cdpr_publish_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, h->stream, u);
+  HIP_TRY(h, hipGetLastError());
+  if (direct) {
+    // wait on the completion word: plain host memory, no runtime call; past the spin budget fall back to the stream wait
+    // (which also surfaces a device fault instead of spinning on a word that will never come)
+    volatile uint64_t* done = h->h_pub_done;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (*done != u.epoch) {
+      if ((++spins & 0x3FFu) == 0 && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() >= 20) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (*done != u.epoch) {
+          h->err = "cdpr_get_observables: the publish kernel finished without its completion word";
+          return CDPR_ERR_DEVICE;
+        }
+        break;
+      }
+    }
+  } else if (count * sizeof(float) <= (2u << 20)) {  // one copy into the pinned image, split up on the host below
+    HIP_TRY(h, hipMemcpyAsync(h->h_pub, h->d_unpack, count * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, wait_stream(h));
+  } else {  // straight into the caller's arrays (reading a large pinned image back on the host costs more than the DMA)
+    const size_t bnl = (size_t)h->batch * n;
+    float* dst[5] = {position, velocity, effort, pose7, twist6};
+    const size_t off[5] = {0, bnl, 2 * bnl, 3 * bnl, 3 * bnl + (size_t)h->batch * 7};
+    const size_t len[5] = {bnl, bnl, bnl, (size_t)h->batch * 7, (size_t)h->batch * 6};
+    for (int k = 0; k < 5; ++k)
+      if (dst[k]) HIP_TRY(h, hipMemcpyAsync(dst[k], h->d_unpack + off[k], len[k] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, wait_stream(h));
+    return CDPR_OK;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const size_t bn = (size_t)h->batch * n;
+  const float* src = h->h_pub;
+  if (position) std::memcpy(position, src, bn * sizeof(float));
+  if (velocity) std::memcpy(velocity, src + bn, bn * sizeof(float));
+  if (effort) std::memcpy(effort, src + 2 * bn, bn * sizeof(float));
+  if (pose7) std::memcpy(pose7, src + 3 * bn, (size_t)h->batch * 7 * sizeof(float));
+  if (twist6) std::memcpy(twist6, src + 3 * bn + (size_t)h->batch * 7, (size_t)h->batch * 6 * sizeof(float));
   return CDPR_OK;
 }
 

@@ -159,4 +159,53 @@ __global__ __launch_bounds__(256) void cdpr_unpack_kernel(const UnpackArgs a) {
   a.out[t] = ((a.as_int >> j) & 1u) ? __int_as_float((int)v) : v;
 }
 
+// One published step of every robot straight into the caller-visible (pinned, device-mapped) host buffer: five
+// robot-major blocks [position | velocity | effort | pose7 | twist6] gathered from the observable rows by one launch,
+// then a completion word written by the last workgroup after a system-scope fence.  The host spins on that word: no
+// copy engine, no runtime call in the wait (cdpr_get_observables).
+struct PublishArgs {
+  const float4* rows;
+  float* out;               // host-mapped
+  uint64_t* done;           // host-mapped completion word
+  uint32_t* arrivals;       // device counter, zero between launches
+  uint64_t epoch;
+  uint32_t stride, batch, n, width;  // width = 3 n + 13
+  uint8_t slot[40], comp[40];
+};
+
+__global__ __launch_bounds__(256) void cdpr_publish_kernel(const PublishArgs a) {
+  // one thread per OUTPUT element, so that a wave writes 256 contiguous bytes (the destination may be host memory behind
+  // PCIe); the output is five robot-major blocks: three joint blocks of n columns, then 7 pose and 6 twist columns
+  const uint32_t o = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t bn = a.batch * a.n, n3 = 3u * a.n;
+  if (o < a.batch * a.width) {
+    uint32_t r, j;
+    if (o < 3u * bn) {
+      const uint32_t f = o / bn, rem = o - f * bn;
+      r = rem / a.n;
+      j = f * a.n + (rem - r * a.n);
+    } else if (o < 3u * bn + 7u * a.batch) {
+      const uint32_t rem = o - 3u * bn;
+      r = rem / 7u;
+      j = n3 + (rem - r * 7u);
+    } else {
+      const uint32_t rem = o - 3u * bn - 7u * a.batch;
+      r = rem / 6u;
+      j = n3 + 7u + (rem - r * 6u);
+    }
+    a.out[o] = comp4(a.rows[(size_t)a.slot[j] * a.stride + r], a.comp[j]);
+  }
+  if (!a.done) return;  // staged read-out: the copy engine and the stream wait finish the job
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t prev = atomicAdd(a.arrivals, 1u);
+    if (prev == gridDim.x - 1u) {
+      *a.arrivals = 0u;
+      __threadfence_system();
+      __hip_atomic_store(a.done, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 }  // namespace cdpr

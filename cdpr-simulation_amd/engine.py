@@ -172,6 +172,14 @@ class Engine:
         self._check(lib().cdpr_get_platform_state(self._h, _fp(p), _fp(t)))
         return p, t
 
+    def observables(self):
+        """JointState + PlatformState arrays of the last published step in one device round trip (cdpr_get_observables):
+        position, velocity, effort [B, n], pose [B, 7], twist [B, 6]."""
+        q, qd, e = (np.empty((self.B, self.n), dtype=np.float32) for _ in range(3))
+        p, t = np.empty((self.B, 7), dtype=np.float32), np.empty((self.B, 6), dtype=np.float32)
+        self._check(lib().cdpr_get_observables(self._h, _fp(q), _fp(qd), _fp(e), _fp(p), _fp(t)))
+        return q, qd, e, p, t
+
     def raw_state(self) -> Tuple[np.ndarray, np.ndarray]:
         p, t = np.empty((self.B, 7), dtype=np.float32), np.empty((self.B, 6), dtype=np.float32)
         self._check(lib().cdpr_get_raw_state(self._h, _fp(p), _fp(t)))

@@ -194,8 +194,7 @@ class CdprGazeboPlugin:
                 self._pub_pid(Joy(axes=eng.pid_debug(), header=Header(stamp=t)))
             if (t - self.mPreviousProcessingTime) > self.mPublishPeriod:
                 self.mPreviousProcessingTime = t
-                self.publishJointStates(t)
-                self.publishPlatformState(t)
+                self._publish(t, *eng.observables())  # publishJointStates + publishPlatformState, one device round trip
 
     def _publish(self, t, q, qd, eff, pose, twist) -> None:
         self._pub_joint(JointState(name=list(self.mJointNames), position=q, velocity=qd, effort=eff, header=Header(stamp=t)))

@@ -115,6 +115,9 @@ class ShardedEngine:
     def platform_state(self):
         return self._gather("platform_state")
 
+    def observables(self):
+        return self._gather("observables")
+
     def raw_state(self):
         return self._gather("raw_state")
 

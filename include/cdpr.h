@@ -226,6 +226,11 @@ int cdpr_get_joint_states(cdpr_handle_t h, float *position, float *velocity, flo
  * pose7[B][7] (x y z qx qy qz qw) and twist6[B][6] (linear, angular), relative
  * to the frame link. */
 int cdpr_get_platform_state(cdpr_handle_t h, float *pose7, float *twist6);
+/* Both messages of one published step in one device round trip: the five arrays of cdpr_get_joint_states and
+ * cdpr_get_platform_state (any of them may be NULL), as of the last published step.  What a per-step caller uses
+ * (PLG.cpp:236-242 publishes jointStates and platformPose on every step): one gather launch into a pinned host image and
+ * a completion word the host spins on, instead of five gather / copy / wait rounds. */
+int cdpr_get_observables(cdpr_handle_t h, float *position, float *velocity, float *effort, float *pose7, float *twist6);
 /* Replaces the `pid` debug topic (PLG.cpp:193-194,223-227,233-235;
  * Pid.cpp:139-142,158-168): axes9[B][9] = P term, I term before clamp, D term,
  * desired, applied force of cable 0, then four unused zeros.  Needs

@@ -1126,3 +1126,32 @@ def test_hip_path_against_the_second_derivation_directly(pkg, mapping):
             assert np.abs(gt[0] - bot.obs["twist"]).max() < TOL["twist"] and np.abs(gq[0] - bot.obs["q"]).max() < TOL["q"], k
             assert np.abs(gqd[0] - bot.obs["qd"]).max() < TOL["qd"] and np.abs(ge[0] - bot.obs["effort"]).max() < TOL["eff"], k
         eng.close()
+
+
+def test_observables_in_one_round_trip_equal_the_separate_getters(pkg, monkeypatch):
+    """cdpr_get_observables (one gather launch into a pinned host image + completion word) returns exactly what
+    cdpr_get_joint_states and cdpr_get_platform_state return, for ragged batches, both cable counts, under publish
+    decimation (as of the last PUBLISHED step), call after call (the completion word's epoch) and with NULL outputs."""
+    import ctypes as C
+
+    from cdpr_simulation_amd._native import lib
+
+    for n, batch, stages, period in ((4, 1, 0, 0.0), (8, 333, 3, 0.0), (8, 4097, 3, 0.0025), (4, 70000, 0, 0.0)):
+        model = pkg.cube_model() if n == 4 else pkg.eight_cable_model()
+        cfg = pkg.Config(model=model, batch=batch, stages=stages)
+        cfg.publishPeriod = period
+        eng = pkg.Engine(cfg, 0)
+        rng = np.random.default_rng(n * 1000 + batch)
+        eng.set_velocity_command(rng.uniform(-0.03, 0.03, size=(batch, n)).astype(np.float32))
+        for rounds in range(4):
+            eng.update(3 + rounds)
+            q, qd, e = eng.joint_states()
+            p, t = eng.platform_state()
+            q2, qd2, e2, p2, t2 = eng.observables()
+            for a, b in ((q, q2), (qd, qd2), (e, e2), (p, p2), (t, t2)):
+                assert a.shape == b.shape and np.array_equal(a, b)
+        only = np.empty((batch, 7), dtype=np.float32)
+        null = C.POINTER(C.c_float)()
+        assert lib().cdpr_get_observables(eng._h, null, null, null, only.ctypes.data_as(C.POINTER(C.c_float)), null) == 0
+        assert np.array_equal(only, p)
+        eng.close()
