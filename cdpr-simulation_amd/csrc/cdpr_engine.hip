@@ -1436,8 +1436,9 @@ int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, floa
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   const uint32_t n = h->n, width = 3u * n + 13u;
   const size_t count = (size_t)h->batch * width;
-  if (!h->h_pub) {
-    HIP_TRY(h, hipHostMalloc((void**)&h->h_pub, count * sizeof(float), hipHostMallocMapped));
+  if (!h->h_pub_done) {
+    if (count * sizeof(float) <= (2u << 20))  // the pinned image serves the two small tiers only
+      HIP_TRY(h, hipHostMalloc((void**)&h->h_pub, count * sizeof(float), hipHostMallocMapped));
     HIP_TRY(h, hipHostMalloc((void**)&h->h_pub_done, sizeof(uint64_t), hipHostMallocMapped));
     *h->h_pub_done = 0;
     HIP_TRY(h, hipMalloc(&h->d_pub_arrivals, sizeof(uint32_t)));
