@@ -70,6 +70,37 @@ def test_two_rank_sharding_matches_unsharded(tmp_path, pkg, oracle):
     assert not os.path.exists(path0)  # and its /dev/shm file is removed at close
 
 
+FALLBACK_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+from cdpr_simulation_amd.sharding import RankContext
+
+ctx = RankContext.from_env(backend="gloo")
+t0 = time.perf_counter()
+if ctx.rank == 1:
+    time.sleep(0.3)
+ctx.fast_barrier()
+open(os.path.join({out!r}, f"fb{{ctx.rank}}.txt"), "w").write(repr((time.perf_counter() - t0, ctx._spin is not None)))
+ctx.close()
+"""
+
+
+def test_spin_barrier_is_taken_by_all_ranks_or_none(tmp_path):
+    """If the shared-memory barrier cannot be set up on ONE rank, every rank must fall back to the process group's barrier
+    (a rank alone in either barrier would hang the job): rank 1's set-up is made to fail, both ranks still rendezvous."""
+    script = tmp_path / "worker.py"
+    script.write_text(FALLBACK_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", CDPR_TEST_SPIN_FAIL_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    w0, spin0 = eval((tmp_path / "fb0.txt").read_text())
+    w1, spin1 = eval((tmp_path / "fb1.txt").read_text())
+    assert not spin0 and not spin1 and w0 >= 0.29  # nobody spins, and the fallback barrier still holds rank 0 back
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("cdpr_bench_barrier_") and f.endswith("_29519")]
+
+
 def test_shard_range_covers_everything(pkg):
     from cdpr_simulation_amd.sharding import shard_range
 
