@@ -396,10 +396,10 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
 //                             observables -> per-cable PID -> forces out -> [tensions from the estimator wave] SetForce
 //                             limits -> remaining observables -> world step -> state
 //
-// Why: one wave issues a vector instruction every 5 cycles at best (8.3 when it needs its predecessor's result), and a
-// second wave on the SIMD issues at the same rate beside it (scripts/micro/valu_issue.hip): the scarce thing is the
-// issue rate of the wave that carries a robot's serial chain, so everything that is not on that chain belongs on
-// another wave.  The lane-pair mapping gets its second wave by giving every robot two lanes, which
+// Why: one wave issues a vector instruction every 5 cycles at best (8.3 when it needs its predecessor's result), while
+// the SIMD takes a plain instruction every 2.5 cycles and a packed one every 4.2 (scripts/micro/valu_issue.hip): the
+// scarce thing is the issue rate of the wave that carries a robot's serial chain, so everything that is not on that
+// chain belongs on another (younger, lower-priority) wave that uses the slots the first leaves.  The lane-pair mapping gets its second wave by giving every robot two lanes, which
 // duplicates the serial 6x6 solves (+46 % instructions: measured slower from 65 536 robots on).  Splitting by ROLE
 // duplicates only the platform-row loads and one length evaluation (~3 %), and it takes the PID, the observable stores
 // and all controller-row traffic off the Newton stage's critical path.  The hand-offs are 8 forces one way and 8

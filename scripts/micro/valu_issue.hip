@@ -8,7 +8,7 @@
 #include <cstdint>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-constexpr int kIters = 64;
+constexpr int kIters = 512;
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
 
@@ -75,6 +75,29 @@ int main() {
     run<8>("v_pk_fma_f32 chain + v_fma_f32 chain interleaved", 128, d, threads);
     run<9>("v_rsq_f32 chain + 2 v_pk_fma_f32 (one dependent chain)", 192, d, threads);
     run<10>("v_add_f32 (halves) -> v_pk_fma_f32, dependent", 128, d, threads);
+  }
+  // whole-launch wall time of single-wave workgroups (events): 1 024 = one wave per SIMD, 2 048 = two, 4 096 = four
+  {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    printf("whole launch, single-wave workgroups, %d x 64 instructions per wave (hipEvent ms):\n", kIters);
+    for (int kind = 0; kind < 3; ++kind)
+      for (int blocks : {256, 1024, 2048, 4096}) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 5; ++rep) {
+          hipEventRecord(e0);
+          if (kind == 0) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(64), 0, 0, d, 1.5f);
+          if (kind == 1) hipLaunchKernelGGL(probe<3>, dim3(blocks), dim3(64), 0, 0, d, 1.5f);
+          if (kind == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(64), 0, 0, d, 1.5f);
+          hipEventRecord(e1);
+          hipEventSynchronize(e1);
+          float ms;
+          hipEventElapsedTime(&ms, e0, e1);
+          best = ms < best ? ms : best;
+        }
+        printf("  %-34s %5d workgroups: %7.2f us\n", kind == 0 ? "v_fma_f32, 8 independent chains" : kind == 1 ? "v_pk_fma_f32, 8 independent chains" : "v_pk_fma_f32, dependent chain", blocks, best * 1e3f);
+      }
   }
   return 0;
 }
