@@ -608,17 +608,19 @@ def test_sharded_engine_equals_single_engine(pkg, mapping):
 # ---------------------------------------------------------------------------------------------
 # randomised configurations: every constant the step depends on, not only the shipped ones
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_randomised_model_and_controller_parameters(pkg, oracle, seed):
     """Random mass / full inertia tensor / gravity direction / damping / effort limit / dt / gains / window length
-    (fast path: N <= 11) / FK iteration count and tolerance / tension bounds, on 4-, 6- and 8-cable robots."""
+    (fast path: N <= 11) / FK iteration count and tolerance / tension bounds, on 4-, 6- and 8-cable robots (seeds 0-5,
+    90 robots) and on 5-, 7- and 8-cable robots in a ragged batch of 257 (seeds 6-11: odd cable counts pad a pair)."""
     rng = np.random.default_rng(100 + seed)
     base = pkg.eight_cable_model()
-    n = [4, 6, 8][seed % 3]
+    n = [4, 6, 8][seed % 3] if seed < 6 else [7, 5, 8][seed % 3]
+    B = 90 if seed < 6 else 257
     if n == 4:
         model = pkg.cube_model()
     else:
-        keep = list(range(8)) if n == 8 else [0, 1, 2, 3, 4, 6]
+        keep = {8: list(range(8)), 7: [0, 1, 2, 3, 4, 5, 6], 6: [0, 1, 2, 3, 4, 6], 5: [0, 1, 2, 4, 6]}[n]
         model = pkg.Model(base.frame_anchors[keep] + rng.uniform(-0.01, 0.01, (n, 3)), base.platform_anchors[keep] * rng.uniform(0.8, 1.3))
     a = rng.uniform(0.5, 2.0, 3)
     off = rng.uniform(-0.1, 0.1, 3)
@@ -626,8 +628,9 @@ def test_randomised_model_and_controller_parameters(pkg, oracle, seed):
     model.inertia = (a[0], a[1], a[2], off[0], off[1], off[2])  # full symmetric tensor -> gyroscopic term active
     model.joint_damping = float(rng.uniform(0.0, 3.0))
     model.effort_limit = float(rng.choice([50.0, 100.0, -1.0]))  # -1: SetForce clamp disabled
-    stages = 0 if n == 4 else int(rng.integers(0, 4))
-    cfg = pkg.Config(model=model, batch=90, stages=stages, dt=float(rng.choice([5e-4, 1e-3, 2e-3])),
+    stages = 0 if n < 6 else int(rng.integers(0, 4))  # the FK / TD stages need six cables
+    dt = float(rng.choice([5e-4, 1e-3, 2e-3]))
+    cfg = pkg.Config(model=model, batch=B, stages=stages, dt=dt,
                      gravity=tuple(rng.normal(0, 1, 3) * [1.0, 1.0, 0.2] + [0, 0, -9.8]),
                      fkMaxIterations=int(rng.integers(1, 7)), fkTolerance=float(rng.choice([0.0, 1e-6])),
                      tdFMin=float(rng.uniform(1.0, 8.0)), tdFMax=float(rng.uniform(60.0, 150.0)))
@@ -637,12 +640,22 @@ def test_randomised_model_and_controller_parameters(pkg, oracle, seed):
         p.dDegree = int(rng.integers(1, min(3, p.dBufferLength - 1) + 1))
         p.iLimit, p.cmdLimit = float(rng.uniform(5, 100)), float(rng.uniform(40, 120))
     cfg.velocityController.forwardGain = float(rng.uniform(0, 20))
-    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, 90, rng, 0.03, 0.08), rng.uniform(-0.02, 0.02, (90, 6)))
+    if seed >= 6:
+        # the second set is about odd cable counts and ragged batches, so its loops must be STABLE: with the free gain draw above
+        # seeds 9 and 11 are not (velocity P = 110 / 208: the efforts flip sign every step with growing amplitude until they sit
+        # on the command limit, -13 -> +17 -> -15 -> ... -> +-84 N, and any fp32 rounding difference grows with them: measured,
+        # 0.2 % of the swing in 2 of 257 robots).  Shipped gains x (0.6 .. 1.1), windows and limits stay random.
+        g = np.random.default_rng(1000 + seed)
+        shipped = pkg.Config()
+        for p, q in ((cfg.velocityController, shipped.velocityController), (cfg.positionController, shipped.positionController)):
+            p.pGain, p.iGain, p.dGain = (float(v * g.uniform(0.6, 1.1)) for v in (q.pGain, q.iGain, q.dGain))
+        cfg.velocityController.forwardGain = float(shipped.velocityController.forwardGain * g.uniform(0.6, 1.1))
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.03, 0.08), rng.uniform(-0.02, 0.02, (B, 6)))
     script = [("run", 17)]
     for j in range(6):
         kind = "vel" if j != 3 else "pos"
         amp = 0.04 if kind == "vel" else 0.004
-        script += [(kind, rng.uniform(-amp, amp, (90, n)).astype(np.float32)), ("run", 9 + j)]
+        script += [(kind, rng.uniform(-amp, amp, (B, n)).astype(np.float32)), ("run", 9 + j)]
     run_script(eng, ora, script, tol=dict(TOL, eff=5e-2, twist=5e-4, qd=5e-4), label=f"seed{seed} n={n} stages={stages}")
 
 
