@@ -1168,3 +1168,51 @@ def test_observables_in_one_round_trip_equal_the_separate_getters(pkg, monkeypat
         assert lib().cdpr_get_observables(eng._h, null, null, null, only.ctypes.data_as(C.POINTER(C.c_float)), null) == 0
         assert np.array_equal(only, p)
         eng.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_call_sequences_stay_on_the_oracle(pkg, oracle, mapping, seed):
+    """The host-side state machine under random call sequences: commands in either mode at random moments, updates of 1..37
+    steps issued one launch per step, fused 2 / 5 / 10 / 20 steps per launch, or as a trajectory record, world resets, state
+    writes, reads in between (hipGraph replays, ring position, Pid call counter, mode switches, first-step rules all have to
+    survive the mix) — compared with the oracle after every update."""
+    rng = np.random.default_rng(500 + seed)
+    n = [8, 4, 6, 8][seed]
+    model = pkg.cube_model() if n == 4 else pkg.eight_cable_model()
+    if n == 6:
+        model = pkg.Model(model.frame_anchors[[0, 1, 2, 3, 4, 6]], model.platform_anchors[[0, 1, 2, 3, 4, 6]])
+    B = [130, 70, 100, 1][seed]
+    stages = {4: 0, 6: 1, 8: 3}[n]  # six cables: FK only (a tension distribution without redundancy is J^-T itself, cond^2 in fp32)
+    cfg = pkg.Config(model=model, batch=B, stages=stages)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05))
+    total = 0
+    for op in range(60):
+        kind = rng.choice(["vel", "vel", "pos", "run", "run", "run", "fused", "record", "reset", "state"], p=[0.15, 0.1, 0.08, 0.2, 0.12, 0.1, 0.12, 0.06, 0.03, 0.04])
+        where = f"seed {seed} op {op} ({kind}) after {total} steps"
+        if kind == "vel":
+            c = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+            eng.set_velocity_command(c), ora.set_velocity_command(c)
+        elif kind == "pos":
+            c = rng.uniform(-0.004, 0.004, (B, n)).astype(np.float32)
+            eng.set_position_command(c), ora.set_position_command(c)
+        elif kind == "reset":
+            eng.reset(), ora.reset()
+            total = 0
+        elif kind == "state":
+            p = perturbed_poses(model, B, rng, 0.02, 0.05).astype(np.float32)
+            eng.set_platform_state(pose7=p), ora.set_platform_state(pose7=p.astype(np.float64))
+        else:
+            k = int(rng.integers(1, 38))
+            if kind == "run":
+                eng.update(k)
+            elif kind == "fused":
+                eng.update(k, int(rng.choice([2, 5, 10, 20])))
+            else:
+                rec = eng.update_record(k, int(rng.choice([1, 4, 10])))
+                assert rec["pose"].shape == (k, B, 7)
+            ora.update(k)
+            total += k
+            compare(eng, ora, where=where)
+            if kind == "record" and total > k:  # the record's last image is the state the getters report
+                assert np.array_equal(rec["pose"][-1], eng.platform_state()[0]), where
+    eng.close()
