@@ -1216,3 +1216,36 @@ def test_random_call_sequences_stay_on_the_oracle(pkg, oracle, mapping, seed):
             if kind == "record" and total > k:  # the record's last image is the state the getters report
                 assert np.array_equal(rec["pose"][-1], eng.platform_state()[0]), where
     eng.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_masked_command_sequences(pkg, oracle, mapping, seed):
+    """The per-robot path (per_robot_commands) under random sequences: Joys of either kind reach random subsets of the
+    robots at random moments (also both kinds before one update, also nobody), resets in between — against the oracle,
+    which is B independent JointForceCalculator sets by construction."""
+    once(mapping)
+    rng = np.random.default_rng(700 + seed)
+    model = [pkg.eight_cable_model(), pkg.cube_model()][seed]
+    n, B = model.n_cables, [193, 65][seed]
+    cfg = pkg.Config(model=model, batch=B, stages=[3, 0][seed], perRobotCommands=True)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05))
+    total = 0
+    for op in range(50):
+        kind = rng.choice(["vel", "pos", "both", "run", "reset"], p=[0.25, 0.15, 0.1, 0.46, 0.04])
+        if kind in ("vel", "both"):
+            c = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+            m = rng.random(B) < rng.choice([0.0, 0.3, 0.7, 1.0])
+            assert eng.set_velocity_command(c, mask=m) == 0 and ora.set_velocity_command(c, mask=m) == 0
+        if kind in ("pos", "both"):
+            c = rng.uniform(-0.003, 0.003, (B, n)).astype(np.float32)
+            m = rng.random(B) < rng.choice([0.0, 0.3, 0.7, 1.0])
+            assert eng.set_position_command(c, mask=m) == 0 and ora.set_position_command(c, mask=m) == 0
+        if kind == "reset":
+            eng.reset(), ora.reset()
+            total = 0
+        if kind == "run":
+            k = int(rng.integers(1, 30))
+            eng.update(k), ora.update(k)
+            total += k
+            compare(eng, ora, where=f"seed {seed} op {op} after {total} steps")
+    eng.close()
