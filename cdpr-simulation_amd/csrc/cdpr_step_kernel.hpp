@@ -636,6 +636,9 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
   return make_float4(lo ? e.x : w[2 * m].x, lo ? e.y : w[2 * m].y, hi ? e.x : w[2 * m + 1].x, hi ? e.y : w[2 * m + 1].y);
 }
 
+#ifndef CDPR_EARLY_OBS
+#define CDPR_EARLY_OBS 1  // first-generation kernel: pose / twist / joint position / joint velocity rows stored right after the IK
+#endif
 #ifndef CDPR_LPR_WAVES
 #define CDPR_LPR_WAVES 1  // minimum waves per SIMD the lane-per-robot kernel is compiled for (register budget 512 / this)
 #endif
@@ -791,6 +794,24 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
                     fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
     }
 
+#if CDPR_EARLY_OBS
+    // the observables that are final already go out here (7 of 10 rows at n = 8): every wave of a launch reaches its
+    // stores at the same moment, and ten rows per robot in one burst back the store path up when each step writes a NEW
+    // image (trajectory record); spread over the step they drain under the Newton stage
+    if (!ROLLOUT && ((a.publish_mask >> step) & 1ull) && live) {
+      float4* const obs = a.obs + (size_t)step * a.obs_step_stride;
+      store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+      store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+      store_slot(obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
+        const bool has = (2 * g + 1 < NP);
+        store_slot(obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
+        store_slot(obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
+      }
+    }
+#endif
     CDPR_STAMP(2);
     // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191), two cables per instruction
     v2f f[NP], e_new[NP];
@@ -971,16 +992,20 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
     // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
     if (!ROLLOUT && ((a.publish_mask >> step) & 1ull) && live) {
       float4* const obs = a.obs + (size_t)step * a.obs_step_stride;
+#if !CDPR_EARLY_OBS
       store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
       store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
       store_slot(obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+#endif
       store_slot(obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
         const bool has = (2 * g + 1 < NP);
+#if !CDPR_EARLY_OBS
         store_slot(obs, st, 4 + g, woff, make_float4(q[k0].x, q[k0].y, has ? q[k1].x : 0.f, has ? q[k1].y : 0.f));
         store_slot(obs, st, 4 + G + g, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
+#endif
         store_slot(obs, st, 4 + 2 * G + g, woff,
                    make_float4(applied[k0].x, applied[k0].y, has ? applied[k1].x : 0.f, has ? applied[k1].y : 0.f));
       }
