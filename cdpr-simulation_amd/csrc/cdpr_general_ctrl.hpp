@@ -117,54 +117,49 @@ __device__ __forceinline__ float gen_derive(const GenPid& p, GenRec& r, float va
   mean /= (double)nbuf;
   double h = (t_new - t_old) / (double)(nbuf - 1);
   if (!(h > 0.0)) h = 1.0;
+  const double inv_h = 1.0 / h;
   const int m = p.degree + 1;
   double sx[2 * kGenMaxDeg + 1], sb[kGenMaxDeg + 1];
+#pragma unroll
   for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) sx[i] = 0.0;
+#pragma unroll
   for (int i = 0; i < kGenMaxDeg + 1; ++i) sb[i] = 0.0;
   for (int j = 0; j < nbuf; ++j) {
-    const double x = ((double)r.geti(kGfWinStamp + j) - mean) / h;
+    const double x = ((double)r.geti(kGfWinStamp + j) - mean) * inv_h;
     const double y = (double)r.f(kGfWinVal + j);
     double pw = 1.0;
-    for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) {
-      if (i < 2 * m - 1) sx[i] += pw;
-      if (i < m) sb[i] += pw * y;
+#pragma unroll
+    for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) {  // powers beyond the fit's degree are summed too and never used
+      sx[i] += pw;
+      if (i < kGenMaxDeg + 1) sb[i] += pw * y;
       pw *= x;
     }
   }
+  // normal equations of the degree-(m-1) fit in the leading m x m block, identity rows below it: every index in the
+  // elimination is a compile-time constant (the matrix stays in registers; a run-time pivot row sends it to scratch memory)
   double a[kGenMaxDeg + 1][kGenMaxDeg + 2];
-  for (int i = 0; i < kGenMaxDeg + 1; ++i)
-    for (int j = 0; j < kGenMaxDeg + 2; ++j) a[i][j] = 0.0;
+#pragma unroll
   for (int i = 0; i < kGenMaxDeg + 1; ++i) {
-    for (int j = 0; j < kGenMaxDeg + 1; ++j)
-      if (i < m && j < m) a[i][j] = sx[i + j];
-    if (i < m) a[i][kGenMaxDeg + 1] = sb[i];
-    if (i >= m) a[i][i] = 1.0;  // inert rows keep the elimination branch-free in its bounds
+#pragma unroll
+    for (int j = 0; j < kGenMaxDeg + 1; ++j) a[i][j] = (i < m && j < m) ? sx[i + j] : ((i == j) ? 1.0 : 0.0);
+    a[i][kGenMaxDeg + 1] = (i < m) ? sb[i] : 0.0;
   }
-  // Gaussian elimination with partial pivoting (the system is SPD and tiny)
+  // Gauss-Jordan without pivoting: the block is symmetric positive definite (centred, scaled abscissae: well conditioned)
+#pragma unroll
   for (int col = 0; col < kGenMaxDeg + 1; ++col) {
-    int piv = col;
-    double best = fabs(a[col][col]);
-    for (int rr = col + 1; rr < kGenMaxDeg + 1; ++rr)
-      if (fabs(a[rr][col]) > best) {
-        best = fabs(a[rr][col]);
-        piv = rr;
-      }
-    if (piv != col)
-      for (int k = 0; k < kGenMaxDeg + 2; ++k) {
-        const double t = a[piv][k];
-        a[piv][k] = a[col][k];
-        a[col][k] = t;
-      }
     const double inv = 1.0 / a[col][col];
+#pragma unroll
     for (int rr = 0; rr < kGenMaxDeg + 1; ++rr) {
       if (rr == col) continue;
       const double fct = a[rr][col] * inv;
+#pragma unroll
       for (int k = col; k < kGenMaxDeg + 2; ++k) a[rr][k] -= fct * a[col][k];
     }
   }
   // derivative of the fitted polynomial at the newest stamp (Pid.cpp:205-212), back to seconds
-  const double xn = (t_new - mean) / h;
+  const double xn = (t_new - mean) * inv_h;
   double deriv = 0.0, pw = 1.0;
+#pragma unroll
   for (int i = 1; i < kGenMaxDeg + 1; ++i) {
     if (i < m) deriv += (double)i * (a[i][kGenMaxDeg + 1] / a[i][i]) * pw;
     pw *= xn;
