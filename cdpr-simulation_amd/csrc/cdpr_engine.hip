@@ -88,6 +88,17 @@ struct cdpr_engine {
   uint8_t* d_mode = nullptr;        // uint8[B]: 1 = Position, 2 = Velocity
   uint8_t* d_mask[2] = {nullptr, nullptr};  // pending masks of the velocity / position command, uint8[B]
   bool vel_masked = false, pos_masked = false;  // the pending command came with a mask
+  // Host-side Joy batches travel on their own stream (cdpr_set_*_command with a host pointer): the caller's rows go into
+  // one of two pinned staging buffers per kind and from there to the PENDING device buffer while earlier launches still
+  // run; the call returns without waiting.  kind 0 = velocity, 1 = position.
+  hipStream_t copy_stream = nullptr;
+  float* h_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipEvent_t stage_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // the copy out of that staging buffer has completed
+  bool stage_ev_set[2][2] = {{false, false}, {false, false}};
+  int stage_idx[2] = {0, 0};
+  hipEvent_t ready_wait[2] = {nullptr, nullptr};  // event the compute stream has to pass before it touches the pending buffer
+  hipEvent_t free_ev[2] = {nullptr, nullptr};     // every launch that read what is now the pending buffer has completed
+  bool free_ev_set[2] = {false, false};
   bool vel_pending = false, pos_pending = false;
   bool have_vel = false, have_pos = false;  // a command of that kind has been latched since Load
   int mode = kModePosition;
@@ -620,6 +631,15 @@ void free_all(cdpr_engine* h) {
     (void)hipGraphExecDestroy(g.exec);
     (void)hipGraphDestroy(g.graph);
   }
+  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+  for (int k = 0; k < 2; ++k) {
+    for (int i = 0; i < 2; ++i) {
+      if (h->h_stage[k][i]) (void)hipHostFree(h->h_stage[k][i]);
+      if (h->stage_ev[k][i]) (void)hipEventDestroy(h->stage_ev[k][i]);
+    }
+    if (h->free_ev[k]) (void)hipEventDestroy(h->free_ev[k]);
+  }
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -637,6 +657,14 @@ void engine_reset_host(cdpr_engine* h) {
   h->prev_publish = 0.0;  // PLG.cpp:59
 }
 
+// Everything the copy stream still has in flight lands before the compute stream (or the host) touches a pending buffer
+// in any other way than latching it (device-side staging, masked merges, resets).
+static int drain_copy_stream(cdpr_engine* h) {
+  if (h->copy_stream) HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
+  h->ready_wait[0] = h->ready_wait[1] = nullptr;
+  return CDPR_OK;
+}
+
 int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bool from_device) {
   const size_t n = h->n, B = h->batch;
   if (!src) {
@@ -645,21 +673,41 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
   }
   if (count != n * B && count != n) return CDPR_IGNORED;  // PLG.cpp:68-73,77-82: silently dropped
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  if (count == n * B) {
-    HIP_TRY(h, hipMemcpyAsync(dst, src, n * B * sizeof(float), from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
-                              h->stream));
-    if (!from_device) HIP_TRY(h, wait_stream(h));  // caller may reuse its buffer on return
-  } else {
-    std::vector<float> one(n);
-    if (from_device)
+  const size_t bytes = n * B * sizeof(float);
+  if (from_device) {
+    if (int rc = drain_copy_stream(h)) return rc;
+    if (count == n * B) {
+      HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    } else {
+      std::vector<float> one(n), all(n * B);
       HIP_TRY(h, hipMemcpy(one.data(), src, n * sizeof(float), hipMemcpyDeviceToHost));
-    else
-      memcpy(one.data(), src, n * sizeof(float));
-    std::vector<float> all(n * B);
-    for (size_t b = 0; b < B; ++b) memcpy(&all[b * n], one.data(), n * sizeof(float));
-    HIP_TRY(h, hipMemcpyAsync(dst, all.data(), n * B * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, wait_stream(h));
+      for (size_t b = 0; b < B; ++b) memcpy(&all[b * n], one.data(), n * sizeof(float));
+      HIP_TRY(h, hipMemcpyAsync(dst, all.data(), bytes, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(h, wait_stream(h));
+    }
+    return CDPR_OK;
   }
+  // host source: rows -> pinned staging -> pending device buffer on the copy stream, no wait for the launches in flight
+  const int kind = (dst == h->d_vel[1]) ? 0 : 1;
+  if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+  const int idx = (h->stage_idx[kind] ^= 1);
+  if (!h->h_stage[kind][idx]) {
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_stage[kind][idx], bytes, hipHostMallocDefault));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->stage_ev[kind][idx], hipEventDisableTiming));
+  }
+  if (!h->free_ev[kind]) HIP_TRY(h, hipEventCreateWithFlags(&h->free_ev[kind], hipEventDisableTiming));
+  if (h->stage_ev_set[kind][idx]) HIP_TRY(h, hipEventSynchronize(h->stage_ev[kind][idx]));  // two commands back: long done
+  float* stage = h->h_stage[kind][idx];
+  if (count == n * B) {
+    memcpy(stage, src, bytes);  // the caller may reuse its buffer on return
+  } else {
+    for (size_t b = 0; b < B; ++b) memcpy(stage + b * n, src, n * sizeof(float));
+  }
+  if (h->free_ev_set[kind]) HIP_TRY(h, hipStreamWaitEvent(h->copy_stream, h->free_ev[kind], 0));
+  HIP_TRY(h, hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, h->copy_stream));
+  HIP_TRY(h, hipEventRecord(h->stage_ev[kind][idx], h->copy_stream));
+  h->stage_ev_set[kind][idx] = true;
+  h->ready_wait[kind] = h->stage_ev[kind][idx];
   return CDPR_OK;
 }
 
@@ -740,6 +788,23 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
 
   // --- PLG.cpp:206-219: latch pending commands, velocity first, then position
+  const bool latch_kind[2] = {h->vel_pending, h->pos_pending};
+  for (int k = 0; k < 2; ++k) {
+    if (latch_kind[k] && h->ready_wait[k]) {  // a host Joy batch is (or was) on its way on the copy stream
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ready_wait[k], 0));
+      h->ready_wait[k] = nullptr;
+    }
+  }
+  // after the latch below, what is then the pending buffer of a latched kind was last read by the launches queued so far
+  auto mark_free = [&]() -> int {
+    for (int k = 0; k < 2; ++k) {
+      if (latch_kind[k] && h->free_ev[k]) {
+        HIP_TRY(h, hipEventRecord(h->free_ev[k], h->stream));
+        h->free_ev_set[k] = true;
+      }
+    }
+    return CDPR_OK;
+  };
   bool reset_pid = false;
   auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path)
     return hipMemsetAsync(h->d_rec + h->tstride * (1 + (size_t)which * kGfRows), 0, (size_t)kGfRows * h->tstride * sizeof(float), h->stream);
@@ -773,6 +838,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       h->pos_pending = h->pos_masked = false;
       h->have_pos = true;
     }
+    if (int rc = mark_free()) return rc;
     return run_steps_general(h, nsteps);
   }
   if (h->vel_pending) {
@@ -803,6 +869,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     if (h->general && reset_pid) HIP_TRY(h, reset_block(0));
     h->mode = kModePosition;
   }
+  if (int rc = mark_free()) return rc;
   if (h->general) return run_steps_general(h, nsteps);
 
   if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller record; rare, so done outside the step kernel
@@ -1162,7 +1229,9 @@ void cdpr_destroy(cdpr_handle_t h) {
 int cdpr_reset(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (int rc = drain_copy_stream(h)) return rc;
   HIP_TRY(h, wait_stream(h));
+  h->free_ev_set[0] = h->free_ev_set[1] = false;
   engine_reset_host(h);
   return upload_home(h);
 }
@@ -1209,6 +1278,7 @@ static int stage_masked(cdpr_engine* h, int which, const float* axes, size_t cou
   const size_t n = h->n, B = h->batch;
   if (count != n * B && count != n) return CDPR_IGNORED;  // PLG.cpp:68-73,77-82
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (int rc = drain_copy_stream(h)) return rc;
   float* pending = which == 0 ? h->d_vel[1] : h->d_pos[1];
   bool& is_pending = which == 0 ? h->vel_pending : h->pos_pending;
   bool& masked = which == 0 ? h->vel_masked : h->pos_masked;

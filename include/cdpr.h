@@ -176,7 +176,10 @@ int cdpr_set_platform_state(cdpr_handle_t h, const float *pose7, const float *tw
  * (PLG.cpp:67-83).  `count` = number of floats in `axes`: n*B (one Joy per
  * robot) or n (one Joy broadcast to every robot).  Any other count returns
  * CDPR_IGNORED and changes nothing.  The command is latched at the next
- * cdpr_update and zero-order-held until replaced (PLG.cpp:206-219). */
+ * cdpr_update and zero-order-held until replaced (PLG.cpp:206-219).
+ * `axes` is host memory; it is copied before the call returns (the caller may
+ * reuse it at once) and travels to the device on a copy stream of the handle's
+ * own while earlier launches still run: the call does not wait for them. */
 int cdpr_set_velocity_command(cdpr_handle_t h, const float *axes, size_t count);
 int cdpr_set_position_command(cdpr_handle_t h, const float *axes, size_t count);
 /* Same, from a device buffer already resident in HBM (float[B][n]); the batch is copied (device to device). */

@@ -1249,3 +1249,39 @@ def test_random_masked_command_sequences(pkg, oracle, mapping, seed):
             total += k
             compare(eng, ora, where=f"seed {seed} op {op} after {total} steps")
     eng.close()
+
+
+def test_host_commands_upload_while_earlier_launches_run(pkg, oracle, mapping):
+    """cdpr_set_*_command with a host pointer returns without waiting for the launches in flight (pinned staging + a copy
+    stream + events): a caller that never synchronises — new Joy batch, ten steps, new Joy batch, ... — must still see
+    every batch latched at exactly its update, whatever overtakes whatever; both kinds, broadcast rows, two commands
+    before one update, a reset in the middle; against the oracle."""
+    rng = np.random.default_rng(77)
+    for n, B, stages in ((8, 4096, 3), (4, 777, 0)):
+        model = pkg.cube_model() if n == 4 else pkg.eight_cable_model()
+        cfg = pkg.Config(model=model, batch=B, stages=stages)
+        eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.04))
+        scratch = np.empty((B, n), dtype=np.float32)  # ONE host buffer, overwritten right after every call
+        for period in range(60):
+            kind = "pos" if period % 7 == 5 else "vel"
+            c = (rng.uniform(-0.03, 0.03, (B, n)) * (0.1 if kind == "pos" else 1.0)).astype(np.float32)
+            scratch[:] = c
+            if period % 11 == 3:  # a broadcast row
+                row = c[0].copy()
+                (eng.set_velocity_command if kind == "vel" else eng.set_position_command)(row)
+                (ora.set_velocity_command if kind == "vel" else ora.set_position_command)(row)
+            else:
+                (eng.set_velocity_command if kind == "vel" else eng.set_position_command)(scratch)
+                (ora.set_velocity_command if kind == "vel" else ora.set_position_command)(c)
+            scratch[:] = np.nan  # the library must not read the caller's buffer after the call returned
+            if period % 13 == 6:  # a second Joy of the same kind before the update: the later one wins (PLG.cpp:69,78)
+                c2 = rng.uniform(-0.02, 0.02, (B, n)).astype(np.float32)
+                scratch[:] = c2
+                eng.set_velocity_command(scratch), ora.set_velocity_command(c2)
+                scratch[:] = np.nan
+            k = int(rng.integers(1, 15))
+            eng.update(k), ora.update(k)  # no synchronisation: the host runs ahead of the device
+            if period == 30:
+                eng.reset(), ora.reset()
+        compare(eng, ora, where=f"n={n} after 60 unsynchronised periods")
+        eng.close()
