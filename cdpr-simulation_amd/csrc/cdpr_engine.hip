@@ -789,16 +789,20 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
 
   // --- PLG.cpp:206-219: latch pending commands, velocity first, then position
   const bool latch_kind[2] = {h->vel_pending, h->pos_pending};
+  bool host_latch[2] = {false, false};  // the command latched now came through the copy stream
   for (int k = 0; k < 2; ++k) {
     if (latch_kind[k] && h->ready_wait[k]) {  // a host Joy batch is (or was) on its way on the copy stream
       HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ready_wait[k], 0));
       h->ready_wait[k] = nullptr;
+      host_latch[k] = true;
     }
   }
-  // after the latch below, what is then the pending buffer of a latched kind was last read by the launches queued so far
+  // After the latch below, what is then the pending buffer of such a kind was last read by the launches queued so far:
+  // the next host batch of that kind may overwrite it once they are through.  (Only then: an event between launches costs
+  // a few microseconds of device time, and commands that are bound or staged on the device never use the copy stream.)
   auto mark_free = [&]() -> int {
     for (int k = 0; k < 2; ++k) {
-      if (latch_kind[k] && h->free_ev[k]) {
+      if (host_latch[k] && h->free_ev[k]) {
         HIP_TRY(h, hipEventRecord(h->free_ev[k], h->stream));
         h->free_ev_set[k] = true;
       }
