@@ -82,3 +82,21 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
+
+
+def test_header_is_valid_c99_and_the_c_example_links(tmp_path):
+    """include/cdpr.h is a C header (not only C++): examples/c_abi_demo.c compiles with gcc -std=c99 -pedantic without a
+    warning and links against the library; without a GPU the program fails loudly at cdpr_create (no CPU fallback)."""
+    import subprocess
+
+    exe = tmp_path / "c_abi_demo"
+    libdir = os.path.join(ROOT, "cdpr-simulation_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L" + libdir, "-lcdpr_hip", "-lm", "-Wl,-rpath," + libdir, "-o", str(exe)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    from cdpr_simulation_amd._native import lib
+
+    if lib().cdpr_device_count() == 0:
+        run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+        assert run.returncode == 1 and "cdpr_create" in run.stderr and not run.stdout

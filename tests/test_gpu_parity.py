@@ -1285,3 +1285,30 @@ def test_host_commands_upload_while_earlier_launches_run(pkg, oracle, mapping):
                 eng.reset(), ora.reset()
         compare(eng, ora, where=f"n={n} after 60 unsynchronised periods")
         eng.close()
+
+
+def test_c_example_matches_the_python_host(pkg, mapping, tmp_path):
+    """examples/c_abi_demo.c (plain C99 against include/cdpr.h: config filled field by field, sine Joy, cdpr_update,
+    cdpr_get_observables) prints what the Python host gets from the same calls."""
+    once(mapping)
+    import os
+    import subprocess
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "c_abi_demo"
+    libdir = os.path.join(ROOT, "cdpr-simulation_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L" + libdir,
+                        "-lcdpr_hip", "-lm", "-Wl,-rpath," + libdir, "-o", str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    run = subprocess.run([str(exe), "3"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    lines = run.stdout.strip().splitlines()
+    assert len(lines) == 6 and lines[-1].startswith("t =  3.00 s")
+    eng = pkg.Engine(pkg.Config(batch=3), 0)
+    for k in range(300):
+        eng.set_velocity_command(np.full(4, np.float32(0.05 * np.sin(2.0 * np.pi * 0.1 * (k * 0.01))), dtype=np.float32))
+        eng.update(10)
+    q, qd, eff, pose, twist = eng.observables()
+    words = lines[-1].replace("=", " ").split()
+    z, vz, q0, f0 = float(words[words.index("z") + 1]), float(words[words.index("vz") + 1]), float(words[words.index("q") + 1]), float(words[words.index("F") + 1])
+    assert abs(z - pose[0, 2]) < 2e-6 and abs(vz - twist[0, 2]) < 2e-6 and abs(q0 - q[0, 0]) < 2e-6 and abs(f0 - eff[0, 0]) < 2e-4
