@@ -167,6 +167,20 @@ def parse_args(argv=None):
     return args
 
 
+def modelled_traffic_bytes(n, fk, batch, steps_per_launch=1):
+    """HBM bytes one launch of the fast path moves, from the data layout: float4 rows of 16 B per
+    robot — read: platform rows (4, +1 with FK), 5 ring rows per cable pair, the integral rows, the Joy; written: the
+    platform rows, ONE ring row per cable pair and the integral rows per step, the observable rows (4 + 3 per four
+    cables) per published step.  Within 0.5 %% of the PMC figure where both exist (n = 8: 800 B against 803 B measured
+    per robot); reported next to it so that the line never depends on a stale profiles/traffic.json alone."""
+    pairs, plat = (n + 1) // 2, 5 if fk else 4
+    hot, groups = (pairs + 1) // 2, (n + 3) // 4
+    read_rows = plat + 5 * pairs + hot
+    write_rows = plat + steps_per_launch * (pairs + hot) + steps_per_launch * (4 + 3 * groups)
+    cmd_bytes = 4 * n  # the latched Joy row of the robot, once per launch
+    return batch * (16 * (read_rows + write_rows) + cmd_bytes)
+
+
 def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` with no launcher around it: start N rank processes (one per GPU) and wait.  Runs
     before this process has loaded the HIP library or torch, so the parent never touches the GPU; rank 0's stdout is
@@ -427,6 +441,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "basis": "algorithmic bytes (SURVEY 8(d), shifted-window accounting) x wall-clock state-steps/s per GPU",
                 "traffic": traffic,
+                "traffic_model": modelled_traffic_bytes(n, n >= 6, args.batch, args.steps_per_launch),  # from the data layout
                 "bytes_per_state_step": bytes_step,
                 # the same algorithmic bytes over the kernel's own average duration (HIP events on the engine's stream)
                 "kernel_us": launch_s * 1e6,

@@ -97,3 +97,17 @@ def test_bench_fails_loudly_without_a_gpu(pkg):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_modelled_traffic_matches_the_measured_bytes():
+    """bench.py's `roofline.traffic_model` (bytes per launch from the data layout) against the rocprofv3 PMC figures that
+    profiles/traffic.json carries: the line must not depend on a stale table alone."""
+    import json
+
+    import bench
+
+    measured = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert bench.modelled_traffic_bytes(8, True, 65536) == 65536 * 800
+    assert abs(bench.modelled_traffic_bytes(8, True, 65536) / measured["n8_b65536_spl1"] - 1) < 0.01
+    assert abs(bench.modelled_traffic_bytes(8, True, 524288) / measured["n8_b524288_spl1"] - 1) < 0.01
+    assert abs(bench.modelled_traffic_bytes(4, False, 4096) / measured["n4_b4096_spl1"] - 1) < 0.06  # 64 waves: per-launch constants show
