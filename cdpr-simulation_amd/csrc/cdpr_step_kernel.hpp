@@ -636,6 +636,9 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
   return make_float4(lo ? e.x : w[2 * m].x, lo ? e.y : w[2 * m].y, hi ? e.x : w[2 * m + 1].x, hi ? e.y : w[2 * m + 1].y);
 }
 
+#ifndef CDPR_LDS_WINDOW
+#define CDPR_LDS_WINDOW 1  // multi-step and rollout launches of the first-generation kernel: the derivative window of every
+#endif                     // lane lives in LDS between the steps (20 KiB per wave at n = 8) instead of in 80 registers
 #ifndef CDPR_EARLY_OBS
 #define CDPR_EARLY_OBS 1  // first-generation kernel: pose / twist / joint position / joint velocity rows stored right after the IK
 #endif
@@ -762,6 +765,20 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       calls = 0;
     }
   }
+  // Launches of several steps keep the window in LDS, one column per lane: the FIR reads it from there (20 ds_read2 per
+  // step), the new error goes to its ring slot with one store per cable pair at a run-time address.  In registers the
+  // window is 80 VGPRs that push the kernel past 256 (hundreds of v_accvgpr moves per step) and a ring push is 80
+  // v_cndmask (the slot is a run-time value): every one of those is a vector instruction of the one wave that is
+  // issue-bound, the LDS operations are not.  Same values either way.
+  constexpr bool kLdsWin = CDPR_LDS_WINDOW && !SINGLE && !EXT;
+  __shared__ v2f lwin[kLdsWin ? kWin : 1][kLdsWin ? NP : 1][64];
+  if (kLdsWin) {
+#pragma unroll
+    for (int j = 0; j < kWin; ++j) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) lwin[j][k][lane] = win[k][j];
+    }
+  }
 
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
     if (ROLLOUT) {  // this step's Joy for this trajectory
@@ -842,7 +859,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 #pragma unroll
         for (int j = 0; j < kWin; ++j) {
 #pragma unroll
-          for (int k = 0; k < NP; ++k) acc[k] = fma2(wt[j], win[k][j], acc[k]);
+          for (int k = 0; k < NP; ++k) acc[k] = fma2(wt[j], kLdsWin ? lwin[j][k][lane] : win[k][j], acc[k]);
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -877,7 +894,14 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       ++calls;
     }
 
-    if (!EXT && !SINGLE && ring_slot >= 0) ring_push<NP>(win, e_new, ring_slot);
+    if (!EXT && !SINGLE && ring_slot >= 0) {
+      if (kLdsWin) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) lwin[ring_slot][k][lane] = e_new[k];
+      } else {
+        ring_push<NP>(win, e_new, ring_slot);
+      }
+    }
     if (!EXT && SINGLE && live) {
       // controller records are final: one ring row per cable pair (the one that takes the new error) + the hot rows
       if (ring_slot >= 0) {
@@ -1057,6 +1081,13 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
     CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
     if (FK) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
     if (!SINGLE && !EXT) {
+      if (kLdsWin) {
+#pragma unroll
+        for (int j = 0; j < kWin; ++j) {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) win[k][j] = lwin[j][k][lane];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
 #pragma unroll
