@@ -406,6 +406,12 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
 // tensions + 6 estimator scalars the other way, through LDS, with two workgroup barriers.  Same arithmetic as the
 // one-wave kernels (shared device functions, -ffp-contract=off): bit-identical, tested.
 // Registers: __launch_bounds__(128, 2) = at most 256 per wave, VGPR + AGPR together.
+#ifndef CDPR_CTL_LOAD_DELAY
+#define CDPR_CTL_LOAD_DELAY 8  // s_sleep units (64 cycles) the controller wave waits before it issues its 22 controller-row loads: the
+#endif                         // estimator waves' two rows (the start of the serial chain) then meet a memory system that is not yet
+                               // flooded by 2 048 x 27 row requests.  Interleaved A/Bs on three leases, us/step against 0: 4: 9.90-10.07
+                               // vs 10.20-10.38; 6 / 8: 10.20-10.34 / 10.12-10.36 vs 10.50-10.72; 6 / 8 / 12: 10.27 / 10.26 / 10.20 vs
+                               // 10.38 (medians); 16: no gain
 #ifndef CDPR_SPLIT_PRIO
 #define CDPR_SPLIT_PRIO 1  // 1 = estimator wave at s_setprio 3 (measured 10.89 vs 11.05 us/step), 2 = controller wave at 3 (11.7), 0 = none
 #endif
@@ -563,6 +569,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   // ---------------------------------------------------------------------------------------------------- controller wave
 #if CDPR_SPLIT_PRIO == 2
   __builtin_amdgcn_s_setprio(3);
+#endif
+#if CDPR_CTL_LOAD_DELAY > 0
+  __builtin_amdgcn_s_sleep(CDPR_CTL_LOAD_DELAY);  // the estimator waves' two rows go first through the memory system
 #endif
   constexpr int kCtrl = 5 * NP + NH;
   float4 wraw[NP][5], hraw[NH];
