@@ -22,6 +22,15 @@ BASELINE.md section 3's `state_steps_per_s x bytes(n) / 8.0e12`; `roofline.achie
 prices the same bytes by the average launch duration measured with HIP events on the
 engine's stream.  `cpu_baseline` = the fp64 oracle (oracle/, "port") timed on this box's
 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+`parity_check` ties the timed run to the oracle: after the timed region (never inside it) the
+first and the last 64 robots are replayed on the fp64 oracle for the same warmup + steps under
+the same command schedule and compared with what the engine holds; likewise 8 robots of the
+rollout leg.  The process exits non-zero when a check fails.  The oracle is the checker and
+the CPU baseline here, never the thing measured.
+
+Multi-rank host placement: every rank pins itself to its own share of the CPUs before it
+touches the GPU (`placement`), and `per_rank` lists each rank's own rate next to the
+max-over-ranks `value`, so a straggler is visible.
 """
 import argparse
 import json
@@ -144,6 +153,94 @@ def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
     }
 
 
+# fp32 engine against the fp64 oracle after `warmup + steps` steps of the timed workload (absolute; the parity tests'
+# tolerances of tests/test_gpu_parity.py widened for a run of several thousand steps under sine commands)
+PARITY_TOL = {"pose": 1e-4, "twist": 1e-3, "q": 1e-4, "qd": 1e-3, "eff": 5e-2}
+
+
+def parity_slices(batch, width=64):
+    """Robots replayed on the oracle: the first `width` and the last `width` of the batch (the two ends of the grid: the
+    role-swapped and the un-swapped workgroups of the split kernel, the ragged tail)."""
+    width = min(width, batch)
+    out = [slice(0, width)]
+    if batch > width:
+        out.append(slice(batch - width, batch))
+    return out
+
+
+def parity_check(pkg, cfg_kwargs, pose, command, refresh, total_steps, got, slices, threads=1):
+    """The checker for the number this run reports: replay the SAME schedule (initial poses, one Joy batch per `refresh`
+    steps, `total_steps` world steps) for the robots of `slices` on the fp64 oracle and compare every published observable
+    of the last step with what the engine held right after the timed region.  got = (pose7, twist6, q, qd, effort)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+
+    worst = {k: 0.0 for k in PARITY_TOL}
+    robots = []
+    for sl in slices:
+        nb = sl.stop - sl.start
+        sim = oracle.OracleSim(pkg.Config(batch=nb, **cfg_kwargs).to_struct(), oracle.DERIV_EXACT)
+        sim.set_platform_state(pose7=pose[sl].astype(np.float64))
+        done = 0
+        while done < total_steps:
+            sim.set_velocity_command(command(done // refresh)[sl])
+            k = min(refresh, total_steps - done)
+            sim.update(k, threads)
+            done += k
+        ref = sim.platform_state() + sim.joint_states()
+        sim.close()
+        for name, g, o in zip(("pose", "twist", "q", "qd", "eff"), got, ref):
+            err = np.abs(np.asarray(g[sl], dtype=np.float64) - o)
+            worst[name] = max(worst[name], float(err.max()) if np.isfinite(err).all() else float("inf"))
+        robots.append([sl.start, sl.stop])
+    return {
+        "robots": robots,
+        "steps": int(total_steps),
+        "max_abs_pose": worst["pose"],
+        "max_abs_twist": worst["twist"],
+        "max_abs_joint_position": worst["q"],
+        "max_abs_joint_velocity": worst["qd"],
+        "max_abs_effort": worst["eff"],
+        "tolerance": PARITY_TOL,
+        "against": "fp64 oracle (oracle/cdpr_oracle.c, EXACT derivative mode), same schedule, observables of the last timed step",
+        "ok": bool(all(worst[k] <= PARITY_TOL[k] for k in PARITY_TOL)),
+    }
+
+
+def rank_cpu_set(local_rank, local_world, cpus=None):
+    """Cores rank `local_rank` of `local_world` pins itself to: an equal, contiguous share of the CPUs this process may
+    run on (disjoint between ranks, so that eight launch loops never meet on one core).  None when there is nothing to
+    split (one rank, or fewer CPUs than ranks)."""
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    per = len(cpus) // max(local_world, 1)
+    if local_world <= 1 or per < 1:
+        return None
+    return set(cpus[local_rank * per:(local_rank + 1) * per])
+
+
+def host_placement(local_rank, local_world):
+    """Called by every rank BEFORE anything touches the GPU (the runtime's helper threads inherit the mask): pin to
+    rank_cpu_set, and when the cgroup grants fewer than 2 CPUs' worth of time per rank, make every wait of the library
+    a blocking one (CDPR_SYNC_SPIN_US=0): a launch loop and a polling wait per rank would otherwise starve each other and
+    show up as "poor scaling".  Returns what was done, for the JSON line."""
+    info = {"cpus_effective": effective_cpu_count(), "pinned": None, "blocking_waits": False}
+    if local_world <= 1:
+        return info
+    if os.environ.get("CDPR_BENCH_NO_PIN") != "1" and hasattr(os, "sched_setaffinity"):
+        mine = rank_cpu_set(local_rank, local_world)
+        if mine:
+            try:
+                os.sched_setaffinity(0, mine)
+                info["pinned"] = [min(mine), max(mine), len(mine)]
+            except OSError:
+                pass
+    info["cpus_per_rank"] = info["cpus_effective"] / local_world
+    if info["cpus_per_rank"] < 2.0 and "CDPR_SYNC_SPIN_US" not in os.environ:
+        os.environ["CDPR_SYNC_SPIN_US"] = "0"
+        info["blocking_waits"] = True
+    return info
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +253,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fused / rollout secondary figures")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the post-timing replay of two robot slices on the fp64 oracle")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (spawn, rendezvous, report): no GPU work, value 0")
     args = ap.parse_args(argv)
     if args.batch is None:
@@ -235,6 +333,9 @@ def main():
 
     from cdpr_simulation_amd.sharding import RankContext
 
+    # host placement first: nothing has touched the GPU yet, so the runtime's threads inherit this rank's core set
+    placement = host_placement(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+
     # torch.distributed (RCCL) only provides the rendezvous: barrier + max over ranks. No data-path collective.
     ctx = RankContext.from_env(backend=os.environ.get("CDPR_BENCH_BACKEND", "nccl"))
     rank, local_rank, world = ctx.rank, ctx.local_rank, ctx.world
@@ -247,9 +348,12 @@ def main():
         t0 = time.perf_counter()
         time.sleep(0.01)
         ctx.fast_barrier()
-        elapsed = ctx.max_over_ranks(time.perf_counter() - t0)
+        mine = time.perf_counter() - t0
+        elapsed = ctx.max_over_ranks(mine)
+        per_rank = ctx.gather_over_ranks([mine, float(len(os.sched_getaffinity(0)))])
         if rank == 0:
-            emit(json.dumps({"metric": METRIC, "value": 0.0, "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
+            emit(json.dumps({"metric": METRIC, "value": 0.0, "placement": placement,
+                             "per_rank": [{"rank": i, "elapsed_s": v[0], "cpus": int(v[1])} for i, v in enumerate(per_rank)], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
                              "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                              "config": {"workload": "dry run: rank plumbing only, no GPU work"}}))
@@ -302,11 +406,22 @@ def main():
     advance(args.warmup, args.steps)
     ev_ms, launches = eng.profile_end()  # records the closing event and synchronises the engine's stream: this rank is done
     ctx.fast_barrier()                   # ... and so is every other rank
-    elapsed = time.perf_counter() - t0
-    elapsed = ctx.max_over_ranks(elapsed)
+    elapsed_mine = time.perf_counter() - t0
+    elapsed = ctx.max_over_ranks(elapsed_mine)
+    # every rank's own figures, so that a straggler shows next to the max-over-ranks value
+    per_rank = ctx.gather_over_ranks([elapsed_mine, ev_ms * 1e3 / max(launches, 1), float(device)])
 
-    pose_end, _ = eng.platform_state()
+    pose_end, twist_end = eng.platform_state()
+    joint_end = eng.joint_states()
     finite = bool(np.isfinite(pose_end).all())
+
+    # ---- parity of what was just timed (outside the timed region): two robot slices replayed on the fp64 oracle
+    parity = None
+    if not args.no_parity_check:
+        parity = parity_check(pkg, cfg_kwargs, pose, command, refresh, total, (pose_end, twist_end) + tuple(joint_end),
+                              parity_slices(args.batch), threads=max(1, min(4, int(placement["cpus_effective"] // max(world, 1)))))
+        worst_ok = ctx.min_over_ranks(1.0 if parity["ok"] else 0.0)
+        parity["ok_all_ranks"] = bool(worst_ok > 0.5)
 
     # ---- secondary figures (every rank runs them, outside the timed region above; never substituted for `value`)
     secondary = {}
@@ -372,11 +487,31 @@ def main():
             d_cost = er.device_alloc(Br * S * 4)
             er.rollout_velocity_device(dptr, S, H, d_ref, d_cost)
             er.synchronize()
+            ctx.fast_barrier()
+            t0 = time.perf_counter()
             er.profile_begin()
             for _ in range(reps):
                 er.rollout_velocity_device(dptr, S, H, d_ref, d_cost)
             msr, nl = er.profile_end()
+            ctx.fast_barrier()
+            el_dev = ctx.max_over_ranks(time.perf_counter() - t0) / reps  # whole node, sampler and costs resident in HBM
             cost_dev = er.device_download(d_cost, (Br, S))
+            roll_parity = None
+            if not args.no_parity_check:  # 8 robots of this rollout on the fp64 oracle
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle
+
+                rs = slice(Br - 8, Br)
+                osim = oracle.OracleSim(pkg.Config(batch=8, **cfg_kwargs).to_struct(), oracle.DERIV_EXACT)
+                osim.set_platform_state(pose7=pose[rs].astype(np.float64))
+                osim.update(20)
+                oc = osim.rollout_velocity(cmds[rs], ref[rs].astype(np.float64))
+                osim.close()
+                rel = float(np.abs(cost[rs] - oc).max() / max(float(np.abs(oc).max()), 1e-30))
+                roll_parity = {"robots": [Br - 8, Br], "trajectories": int(8 * S), "max_rel_cost": rel, "tolerance": 2e-4,
+                               "same_best_sample": float((cost[rs].argmin(axis=1) == oc.argmin(axis=1)).mean()),
+                               "ok": bool(np.isfinite(cost).all() and rel <= 2e-4)}
+                roll_parity["ok_all_ranks"] = bool(ctx.min_over_ranks(1.0 if roll_parity["ok"] else 0.0) > 0.5)
             for p_ in (dptr, d_ref, d_cost):
                 er.device_free(p_)
             er.close()
@@ -390,8 +525,12 @@ def main():
                 "kernel_value_per_gpu": Br * S * H / kern_s,
                 "f32_tflops": Br * S * H / kern_s * FLOP_PER_STATE_STEP[n] / 1e12,
                 "f32_vector_frac": Br * S * H / kern_s * FLOP_PER_STATE_STEP[n] / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                # the same rollout with the sampler's commands, the reference and the costs resident in HBM
+                # (cdpr_rollout_velocity_device): wall clock over all ranks, no host copy inside
+                "value_device_resident": world * Br * S * H / el_dev,
                 "cost_finite": bool(np.isfinite(cost).all()),
                 "device_path_identical": bool(np.array_equal(cost, cost_dev)),
+                "parity_check": roll_parity,
             }
 
     if rank == 0:
@@ -454,6 +593,10 @@ def main():
                 "limiter": "instruction issue of the one wave that carries a robot's serial chain (5 cycles per vector instruction, DESIGN.md section 4), not HBM bandwidth",
             },
         }
+        out["parity_check"] = parity
+        out["placement"] = placement
+        out["per_rank"] = [{"rank": i, "value": args.batch * args.steps / v[0], "ms_per_step": v[0] / args.steps * 1e3, "kernel_us": v[1],
+                            "device": int(v[2])} for i, v in enumerate(per_rank)]
         out.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, args.cpu_seconds)
@@ -462,6 +605,11 @@ def main():
         eng.device_free(p)
     eng.close()
     ctx.close()
+    # a number that is not tied to a verified computation is not reported as a success
+    failed = [name for name, chk in (("step", parity), ("rollout", (secondary.get("rollout") or {}).get("parity_check"))) if chk and not chk.get("ok_all_ranks", chk["ok"])]
+    if failed:
+        print(f"bench.py: parity check against the oracle FAILED for: {', '.join(failed)}", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

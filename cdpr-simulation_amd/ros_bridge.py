@@ -20,6 +20,7 @@ which is what `use_sim_time` (cdpr_gazebo.launch:5) makes `ros::Time::now()` rea
 from __future__ import annotations
 
 import importlib
+import threading
 from typing import List, Optional
 
 import numpy as np
@@ -56,7 +57,11 @@ class CdprRosBridge:
             Clock = importlib.import_module("rosgraph_msgs.msg").Clock
             self._Clock = Clock
             self._clock = rospy.Publisher("/clock", Clock, queue_size=10)
-        # commands: one subscriber per robot; a robot's Joy is held until every update() and merged into one batch
+        # commands: one subscriber per robot; a robot's Joy is held until every update() and merged into one batch.
+        # rospy runs subscriber callbacks on threads of its own, so the mailbox is the counterpart of the reference's private
+        # ros::CallbackQueue (PLG.cpp:177-185): callbacks only deposit under the lock, the stepping thread takes the whole
+        # mailbox at the top of step() (callAvailable, PLG.cpp:203-204) and works on its private snapshot.
+        self._pending_lock = threading.Lock()
         self._pending = {_plugin.cVelocityTopic: {}, _plugin.cPositionTopic: {}}
         self._last = {}
         self._subs = []
@@ -75,7 +80,8 @@ class CdprRosBridge:
         topic, b = args
         axes = np.asarray(msg.axes, dtype=np.float32)
         if axes.size == self.n:  # anything else is dropped, as the plugin's callbacks do (PLG.cpp:68-73, 77-82)
-            self._pending[topic][b] = axes
+            with self._pending_lock:
+                self._pending[topic][b] = axes  # a later Joy of the same robot replaces the earlier one (PLG.cpp:69,78)
 
     def _flush_commands(self) -> None:
         """Hand the Joys received since the last update to the facade's own subscriptions (its callback queues are drained
@@ -83,7 +89,8 @@ class CdprRosBridge:
         got a Joy are addressed; otherwise the batch-uniform engine latches all robots together, so robots that sent
         none repeat their last Joy."""
         for topic in (_plugin.cVelocityTopic, _plugin.cPositionTopic):
-            got = self._pending[topic]
+            with self._pending_lock:  # take the mailbox; Joys that arrive from here on wait for the next update()
+                got, self._pending[topic] = self._pending[topic], {}
             if not got:
                 continue
             last = self._last.setdefault(topic, np.zeros((self.B, self.n), dtype=np.float32))
@@ -91,7 +98,6 @@ class CdprRosBridge:
             for b, axes in got.items():
                 last[b] = axes
                 mask[b] = 1
-            got.clear()
             partial = self.B > 1 and not mask.all() and self.facade.config.perRobotCommands
             self.facade.bus.publish(topic, Joy(axes=last.copy(), robots=mask if partial else None))
 

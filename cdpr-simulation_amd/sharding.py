@@ -263,6 +263,20 @@ class RankContext:
     def min_over_ranks(self, value: float) -> float:
         return -self.max_over_ranks(-value)
 
+    def gather_over_ranks(self, values) -> list:
+        """values (a short list of floats) of every rank, indexed by rank: what makes a straggler visible next to the
+        max-over-ranks figure.  One all_gather of a few doubles, outside every timed region."""
+        vals = [float(v) for v in values]
+        if self._dist is None:
+            return [vals]
+        import torch
+
+        dev = "cuda" if self._dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor(vals, dtype=torch.float64, device=dev)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        self._dist.all_gather(out, mine)
+        return [[float(x) for x in t.cpu().tolist()] for t in out]
+
     def close(self) -> None:
         if self._dist is not None:
             self._dist.barrier()

@@ -79,6 +79,49 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     assert out["metric"].startswith("CDPR sim-steps/sec")
 
 
+def test_bench_gpus_8_dry_run_pins_and_reports_every_rank():
+    """The driver's N = 8 launch, rank plumbing only: eight ranks, disjoint core sets (when the box has at least eight
+    CPUs), one JSON line carrying every rank's own figure."""
+    out = _run_bench(["--gpus", "8", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--dry-run"], timeout=600)
+    assert out["n_gpus"] == 8 and out["dry_run"] is True
+    assert [r["rank"] for r in out["per_rank"]] == list(range(8))
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:
+        assert all(r["cpus"] == ncpu // 8 for r in out["per_rank"])
+        assert out["placement"]["pinned"][2] == ncpu // 8
+
+
+def test_rank_cpu_sets_are_disjoint_and_cover_equal_shares():
+    import bench
+
+    cpus = list(range(3, 35))  # 32 CPUs, not starting at 0
+    sets = [bench.rank_cpu_set(r, 8, cpus) for r in range(8)]
+    assert all(len(s) == 4 for s in sets) and len(set().union(*sets)) == 32
+    assert bench.rank_cpu_set(0, 1, cpus) is None and bench.rank_cpu_set(0, 64, cpus) is None
+    assert [sl for sl in bench.parity_slices(65536)] == [slice(0, 64), slice(65472, 65536)]
+    assert bench.parity_slices(40) == [slice(0, 40)]
+
+
+def test_parity_check_flags_a_wrong_result(pkg, oracle):
+    """bench.py's post-timing check against the oracle: the oracle's own result passes, a perturbed one fails."""
+    import bench
+
+    model, pose, command, n_cmd = bench.make_workload(pkg, 96, 8, 1235, 25)
+    kw = dict(model=model, stages=3)
+    sim = oracle.OracleSim(pkg.Config(batch=96, **kw).to_struct(), oracle.DERIV_EXACT)
+    sim.set_platform_state(pose7=pose.astype(np.float64))
+    for j in range(3):
+        sim.set_velocity_command(command(j))
+        sim.update(10 if j < 2 else 5)
+    got = sim.platform_state() + sim.joint_states()
+    good = bench.parity_check(pkg, kw, pose, command, 10, 25, got, bench.parity_slices(96, 32))
+    assert good["ok"] and good["robots"] == [[0, 32], [64, 96]] and good["max_abs_pose"] < 1e-12 and good["steps"] == 25
+    bad = [g.copy() for g in got]
+    bad[4][70, 3] += 0.2
+    res = bench.parity_check(pkg, kw, pose, command, 10, 25, bad, bench.parity_slices(96, 32))
+    assert not res["ok"] and abs(res["max_abs_effort"] - 0.2) < 1e-9
+
+
 def test_bench_single_rank_needs_no_rendezvous():
     out = _run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"])
     assert out["n_gpus"] == 1

@@ -20,27 +20,10 @@ import sys
 import numpy as np
 import pytest
 
-from test_gpu_parity import TOL, perturbed_poses
+from test_gpu_parity import TOL, check_slice, perturbed_poses
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def check_slice(pkg, oracle, cfg_kwargs, sl, pose, script, got, tol=TOL):
-    """Replay `script` ([(nsteps, velocity command or None)]) on the oracle for robots `sl` and compare with `got`
-    = (pose, twist, q, qd, effort) of the full GPU run."""
-    n = sl.stop - sl.start
-    ora = oracle.OracleSim(pkg.Config(batch=n, **cfg_kwargs).to_struct(), oracle.DERIV_EXACT)
-    ora.set_platform_state(pose7=pose[sl].astype(np.float64))
-    for nsteps, cmd in script:
-        if cmd is not None:
-            ora.set_velocity_command(cmd[sl])
-        ora.update(nsteps)
-    op, ot = ora.platform_state()
-    oq, oqd, oe = ora.joint_states()
-    for name, g, o in zip(("pose", "twist", "q", "qd", "eff"), got, (op, ot, oq, oqd, oe)):
-        err = float(np.abs(g[sl] - o).max())
-        assert err <= tol[name], f"{name} differs from the oracle by {err:.3e} on robots {sl}"
 
 
 @pytest.mark.parametrize("mapping_id", [1, 2])
@@ -214,6 +197,32 @@ def test_bench_gpus_2_is_its_own_launcher_on_the_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 1e7 and out["config"]["state_finite"] is True
     assert out["rollout"]["cost_finite"] is True and "config5: 2 x 512" in out["rollout"]["workload"]
+    assert out["parity_check"]["ok_all_ranks"] and out["rollout"]["parity_check"]["ok_all_ranks"] and len(out["per_rank"]) == 2
+
+
+def test_bench_gpus_8_on_the_one_gpu():
+    """The N = 8 launch the driver makes at round end, rehearsed on a 1-GPU lease: eight ranks sharing device 0, each
+    pinned to its own cores, the real step kernels and the rollout leg, per-rank figures and the parity checks in the
+    one JSON line.  (What it cannot show is scaling; what it does show is that eight ranks start, rendezvous, time,
+    check themselves against the oracle and finish.)"""
+    import time
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CDPR_MAPPING", "CDPR_LOWREG"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "50", "--warmup", "10", "--batch", "4096",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    took = time.monotonic() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["value"] > 1e7 and out["config"]["state_finite"] is True
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and all(p["value"] > 1e6 for p in out["per_rank"])
+    assert out["parity_check"]["ok"] and out["parity_check"]["ok_all_ranks"]
+    assert out["rollout"]["parity_check"]["ok_all_ranks"] and out["rollout"]["value_device_resident"] > 0
+    assert took < 120.0, f"eight ranks on one GPU took {took:.0f} s"
 
 
 def test_bench_rccl_rendezvous_on_one_rank():

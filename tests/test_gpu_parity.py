@@ -51,6 +51,26 @@ def pair(pkg, oracle, cfg, pose=None, twist=None):
     return eng, ora
 
 
+def check_slice(pkg, oracle, cfg_kwargs, sl, pose, script, got, tol=TOL):
+    """Replay `script` ([(nsteps, command or None)]; a command is an array = jointVelocities, or ("pos", array) =
+    jointPositions) on the oracle for robots `sl` and compare with `got` = (pose, twist, q, qd, effort) of the full GPU run.
+    Robots are independent, so a slice of the batch is its own problem."""
+    n = sl.stop - sl.start
+    ora = oracle.OracleSim(pkg.Config(batch=n, **cfg_kwargs).to_struct(), oracle.DERIV_EXACT)
+    ora.set_platform_state(pose7=pose[sl].astype(np.float64))
+    for nsteps, cmd in script:
+        if isinstance(cmd, tuple):
+            ora.set_position_command(cmd[1][sl])
+        elif cmd is not None:
+            ora.set_velocity_command(cmd[sl])
+        ora.update(nsteps)
+    op, ot = ora.platform_state()
+    oq, oqd, oe = ora.joint_states()
+    for name, g, o in zip(("pose", "twist", "q", "qd", "eff"), got, (op, ot, oq, oqd, oe)):
+        err = float(np.abs(g[sl] - o).max())
+        assert err <= tol[name], f"{name} differs from the oracle by {err:.3e} on robots {sl}"
+
+
 def perturbed_poses(model, B, rng, dp=0.05, dr=0.1):
     pose = np.tile(model.home_pose(), (B, 1))
     pose[:, :3] += rng.uniform(-dp, dp, (B, 3))
@@ -286,10 +306,17 @@ def test_plugin_facade_end_to_end(pkg, oracle):
     assert abs(js.header.stamp - 0.499) < 1e-12
 
 
-def test_full_size_properties_config3(pkg):
-    """BASELINE config 3 at full size (65 536 x 8 cables): size-independent properties instead of the oracle —
-    unit quaternions, FK estimate == true pose, tensions inside [f_min, f_max], robots started identically stay
-    identical (no cross-robot leakage), and a permutation of the batch permutes the result."""
+# 128-robot slices of a 65 536-robot run that the oracle replays: workgroups 0-1, 9-10 and 1022-1023 of the split kernel;
+# under the role-swap mask 0x9 (StepArgs::split_swap) each pair holds one swapped and one un-swapped workgroup
+# (popcount(block & 9): 0, 1 | 2, 1 | 1, 2), and the last pair sits at the far end of the grid
+FULL_SIZE_SLICES = (slice(0, 128), slice(576, 704), slice(65408, 65536))
+
+
+def test_full_size_properties_config3(pkg, oracle):
+    """BASELINE config 3 at full size (65 536 x 8 cables), the headline kernel at the headline size (every SIMD of the
+    chip hosting an estimator and a controller wave): three 128-robot slices against the ORACLE, and on the whole batch
+    the size-independent properties — unit quaternions, FK estimate == true pose, tensions inside [f_min, f_max], robots
+    started identically stay identical (no cross-robot leakage), a permutation of the batch permutes the result."""
     B = 65536
     rng = np.random.default_rng(1235)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
@@ -311,6 +338,8 @@ def test_full_size_properties_config3(pkg):
     assert res.max() < 1e-6 and np.all(it == 4) and np.abs(fk_pose[:, :3] - p[:, :3]).max() < 5e-6
     ten, flag = eng.td_state()
     assert ten.min() >= 5.0 and ten.max() <= 100.0
+    for sl in FULL_SIZE_SLICES:
+        check_slice(pkg, oracle, dict(model=cfg.model, stages=3), sl, pose, [(20, None), (200, cmd)], (p, t, q, qd, eff))
     # permutation equivariance on a slice
     perm = rng.permutation(4096)
     cfg2 = pkg.Config(model=pkg.eight_cable_model(), batch=4096, stages=3)
@@ -320,6 +349,33 @@ def test_full_size_properties_config3(pkg):
     e2.set_velocity_command(cmd[:4096][perm])
     e2.update(200)
     assert np.array_equal(e2.platform_state()[0], p[:4096][perm])
+
+
+def test_full_size_position_mode_config3(pkg, oracle):
+    """The same 65 536 x 8 launch shape in Position mode (jointPositions Joys, the position Pid's gains 200 / 70 / 80):
+    a velocity phase first, so that the mode switch resets the Pid records of the whole batch (JFC.cpp:101-103), then two
+    position targets; three slices against the oracle."""
+    B = 65536
+    rng = np.random.default_rng(1237)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3)
+    pose = perturbed_poses(cfg.model, B, rng, 0.03, 0.06).astype(np.float32)
+    vel = rng.uniform(-0.03, 0.03, (B, 8)).astype(np.float32)
+    pos1 = rng.uniform(-0.004, 0.004, (B, 8)).astype(np.float32)
+    pos2 = rng.uniform(-0.004, 0.004, (B, 8)).astype(np.float32)
+    eng = pkg.Engine(cfg, 0)
+    eng.set_platform_state(pose7=pose)
+    eng.update(15)
+    eng.set_velocity_command(vel)
+    eng.update(40)
+    eng.set_position_command(pos1)
+    eng.update(90)
+    eng.set_position_command(pos2)
+    eng.update(75)
+    got = eng.platform_state() + eng.joint_states()
+    assert all(np.isfinite(x).all() for x in got)
+    script = [(15, None), (40, vel), (90, ("pos", pos1)), (75, ("pos", pos2))]
+    for sl in FULL_SIZE_SLICES:
+        check_slice(pkg, oracle, dict(model=cfg.model, stages=3), sl, pose, script, got)
 
 
 # ---------------------------------------------------------------------------------------------

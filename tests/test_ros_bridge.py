@@ -157,3 +157,89 @@ def test_bridge_module_imports_without_ros(pkg):
     assert "rospy" not in sys.modules or True
     with pytest.raises(ImportError):
         rb.CdprRosBridge(types.SimpleNamespace())  # no ROS in this image: the constructor is where it is needed
+
+
+def test_subscriber_threads_may_deliver_while_the_world_steps(pkg, monkeypatch):
+    """rospy runs subscriber callbacks on its own threads (the reference avoids the race with private callback queues
+    drained on the physics thread, PLG.cpp:177-185, 203-204): publisher threads hammer every robot's Joy topic while
+    step() runs.  Nothing may raise, and every robot's LAST Joy must reach the facade: none is lost between the snapshot
+    and the next update()."""
+    import threading
+
+    from cdpr_simulation_amd.ros_bridge import CdprRosBridge
+
+    log = install_fake_ros(monkeypatch)
+    B = 16
+    f = StubFacade(pkg, B, per_robot=True)
+    br = CdprRosBridge(f, namespace="/sim", init_node=False)
+    Joy = sys.modules["sensor_msgs.msg"].Joy
+    errors, stop = [], threading.Event()
+    last_sent = [0.0] * B
+    per_thread = 4000
+
+    def hammer(robots):
+        try:
+            for k in range(1, per_thread + 1):
+                for b in robots:
+                    v = b + k * 1e-4
+                    log["subs"][f"/sim/robot{b}/jointVelocities"].deliver(Joy(axes=[v] * 4))
+                    last_sent[b] = v
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=hammer, args=(range(t, B, 4),)) for t in range(4)]
+    old_interval = sys.getswitchinterval()
+    sys.setswitchinterval(1e-6)  # thread switches every few bytecodes: an unguarded mailbox loses Joys or raises within milliseconds
+    steps = 0
+    try:
+        for t in threads:
+            t.start()
+        while any(t.is_alive() for t in threads):
+            br.step()
+            steps += 1
+    except Exception as exc:  # noqa: BLE001
+        errors.append(exc)
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+        sys.setswitchinterval(old_interval)
+    br.step()  # whatever arrived after the last snapshot is delivered by the next update, not dropped
+    assert not errors, errors
+    assert steps > 1 and f.updates == steps + 1
+    seen = np.full(B, np.nan)
+    for kind, joy in f.joys:
+        assert kind == "v"
+        rows = range(B) if joy.robots is None else np.nonzero(joy.robots)[0]
+        for b in rows:
+            assert joy.axes[b, 0] >= (seen[b] if np.isfinite(seen[b]) else -1.0)  # per robot, Joys arrive in order
+            seen[b] = joy.axes[b, 0]
+    assert np.allclose(seen, np.asarray(last_sent, dtype=np.float32))
+
+
+def test_a_joy_that_arrives_while_the_mailbox_is_being_emptied_is_kept(pkg, monkeypatch):
+    """The deterministic form of the race above: a subscriber thread delivers robot 2's Joy exactly while the stepping
+    thread is working through the mailbox.  It must not disturb that pass and must go out with the NEXT update()."""
+    from cdpr_simulation_amd.ros_bridge import CdprRosBridge
+
+    log = install_fake_ros(monkeypatch)
+    f = StubFacade(pkg, 3, per_robot=True)
+    br = CdprRosBridge(f, namespace="/sim", init_node=False)
+    Joy = sys.modules["sensor_msgs.msg"].Joy
+    late = []
+
+    class Mailbox(dict):  # the stepping thread is interrupted after the first entry it reads
+        def items(self):
+            for kv in list(dict.items(self)):
+                yield kv
+                if not late:
+                    late.append(True)
+                    log["subs"]["/sim/robot2/jointVelocities"].deliver(Joy(axes=[0.7] * 4))
+
+    br._pending["jointVelocities"] = Mailbox()
+    log["subs"]["/sim/robot0/jointVelocities"].deliver(Joy(axes=[0.1] * 4))
+    br.step()
+    assert late and list(f.joys[-1][1].robots) == [1, 0, 0]
+    br.step()
+    kind, joy = f.joys[-1]
+    assert len(f.joys) == 2 and list(joy.robots) == [0, 0, 1] and np.allclose(joy.axes[2], 0.7)
