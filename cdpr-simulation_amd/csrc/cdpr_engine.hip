@@ -778,6 +778,63 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
   return CDPR_OK;
 }
 
+// The kernel a fast-path launch of k world steps uses on this handle, and its workgroup size.
+StepKernel select_step_kernel(const cdpr_engine* h, int k) {
+  return h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
+         : h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
+                        : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
+                                                 : h->split ? pick_split_kernel(h->n)
+                                                 : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_kernel<true>(h->n, h->fk, h->td)))
+                                    : pick_kernel<false>(h->n, h->fk, h->td));
+}
+uint32_t step_block_threads(const cdpr_engine* h, int k) {
+  // the role-split kernel runs two waves (estimator, controller) per 64 robots
+  return (k == 1 && h->split && !h->phys && !h->lane_pair && !h->lowreg) ? 128u : 64u;
+}
+
+// cdpr_create pays the cold costs of the handle's one-step kernel (the runtime loads a kernel's code object and sets up
+// its argument buffers on the FIRST launch: measured ~1 ms), not the first cdpr_update: one launch of exactly that kernel
+// over one workgroup of home-state robots in a scratch buffer, which is then freed.  The handle's own state is not touched.
+int warm_first_launch(cdpr_engine* h) {
+  if (h->general) return CDPR_OK;
+  if (const char* w = std::getenv("CDPR_NO_WARM_LAUNCH"))
+    if (w[0] == '1') return CDPR_OK;
+  const uint32_t rows = 64;
+  std::vector<float4> s((size_t)h->n_state * rows, make_float4(0.f, 0.f, 0.f, 0.f));
+  const double* hp = h->cfg.home_pose;
+  for (uint32_t r = 0; r < rows; ++r) {
+    s[0 * (size_t)rows + r] = make_float4((float)hp[0], (float)hp[1], (float)hp[2], (float)hp[3]);
+    s[1 * (size_t)rows + r] = make_float4((float)hp[4], (float)hp[5], (float)hp[6], 0.f);
+    s[3 * (size_t)rows + r] = make_float4(0.f, (float)hp[0], (float)hp[1], (float)hp[2]);
+    if (h->fk) s[4 * (size_t)rows + r] = make_float4((float)hp[3], (float)hp[4], (float)hp[5], (float)hp[6]);
+  }
+  DevBuf st, ob, cm;
+  HIP_TRY(h, st.alloc(s.size() * sizeof(float4)));
+  HIP_TRY(h, ob.alloc((size_t)h->n_obs * rows * sizeof(float4)));
+  HIP_TRY(h, cm.alloc((size_t)rows * h->n * sizeof(float)));
+  HIP_TRY(h, hipMemcpyAsync(st.p, s.data(), s.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemsetAsync(cm.p, 0, (size_t)rows * h->n * sizeof(float), h->stream));
+  StepArgs a = h->base;
+  a.state = st.as<float4>();
+  a.obs = ob.as<float4>();
+  a.cmd = cm.as<float>();
+  a.dbg = nullptr;
+  a.geom = h->d_geom;
+  a.batch = h->lane_pair ? 32u : 64u;
+  a.stride = rows;
+  a.nsteps = 1;
+  a.obs_step_stride = 0;
+  a.flags = 0u;
+  a.publish_mask = 1ull;
+  copy_pid(h->pid_pos, a);
+  a.pid_calls = 60;  // steady state: every branch of the step is taken, as in the launches that follow
+  set_weight_row(h, a);
+  hipLaunchKernelGGL(select_step_kernel(h, 1), dim3(1), dim3(step_block_threads(h, 1)), 0, h->stream, a);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, wait_stream(h));
+  return CDPR_OK;
+}
+
 int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullptr) {
   if (!h) return CDPR_ERR_INVALID;
   if (nsteps < 0 || per_launch < 1 || per_launch > 64) {
@@ -789,23 +846,25 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
 
   // --- PLG.cpp:206-219: latch pending commands, velocity first, then position
   const bool latch_kind[2] = {h->vel_pending, h->pos_pending};
-  bool host_latch[2] = {false, false};  // the command latched now came through the copy stream
   for (int k = 0; k < 2; ++k) {
     if (latch_kind[k] && h->ready_wait[k]) {  // a host Joy batch is (or was) on its way on the copy stream
       HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ready_wait[k], 0));
       h->ready_wait[k] = nullptr;
-      host_latch[k] = true;
     }
   }
-  // After the latch below, what is then the pending buffer of such a kind was last read by the launches queued so far:
-  // the next host batch of that kind may overwrite it once they are through.  (Only then: an event between launches costs
-  // a few microseconds of device time, and commands that are bound or staged on the device never use the copy stream.)
+  // After the latch below, what is then the PENDING buffer of a kind whose buffers were swapped (or, on per-robot handles,
+  // read by the latch kernel) was last touched by the work queued on the compute stream so far: the next host batch of
+  // that kind, which travels on the copy stream, may overwrite it only once that work is through.  The event is recorded
+  // on EVERY such latch once a copy stream exists, however the latched command itself arrived (host, _device or masked):
+  // a stale event from an earlier host batch would let the copy run into launches that still read the buffer.  Bound
+  // commands swap nothing and handles that never saw a host batch have no copy stream: no event, no device time.
+  bool touched[2] = {false, false};
   auto mark_free = [&]() -> int {
     for (int k = 0; k < 2; ++k) {
-      if (host_latch[k] && h->free_ev[k]) {
-        HIP_TRY(h, hipEventRecord(h->free_ev[k], h->stream));
-        h->free_ev_set[k] = true;
-      }
+      if (!touched[k] || !h->copy_stream) continue;
+      if (!h->free_ev[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->free_ev[k], hipEventDisableTiming));
+      HIP_TRY(h, hipEventRecord(h->free_ev[k], h->stream));
+      h->free_ev_set[k] = true;
     }
     return CDPR_OK;
   };
@@ -836,11 +895,13 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       if (int rc = latch(h->d_vel[1], h->d_vel[0], h->vel_masked ? h->d_mask[0] : nullptr, 1, kModeVelocity)) return rc;
       h->vel_pending = h->vel_masked = false;
       h->have_vel = true;
+      touched[0] = true;  // the latch kernel reads the pending buffer
     }
     if (h->pos_pending) {
       if (int rc = latch(h->d_pos[1], h->d_pos[0], h->pos_masked ? h->d_mask[1] : nullptr, 0, kModePosition)) return rc;
       h->pos_pending = h->pos_masked = false;
       h->have_pos = true;
+      touched[1] = true;
     }
     if (int rc = mark_free()) return rc;
     return run_steps_general(h, nsteps);
@@ -852,6 +913,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     } else {
       std::swap(h->d_vel[0], h->d_vel[1]);
       h->ext_vel[0] = nullptr;
+      touched[0] = true;  // what is pending now was the latched buffer of the launches queued so far
     }
     h->vel_pending = false;
     h->have_vel = true;
@@ -866,6 +928,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     } else {
       std::swap(h->d_pos[0], h->d_pos[1]);
       h->ext_pos[0] = nullptr;
+      touched[1] = true;
     }
     h->pos_pending = false;
     h->have_pos = true;
@@ -913,15 +976,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // into [60, 70) so they stay small and steady-state launch sequences repeat with period 10
     a.pid_calls = fold_pid_calls(h->pid_calls);
     set_weight_row(h, a);
-    StepKernel kern = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
-                      : h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
-                                   : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
-                                                            : h->split ? pick_split_kernel(h->n)
-                                                            : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_kernel<true>(h->n, h->fk, h->td)))
-                                               : pick_kernel<false>(h->n, h->fk, h->td));
-
-    // the role-split kernel runs two waves (estimator, controller) per 64 robots
-    const dim3 block((k == 1 && h->split && !h->phys && !h->lane_pair && !h->lowreg) ? 128 : 64);
+    StepKernel kern = select_step_kernel(h, k);
+    const dim3 block(step_block_threads(h, k));
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
@@ -1214,7 +1270,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   if (h->dbg)
     if ((e = hipMalloc(&h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float))) != hipSuccess)
       return fail("hipMalloc(dbg)", e);
-  if (upload_home(h) != CDPR_OK) {
+  if (upload_home(h) != CDPR_OK || warm_first_launch(h) != CDPR_OK) {
     g_create_error = h->err;
     free_all(h);
     return CDPR_ERR_DEVICE;
@@ -1510,13 +1566,22 @@ int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, floa
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   const uint32_t n = h->n, width = 3u * n + 13u;
   const size_t count = (size_t)h->batch * width;
+  // lazy set-up, every allocation guarded on its own pointer (a failure half way leaves nothing to leak or to skip next
+  // time).  Coherent host memory: the host spins on the completion word while the kernel is still running.
+  if (!h->h_pub && count * sizeof(float) <= (2u << 20))  // the pinned image serves the two small tiers only
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_pub, count * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
   if (!h->h_pub_done) {
-    if (count * sizeof(float) <= (2u << 20))  // the pinned image serves the two small tiers only
-      HIP_TRY(h, hipHostMalloc((void**)&h->h_pub, count * sizeof(float), hipHostMallocMapped));
-    HIP_TRY(h, hipHostMalloc((void**)&h->h_pub_done, sizeof(uint64_t), hipHostMallocMapped));
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_pub_done, sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent));
     *h->h_pub_done = 0;
+  }
+  if (!h->d_pub_arrivals) {
     HIP_TRY(h, hipMalloc(&h->d_pub_arrivals, sizeof(uint32_t)));
-    HIP_TRY(h, hipMemsetAsync(h->d_pub_arrivals, 0, sizeof(uint32_t), h->stream));
+    hipError_t me = hipMemsetAsync(h->d_pub_arrivals, 0, sizeof(uint32_t), h->stream);
+    if (me != hipSuccess) {  // never launch the publish kernel on an uninitialised arrival counter
+      (void)hipFree(h->d_pub_arrivals);
+      h->d_pub_arrivals = nullptr;
+      HIP_TRY(h, me);
+    }
   }
   // small images go straight to host memory from the gather kernel (a per-step caller of a few robots: ~5 us); large
   // ones through device scratch and the copy engine (kernel stores over PCIe reach ~7 GB/s, the copy engine ~30)

@@ -230,6 +230,8 @@ class Engine:
     def rollout_launch(self, commands, ref_position):
         """Queue one rollout and return at once (cdpr_rollout_velocity_launch): commands[B, H, S, n] as a host array
         (uploaded here, freed by rollout_fetch) or a (device_pointer, S, H) tuple for a buffer already in HBM."""
+        if self._rollout_pending is not None:
+            raise RuntimeError("rollout_launch: the previous rollout has not been fetched (call rollout_fetch first)")
         ref = np.ascontiguousarray(ref_position, dtype=np.float32).reshape(self.B, 3)
         if isinstance(commands, tuple):
             dptr, S, H = commands
@@ -249,6 +251,8 @@ class Engine:
 
     def rollout_fetch(self) -> np.ndarray:
         """cost[B, S] of the rollout queued by rollout_launch (synchronises the stream)."""
+        if self._rollout_pending is None:
+            raise RuntimeError("rollout_fetch: no rollout pending (call rollout_launch first)")
         S, owned = self._rollout_pending
         cost = np.empty((self.B, S), dtype=np.float32)
         try:
@@ -258,6 +262,18 @@ class Engine:
             if owned is not None:
                 self.device_free(owned)
         return cost
+
+    def rollout_discard(self) -> None:
+        """Drop a launched rollout without reading its costs (waits for it; frees an uploaded command buffer)."""
+        if self._rollout_pending is None:
+            return
+        _, owned = self._rollout_pending
+        self._rollout_pending = None
+        try:
+            self.synchronize()
+        finally:
+            if owned is not None:
+                self.device_free(owned)
 
     def rollout_velocity(self, commands, ref_position) -> np.ndarray:
         """commands[B, H, S, n] (host array, or a (device_pointer, S, H) tuple for a buffer already in HBM),

@@ -105,8 +105,15 @@ class ShardedEngine:
         c = np.asarray(commands, dtype=np.float32)
         ref = np.asarray(ref_position, dtype=np.float32).reshape(self.B, 3)
         # queue on every device first (upload + launch return at once), then collect: the GPUs run concurrently
-        for e, (lo, hi) in zip(self.engines, self.spans):
-            e.rollout_launch(c[lo:hi], ref[lo:hi])
+        launched = []
+        try:
+            for e, (lo, hi) in zip(self.engines, self.spans):
+                e.rollout_launch(c[lo:hi], ref[lo:hi])
+                launched.append(e)
+        except Exception:
+            for e in launched:  # a device that failed to launch must not leave the others with a pending rollout
+                e.rollout_discard()
+            raise
         return np.concatenate([e.rollout_fetch() for e in self.engines])
 
     def joint_states(self):

@@ -1343,6 +1343,74 @@ def test_host_commands_upload_while_earlier_launches_run(pkg, oracle, mapping):
         eng.close()
 
 
+def test_mixed_host_and_device_commands_with_long_updates_in_flight(pkg, oracle, mapping):
+    """the host-batch double buffer under commands that arrive by DIFFERENT routes.  Host Joy A, a long
+    update (thousands of launches in flight reading A), a Joy staged from a DEVICE buffer and latched (the buffers swap:
+    the one holding A becomes the pending one), then host Joy C at once: its copy travels on the copy stream and must wait
+    for the launches that still read A.  A stale 'buffer is free' event lets C land early and those steps silently run
+    under C.  Large batch + long update so that the device is far behind the host; the oracle sees the Joys in order."""
+    B, n = 32768, 8
+    rng = np.random.default_rng(91)
+    model = pkg.eight_cable_model()
+    cfg = pkg.Config(model=model, batch=B, stages=3)
+    pose = perturbed_poses(model, B, rng, 0.02, 0.04).astype(np.float32)
+    eng = pkg.Engine(cfg, 0)
+    eng.set_platform_state(pose7=pose)
+    a, b, c = (rng.uniform(-0.01, 0.01, (B, n)).astype(np.float32) for _ in range(3))
+    d_b = eng.device_upload(b)
+    script = []
+    for rep in range(3):  # the third round starts from a swapped pair of buffers
+        eng.set_velocity_command(a)           # host route (copy stream)
+        eng.update(1500)                      # far ahead of the device: ~12 ms of launches queued
+        eng.set_velocity_command_device(d_b, B * n)  # device route: staged on the compute stream
+        eng.update(7)                         # latches B: the buffer that held A is the pending one now
+        eng.set_velocity_command(c)           # host route again, right away
+        eng.update(5)
+        script += [(1500, a), (7, b), (5, c)]
+        a, c = c * np.float32(0.5), a
+    got = eng.platform_state() + eng.joint_states()
+    for sl in (slice(0, 64), slice(B - 64, B)):
+        check_slice(pkg, oracle, dict(model=model, stages=3), sl, pose, script, got, tol=dict(TOL, pose=3e-5, q=3e-5))
+    eng.device_free(d_b)
+    eng.close()
+    # per-robot handle: the latch KERNEL reads the pending buffer; a host Joy right behind it must wait for that read
+    once_B = 20000
+    cfg2 = pkg.Config(model=pkg.cube_model(), batch=once_B, perRobotCommands=True)
+    pose2 = perturbed_poses(cfg2.model, once_B, rng, 0.02, 0.04).astype(np.float32)
+    e2, o2 = pkg.Engine(cfg2, 0), oracle.OracleSim(pkg.Config(model=pkg.cube_model(), batch=64, perRobotCommands=True).to_struct(), oracle.DERIV_EXACT)
+    e2.set_platform_state(pose7=pose2), o2.set_platform_state(pose7=pose2[:64].astype(np.float64))
+    v = [rng.uniform(-0.03, 0.03, (once_B, 4)).astype(np.float32) for _ in range(6)]
+    for j in range(6):
+        e2.set_velocity_command(v[j]), o2.set_velocity_command(v[j][:64])
+        e2.update(40), o2.update(40)  # no synchronisation in between
+    gp, _ = e2.platform_state()
+    ge = e2.joint_states()[2]
+    assert np.abs(gp[:64] - o2.platform_state()[0]).max() <= TOL["pose"] and np.abs(ge[:64] - o2.joint_states()[2]).max() <= TOL["eff"]
+    e2.close()
+
+
+def test_rollout_launch_and_fetch_guard_their_order(pkg, mapping):
+    """a second rollout_launch before the fetch must not leak the first one's buffer, a fetch with
+    nothing pending says so, and rollout_discard drops a launched rollout."""
+    once(mapping)
+    B = 16
+    eng = pkg.Engine(pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3), 0)
+    cmds = np.zeros((B, 4, 3, 8), dtype=np.float32)
+    ref = np.zeros((B, 3), dtype=np.float32)
+    with pytest.raises(RuntimeError):
+        eng.rollout_fetch()
+    eng.rollout_launch(cmds, ref)
+    with pytest.raises(RuntimeError):
+        eng.rollout_launch(cmds, ref)
+    cost = eng.rollout_fetch()
+    assert cost.shape == (B, 3)
+    eng.rollout_launch(cmds, ref)
+    eng.rollout_discard()
+    eng.rollout_launch(cmds, ref)
+    assert np.array_equal(eng.rollout_fetch(), cost)
+    eng.close()
+
+
 def test_c_example_matches_the_python_host(pkg, mapping, tmp_path):
     """examples/c_abi_demo.c (plain C99 against include/cdpr.h: config filled field by field, sine Joy, cdpr_update,
     cdpr_get_observables) prints what the Python host gets from the same calls."""
