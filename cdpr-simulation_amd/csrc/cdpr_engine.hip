@@ -85,7 +85,9 @@ struct cdpr_engine {
   const float* ext_pos[2] = {nullptr, nullptr};
   // per-robot command arrival (cfg.per_robot_commands): every robot has its own mode; general controller path only
   bool per_robot = false;
-  uint8_t* d_mode = nullptr;        // uint8[B]: 1 = Position, 2 = Velocity
+  uint8_t* d_mode = nullptr;        // uint8[B]: 1 = Position, 2 = Velocity; on the register-resident path also the robot's
+                                    // Pid call count in bits 2-7 (StepArgs::meta)
+  float* d_target = nullptr;        // per-robot handles on the register-resident path: float[B][n], every robot's ACTIVE target row
   uint8_t* d_mask[2] = {nullptr, nullptr};  // pending masks of the velocity / position command, uint8[B]
   bool vel_masked = false, pos_masked = false;  // the pending command came with a mask
   // Host-side Joy batches travel on their own stream (cdpr_set_*_command with a host pointer): the caller's rows go into
@@ -273,6 +275,13 @@ void copy_pid(const StepArgs& src, StepArgs& dst) {
   dst.imax = src.imax; dst.imin = src.imin; dst.cmax = src.cmax; dst.cmin = src.cmin; dst.inv_dt = src.inv_dt;
   dst.wtab = src.wtab;
   dst.nbuf = src.nbuf; dst.clamp_cmd = src.clamp_cmd;
+}
+
+// per-robot kernels: the position Pid rides along as StepArgs::alt (the primary fields hold the velocity Pid)
+void copy_pid_alt(const StepArgs& src, PidSet& dst) {
+  dst.kf = src.kf; dst.kp = src.kp; dst.ki = src.ki; dst.kd = src.kd; dst.inv_ki = src.inv_ki;
+  dst.imax = src.imax; dst.imin = src.imin; dst.cmax = src.cmax; dst.cmin = src.cmin;
+  dst.clamp_cmd = src.clamp_cmd;
 }
 
 void fill_consts(const cdpr_config_t& c, StepArgs& k) {
@@ -522,6 +531,42 @@ StepKernel pick_rollout_kernel(uint32_t n, bool fk, bool td) {
   return nullptr;
 }
 
+// per-robot handles on the register-resident path (PR = true): the first-generation kernel in every shape (one step, several
+// steps, low-register, rollout) and the role-split kernel for FK + TD one-step launches
+template <int N, bool SINGLE, bool ROLLOUT, bool LOWREG>
+StepKernel pick_pr_stage(bool fk, bool td) {
+  if constexpr (N >= 6) {
+    if (fk && td) return cdpr_step_kernel<N, true, true, SINGLE, false, ROLLOUT, LOWREG, false, true>;
+    if (fk) return cdpr_step_kernel<N, true, false, SINGLE, false, ROLLOUT, LOWREG, false, true>;
+    if constexpr (!LOWREG)
+      if (td) return cdpr_step_kernel<N, false, true, SINGLE, false, ROLLOUT, false, false, true>;
+  }
+  if constexpr (!LOWREG) return cdpr_step_kernel<N, false, false, SINGLE, false, ROLLOUT, false, false, true>;
+  return nullptr;
+}
+template <bool SINGLE, bool ROLLOUT, bool LOWREG = false>
+StepKernel pick_pr_kernel(uint32_t n, bool fk, bool td) {
+  switch (n) {
+    case 1: return pick_pr_stage<1, SINGLE, ROLLOUT, LOWREG>(fk, td);
+    case 2: return pick_pr_stage<2, SINGLE, ROLLOUT, LOWREG>(fk, td);
+    case 3: return pick_pr_stage<3, SINGLE, ROLLOUT, LOWREG>(fk, td);
+    case 4: return pick_pr_stage<4, SINGLE, ROLLOUT, LOWREG>(fk, td);
+    case 5: return pick_pr_stage<5, SINGLE, ROLLOUT, LOWREG>(fk, td);
+    case 6: return pick_pr_stage<6, SINGLE, ROLLOUT, LOWREG>(fk, td);
+    case 7: return pick_pr_stage<7, SINGLE, ROLLOUT, LOWREG>(fk, td);
+    case 8: return pick_pr_stage<8, SINGLE, ROLLOUT, LOWREG>(fk, td);
+  }
+  return nullptr;
+}
+StepKernel pick_pr_split_kernel(uint32_t n) {
+  switch (n) {
+    case 6: return cdpr_split_kernel<6, true>;
+    case 7: return cdpr_split_kernel<7, true>;
+    case 8: return cdpr_split_kernel<8, true>;
+  }
+  return nullptr;
+}
+
 using SolveKernel = void (*)(const SolveArgs);
 
 template <int N>
@@ -598,7 +643,8 @@ int upload_home(cdpr_engine* h) {
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   }
   if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows() * h->tstride * sizeof(float), h->stream));
-  if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157
+  if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157 (call count 0)
+  if (h->d_target) HIP_TRY(h, hipMemsetAsync(h->d_target, 0, (size_t)h->stride * h->n * sizeof(float), h->stream));  // target 0 after Load
   HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
@@ -615,6 +661,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_force) (void)hipFree(h->d_force);
   if (h->d_cable) (void)hipFree(h->d_cable);
   if (h->d_mode) (void)hipFree(h->d_mode);
+  if (h->d_target) (void)hipFree(h->d_target);
   for (int i = 0; i < 2; ++i)
     if (h->d_mask[i]) (void)hipFree(h->d_mask[i]);
   if (h->d_unpack) (void)hipFree(h->d_unpack);
@@ -711,14 +758,17 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
   return CDPR_OK;
 }
 
-// The stored Pid call counter only matters through calls != 0, calls >= nbuf (<= 11 on the fast path) and the ring
-// position (calls - 1) % 10: fold it into [60, 70) so it never saturates and never loses its phase.
-inline int fold_pid_calls(int calls) { return calls < 70 ? calls : 60 + calls % 10; }
+// The Pid call counter only matters through calls != 0 and calls >= nbuf (<= 11 on the fast path): it saturates.  The
+// ring position does not come from it but from the world step (StepArgs::ring_slot).
+constexpr int kCallSat = 64;
+inline int sat_pid_calls(int calls) { return calls < kCallSat ? calls : kCallSat; }
+inline int ring_slot_of(uint64_t step) { return (int)((step + 8u) % (uint64_t)kWin); }
 
 // Weights of the ring position a launch starts at, copied into its arguments (see StepArgs::wrow).
 inline void set_weight_row(const cdpr_engine* h, StepArgs& a) {
-  const int slot = a.pid_calls > 0 ? (a.pid_calls - 1) % kWin : 0;
-  memcpy(a.wrow, &h->wtab_host[h->mode == kModeVelocity ? 0 : 1][slot * (kWin + 2)], sizeof a.wrow);
+  const int slot = a.ring_slot;
+  // (per-robot handles: both Pids share one window, so the velocity Pid's table serves every lane)
+  memcpy(a.wrow, &h->wtab_host[(h->per_robot || h->mode == kModeVelocity) ? 0 : 1][slot * (kWin + 2)], sizeof a.wrow);
 }
 
 int run_steps_general(cdpr_engine* h, int nsteps) {
@@ -780,6 +830,10 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
 
 // The kernel a fast-path launch of k world steps uses on this handle, and its workgroup size.
 StepKernel select_step_kernel(const cdpr_engine* h, int k) {
+  if (h->per_robot)
+    return (k == 1) ? (h->lowreg ? pick_pr_kernel<true, false, true>(h->n, h->fk, h->td)
+                                 : h->split ? pick_pr_split_kernel(h->n) : pick_pr_kernel<true, false>(h->n, h->fk, h->td))
+                    : pick_pr_kernel<false, false>(h->n, h->fk, h->td);
   return h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
          : h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
                         : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
@@ -808,7 +862,9 @@ int warm_first_launch(cdpr_engine* h) {
     s[3 * (size_t)rows + r] = make_float4(0.f, (float)hp[0], (float)hp[1], (float)hp[2]);
     if (h->fk) s[4 * (size_t)rows + r] = make_float4((float)hp[3], (float)hp[4], (float)hp[5], (float)hp[6]);
   }
-  DevBuf st, ob, cm;
+  DevBuf st, ob, cm, mt;
+  HIP_TRY(h, mt.alloc(rows));
+  HIP_TRY(h, hipMemsetAsync(mt.p, (int)(kMetaPosition | (20u << kMetaCallShift)), rows, h->stream));
   HIP_TRY(h, st.alloc(s.size() * sizeof(float4)));
   HIP_TRY(h, ob.alloc((size_t)h->n_obs * rows * sizeof(float4)));
   HIP_TRY(h, cm.alloc((size_t)rows * h->n * sizeof(float)));
@@ -826,8 +882,11 @@ int warm_first_launch(cdpr_engine* h) {
   a.obs_step_stride = 0;
   a.flags = 0u;
   a.publish_mask = 1ull;
-  copy_pid(h->pid_pos, a);
-  a.pid_calls = 60;  // steady state: every branch of the step is taken, as in the launches that follow
+  copy_pid(h->per_robot ? h->pid_vel : h->pid_pos, a);
+  copy_pid_alt(h->pid_pos, a.alt);
+  a.meta = mt.as<uint8_t>();
+  a.pid_calls = kCallSat;  // steady state: every branch of the step is taken, as in the launches that follow
+  a.ring_slot = 0;
   set_weight_row(h, a);
   hipLaunchKernelGGL(select_step_kernel(h, 1), dim3(1), dim3(step_block_threads(h, 1)), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
@@ -875,6 +934,22 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   if (h->per_robot) {
     // every robot has its own mode: commands (masked or not) are latched on the device, robot by robot
     auto latch = [&](float* pending, float* latched, const uint8_t* mask, int which, int new_mode) -> int {
+      if (!h->general) {  // register-resident path: one active target row and one Pid record per robot
+        LatchFastArgs lf{};
+        lf.mask = mask;
+        lf.meta = h->d_mode;
+        lf.pending = pending;
+        lf.target = h->d_target;
+        lf.hot = h->d_state + (size_t)(plat_slots(h->fk) + 5 * cable_pairs((int)h->n)) * h->stride;
+        lf.stride = h->stride;
+        lf.batch = h->batch;
+        lf.n = h->n;
+        lf.hot_rows = (uint32_t)((cable_pairs((int)h->n) + 1) / 2);
+        lf.new_mode = (new_mode == kModeVelocity) ? kMetaVelocity : kMetaPosition;
+        hipLaunchKernelGGL(cdpr_latch_fast_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, lf);
+        HIP_TRY(h, hipGetLastError());
+        return CDPR_OK;
+      }
       LatchArgs la{};
       la.mask = mask;
       la.mode = h->d_mode;
@@ -904,7 +979,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       touched[1] = true;
     }
     if (int rc = mark_free()) return rc;
-    return run_steps_general(h, nsteps);
+    if (h->general) return run_steps_general(h, nsteps);
   }
   if (h->vel_pending) {
     if (h->ext_vel[1]) {  // bound caller buffer: latched by pointer, nothing copied
@@ -954,7 +1029,12 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   // trajectory record: the observable image of step j of the call goes to record + j * n_obs * stride
   const size_t image = (size_t)h->n_obs * h->stride;
   a.obs_step_stride = record ? image : 0;
-  if (h->mode == kModeVelocity) {
+  if (h->per_robot) {
+    copy_pid(h->pid_vel, a);
+    copy_pid_alt(h->pid_pos, a.alt);
+    a.cmd = h->d_target;
+    a.meta = h->d_mode;
+  } else if (h->mode == kModeVelocity) {
     copy_pid(h->pid_vel, a);
     a.cmd = h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0];
   } else {
@@ -969,12 +1049,13 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
     a.nsteps = k;
-    a.flags = (h->mode == kModeVelocity ? kFlagActualIsVelocity : 0u);
+    a.flags = (!h->per_robot && h->mode == kModeVelocity ? kFlagActualIsVelocity : 0u);
     const bool first_world = (h->step == 0);
     if (first_world) a.flags |= kFlagFirstWorldStep;
-    // the kernel uses calls != 0, calls >= nbuf (<= 32) and the ring position (calls - 1) % 10: fold large counts
-    // into [60, 70) so they stay small and steady-state launch sequences repeat with period 10
-    a.pid_calls = fold_pid_calls(h->pid_calls);
+    // the kernel uses calls != 0 and calls >= nbuf (<= 11): the count saturates, and the ring position follows the world
+    // step, so steady-state launch sequences repeat with period 10
+    a.pid_calls = sat_pid_calls(h->pid_calls);
+    a.ring_slot = ring_slot_of(h->step);
     set_weight_row(h, a);
     StepKernel kern = select_step_kernel(h, k);
     const dim3 block(step_block_threads(h, k));
@@ -984,10 +1065,10 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // (measured on MI355X: 3.57 -> 3.41 us/step at 4 096 x 4 cables; at 65 536 x 8 cables the 15 us kernels already
     // hide the host launch and the replay's fixed cost makes it 2 % slower, so only small batches use it)
     // (the ring position advances with every step, so a captured chain is only valid from the same position: chains
-    //  are captured and replayed at a.pid_calls == 60, i.e. window full and ring position 9 -> 0)
+    //  are captured and replayed from ring position 0 with the call count saturated (per-robot handles keep theirs on the device))
     if (record) a.obs = record + (size_t)done * image;
-    const bool steady = !record && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && a.pid_calls == 60 && (10 % k == 0) && h->cfg.publish_period == 0.0 &&
-                        (nsteps - done) >= kGraphChunk * k;
+    const bool steady = !record && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && (h->per_robot || a.pid_calls == kCallSat) &&
+                        a.ring_slot == 0 && (10 % k == 0) && h->cfg.publish_period == 0.0 && (nsteps - done) >= kGraphChunk * k;
     if (steady) {
       a.publish_mask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
       cdpr_engine::GraphEntry* ge = nullptr;
@@ -1002,7 +1083,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
           bool launched = true;
           for (int j = 0; j < kGraphChunk; ++j) {
             StepArgs aj = a;  // each node carries its own ring position
-            aj.pid_calls = 60 + (j * k) % 10;
+            aj.ring_slot = (j * k) % kWin;
             set_weight_row(h, aj);
             hipLaunchKernelGGL(kern, grid, block, 0, h->stream, aj);
             launched = launched && (hipGetLastError() == hipSuccess);
@@ -1028,7 +1109,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       const int steps = kGraphChunk * k;
       h->launches += kGraphChunk;
       h->step += (uint64_t)steps;
-      h->pid_calls = fold_pid_calls(h->pid_calls + steps);
+      h->pid_calls = sat_pid_calls(h->pid_calls + steps);
       h->prev_publish = sim_time(h->step - 1, h->cfg.dt);
       done += steps;
       continue;
@@ -1046,7 +1127,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;
-    h->pid_calls = fold_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
+    h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
     done += k;
   }
   if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
@@ -1145,7 +1226,13 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     g_create_error = why;
     return CDPR_ERR_INVALID;
   }
-  const bool general = cfg->per_robot_commands != 0 || !fast_path_obstacle(*cfg).empty();
+  const bool phys_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 ||
+                        cfg->anchor_inertia != 0.0;
+  // per-robot commands run on the register-resident kernels too (PR instantiations); only what those cannot represent
+  // (hold branch, cascades, long windows, cmdLimit 0), and per-robot modes combined with the lumped-leg physics or with
+  // two Pids that fit different derivative windows, take the general controller path
+  const bool pr_windows_differ = cfg->velocity_pid.d_buffer_length != cfg->position_pid.d_buffer_length || cfg->velocity_pid.d_degree != cfg->position_pid.d_degree;
+  const bool general = !fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && (phys_cfg || pr_windows_differ));
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -1175,7 +1262,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     // (16.4 vs 15.7 us/step: the duplicated 6x6 solves cost more than the second wave per SIMD hides), so AUTO
     // takes the pair mapping up to 32 768 robots at n = 8 (32 768: 9.5 vs 10.5 us/step; 49 152: 13.6 vs 11.2) and up
     // to 65 536 at n = 4 (65 536: 4.9 vs 5.2; 131 072: 8.5 vs 8.1).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
-    const bool can_pair = !general && !h->phys && (cfg->n_cables == 4 || cfg->n_cables == 8);
+    const bool can_pair = !general && !h->phys && !h->per_robot && (cfg->n_cables == 4 || cfg->n_cables == 8);
     uint32_t mapping = cfg->mapping;
     if (mapping == CDPR_MAP_AUTO) {
       const char* mv = std::getenv("CDPR_MAPPING");
@@ -1201,7 +1288,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   // latency and the extra LDS round trip loses (4 096 x 4: 4.18 vs 3.99 us by rocprofv3)
   h->onestep_v2 = h->fk || cfg->batch > 32768u;
   if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
-  h->split = h->onestep_v2 && !general && !h->phys && !h->lane_pair && !h->lowreg && h->fk && h->td && cfg->n_cables >= 6;
+  h->split = (h->onestep_v2 || h->per_robot) && !general && !h->phys && !h->lane_pair && !h->lowreg && h->fk && h->td && cfg->n_cables >= 6;
   if (const char* sp = std::getenv("CDPR_SPLIT")) h->split = h->split && sp[0] != '0';
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
@@ -1263,6 +1350,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     fill_gen_pid(cfg->velocity_pid, h->gpid[1]);
   }
   if (h->per_robot) {
+    if (!h->general && (e = hipMalloc(&h->d_target, cmd_bytes)) != hipSuccess) return fail("hipMalloc(target)", e);
     if ((e = hipMalloc(&h->d_mode, h->batch)) != hipSuccess) return fail("hipMalloc(mode)", e);
     for (int i = 0; i < 2; ++i)
       if ((e = hipMalloc(&h->d_mask[i], h->batch)) != hipSuccess) return fail("hipMalloc(mask)", e);
@@ -1728,15 +1816,21 @@ static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float
   a.flags = kFlagActualIsVelocity;
   if (h->step == 0) a.flags |= kFlagFirstWorldStep;
   // a Joy on jointVelocities while in Position mode resets the velocity Pid (JFC.cpp:113-115); the handle's own
-  // records stay untouched, the rollout starts from zeroed copies
-  if (h->mode != kModeVelocity) a.flags |= kFlagRolloutResetPid;
-  a.pid_calls = (h->mode == kModeVelocity) ? fold_pid_calls(h->pid_calls) : 0;
+  // records stay untouched, the rollout starts from zeroed copies (per-robot handles: decided per lane from meta)
+  if (!h->per_robot && h->mode != kModeVelocity) a.flags |= kFlagRolloutResetPid;
+  a.pid_calls = (h->mode == kModeVelocity) ? sat_pid_calls(h->pid_calls) : 0;
+  a.ring_slot = ring_slot_of(h->step);
+  if (h->per_robot) {
+    copy_pid_alt(h->pid_pos, a.alt);
+    a.meta = h->d_mode;
+  }
   a.roll_cmd = d_commands;
   a.roll_ref = d_ref;
   a.roll_cost = d_cost;
   a.roll_samples = (uint32_t)samples;
   const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  StepKernel kern = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysRollout) : pick_rollout_kernel(h->n, h->fk, h->td);
+  StepKernel kern = h->per_robot ? pick_pr_kernel<false, true>(h->n, h->fk, h->td)
+                    : h->phys  ? pick_phys_kernel(h->n, h->fk, h->td, kPhysRollout) : pick_rollout_kernel(h->n, h->fk, h->td);
   hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   ++h->launches;

@@ -36,13 +36,19 @@ CDPR_DEV void row_to_lds(const float4* src, float4* dst_row) {
 // parity tests on MI355X (cause not found in the ISA), so that form is not in the tree.  Also measured, neither faster:
 // weights staged in LDS instead of kernel arguments, cable constants re-read per Newton iteration.
 
-// Pid::update for every cable pair (Pid.cpp:122-191; the same statements as in cdpr_step_kernel).
-template <int NP>
-CDPR_DEV void pid_pairs(const StepArgs& a, int calls, const v2f (&desired)[NP], const v2f (&actual)[NP], const v2f (&win)[NP][kWin],
-                        v2f (&ierr)[NP], v2f (&f)[NP], v2f (&e_new)[NP], int& ring_slot, float& dbg_p, float& dbg_i, float& dbg_d) {
-  const bool full = calls >= a.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
-  ring_slot = (calls - 1) % kWin;     // the oldest sample sits there and is overwritten by the caller
-  const float (&wt)[kWin + 2] = a.wrow;  // the host put the weights of this ring position into the arguments
+// Pid::update for every cable pair (Pid.cpp:122-191; the same statements as in cdpr_step_kernel).  PR (per-robot handles):
+// `calls` and `is_vel` are the lane's own, the coefficients and weights are selected per lane, and a robot whose Pid was
+// just reset (calls == 0: "first call returns 0", Pid.cpp:123-126) keeps force 0 and its integral.
+template <int NP, bool PR = false>
+CDPR_DEV void pid_pairs(const StepArgs& a, int calls, bool is_vel, const v2f (&desired)[NP], const v2f (&actual)[NP], const v2f (&win)[NP][kWin],
+                        v2f (&ierr)[NP], v2f (&f)[NP], v2f (&e_new)[NP], float& dbg_p, float& dbg_i, float& dbg_d) {
+  const PidCoef c = pid_coef<PR>(a, is_vel);
+  const bool run = !PR || calls != 0;
+  const bool full = calls >= c.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
+  // the host put the weights of this launch's ring position (StepArgs::ring_slot) into the arguments; on per-robot handles
+  // both Pids fit the same window (same length and degree: cdpr_create sends anything else down the general path), so
+  // the weights stay scalars whatever the lane's mode
+  const float (&wt)[kWin + 2] = a.wrow;
   v2f error[NP], acc[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -56,25 +62,25 @@ CDPR_DEV void pid_pairs(const StepArgs& a, int calls, const v2f (&desired)[NP], 
   }
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const v2f p_term = splat(a.kp) * error[k];
+    const v2f p_term = splat(c.kp) * error[k];
     const v2f prev_ierr = ierr[k];
     v2f ie = fma2(a.dt, error[k], prev_ierr);
-    const v2f i_term = splat(a.ki) * ie;
-    const v2f i_cl = max2(min2(i_term, splat(a.imax)), splat(a.imin));  // Pid.cpp:143-152
-    const v2f ie_cl = i_cl * splat(a.inv_ki);
+    const v2f i_term = splat(c.ki) * ie;
+    const v2f i_cl = max2(min2(i_term, splat(c.imax)), splat(c.imin));  // Pid.cpp:143-152
+    const v2f ie_cl = i_cl * splat(c.inv_ki);
     ie.x = (i_cl.x != i_term.x) ? ie_cl.x : ie.x;
     ie.y = (i_cl.y != i_term.y) ? ie_cl.y : ie.y;
     const v2f derived = full ? acc[k] * splat(a.inv_dt) : splat(0.f);
-    const v2f d_term = splat(a.kd) * derived;
-    const v2f cmd = fma2(a.kf, desired[k], p_term) + i_cl + d_term;
-    v2f out = a.clamp_cmd ? max2(min2(cmd, splat(a.cmax)), splat(a.cmin)) : cmd;  // Pid.cpp:175-177
-    const v2f bumped = fma2(splat(a.dt) * error[k], splat(a.ki), out);             // Pid.cpp:181-184
+    const v2f d_term = splat(c.kd) * derived;
+    const v2f cmd = fma2(c.kf, desired[k], p_term) + i_cl + d_term;
+    v2f out = c.clamp ? max2(min2(cmd, splat(c.cmax)), splat(c.cmin)) : cmd;  // Pid.cpp:175-177
+    const v2f bumped = fma2(splat(a.dt) * error[k], splat(c.ki), out);             // Pid.cpp:181-184
     ie.x = (out.x != cmd.x) ? prev_ierr.x : ie.x;
     ie.y = (out.y != cmd.y) ? prev_ierr.y : ie.y;
     out.x = (out.x != cmd.x) ? bumped.x : out.x;
     out.y = (out.y != cmd.y) ? bumped.y : out.y;
-    ierr[k] = ie;
-    f[k] = out;
+    ierr[k] = run ? ie : prev_ierr;
+    f[k] = run ? out : splat(0.f);
     e_new[k] = error[k];
     if (k == 0) {
       dbg_p = p_term.x;
@@ -267,8 +273,8 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     v2f actual[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) actual[k] = actual_is_vel ? qd[k] : q[k];
-    int ring_slot;
-    pid_pairs<NP>(a, a.pid_calls, desired, actual, win, ierr, f, e_new, ring_slot, dbg_p, dbg_i, dbg_d);
+    const int ring_slot = a.ring_slot;
+    pid_pairs<NP>(a, a.pid_calls, actual_is_vel, desired, actual, win, ierr, f, e_new, dbg_p, dbg_i, dbg_d);
     dbg_wrote = true;
     if (live) {  // one ring row per cable pair (the one that takes the new error) + the integral rows
 #pragma unroll
@@ -431,7 +437,9 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
 #define CDPR_CTL_STAMP(i) CDPR_SPLIT_STAMP(i)
 #endif
 
-template <int N>
+// PR = true: per-robot handles (StepArgs::meta, see cdpr_step_kernel.hpp): the controller wave takes mode and Pid call
+// count per lane; the estimator wave is the same.
+template <int N, bool PR = false>
 __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(true);
@@ -651,7 +659,11 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f;
   bool dbg_wrote = false;
   const bool first_world = (a.flags & kFlagFirstWorldStep) != 0u;
-  if (!first_world && a.pid_calls != 0) {
+  uint32_t meta = 0u;
+  if (PR) meta = a.meta[rr];
+  const int calls = PR ? (int)(meta >> kMetaCallShift) : a.pid_calls;
+  if (PR && live && !first_world) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)min(calls + 1, (int)kMetaCallMax) << kMetaCallShift));
+  if (!first_world && (PR || calls != 0)) {
     v2f win[NP][kWin];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -661,13 +673,13 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
         win[k][2 * m + 1] = (v2f){wraw[k][m].z, wraw[k][m].w};
       }
     }
-    const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
+    const bool actual_is_vel = PR ? ((meta & kMetaModeMask) == kMetaVelocity) : ((a.flags & kFlagActualIsVelocity) != 0u);
     v2f actual[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) actual[k] = actual_is_vel ? qd[k] : q[k];
-    int ring_slot;
-    pid_pairs<NP>(a, a.pid_calls, desired, actual, win, ierr, f, e_new, ring_slot, dbg_p, dbg_i, dbg_d);
-    dbg_wrote = true;
+    const int ring_slot = a.ring_slot;
+    pid_pairs<NP, PR>(a, calls, actual_is_vel, desired, actual, win, ierr, f, e_new, dbg_p, dbg_i, dbg_d);
+    dbg_wrote = !PR || calls != 0;
     if (live) {
 #pragma unroll
       for (int m = 0; m < 5; ++m) {

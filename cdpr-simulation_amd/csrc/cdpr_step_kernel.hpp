@@ -54,6 +54,12 @@ enum StepFlags : uint32_t {
   kFlagActualIsVelocity = 1u << 2,  // velocity mode: Pid sees joint velocity (JFC.cpp:76), else position (JFC.cpp:88)
 };
 
+// One Pid's parameters as the kernels take them (Pid.cpp:64-73); see the "active Pid" fields of StepArgs.
+struct PidSet {
+  float kf, kp, ki, kd, inv_ki, imax, imin, cmax, cmin;
+  int clamp_cmd;
+};
+
 struct StepArgs {
   float4* state;
   float4* obs;
@@ -74,7 +80,22 @@ struct StepArgs {
   uint64_t publish_mask;  // bit k: publish observables at step k of this launch (PLG.cpp:236-242)
   size_t obs_step_stride; // float4 elements between the observable images of consecutive steps (0: every step
                           // overwrites the same image, as a topic does; > 0: a trajectory record keeps them all)
-  int pid_calls;      // Pid::update calls since the last reset, before this launch (uniform over the batch)
+  int pid_calls;      // Pid::update calls since the last reset, before this launch (uniform over the batch; the host lets
+                      // it saturate: only == 0 and >= nbuf matter)
+  int ring_slot;      // ring slot the error of this launch's FIRST step goes to; every further step takes the next one.
+                      // The ring position follows the WORLD step, (step + 8) % 10 (= the slot a handle that has run
+                      // without a Pid reset since Load would use), not the time of the last Pid reset: a reset robot
+                      // simply starts filling the ring wherever it stands, and derive() returns 0 until nbuf samples
+                      // are in (Pid.cpp:200-203), by when every slot the weights reach has been overwritten.  So robots
+                      // whose Pids were reset at different times (per-robot handles) share one pre-rotated weight row.
+  // per-robot handles (PR instantiations; cdpr_config_t.per_robot_commands): every robot has its own JointForceCalculator
+  // mode and Pid call count, as B independent plugin instances have (PLG.cpp:206-219).  meta[r]: bits 0-1 = mode
+  // (1 Position, 2 Velocity, JFC.h:35-37), bits 2-7 = Pid::update calls since the robot's last Pid reset, saturating at
+  // 63.  `cmd` is then the robot's ACTIVE target row (the latch kernel copies a Joy's row there when it reaches the
+  // robot), the "active Pid" fields below hold the VELOCITY Pid and `alt` the POSITION Pid's gains and limits (the two
+  // fit the same derivative window on such handles: one weight table, one nbuf).
+  uint8_t* meta;
+  PidSet alt;
   // world / body
   float dt, half_dt, dt_inv_mass, fgx, fgy, fgz;  // fg = m * g
   float ib[6], ibinv[6];                           // body inertia and inverse: xx yy zz xy xz yz
@@ -402,6 +423,33 @@ CDPR_DEV void normal_solve(const v2f (&jac)[NP][6], float lambda, float (&g)[6])
 #endif
 }
 
+// The Pid a lane runs this step.  Uniform handles: the kernel arguments themselves (scalars).  PR: the velocity or the
+// position Pid by the robot's own mode, one v_cndmask per coefficient.
+struct PidCoef {
+  float kf, kp, ki, kd, inv_ki, imax, imin, cmax, cmin;
+  int nbuf;
+  bool clamp;
+};
+template <bool PR>
+CDPR_DEV PidCoef pid_coef(const StepArgs& a, bool is_vel) {
+  PidCoef c;
+  const bool alt = PR && !is_vel;
+  c.kf = alt ? a.alt.kf : a.kf;
+  c.kp = alt ? a.alt.kp : a.kp;
+  c.ki = alt ? a.alt.ki : a.ki;
+  c.kd = alt ? a.alt.kd : a.kd;
+  c.inv_ki = alt ? a.alt.inv_ki : a.inv_ki;
+  c.imax = alt ? a.alt.imax : a.imax;
+  c.imin = alt ? a.alt.imin : a.imin;
+  c.cmax = alt ? a.alt.cmax : a.cmax;
+  c.cmin = alt ? a.alt.cmin : a.cmin;
+  c.nbuf = a.nbuf;  // per-robot handles: the same window for both Pids
+  c.clamp = (alt ? a.alt.clamp_cmd : a.clamp_cmd) != 0;
+  return c;
+}
+constexpr uint32_t kMetaModeMask = 3u, kMetaCallShift = 2u, kMetaCallMax = 63u;
+constexpr uint32_t kMetaPosition = 1u, kMetaVelocity = 2u;  // JFC.h:35-37
+
 struct Platform {
   float px, py, pz, qx, qy, qz, qw;
   float vx, vy, vz, wx, wy, wz;
@@ -661,7 +709,8 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
 // registers, and the true structure matrix is rebuilt after the Newton stage instead of living through it.
 // PHYS = true: the world step carries the lumped legs (integrate_lumped): handles created with any of
 // cdpr_config_t.passive_damping / leg_inertia / cable_axial_mass / anchor_point_mass / anchor_inertia.
-template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false, bool LOWREG = false, bool PHYS = false>
+// PR = true: per-robot handles (StepArgs::meta): mode, Pid call count and therefore the Pid in use are per lane.
+template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false, bool LOWREG = false, bool PHYS = false, bool PR = false>
 __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
@@ -748,14 +797,24 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
     }
     ierr[k] = (k & 1) ? (v2f){hraw[k / 2].z, hraw[k / 2].w} : (v2f){hraw[k / 2].x, hraw[k / 2].y};
   }
-  const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
-  int calls = a.pid_calls;
+  // uniform handles: mode and call count are launch arguments; PR: this robot's own (per lane)
+  uint32_t meta = 0u;
+  if (PR && !EXT) meta = a.meta[rr];
+  bool actual_is_vel = PR ? ((meta & kMetaModeMask) == kMetaVelocity) : ((a.flags & kFlagActualIsVelocity) != 0u);
+  int calls = PR ? (int)(meta >> kMetaCallShift) : a.pid_calls;
   float cost = 0.f, refx = 0.f, refy = 0.f, refz = 0.f;
   if (ROLLOUT) {
     refx = a.roll_ref[(size_t)rr * 3 + 0];
     refy = a.roll_ref[(size_t)rr * 3 + 1];
     refz = a.roll_ref[(size_t)rr * 3 + 2];
-    if (a.flags & kFlagRolloutResetPid) {
+    if (PR) {  // a jointVelocities Joy reaches a robot in Position mode: its velocity Pid starts from reset (JFC.cpp:113-115)
+      if (!actual_is_vel) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) ierr[k] = splat(0.f);
+        calls = 0;
+      }
+      actual_is_vel = true;
+    } else if (a.flags & kFlagRolloutResetPid) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
 #pragma unroll
@@ -845,10 +904,15 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 #pragma unroll
       for (int k = 0; k < NP; ++k) f[k] = first_world ? splat(0.f) : desired[k];
     } else if (!first_world) {
-      if (calls != 0) {  // not the first call since reset (Pid.cpp:123-126: that one returns 0)
-        const bool full = calls >= a.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
-        ring_slot = (calls - 1) % kWin;     // the oldest sample sits there and is overwritten below
-        const float* wt = a.wtab + ring_slot * (kWin + 2);  // weights pre-rotated for this ring position (scalar loads)
+      // PR: every lane runs the arithmetic, a robot whose Pid has just been reset (calls == 0) keeps force 0 and its integral
+      if (PR || calls != 0) {  // not the first call since reset (Pid.cpp:123-126: that one returns 0)
+        const PidCoef c = pid_coef<PR>(a, actual_is_vel);
+        const bool run = !PR || calls != 0;
+        const bool full = calls >= c.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
+        ring_slot = (a.ring_slot + step) % kWin;  // the oldest sample sits there and is overwritten below
+        // weights pre-rotated for this ring position (scalar loads); per-robot handles: both Pids fit the same window
+        // (cdpr_create sends anything else down the general path), so one row serves every lane whatever its mode
+        const float* wt = a.wtab + ring_slot * (kWin + 2);
         v2f error[NP], acc[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -863,25 +927,25 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
         }
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-          const v2f p_term = splat(a.kp) * error[k];
+          const v2f p_term = splat(c.kp) * error[k];
           const v2f prev_ierr = ierr[k];
           v2f ie = fma2(a.dt, error[k], prev_ierr);
-          const v2f i_term = splat(a.ki) * ie;
-          const v2f i_cl = max2(min2(i_term, splat(a.imax)), splat(a.imin));  // Pid.cpp:143-152
-          const v2f ie_cl = i_cl * splat(a.inv_ki);
+          const v2f i_term = splat(c.ki) * ie;
+          const v2f i_cl = max2(min2(i_term, splat(c.imax)), splat(c.imin));  // Pid.cpp:143-152
+          const v2f ie_cl = i_cl * splat(c.inv_ki);
           ie.x = (i_cl.x != i_term.x) ? ie_cl.x : ie.x;
           ie.y = (i_cl.y != i_term.y) ? ie_cl.y : ie.y;
           const v2f derived = full ? acc[k] * splat(a.inv_dt) : splat(0.f);
-          const v2f d_term = splat(a.kd) * derived;
-          const v2f cmd = fma2(a.kf, desired[k], p_term) + i_cl + d_term;
-          v2f out = a.clamp_cmd ? max2(min2(cmd, splat(a.cmax)), splat(a.cmin)) : cmd;  // Pid.cpp:175-177
-          const v2f bumped = fma2(splat(a.dt) * error[k], splat(a.ki), out);             // Pid.cpp:181-184
+          const v2f d_term = splat(c.kd) * derived;
+          const v2f cmd = fma2(c.kf, desired[k], p_term) + i_cl + d_term;
+          v2f out = c.clamp ? max2(min2(cmd, splat(c.cmax)), splat(c.cmin)) : cmd;  // Pid.cpp:175-177
+          const v2f bumped = fma2(splat(a.dt) * error[k], splat(c.ki), out);             // Pid.cpp:181-184
           ie.x = (out.x != cmd.x) ? prev_ierr.x : ie.x;
           ie.y = (out.y != cmd.y) ? prev_ierr.y : ie.y;
           out.x = (out.x != cmd.x) ? bumped.x : out.x;
           out.y = (out.y != cmd.y) ? bumped.y : out.y;
-          ierr[k] = ie;
-          f[k] = out;
+          ierr[k] = run ? ie : prev_ierr;
+          f[k] = run ? out : splat(0.f);
           e_new[k] = error[k];
           if (k == 0) {
             dbg_p = p_term.x;
@@ -889,9 +953,9 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
             dbg_d = d_term.x;
           }
         }
-        dbg_wrote = true;
+        dbg_wrote = run;
       }
-      ++calls;
+      calls = PR ? min(calls + 1, (int)kMetaCallMax) : calls + 1;
     }
 
     if (!EXT && !SINGLE && ring_slot >= 0) {
@@ -1074,6 +1138,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 
   CDPR_STAMP(6);
   // ---- store
+  if (PR && !EXT && live) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)calls << kMetaCallShift));
   if (live) {
     CDPR_STORE_STATE(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
     CDPR_STORE_STATE(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));

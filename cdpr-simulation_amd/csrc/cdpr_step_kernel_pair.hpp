@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
     if (!first_world) {
       if (calls != 0) {
         const bool full = calls >= a.nbuf;
-        ring_slot = (calls - 1) % kWin;
+        ring_slot = (a.ring_slot + step) % kWin;
         const float* wt = a.wtab + ring_slot * (kWin + 2);
         v2f error[NPL], acc[NPL];
 #pragma unroll

@@ -1411,6 +1411,94 @@ def test_rollout_launch_and_fetch_guard_their_order(pkg, mapping):
     eng.close()
 
 
+def test_per_robot_handle_is_bit_identical_to_the_uniform_one_when_every_robot_hears_every_joy(pkg, oracle, mapping):
+    """Per-robot handles run on the same register-resident kernels as uniform ones (PR instantiations: mode and Pid call
+    count per lane).  When every Joy reaches every robot the two must agree BIT FOR BIT — one-step launches (role-split
+    kernel at n = 8 with FK + TD, first-generation kernel otherwise), fused launches, the trajectory record, the MPC
+    rollout — through mode switches in both directions and both kinds in one update."""
+    once(mapping)
+    rng = np.random.default_rng(53)
+    for model, stages, B in ((pkg.eight_cable_model(), 3, 200), (pkg.cube_model(), 0, 130), (pkg.eight_cable_model(), 1, 70)):
+        n = model.n_cables
+        pose = perturbed_poses(model, B, rng, 0.03, 0.05).astype(np.float32)
+        uni = pkg.Engine(pkg.Config(model=model, batch=B, stages=stages), 0)
+        per = pkg.Engine(pkg.Config(model=model, batch=B, stages=stages, perRobotCommands=True), 0)
+        v = [rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32) for _ in range(3)]
+        p = [rng.uniform(-0.003, 0.003, (B, n)).astype(np.float32) for _ in range(2)]
+        everyone = np.ones(B, dtype=np.uint8)
+        for e in (uni, per):
+            e.set_platform_state(pose7=pose)
+            e.update(13)
+        def both(name, arr, masked):
+            getattr(uni, name)(arr)
+            getattr(per, name)(arr, mask=everyone) if masked else getattr(per, name)(arr)
+        def same(where):
+            for x, y in zip(uni.raw_state() + uni.joint_states() + uni.platform_state(), per.raw_state() + per.joint_states() + per.platform_state()):
+                assert np.array_equal(x, y), where
+        both("set_velocity_command", v[0], True)
+        uni.update(37), per.update(37)
+        same("velocity Joy, one-step launches")
+        both("set_position_command", p[0], False)
+        uni.update(30, 10), per.update(30, 10)
+        same("position Joy, fused launches")
+        both("set_velocity_command", v[1], True)
+        both("set_position_command", p[1], True)  # both kinds before one update: velocity first, then position (PLG.cpp:206-219)
+        uni.update(12), per.update(12)
+        same("both kinds in one update")
+        both("set_velocity_command", v[2], False)
+        ru, rp = uni.update_record(24, 8), per.update_record(24, 8)
+        for k in ru:
+            assert np.array_equal(ru[k], rp[k]), f"trajectory record {k}"
+        same("trajectory record")
+        cmds = rng.uniform(-0.03, 0.03, (B, 9, 5, n)).astype(np.float32)
+        ref = pose[:, :3] + np.float32([0.0, 0.0, 0.01])
+        assert np.array_equal(uni.rollout_velocity(cmds, ref), per.rollout_velocity(cmds, ref))
+        both("set_position_command", p[0], True)
+        uni.update(5), per.update(5)
+        assert np.array_equal(uni.rollout_velocity(cmds, ref), per.rollout_velocity(cmds, ref))  # rollout entered from Position mode
+        uni.close(), per.close()
+
+
+@pytest.mark.parametrize("kind", ["fast", "general"])
+def test_per_robot_rollout_record_and_fused_updates_against_the_oracle(pkg, oracle, mapping, kind):
+    """What per-robot handles gained with the register-resident path: fused launches, the trajectory record and the MPC
+    rollout, with robots in DIFFERENT modes and with Pids reset at different times — against the oracle (B independent
+    JointForceCalculator sets).  `general`: the same Joy sequence on a handle that still takes the general controller
+    path (velocityEpsilon = 0 keeps the hold branch formally alive), one-step updates only."""
+    once(mapping)
+    rng = np.random.default_rng(59)
+    B, n = 150, 8
+    model = pkg.eight_cable_model()
+    cfg = pkg.Config(model=model, batch=B, stages=3, perRobotCommands=True, **({"velocityEpsilon": 0.0} if kind == "general" else {}))
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.03, 0.05))
+    grp = rng.integers(0, 3, B)
+    v = rng.uniform(0.004, 0.03, (B, n)).astype(np.float32) * rng.choice([-1.0, 1.0], (B, n)).astype(np.float32)  # |v| > eps: no hold branch
+    p = rng.uniform(-0.003, 0.003, (B, n)).astype(np.float32)
+    spl = 10 if kind == "fast" else 1
+    for e in (eng, ora):
+        e.update(9)
+        e.set_velocity_command(v, mask=grp >= 1)
+    eng.update(23, spl), ora.update(23)
+    compare(eng, ora, where=f"{kind}: masked velocity Joy, fused")
+    for e in (eng, ora):
+        e.set_position_command(p, mask=grp == 2)   # group 2 back to Position: its Pid restarts 23 steps after group 1's
+        e.set_velocity_command(-v, mask=grp == 0)  # group 0 hears its first Joy now
+    eng.update(31, spl), ora.update(31)
+    compare(eng, ora, where=f"{kind}: mixed modes, fused")
+    if kind == "general":
+        return
+    rec = eng.update_record(17, 6)
+    ora.update(17)
+    compare(eng, ora, where="trajectory record")
+    assert np.array_equal(rec["pose"][-1], eng.platform_state()[0])
+    cmds = rng.uniform(-0.03, 0.03, (B, 12, 4, n)).astype(np.float32)
+    ref = (eng.platform_state()[0][:, :3] + np.float32([0.0, 0.0, 0.01])).astype(np.float32)
+    gc, oc = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref.astype(np.float64))
+    assert np.abs(gc - oc).max() < 1e-6 + 2e-4 * np.abs(oc).max()
+    eng.update(3), ora.update(3)  # the rollout left the handle's own state alone
+    compare(eng, ora, where="after the rollout")
+
+
 def test_c_example_matches_the_python_host(pkg, mapping, tmp_path):
     """examples/c_abi_demo.c (plain C99 against include/cdpr.h: config filled field by field, sine Joy, cdpr_update,
     cdpr_get_observables) prints what the Python host gets from the same calls."""
