@@ -5,6 +5,9 @@
   lowreg     524 288 x 8, all stages, one launch per step (auto-selected low-register kernel)
   general    16 384 x 8 on the general controller path (velocityEpsilon = 0.001: hold branch live)
   onestep    65 536 x 8, all stages, one launch per step (the headline kernel)
+  perrobot   65 536 x 8, all stages, one launch per step on a per_robot_commands handle: a third of the robots in
+             Position mode, the rest in Velocity mode with Pids reset at two different times (PR split kernel)
+  perrobot_general  16 384 x 8 per-robot handle forced onto the general controller path (velocityEpsilon = 0)
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,6 +47,17 @@ elif case in ("config2m1", "config2m2"):
     model, pose, command, _ = bench.make_workload(pkg, 4096, 4, 1234, 10)
     eng = pkg.Engine(pkg.Config(model=model, batch=4096), 0)
     eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
+    eng.update(reps * 3); eng.synchronize()
+elif case in ("perrobot", "perrobot_general"):
+    B = 65536 if case == "perrobot" else 16384
+    model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 10)
+    extra = {} if case == "perrobot" else {"velocityEpsilon": 0.0}
+    eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3, perRobotCommands=True, **extra), 0)
+    eng.set_platform_state(pose7=pose)
+    grp = np.arange(B) % 3
+    eng.set_velocity_command(np.where(np.abs(command(0)) < 1e-3, 1e-3, command(0)).astype(np.float32), mask=grp >= 1); eng.update(30)
+    eng.set_velocity_command(np.where(np.abs(command(1)) < 1e-3, 1e-3, command(1)).astype(np.float32), mask=grp == 2)
+    eng.set_position_command(np.zeros((B, 8), np.float32), mask=grp == 0); eng.update(20); eng.synchronize()
     eng.update(reps * 3); eng.synchronize()
 elif case == "general":
     B = 16384
