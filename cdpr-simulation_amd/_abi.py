@@ -5,7 +5,7 @@ loader and the function prototypes are in `_native.py`.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_CABLES = 8
 MAX_D_BUFFER = 32
 MAX_D_DEGREE = 4
@@ -82,4 +82,8 @@ class ConfigStruct(C.Structure):
         ("cable_axial_mass", C.c_double),
         ("anchor_point_mass", C.c_double),
         ("anchor_inertia", C.c_double),
+        ("travel_lower", C.c_double),
+        ("travel_upper", C.c_double),
+        ("travel_stop", C.c_uint32),
+        ("reserved3_", C.c_uint32),
     ]

@@ -68,6 +68,12 @@ class Model:
     cable_axial_mass: float = 0.0   # cable link sliding along the cable axis, cube.sdf:368 (0.001)
     anchor_point_mass: float = 0.0  # virt_Xpf + virt_Ypf at each platform anchor (2 x 0.001)
     anchor_inertia: float = 0.0     # virt_Xpf turning with the platform (0.001)
+    # travel limits of the prismatic joints (cube.sdf:436-437: -0.5196 / 0.5196); (0, 0) = none.  travel_stop > 0: model
+    # the joint stop itself (inelastic; that many Gauss-Seidel sweeps over the cables per step, 4 hold several joints on
+    # their stops at once), not only the flag (Engine.limit_state)
+    travel_lower: float = 0.0
+    travel_upper: float = 0.0
+    travel_stop: int = 0
     f_min: float = 5.0  # cube.yaml:9 `min`
     f_max: float = 100.0  # cube.yaml:9 `effort`
 
@@ -226,6 +232,10 @@ class Config:
                 raise ValueError(f"{name}Controller Ddegree must be in 1..{_abi.MAX_D_DEGREE} and < Dbuffer")
             if not 0 <= p.pFilter.cascade <= _abi.MAX_CASCADE or not 0 <= p.dFilter.cascade <= _abi.MAX_CASCADE:
                 raise ValueError(f"{name}Controller cascade must be in 0..{_abi.MAX_CASCADE}")
+        if self.model.travel_lower > self.model.travel_upper or (self.model.travel_stop and self.model.travel_lower == self.model.travel_upper):
+            raise ValueError("travel limits need lower < upper (lower == upper == 0: no limits, and then no stop)")
+        if not 0 <= int(self.model.travel_stop) <= 64:
+            raise ValueError("travel_stop (sweeps of the joint stop) must be in 0..64")
         if self.stages & (_abi.STAGE_FK | _abi.STAGE_TD) and n < 6:
             raise ValueError("FK / tension distribution need at least 6 cables")
 
@@ -261,6 +271,9 @@ class Config:
         s.cable_axial_mass = float(m.cable_axial_mass)
         s.anchor_point_mass = float(m.anchor_point_mass)
         s.anchor_inertia = float(m.anchor_inertia)
+        s.travel_lower = float(m.travel_lower)
+        s.travel_upper = float(m.travel_upper)
+        s.travel_stop = int(m.travel_stop)
         _fill_pid(s.velocity_pid, self.velocityController)
         _fill_pid(s.position_pid, self.effective_position_pid())
         s.velocity_epsilon = float(self.velocityEpsilon)

@@ -216,6 +216,9 @@ std::string validate(const cdpr_config_t& c) {
     if (p->d_degree < 1 || p->d_degree > CDPR_MAX_D_DEGREE || p->d_degree >= p->d_buffer_length) return "d_degree out of range";
     if (p->p_filter.cascade > CDPR_MAX_CASCADE || p->d_filter.cascade > CDPR_MAX_CASCADE) return "filter cascade out of range";
   }
+  if (c.travel_lower > c.travel_upper) return "travel_lower must not exceed travel_upper";
+  if (c.travel_stop && !(c.travel_lower < c.travel_upper)) return "travel_stop needs travel limits (travel_lower < travel_upper)";
+  if (c.travel_stop > 64) return "travel_stop (sweeps of the joint stop) must be <= 64";
   if ((c.stages & (CDPR_STAGE_FK | CDPR_STAGE_TD)) && c.n_cables < 6) return "FK / tension distribution need >= 6 cables";
   if ((c.stages & CDPR_STAGE_FK) && (c.fk_max_iterations < 1 || c.fk_max_iterations > 64)) return "fk_max_iterations out of range";
   if ((c.stages & CDPR_STAGE_TD) && !(c.td_f_max > c.td_f_min)) return "td_f_max must exceed td_f_min";
@@ -301,6 +304,12 @@ void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   k.effort = (float)c.effort_limit;
   k.vel_limit = (float)c.velocity_limit;
   k.unilateral = c.unilateral_cables ? 1 : 0;
+  k.travel_lo = (float)c.travel_lower;
+  k.travel_hi = (float)c.travel_upper;
+  k.travel_on = (c.travel_lower != 0.0 || c.travel_upper != 0.0) ? 1 : 0;
+  k.travel_stop = k.travel_on ? (int)c.travel_stop : 0;
+  k.inv_mass = (float)(1.0 / c.mass);
+  k.ph_lumped = (c.passive_damping != 0.0 || c.leg_inertia != 0.0 || c.cable_axial_mass != 0.0 || c.anchor_point_mass != 0.0 || c.anchor_inertia != 0.0) ? 1 : 0;
   k.ph_c = (float)c.passive_damping;
   k.ph_jleg = (float)c.leg_inertia;
   k.ph_max = (float)c.cable_axial_mass;
@@ -1226,8 +1235,9 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     g_create_error = why;
     return CDPR_ERR_INVALID;
   }
+  // the PHYS instantiations carry the lumped legs and the joint stop
   const bool phys_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 ||
-                        cfg->anchor_inertia != 0.0;
+                        cfg->anchor_inertia != 0.0 || cfg->travel_stop != 0;
   // per-robot commands run on the register-resident kernels too (PR instantiations); only what those cannot represent
   // (hold branch, cascades, long windows, cmdLimit 0), and per-robot modes combined with the lumped-leg physics or with
   // two Pids that fit different derivative windows, take the general controller path
@@ -1254,15 +1264,15 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
   h->general = general;
   h->per_robot = cfg->per_robot_commands != 0;
-  h->phys = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 ||
-            cfg->anchor_inertia != 0.0;
+  h->phys = phys_cfg;
   {
     // Mapping: measured on MI355X (scripts/ab_bench.py), two lanes per robot win while the batch leaves SIMDs
     // under-filled (16 384 x 8 cables: 9.0 vs 10.2 us/step; 4 096 x 4: 3.0 vs 3.4) and lose from 65 536 robots on
     // (16.4 vs 15.7 us/step: the duplicated 6x6 solves cost more than the second wave per SIMD hides), so AUTO
     // takes the pair mapping up to 32 768 robots at n = 8 (32 768: 9.5 vs 10.5 us/step; 49 152: 13.6 vs 11.2) and up
     // to 65 536 at n = 4 (65 536: 4.9 vs 5.2; 131 072: 8.5 vs 8.1).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
-    const bool can_pair = !general && !h->phys && !h->per_robot && (cfg->n_cables == 4 || cfg->n_cables == 8);
+    const bool travel_on = cfg->travel_lower != 0.0 || cfg->travel_upper != 0.0;  // the lane-pair kernel has no travel-limit flag
+    const bool can_pair = !general && !h->phys && !h->per_robot && !travel_on && (cfg->n_cables == 4 || cfg->n_cables == 8);
     uint32_t mapping = cfg->mapping;
     if (mapping == CDPR_MAP_AUTO) {
       const char* mv = std::getenv("CDPR_MAPPING");
@@ -1796,7 +1806,19 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
   }
   int rc = cdpr_get_joint_states(h, nullptr, nullptr, tension);  // applied force == distributed tension
   if (rc != CDPR_OK) return rc;
-  return fetch_fields(h, h->d_obs, {{3, 3}}, infeasible, 1u);
+  rc = fetch_fields(h, h->d_obs, {{3, 3}}, infeasible, 1u);
+  if (rc == CDPR_OK && infeasible)
+    for (uint32_t b = 0; b < h->batch; ++b) infeasible[b] &= 1;  // the travel-limit mask shares the component (pack_flags)
+  return rc;
+}
+
+int cdpr_get_limit_state(cdpr_handle_t h, uint32_t* cable_mask) {
+  if (!h || !cable_mask) return CDPR_ERR_INVALID;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  int rc = fetch_fields(h, h->d_obs, {{3, 3}}, cable_mask, 1u);
+  if (rc == CDPR_OK)
+    for (uint32_t b = 0; b < h->batch; ++b) cable_mask[b] >>= 1;  // bit 0 is the tension-distribution flag
+  return rc;
 }
 
 // Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in

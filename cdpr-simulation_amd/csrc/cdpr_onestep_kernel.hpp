@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     d[4] = applied[0].x;
   }
   if (publish && live) {  // the rest of the observables
-    store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+    store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, pack_flags(td_flag, travel_mask<N>(a, q))));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     d[4] = applied[0].x;
   }
   if (publish && live) {
-    store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, fk_it, td_flag));
+    store_slot(a.obs, st, 3, woff, make_float4(s.wz, fk_res, fk_it, a.travel_on ? pack_flags((int)td_flag, travel_mask<N>(a, q)) : td_flag));
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;

@@ -102,6 +102,11 @@ struct StepArgs {
   float damping, effort;                           // joint damping; SetForce clamp (effort < 0: none)
   float vel_limit;                                 // SetForce velocity truncation (<= 0: none)
   int unilateral;                                  // cables cannot push
+  // travel limits of the prismatic joints (cube.sdf:436-437): flag q outside [lo, hi] per cable (travel_on); PHYS
+  // instantiations also model the stop (travel_stop, see apply_travel_stop)
+  float travel_lo, travel_hi, inv_mass;
+  int travel_on, travel_stop;
+  int ph_lumped;                                   // PHYS instantiations: any lumped-leg term non-zero (else the plain world step)
   // lumped legs (PHYS instantiations only; cdpr_config_t.passive_damping ...): joint damping c of the passive
   // revolutes, inertia turning with a leg, mass sliding along the cable, point mass at each platform anchor,
   // n x the inertia each leg adds to the platform, gravity (for the point masses' weight)
@@ -457,7 +462,8 @@ struct Platform {
 
 // World step (Gazebo/ODE restated): semi-implicit Euler on the free platform
 // under the wrench w (force, torque about the platform origin, world frame).
-CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
+CDPR_DEV void integrate_pose(const StepArgs& a, Platform& s);
+CDPR_DEV void integrate_velocity(const StepArgs& a, Platform& s, const float (&w)[6]) {
   const Rot r = quat_to_rot(s.qx, s.qy, s.qz, s.qw);
   s.vx = fmaf(a.dt_inv_mass, w[0], s.vx);
   s.vy = fmaf(a.dt_inv_mass, w[1], s.vy);
@@ -481,6 +487,10 @@ CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
   s.wx = fmaf(a.dt, fmaf(r.r02, abz, fmaf(r.r01, aby, r.r00 * abx)), s.wx);
   s.wy = fmaf(a.dt, fmaf(r.r12, abz, fmaf(r.r11, aby, r.r10 * abx)), s.wy);
   s.wz = fmaf(a.dt, fmaf(r.r22, abz, fmaf(r.r21, aby, r.r20 * abx)), s.wz);
+}
+
+// second half of the world step: p+ = p + dt v+, q+ = normalize(q + dt/2 [w+, 0] (x) q)
+CDPR_DEV void integrate_pose(const StepArgs& a, Platform& s) {
   s.px = fmaf(a.dt, s.vx, s.px);
   s.py = fmaf(a.dt, s.vy, s.py);
   s.pz = fmaf(a.dt, s.vz, s.pz);
@@ -496,6 +506,67 @@ CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
   s.qw = nw * inv;
 }
 
+CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
+  integrate_velocity(a, s, w);
+  integrate_pose(a, s);
+}
+
+// Travel limits of the prismatic joints (cube.sdf:436-437): bit i set where joint i's position lies outside [lo, hi].
+template <int N>
+CDPR_DEV uint32_t travel_mask(const StepArgs& a, const v2f (&q)[cable_pairs(N)]) {
+  uint32_t m = 0u;
+  if (a.travel_on) {
+#pragma unroll
+    for (int k = 0; k < cable_pairs(N); ++k) {
+      m |= (q[k].x < a.travel_lo || q[k].x > a.travel_hi) ? (1u << (2 * k)) : 0u;
+      if (2 * k + 1 < N) m |= (q[k].y < a.travel_lo || q[k].y > a.travel_hi) ? (1u << (2 * k + 1)) : 0u;
+    }
+  }
+  return m;
+}
+// observable slot 3, component w: tension-distribution flag in bit 0, travel-limit mask above it (<= 511: exact in a float)
+CDPR_DEV float pack_flags(int td_flag, uint32_t limit_mask) { return (float)((uint32_t)td_flag | (limit_mask << 1)); }
+
+// The joint stop itself ([EXT] Gazebo/ODE -> reduced; cdpr_config_t.travel_stop), between the velocity and the pose half
+// of the world step: a joint at or beyond a limit that still moves outward takes the impulse that brings its rate to
+// zero, lambda = qdot_i / (J_i M^-1 J_i^T), twist += M^-1 J_i^T lambda, M the platform's own mass and inertia; cables in
+// index order, a.travel_stop sweeps (projected Gauss-Seidel; with several joints on their stops one sweep lets them creep).
+// q and jac are those of the state at t_k (the pose has not moved yet).
+template <int N>
+CDPR_DEV void apply_travel_stop(const StepArgs& a, Platform& s, const v2f (&q)[cable_pairs(N)], const v2f (&jac)[cable_pairs(N)][6]) {
+  const Rot r = quat_to_rot(s.qx, s.qy, s.qz, s.qw);
+  for (int sweep = 0; sweep < a.travel_stop; ++sweep)
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int k = i / 2;
+    float j[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) j[c] = (i & 1) ? jac[k][c].y : jac[k][c].x;
+    const float qi = (i & 1) ? q[k].y : q[k].x;
+    const float qdn = -fmaf(j[5], s.wz, fmaf(j[4], s.wy, fmaf(j[3], s.wx, fmaf(j[2], s.vz, fmaf(j[1], s.vy, j[0] * s.vx)))));
+    const bool hit = (qi >= a.travel_hi && qdn > 0.f) || (qi <= a.travel_lo && qdn < 0.f);
+    // Iw^-1 (rb x u) = R Ib^-1 R^T (rb x u)
+    const float tbx = fmaf(r.r20, j[5], fmaf(r.r10, j[4], r.r00 * j[3]));
+    const float tby = fmaf(r.r21, j[5], fmaf(r.r11, j[4], r.r01 * j[3]));
+    const float tbz = fmaf(r.r22, j[5], fmaf(r.r12, j[4], r.r02 * j[3]));
+    const float abx = fmaf(a.ibinv[4], tbz, fmaf(a.ibinv[3], tby, a.ibinv[0] * tbx));
+    const float aby = fmaf(a.ibinv[5], tbz, fmaf(a.ibinv[1], tby, a.ibinv[3] * tbx));
+    const float abz = fmaf(a.ibinv[2], tbz, fmaf(a.ibinv[5], tby, a.ibinv[4] * tbx));
+    const float awx = fmaf(r.r02, abz, fmaf(r.r01, aby, r.r00 * abx));
+    const float awy = fmaf(r.r12, abz, fmaf(r.r11, aby, r.r10 * abx));
+    const float awz = fmaf(r.r22, abz, fmaf(r.r21, aby, r.r20 * abx));
+    const float d = fmaf(j[5], awz, fmaf(j[4], awy, fmaf(j[3], awx, fmaf(j[2], j[2], fmaf(j[1], j[1], j[0] * j[0])) * a.inv_mass)));
+    const float lam = hit ? qdn / d : 0.f;
+    const float lm = lam * a.inv_mass;
+    s.vx = fmaf(lm, j[0], s.vx);
+    s.vy = fmaf(lm, j[1], s.vy);
+    s.vz = fmaf(lm, j[2], s.vz);
+    s.wx = fmaf(lam, awx, s.wx);
+    s.wy = fmaf(lam, awy, s.wy);
+    s.wz = fmaf(lam, awz, s.wz);
+  }
+}
+
 // World step with the lumped legs ([EXT] -> reduced; closed forms in DESIGN.md section 1).  Leg i turns about its frame anchor with angular velocity (u x vP)/L, vP = v + omega x rb.  The
 // passive joint dampers (universal pair at the frame, spherical triple at the platform, c each) act on the platform
 // through a transverse force at the anchor, Fd = -(c/L)(2 vt/L - omega x u) (massless-leg torque balance), plus the
@@ -505,8 +576,8 @@ CDPR_DEV void integrate(const StepArgs& a, Platform& s, const float (&w)[6]) {
 // matrix row).  w comes in as the cable + gravity wrench and leaves untouched; velocity-product terms of the legs are
 // neglected.  Two cables per instruction, like everything per-cable here.
 template <int N>
-CDPR_DEV void integrate_lumped(const StepArgs& a, const float* lds, Platform& s, const v2f (&jac)[cable_pairs(N)][6],
-                               const v2f (&len)[cable_pairs(N)], float (&w)[6]) {
+CDPR_DEV void integrate_lumped_velocity(const StepArgs& a, const float* lds, Platform& s, const v2f (&jac)[cable_pairs(N)][6],
+                                        const v2f (&len)[cable_pairs(N)], float (&w)[6]) {
   constexpr int NP = cable_pairs(N);
   const Rot r = quat_to_rot(s.qx, s.qy, s.qz, s.qw);
   v2f fx = splat(0.f), fy = splat(0.f), fz = splat(0.f), tx = splat(0.f), ty = splat(0.f), tz = splat(0.f);
@@ -615,19 +686,6 @@ CDPR_DEV void integrate_lumped(const StepArgs& a, const float* lds, Platform& s,
   s.wx = fmaf(a.dt, rhs[3], s.wx);
   s.wy = fmaf(a.dt, rhs[4], s.wy);
   s.wz = fmaf(a.dt, rhs[5], s.wz);
-  s.px = fmaf(a.dt, s.vx, s.px);
-  s.py = fmaf(a.dt, s.vy, s.py);
-  s.pz = fmaf(a.dt, s.vz, s.pz);
-  const float h = a.half_dt;
-  const float nx = fmaf(h, fmaf(-s.wz, s.qy, fmaf(s.wy, s.qz, s.qw * s.wx)), s.qx);
-  const float ny = fmaf(h, fmaf(-s.wx, s.qz, fmaf(s.wz, s.qx, s.qw * s.wy)), s.qy);
-  const float nz = fmaf(h, fmaf(-s.wy, s.qx, fmaf(s.wx, s.qy, s.qw * s.wz)), s.qz);
-  const float nw = fmaf(-h, fmaf(s.wz, s.qz, fmaf(s.wy, s.qy, s.wx * s.qx)), s.qw);
-  const float inv = __frsqrt_rn(fmaf(nw, nw, fmaf(nz, nz, fmaf(ny, ny, nx * nx))));
-  s.qx = nx * inv;
-  s.qy = ny * inv;
-  s.qz = nz * inv;
-  s.qw = nw * inv;
 }
 
 // Slot row `slot` of robot at byte offset `off` (= 16 * robot, 32-bit): SGPR row base + one shared VGPR
@@ -1085,7 +1143,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
       store_slot(obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
 #endif
-      store_slot(obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+      store_slot(obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, pack_flags(td_flag, travel_mask<N>(a, q))));
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int k0 = 2 * g, k1 = (2 * g + 1 < NP) ? 2 * g + 1 : 2 * g;
@@ -1121,10 +1179,16 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       w[3] = -w[3];
       w[4] = -w[4];
       w[5] = -w[5];
-      if (PHYS)
-        integrate_lumped<N>(a, lds, s, jac, len, w);
-      else
+      if (PHYS) {  // lumped legs and / or the joint stop (wave-uniform choices)
+        if (a.ph_lumped)
+          integrate_lumped_velocity<N>(a, lds, s, jac, len, w);
+        else
+          integrate_velocity(a, s, w);
+        if (a.travel_stop) apply_travel_stop<N>(a, s, q, jac);
+        integrate_pose(a, s);
+      } else {
         integrate(a, s, w);
+      }
     }
     if (ROLLOUT) {
       const float ex = s.px - refx, ey = s.py - refy, ez = s.pz - refz;

@@ -200,6 +200,13 @@ class Engine:
         self._check(lib().cdpr_get_td_state(self._h, _fp(t), f.ctypes.data_as(C.POINTER(C.c_int32))))
         return t, f
 
+    def limit_state(self) -> np.ndarray:
+        """Travel limits (Model.travel_lower / travel_upper; cube.sdf:436-437): uint32[B], bit i set where joint i's
+        position was outside the range at the last published step."""
+        m = np.empty(self.B, dtype=np.uint32)
+        self._check(lib().cdpr_get_limit_state(self._h, m.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return m
+
     # -- one-shot batched kinematics on caller data
     def solve_ik(self, pose7, twist6=None):
         """Joint::Position / GetVelocity restated: q[B,n], qdot[B,n], J[B,n,6] for the given poses (and twists)."""

@@ -29,8 +29,10 @@ def rpy_to_quat(roll: float, pitch: float, yaw: float) -> np.ndarray:
     return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
 
 
-def load_yaml(path_or_text: str, home_xyz: Optional[Sequence[float]] = None) -> Model:
-    """`home_xyz` overrides `platform.position.xyz` (for cube.yaml pass (0, 0, 0.3): the SDF that is actually loaded
+def load_yaml(path_or_text: str, home_xyz: Optional[Sequence[float]] = None, travel_limits: bool = True) -> Model:
+    """The prismatic joints' travel range is what gen_cdpr.py derives from the frame box (gen_cdpr.py:104,182-183:
+    +-0.5 |frame.upper - frame.lower|, the 0.51961524 of cube.sdf:436-437); `travel_limits=False` leaves it out.
+    `home_xyz` overrides `platform.position.xyz` (for cube.yaml pass (0, 0, 0.3): the SDF that is actually loaded
     has the platform there, cube.sdf:310, while the yaml still says z = 2)."""
     import yaml
 
@@ -44,6 +46,10 @@ def load_yaml(path_or_text: str, home_xyz: Optional[Sequence[float]] = None) -> 
     xyz = list(home_xyz) if home_xyz is not None else list(pos.get("xyz", [0.0, 0.0, 0.0]))
     rpy = list(pos.get("rpy", [0.0, 0.0, 0.0]))
     act = y.get("joints", {}).get("actuated", {})
+    frame = y.get("frame", {}) or {}
+    half = 0.0
+    if travel_limits and "lower" in frame and "upper" in frame:
+        half = 0.5 * float(np.linalg.norm(np.asarray(frame["upper"], dtype=np.float64) - np.asarray(frame["lower"], dtype=np.float64)))
     return Model(
         frame_anchors=fa,
         platform_anchors=pa,
@@ -55,6 +61,8 @@ def load_yaml(path_or_text: str, home_xyz: Optional[Sequence[float]] = None) -> 
         effort_limit=float(act.get("effort", 100.0)),
         f_min=float(act.get("min", 5.0)),
         f_max=float(act.get("effort", 100.0)),
+        travel_lower=-half,
+        travel_upper=half,
     )
 
 
@@ -63,8 +71,10 @@ def _pose(elem) -> np.ndarray:
     return np.array([float(v) for v in p.text.split()]) if p is not None else np.zeros(6)
 
 
-def load_sdf(path_or_text: str, f_min: float = 5.0, lumped_links: bool = False) -> Model:
-    """`lumped_links=True` also reads what the massless-cable reduction drops into the model's lumped
+def load_sdf(path_or_text: str, f_min: float = 5.0, lumped_links: bool = False, travel_limits: bool = True, travel_stop: int = 0) -> Model:
+    """The prismatic joints' travel limits `<lower>` / `<upper>` (cube.sdf:436-437) go into the model (`travel_limits=False`
+    leaves them out): the engine then flags every joint that leaves the range (`Engine.limit_state`); `travel_stop=k`
+    also models the stop (k Gauss-Seidel sweeps per step; 4 is plenty).  `lumped_links=True` also reads what the massless-cable reduction drops into the model's lumped
     leg terms: the damping of the passive revolute joints (`rev_X<i>`, cube.sdf:396) and the masses / inertias of the
     five small links of every leg (cube.sdf:359-369, 372-382, ...): virt_X + virt_Y + cable + virt_Ypf turn with the leg
     (leg_inertia), the cable link slides along the axis (cable_axial_mass), virt_Xpf + virt_Ypf ride on the platform
@@ -93,6 +103,7 @@ def load_sdf(path_or_text: str, f_min: float = 5.0, lumped_links: bool = False) 
     if not idx or idx != list(range(len(idx))):
         raise ValueError("invalid joint count")  # CdprGazeboPlugin.cpp:167-168
     fa, pa, damping, effort = [], [], None, None
+    lower = upper = 0.0
     for i in idx:
         fa.append(_pose(links[f"virt_X{i}"])[:3])
         world_attach = _pose(links[f"virt_Xpf{i}"])[:3]
@@ -100,6 +111,11 @@ def load_sdf(path_or_text: str, f_min: float = 5.0, lumped_links: bool = False) 
         axis = joints[f"cable{i}"].find("axis")
         damping = float(axis.find("dynamics/damping").text)
         effort = float(axis.find("limit/effort").text)
+        lo, hi = axis.find("limit/lower"), axis.find("limit/upper")
+        if travel_limits and lo is not None and hi is not None and i == idx[0]:
+            lower, upper = float(lo.text), float(hi.text)
+        elif travel_limits and lo is not None and hi is not None and (float(lo.text), float(hi.text)) != (lower, upper):
+            raise ValueError("the engine takes one travel range for all cables; the SDF gives different ones")
     lumped = {}
     if lumped_links:
         def inertial(name):
@@ -129,5 +145,8 @@ def load_sdf(path_or_text: str, f_min: float = 5.0, lumped_links: bool = False) 
         effort_limit=effort,
         f_min=f_min,
         f_max=effort,
+        travel_lower=lower,
+        travel_upper=upper,
+        travel_stop=int(travel_stop) if lower < upper else 0,
         **lumped,
     )

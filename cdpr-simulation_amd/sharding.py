@@ -134,6 +134,11 @@ class ShardedEngine:
     def td_state(self):
         return self._gather("td_state")
 
+    def limit_state(self):
+        import numpy as np
+
+        return np.concatenate([e.limit_state() for e in self.engines])
+
 
 class LocalSpinBarrier:
     """Barrier between the rank processes of ONE node through a few bytes of shared memory (/dev/shm): every rank owns

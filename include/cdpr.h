@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CDPR_ABI_VERSION 2u
+#define CDPR_ABI_VERSION 3u
 #define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
 #define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
 #define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
@@ -140,6 +140,21 @@ typedef struct cdpr_config {
                                        (cube.sdf:368: 0.001 kg) */
   double anchor_point_mass;         /* mass carried at each platform anchor: virt_Xpf, virt_Ypf (cube.sdf:456,485: 2 x 0.001 kg) */
   double anchor_inertia;            /* inertia each leg adds to the platform: virt_Xpf (cube.sdf:448-455: 0.001 kg m^2) */
+
+  /* Travel limits of the prismatic joints (cube.sdf:436-437: <lower>-0.5196</lower> <upper>0.5196</upper>; [EXT]
+   * Gazebo/ODE enforces them as joint stops).  lower == upper == 0 (a zero-initialised struct): no limits.  With limits
+   * set, every step raises a per-cable flag where the joint position q_i = L0_i - L_i lies outside [lower, upper]
+   * (cdpr_get_limit_state).  travel_stop > 0 additionally models the stop itself, inelastically: after the velocity
+   * update of the world step, a joint at or beyond a limit that is still moving outward (q_i >= upper and qdot_i > 0, or
+   * q_i <= lower and qdot_i < 0) takes the impulse that brings its rate to zero, lambda = qdot_i / (J_i M^-1 J_i^T),
+   * twist += M^-1 J_i^T lambda, with M the platform's own mass and inertia; cables in index order, travel_stop sweeps
+   * over the cables (projected Gauss-Seidel on the velocity constraints: what ODE's quickstep iterates 50 times [EXT];
+   * with several joints on their stops one sweep lets them creep, 4 sweeps hold them to within one step's travel;
+   * DESIGN.md section 1). */
+  double travel_lower;
+  double travel_upper;
+  uint32_t travel_stop;             /* 0: flag only; k > 0: k sweeps of the stop (<= 64) */
+  uint32_t reserved3_;
 } cdpr_config_t;
 
 typedef struct cdpr_engine *cdpr_handle_t;
@@ -245,6 +260,10 @@ int cdpr_get_fk_state(cdpr_handle_t h, float *pose7, float *residual, int32_t *i
 /* Tension distribution of the last PUBLISHED step (CDPR_STAGE_TD): tension[B][n] = the force applied to the joints
  * (after the bounds and the SetForce limits: the `effort` observable), infeasible[B] = 1 where a bound was active. */
 int cdpr_get_td_state(cdpr_handle_t h, float *tension, int32_t *infeasible);
+/* Travel limits (cdpr_config_t.travel_lower / travel_upper; cube.sdf:436-437): cable_mask[B], bit i set where joint i's
+ * position was outside [lower, upper] at the last PUBLISHED step (travels with the observables).  All zero when the
+ * configuration sets no limits. */
+int cdpr_get_limit_state(cdpr_handle_t h, uint32_t *cable_mask);
 /* Current platform state (not decimated by publish_period), for checkpoints
  * and tests: pose7[B][7], twist6[B][6]. */
 int cdpr_get_raw_state(cdpr_handle_t h, float *pose7, float *twist6);

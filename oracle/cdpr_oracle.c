@@ -571,6 +571,7 @@ typedef struct orc_robot {
   double pub_pose[7], pub_twist[6];
   double pub_fk_res;            /* estimator residual / iteration count and the infeasibility flag travel with the */
   int32_t pub_fk_iters, pub_td_flag; /* observables (they share a row with them on the device): as of the last PUBLISHED step */
+  uint32_t limit_mask, pub_limit_mask; /* bit i: joint i outside its travel range (cube.sdf:436-437) at this / the last published step */
   double dbg[CDPR_PID_DEBUG_AXES];
 } orc_robot;
 
@@ -705,6 +706,13 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
   /* PLG.cpp:222-228: per-cable force from the state at t_k */
   for (unsigned i = 0; i < n; ++i) f[i] = jfc_update(&r->jfc[i], now_ns, now, q[i], qd[i]);
 
+  /* travel limits of the prismatic joints (cube.sdf:436-437; [EXT] Gazebo/ODE joint stops): which joints are outside */
+  const int travel_on = cfg->travel_lower != 0.0 || cfg->travel_upper != 0.0;
+  r->limit_mask = 0;
+  if (travel_on)
+    for (unsigned i = 0; i < n; ++i)
+      if (q[i] < cfg->travel_lower || q[i] > cfg->travel_upper) r->limit_mask |= 1u << i;
+
   /* `pid` debug topic: the global pidMsg keeps stale entries when a branch does
    * not write them (Pid.cpp:139-142,158-168) */
   {
@@ -770,6 +778,7 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
     r->pub_fk_res = r->fk_res;
     r->pub_fk_iters = r->fk_iters;
     r->pub_td_flag = r->td_flag;
+    r->pub_limit_mask = r->limit_mask;
   }
 
   /* world step: explicit joint damping, wrench = -J^T T + m g, semi-implicit Euler */
@@ -887,6 +896,29 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
       om[a] += cfg->dt * acc6[3 + a];
     }
   }
+  /* [EXT] -> reduced: the joint stop, inelastic.  A joint at or beyond a travel limit that still moves outward after the
+   * velocity update takes the impulse that brings its rate to zero: qdot_i = -J_i twist; lambda = qdot_i / (J_i M^-1 J_i^T);
+   * twist += M^-1 J_i^T lambda (then qdot_i = 0), M = the platform's own mass and inertia (massless-cable reduction); cables in
+   * index order (a later cable sees the twist the earlier ones left), cfg->travel_stop sweeps over the cables: projected
+   * Gauss-Seidel on the velocity constraints, what ODE's quickstep iterates 50 times [EXT]. */
+  for (unsigned sweep = 0; travel_on && sweep < cfg->travel_stop; ++sweep) {
+    for (unsigned i = 0; i < n; ++i) {
+      const double *ji = jac + i * 6;
+      const double qdn = -(ji[0] * v[0] + ji[1] * v[1] + ji[2] * v[2] + ji[3] * om[0] + ji[4] * om[1] + ji[5] * om[2]);
+      const int out_hi = q[i] >= cfg->travel_upper && qdn > 0.0, out_lo = q[i] <= cfg->travel_lower && qdn < 0.0;
+      if (!out_hi && !out_lo) continue;
+      double tb[3], ab[3], aw[3];
+      for (int a = 0; a < 3; ++a) tb[a] = rm[0 + a] * ji[3] + rm[3 + a] * ji[4] + rm[6 + a] * ji[5]; /* R^T (rb x u) */
+      for (int a = 0; a < 3; ++a) ab[a] = s->ib_inv[3 * a] * tb[0] + s->ib_inv[3 * a + 1] * tb[1] + s->ib_inv[3 * a + 2] * tb[2];
+      for (int a = 0; a < 3; ++a) aw[a] = rm[3 * a] * ab[0] + rm[3 * a + 1] * ab[1] + rm[3 * a + 2] * ab[2]; /* Iw^-1 (rb x u) */
+      const double d = (ji[0] * ji[0] + ji[1] * ji[1] + ji[2] * ji[2]) / cfg->mass + ji[3] * aw[0] + ji[4] * aw[1] + ji[5] * aw[2];
+      const double lam = qdn / d;
+      for (int a = 0; a < 3; ++a) {
+        v[a] += lam * ji[a] / cfg->mass;
+        om[a] += lam * aw[a];
+      }
+    }
+  }
   for (int a = 0; a < 3; ++a) r->pose[a] += cfg->dt * v[a];
   {
     double *qq = r->pose + 3;
@@ -1000,6 +1032,10 @@ void orc_get_raw_state(const orc_sim *s, double *pose7, double *twist6) {
 void orc_get_pid_debug(const orc_sim *s, double *axes9) {
   for (uint64_t b = 0; b < s->cfg.batch; ++b)
     memcpy(axes9 + CDPR_PID_DEBUG_AXES * b, s->rob[b].dbg, CDPR_PID_DEBUG_AXES * sizeof(double));
+}
+
+void orc_get_limit_state(const orc_sim *s, uint32_t *cable_mask) {
+  for (uint64_t b = 0; b < s->cfg.batch; ++b) cable_mask[b] = s->rob[b].pub_limit_mask;
 }
 
 void orc_get_fk_state(const orc_sim *s, double *pose7, double *residual, int32_t *iterations) {

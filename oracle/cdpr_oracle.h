@@ -103,6 +103,8 @@ void orc_get_raw_state(const orc_sim *s, double *pose7, double *twist6);
 void orc_get_pid_debug(const orc_sim *s, double *axes9);
 void orc_get_fk_state(const orc_sim *s, double *pose7, double *residual, int32_t *iterations);
 void orc_get_td_state(const orc_sim *s, double *tension, int32_t *infeasible);
+/* travel limits (cube.sdf:436-437): bit i of cable_mask[b] = joint i outside [travel_lower, travel_upper] at the last published step */
+void orc_get_limit_state(const orc_sim *s, uint32_t *cable_mask);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -53,6 +53,7 @@ def lib():
         L.orc_get_pid_debug.argtypes = [C.c_void_p, dp]
         L.orc_get_fk_state.argtypes = [C.c_void_p, dp, dp, ip]
         L.orc_get_td_state.argtypes = [C.c_void_p, dp, ip]
+        L.orc_get_limit_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         L.orc_ik.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp]
         L.orc_fk.restype = C.c_int
         L.orc_fk.argtypes = [C.c_void_p, dp, dp, dp, dp]
@@ -171,6 +172,11 @@ class OracleSim:
         t, f = np.empty((self.B, self.n)), np.empty(self.B, dtype=np.int32)
         lib().orc_get_td_state(self._h, _dp(t), f.ctypes.data_as(C.POINTER(C.c_int32)))
         return t, f
+
+    def limit_state(self):
+        m = np.empty(self.B, dtype=np.uint32)
+        lib().orc_get_limit_state(self._h, m.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return m
 
 
 def ik(cfg_struct, pose7, twist6=None):

@@ -1499,6 +1499,74 @@ def test_per_robot_rollout_record_and_fused_updates_against_the_oracle(pkg, orac
     compare(eng, ora, where="after the rollout")
 
 
+@pytest.mark.parametrize("case", ["split", "onestep", "fused", "general", "four_cable"])
+def test_travel_limit_flags_against_the_oracle(pkg, oracle, mapping, case):
+    """Prismatic travel limits (cube.sdf:436-437) as per-cable flags in the observables, on every kernel family that
+    publishes: role-split (FK + TD, n = 8), second-generation one-step (FK only), first-generation fused, the general
+    path's platform kernel, and the shipped 4-cable robot.  A geometry that reaches the limits: +-4 mm."""
+    once(mapping)
+    rng = np.random.default_rng(61)
+    four = case == "four_cable"
+    model = pkg.cube_model() if four else pkg.eight_cable_model()
+    model.travel_lower, model.travel_upper = -0.004, 0.004
+    n, B = model.n_cables, 150
+    kw = {"split": dict(stages=3), "onestep": dict(stages=1), "fused": dict(stages=3), "general": dict(stages=3, velocityEpsilon=0.0), "four_cable": {}}[case]
+    cfg = pkg.Config(model=model, batch=B, **kw)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.002, 0.01))
+    jac = oracle.ik(cfg.to_struct(), model.home_pose())[3]
+    tw = np.concatenate([rng.uniform(-0.05, 0.05, (B, 3)), rng.uniform(-0.2, 0.2, (B, 3))], axis=1)
+    cmd = (-(jac @ tw.T).T).astype(np.float32)
+    cmd[np.abs(cmd) < 1e-4] = 1e-4  # |v| > eps on the general path: no hold branch
+    spl = 10 if case == "fused" else 1
+    seen = np.zeros(B, dtype=np.uint32)
+    for e in (eng, ora):
+        e.update(10)
+        e.set_velocity_command(cmd)
+    for k in range(12):
+        eng.update(20, spl), ora.update(20)
+        gm, om = eng.limit_state(), ora.limit_state()
+        q = ora.joint_states()[0]
+        near = (np.abs(np.abs(q) - 0.004) < 2e-5).any(axis=1)  # fp32 vs fp64 may disagree on a joint that sits ON a limit
+        assert np.array_equal(gm[~near], om[~near]), f"{case}: limit masks differ after {10 + 20 * (k + 1)} steps"
+        seen |= gm
+        if case in ("split", "fused", "general"):
+            assert np.array_equal(eng.td_state()[1], ora.td_state()[1])  # the tension-distribution flag shares the component
+    compare(eng, ora, where=case)
+    assert (seen != 0).mean() > 0.5 and (seen == 0).any()  # most robots reached a limit, some never did
+    plain = pkg.Engine(pkg.Config(model=pkg.cube_model() if four else pkg.eight_cable_model(), batch=4, **kw), 0)
+    plain.update(30)
+    assert np.all(plain.limit_state() == 0)
+
+
+@pytest.mark.parametrize("lumped", [False, True])
+def test_travel_stop_against_the_oracle(pkg, oracle, mapping, lumped):
+    """The inelastic joint stop (cdpr_config_t.travel_stop sweeps) in the PHYS instantiations, against the oracle:
+    one-step and fused launches, alone and together with the lumped-leg terms; joints stay within one step's travel
+    of their limits."""
+    once(mapping)
+    rng = np.random.default_rng(67)
+    model = pkg.eight_cable_model()
+    model.travel_lower, model.travel_upper, model.travel_stop = -0.004, 0.004, 4
+    if lumped:
+        model.passive_damping, model.leg_inertia, model.cable_axial_mass, model.anchor_point_mass, model.anchor_inertia = 0.01, 0.004, 0.001, 0.002, 0.001
+    B = 120
+    cfg = pkg.Config(model=model, batch=B, stages=3)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.002, 0.01))
+    jac = oracle.ik(cfg.to_struct(), model.home_pose())[3]
+    tw = np.concatenate([rng.uniform(-0.05, 0.05, (B, 3)), rng.uniform(-0.2, 0.2, (B, 3))], axis=1)
+    cmd = (-(jac @ tw.T).T).astype(np.float32)
+    for e in (eng, ora):
+        e.update(10)
+        e.set_velocity_command(cmd)
+    eng.update(150), ora.update(150)
+    compare(eng, ora, tol=dict(TOL, eff=5e-2), where=f"stop, one-step launches, lumped={lumped}")
+    eng.update(150, 10), ora.update(150)
+    compare(eng, ora, tol=dict(TOL, eff=5e-2), where=f"stop, fused launches, lumped={lumped}")
+    q = eng.joint_states()[0]
+    assert np.abs(q).max() < 0.004 + 1e-4 and (np.abs(q) > 0.004 - 1e-5).any()
+    assert (eng.limit_state() != 0).any()
+
+
 def test_c_example_matches_the_python_host(pkg, mapping, tmp_path):
     """examples/c_abi_demo.c (plain C99 against include/cdpr.h: config filled field by field, sine Joy, cdpr_update,
     cdpr_get_observables) prints what the Python host gets from the same calls."""

@@ -67,6 +67,40 @@ def test_sdf_loader_recovers_anchors_through_a_rotated_spawn_pose(pkg):
     assert m.n_cables == 6 and np.allclose(m.frame_anchors, fa) and np.allclose(m.platform_anchors, pb, atol=1e-12)
     assert m.mass == 3.0 and m.inertia == (1.5, 2.0, 2.5, 0.1, 0.0, 0.0) and m.joint_damping == 0.7 and m.effort_limit == 80.0
     assert np.allclose(m.home_quaternion, q) and np.allclose(m.reference_lengths(), np.linalg.norm(world - fa, axis=1))
+    # the prismatic joints' travel range comes along (cube.sdf:436-437 layout: <limit><lower/><upper/>), flag only by default
+    assert (m.travel_lower, m.travel_upper, m.travel_stop) == (-0.5, 0.5, 0)
+    assert pkg.load_sdf(mini_sdf(fa, world, pose), travel_stop=4).travel_stop == 4
+    assert pkg.load_sdf(mini_sdf(fa, world, pose), travel_limits=False).travel_upper == 0.0
+    s = pkg.Config(model=m, stages=1).to_struct()
+    assert (s.travel_lower, s.travel_upper, s.travel_stop) == (-0.5, 0.5, 0)
+
+
+def test_travel_limits_match_the_golden_model_data(pkg):
+    """tests/golden/cube_model.json holds what cube.sdf says about every prismatic joint (data read out of the reference's
+    file by make_golden.py): the loader's range for EIGHT_YAML's frame box is the same +-0.51961524 (gen_cdpr.py:104)."""
+    import json
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cube_model.json")))
+    lows, ups = [], []
+
+    def walk(o):
+        if isinstance(o, dict):
+            if isinstance(o.get("lower"), float) and isinstance(o.get("upper"), float):
+                lows.append(o["lower"]), ups.append(o["upper"])
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+
+    walk(gold)
+    assert len(lows) == 4 and set(lows) == {-0.51961524} and set(ups) == {0.51961524}
+    m = pkg.load_yaml(EIGHT_YAML)
+    assert abs(m.travel_upper - 0.51961524) < 1e-8 and abs(m.travel_lower + 0.51961524) < 1e-8
+    with pytest.raises(ValueError):
+        bad = pkg.eight_cable_model()
+        bad.travel_lower, bad.travel_upper = 0.1, -0.1
+        pkg.Config(model=bad).to_struct()
 
 
 def test_sdf_without_contiguous_cable_joints_is_rejected(pkg):
@@ -93,6 +127,10 @@ def test_reference_files_load_to_the_transcribed_model(pkg):
         assert (m.mass, tuple(m.inertia), m.joint_damping, m.effort_limit) == (ref.mass, tuple(ref.inertia), ref.joint_damping, ref.effort_limit)
         assert np.allclose(m.reference_lengths(), 0.485592422, atol=1e-6)
     assert pkg.load_yaml(os.path.join(REF, "cube.yaml")).home_position == (0.0, 0.0, 2.0)  # what the yaml itself says (cube.yaml:17)
+    # travel limits: the SDF's own numbers (cube.sdf:436-437) and the yaml's via gen_cdpr.py:104,182-183 (half the frame diagonal)
+    sdf, yml = pkg.load_sdf(os.path.join(REF, "cube.sdf")), pkg.load_yaml(os.path.join(REF, "cube.yaml"))
+    assert (sdf.travel_lower, sdf.travel_upper) == (-0.51961524, 0.51961524)
+    assert abs(yml.travel_upper - 0.51961524) < 1e-8 and yml.travel_lower == -yml.travel_upper
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")

@@ -163,3 +163,77 @@ def test_full_pipeline_tracks_and_estimates(pkg, oracle):
     t, flag = sim.td_state()
     assert t.min() >= 5.0 - 1e-12 and t.max() <= 100.0 + 1e-12
     assert np.isfinite(true_pose).all()
+
+
+def travel_model(pkg, half=0.004, stop=0):
+    m = pkg.eight_cable_model()
+    m.travel_lower, m.travel_upper, m.travel_stop = -half, half, stop
+    return m
+
+
+def drive_sideways(pkg, oracle, model, B=1, vx=0.05, steps=400):
+    """Velocity Joys that ask for a steady platform translation along +x (qdot = -J twist at the home pose)."""
+    cfg = pkg.Config(model=model, batch=B)
+    s = cfg.to_struct()
+    jac = oracle.ik(s, model.home_pose())[3]
+    cmd = (-jac @ np.array([vx, 0, 0, 0, 0, 0])).astype(np.float32)
+    sim = oracle.OracleSim(s)
+    sim.update(20)
+    sim.set_velocity_command(cmd)
+    hist = []
+    for _ in range(steps):
+        sim.update(1)
+        hist.append((sim.joint_states()[0][0].copy(), sim.joint_states()[1][0].copy(), sim.limit_state()[0], sim.raw_state()[1][0].copy()))
+    return cfg, cmd, hist
+
+
+def test_travel_limit_flag_follows_the_joint_positions(pkg, oracle):
+    """cube.sdf:436-437 as a flag: bit i of the limit mask is set exactly where q_i is outside [lower, upper]."""
+    model = travel_model(pkg)
+    cfg, cmd, hist = drive_sideways(pkg, oracle, model)
+    assert hist[0][2] == 0 and hist[-1][2] != 0  # inside at first, some joint outside at the end
+    for q, qd, mask, _ in hist:
+        want = sum(1 << i for i in range(8) if q[i] < model.travel_lower or q[i] > model.travel_upper)
+        assert mask == want
+    # no limits configured: never a flag
+    free = pkg.eight_cable_model()
+    assert all(h[2] == 0 for h in drive_sideways(pkg, oracle, free, steps=300)[2])
+
+
+def test_travel_stop_holds_the_joint_at_its_limit_and_only_removes_energy(pkg, oracle):
+    """The inelastic stop: once a joint has reached its limit it does not travel further out than one step's worth of
+    motion, its outward rate after the step is ~0, and an impulse never adds kinetic energy (single active stop:
+    exactly the component along M^-1 J^T is removed)."""
+    half = 0.004
+    stop = travel_model(pkg, half, 4)
+    cfg, cmd, hist = drive_sideways(pkg, oracle, stop, steps=1500)
+    qmax = max(np.abs(h[0]).max() for h in hist)
+    assert half < qmax < half + 5e-5  # reached; overshoot bounded by one step's travel (dt * 0.05 m/s), with up to five joints on their stops
+    one = max(np.abs(h[0]).max() for h in drive_sideways(pkg, oracle, travel_model(pkg, half, 1), steps=1500)[2])
+    assert one > half + 1e-3  # a single sweep lets them creep (why the stop takes a sweep count)
+    free_cfg, _, free_hist = drive_sideways(pkg, oracle, travel_model(pkg, half, 0))
+    assert max(np.abs(h[0]).max() for h in free_hist) > 2 * half  # without the stop the same Joys carry it far beyond
+    # one step in isolation: robot sitting at the limit with an outward twist; compare the twist after the step with the
+    # unconstrained step's twist projected by hand
+    s = cfg.to_struct()
+    home = stop.home_pose()
+    jac = oracle.ik(s, home)[3]
+    zero = pkg.PidParameters(0.0, 0.0, 0.0, 0.0, 2, 11, 100.0, 100.0)
+    tight = travel_model(pkg, 1e-9, 1)  # one sweep
+    tight.travel_lower, tight.travel_upper = -1.0, -1e-9  # q = 0 at home: every joint is beyond its UPPER stop
+    tight.joint_damping = 0.0
+    c2 = pkg.Config(model=tight, batch=1, velocityController=zero, positionController=zero, gravity=(0.0, 0.0, 0.0))
+    twist0 = np.array([0.02, -0.01, 0.015, 0.1, -0.05, 0.08])
+    sim = oracle.OracleSim(c2.to_struct())
+    sim.set_platform_state(pose7=home[None], twist6=twist0[None])
+    sim.update(1)
+    got = sim.raw_state()[1][0]
+    minv = np.diag([1.0] * 3 + [1.0] * 3)  # mass 1, inertia diag(1,1,1) (cube.sdf:332-340)
+    t = twist0.copy()
+    for i in range(8):
+        qd = -jac[i] @ t
+        if qd > 0.0:  # beyond the upper stop: only a rate that leads further out is taken away
+            lam = qd / (jac[i] @ minv @ jac[i])
+            t = t + minv @ jac[i] * lam
+    assert np.abs(got - t).max() < 1e-13
+    assert 0.5 * got @ got <= 0.5 * twist0 @ twist0 + 1e-15
