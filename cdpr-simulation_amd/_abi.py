@@ -26,6 +26,7 @@ STAGE_PID_DEBUG = 0x4
 MAP_AUTO = 0
 MAP_LANE_PER_ROBOT = 1
 MAP_LANE_PAIR = 2
+MAP_LANE_PER_CABLE = 3
 
 
 class FilterParams(C.Structure):

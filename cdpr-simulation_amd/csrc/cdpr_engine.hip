@@ -21,6 +21,7 @@
 #include "cdpr_step_kernel.hpp"
 #include "cdpr_onestep_kernel.hpp"
 #include "cdpr_step_kernel_pair.hpp"
+#include "cdpr_step_kernel_cable.hpp"
 #include "cdpr_general_ctrl.hpp"
 #include "cdpr_solvers.hpp"
 
@@ -56,6 +57,7 @@ struct cdpr_engine {
   float* d_geom = nullptr;  // pair-interleaved cable geometry, staged in LDS by the kernel
   int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
   bool lane_pair = false;   // two lanes per robot (cdpr_step_kernel_pair.hpp) instead of one
+  bool lane_cable = false;  // one lane per cable, 8 (or 4) lanes per robot (cdpr_step_kernel_cable.hpp)
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
   bool split = false;       // FK + TD one-step launches use cdpr_split_kernel (estimator wave + controller wave per 64 robots)
@@ -222,7 +224,7 @@ std::string validate(const cdpr_config_t& c) {
   if ((c.stages & (CDPR_STAGE_FK | CDPR_STAGE_TD)) && c.n_cables < 6) return "FK / tension distribution need >= 6 cables";
   if ((c.stages & CDPR_STAGE_FK) && (c.fk_max_iterations < 1 || c.fk_max_iterations > 64)) return "fk_max_iterations out of range";
   if ((c.stages & CDPR_STAGE_TD) && !(c.td_f_max > c.td_f_min)) return "td_f_max must exceed td_f_min";
-  if (c.mapping > CDPR_MAP_LANE_PAIR) return "unknown mapping";
+  if (c.mapping > CDPR_MAP_LANE_PER_CABLE) return "unknown mapping";
   if (c.mapping == CDPR_MAP_LANE_PAIR && c.n_cables != 4 && c.n_cables != 8) return "the lane-pair mapping needs 4 or 8 cables";
   return "";
 }
@@ -438,6 +440,30 @@ StepKernel pick_pair_stage(bool fk, bool td) {
 template <bool SINGLE>
 StepKernel pick_pair_kernel(uint32_t n, bool fk, bool td) {
   return n == 4 ? pick_pair_stage<4, SINGLE>(fk, td) : pick_pair_stage<8, SINGLE>(fk, td);
+}
+
+// one lane per cable (cdpr_step_kernel_cable.hpp): one kernel for any number of steps per launch
+template <int N>
+StepKernel pick_cable_stage(bool fk, bool td) {
+  if constexpr (N >= 6) {
+    if (fk && td) return cdpr_step_kernel_cable<N, true, true>;
+    if (fk) return cdpr_step_kernel_cable<N, true, false>;
+    if (td) return cdpr_step_kernel_cable<N, false, true>;
+  }
+  return cdpr_step_kernel_cable<N, false, false>;
+}
+StepKernel pick_cable_kernel(uint32_t n, bool fk, bool td) {
+  switch (n) {
+    case 1: return pick_cable_stage<1>(fk, td);
+    case 2: return pick_cable_stage<2>(fk, td);
+    case 3: return pick_cable_stage<3>(fk, td);
+    case 4: return pick_cable_stage<4>(fk, td);
+    case 5: return pick_cable_stage<5>(fk, td);
+    case 6: return pick_cable_stage<6>(fk, td);
+    case 7: return pick_cable_stage<7>(fk, td);
+    case 8: return pick_cable_stage<8>(fk, td);
+  }
+  return nullptr;
 }
 
 // second-generation one-step kernel (controller rows staged through LDS, cdpr_onestep_kernel.hpp)
@@ -843,6 +869,7 @@ StepKernel select_step_kernel(const cdpr_engine* h, int k) {
     return (k == 1) ? (h->lowreg ? pick_pr_kernel<true, false, true>(h->n, h->fk, h->td)
                                  : h->split ? pick_pr_split_kernel(h->n) : pick_pr_kernel<true, false>(h->n, h->fk, h->td))
                     : pick_pr_kernel<false, false>(h->n, h->fk, h->td);
+  if (h->lane_cable) return pick_cable_kernel(h->n, h->fk, h->td);
   return h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
          : h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
                         : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
@@ -885,7 +912,7 @@ int warm_first_launch(cdpr_engine* h) {
   a.cmd = cm.as<float>();
   a.dbg = nullptr;
   a.geom = h->d_geom;
-  a.batch = h->lane_pair ? 32u : 64u;
+  a.batch = h->lane_cable ? (h->n <= 4 ? 16u : 8u) : h->lane_pair ? 32u : 64u;
   a.stride = rows;
   a.nsteps = 1;
   a.obs_step_stride = 0;
@@ -1050,7 +1077,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     copy_pid(h->pid_pos, a);
     a.cmd = h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0];  // all zeros until the first jointPositions message: target 0 (PLG.cpp:153-157)
   }
-  const uint32_t robots_per_block = h->lane_pair ? 32u : 64u;
+  const uint32_t robots_per_block = h->lane_cable ? (h->n <= 4 ? 16u : 8u) : h->lane_pair ? 32u : 64u;
   const dim3 grid((h->batch + robots_per_block - 1u) / robots_per_block);
 
   constexpr int kGraphChunk = 20;  // launches per captured graph (a multiple of the ring period 10)
@@ -1276,7 +1303,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     uint32_t mapping = cfg->mapping;
     if (mapping == CDPR_MAP_AUTO) {
       const char* mv = std::getenv("CDPR_MAPPING");
-      if (mv && (mv[0] == '1' || mv[0] == '2')) mapping = (uint32_t)(mv[0] - '0');
+      if (mv && (mv[0] == '1' || mv[0] == '2' || mv[0] == '3')) mapping = (uint32_t)(mv[0] - '0');
     }
     // FK + TD handles: the role-split kernel (cdpr_split_kernel: two waves per 64 robots with different roles) beats both
     // mappings up to one robot per hardware lane (profiles/r02o_split_kernel_batch_scan.txt, us/step pair or one-wave ->
@@ -1286,19 +1313,22 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     if (mapping == CDPR_MAP_AUTO)
       mapping = (can_pair && !split_case && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
     h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
+    // one lane per cable: any cable count; not with the optional physics, per-robot modes or the general path (those
+    // handles silently keep the lane-per-robot mapping, as the lane-pair request does where it cannot be served)
+    h->lane_cable = (mapping == CDPR_MAP_LANE_PER_CABLE) && !general && !h->phys && !h->per_robot;
     // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
     // Measured (scripts/ab_bench.py with CDPR_LOWREG=0|1, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
     // 131 072: 29.9 -> 27.0; 196 608: 41.2 -> 36.3; 524 288: 89.9 -> 79.0 (6.6e9 state-steps/s)
-    h->lowreg = !general && !h->phys && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
+    h->lowreg = !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
     if (const char* lr = std::getenv("CDPR_LOWREG"))
-      h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
+      h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
   }
   // second-generation one-step kernel: wins wherever there is a Newton stage to hide the controller rows under, and
   // without one from ~32 768 robots on (65 536 x 8, no FK: 6.3 vs 7.0 us/step); small batches without FK are pure
   // latency and the extra LDS round trip loses (4 096 x 4: 4.18 vs 3.99 us by rocprofv3)
   h->onestep_v2 = h->fk || cfg->batch > 32768u;
   if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
-  h->split = (h->onestep_v2 || h->per_robot) && !general && !h->phys && !h->lane_pair && !h->lowreg && h->fk && h->td && cfg->n_cables >= 6;
+  h->split = (h->onestep_v2 || h->per_robot) && !general && !h->phys && !h->lane_pair && !h->lane_cable && !h->lowreg && h->fk && h->td && cfg->n_cables >= 6;
   if (const char* sp = std::getenv("CDPR_SPLIT")) h->split = h->split && sp[0] != '0';
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
@@ -1638,7 +1668,9 @@ int cdpr_synchronize(cdpr_handle_t h) {
   return CDPR_OK;
 }
 
-uint32_t cdpr_mapping(cdpr_handle_t h) { return !h ? CDPR_MAP_AUTO : (h->lane_pair ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT); }
+uint32_t cdpr_mapping(cdpr_handle_t h) {
+  return !h ? CDPR_MAP_AUTO : (h->lane_cable ? CDPR_MAP_LANE_PER_CABLE : h->lane_pair ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT);
+}
 
 uint64_t cdpr_step_count(cdpr_handle_t h) { return h ? h->step : 0; }
 

@@ -155,7 +155,7 @@ class Engine:
 
     @property
     def mapping(self) -> str:
-        return {_abi.MAP_LANE_PER_ROBOT: "lane-per-robot", _abi.MAP_LANE_PAIR: "lane-pair"}.get(int(lib().cdpr_mapping(self._h)), "auto")
+        return {_abi.MAP_LANE_PER_ROBOT: "lane-per-robot", _abi.MAP_LANE_PAIR: "lane-pair", _abi.MAP_LANE_PER_CABLE: "lane-per-cable"}.get(int(lib().cdpr_mapping(self._h)), "auto")
 
     @property
     def sim_time(self) -> float:

@@ -61,6 +61,10 @@ extern "C" {
 #define CDPR_MAP_LANE_PER_ROBOT 1u  /* one lane owns one robot                                               */
 #define CDPR_MAP_LANE_PAIR 2u       /* two adjacent lanes share a robot, half the cables each (n = 4 or 8):   */
                                     /* twice the wavefronts, partial sums meet through a DPP add             */
+#define CDPR_MAP_LANE_PER_CABLE 3u  /* one lane owns one cable, 8 (n <= 4: 4) adjacent lanes a robot: the structure matrix */
+                                    /* row by row in registers, J^T J / J^T r by DPP reductions inside the group, the 6x6  */
+                                    /* solve redundantly in every lane (BASELINE.json's north-star mapping; wins only     */
+                                    /* while the batch leaves most SIMDs empty: DESIGN.md section 4)                     */
 
 /* Pid::FilterParameters (Pid.h:64-68) */
 typedef struct cdpr_filter_params {

@@ -14,12 +14,24 @@ pytestmark = pytest.mark.gpu
 TOL = {"pose": 1e-5, "twist": 2e-4, "q": 1e-5, "qd": 2e-4, "eff": 2e-2}
 
 
-@pytest.fixture(autouse=True, params=["lane_per_robot", "lane_pair"])
+# what runs under the lane-per-cable mapping too (one lane per cable, 8 lanes per robot: cdpr_step_kernel_cable.hpp)
+CABLE_MAPPING_TESTS = {
+    "test_config1_sine_velocity_trajectory", "test_position_hold_from_load", "test_first_steps_match_exactly_in_structure",
+    "test_config2_random_batch_four_cable", "test_config3_eight_cable_stage_combinations", "test_mode_switching_resets_the_right_pid",
+    "test_saturation_and_anti_windup", "test_publish_period_decimation", "test_pid_debug_topic", "test_reset_restores_load_state",
+    "test_random_call_sequences_stay_on_the_oracle", "test_randomised_model_and_controller_parameters", "test_trajectory_record_keeps_every_published_step",
+    "test_bound_command_buffers_are_used_in_place", "test_cable_mapping_runs_on_the_same_state_as_the_others",
+}
+
+
+@pytest.fixture(autouse=True, params=["lane_per_robot", "lane_pair", "lane_per_cable"])
 def mapping(request, monkeypatch):
-    """Every test runs under both wavefront mappings (CDPR_MAPPING overrides CDPR_MAP_AUTO at cdpr_create): one lane
-    per robot, and two lanes per robot (n = 4 or 8; other cable counts and the general controller path fall back to
-    one lane per robot by themselves)."""
-    monkeypatch.setenv("CDPR_MAPPING", "1" if request.param == "lane_per_robot" else "2")
+    """Every test runs under the wavefront mappings (CDPR_MAPPING overrides CDPR_MAP_AUTO at cdpr_create): one lane per
+    robot, two lanes per robot (n = 4 or 8; other cable counts and the general controller path fall back to one lane
+    per robot by themselves), and - for the tests of CABLE_MAPPING_TESTS - one lane per cable."""
+    if request.param == "lane_per_cable" and request.node.originalname not in CABLE_MAPPING_TESTS:
+        pytest.skip("not part of the lane-per-cable selection")
+    monkeypatch.setenv("CDPR_MAPPING", {"lane_per_robot": "1", "lane_pair": "2", "lane_per_cable": "3"}[request.param])
     return request.param
 
 
@@ -1565,6 +1577,34 @@ def test_travel_stop_against_the_oracle(pkg, oracle, mapping, lumped):
     q = eng.joint_states()[0]
     assert np.abs(q).max() < 0.004 + 1e-4 and (np.abs(q) > 0.004 - 1e-5).any()
     assert (eng.limit_state() != 0).any()
+
+
+def test_cable_mapping_runs_on_the_same_state_as_the_others(pkg, oracle, mapping):
+    """The three mappings share one HBM layout: the lane-per-cable kernel reads the ring rows of a cable PAIR and writes
+    single dwords into them.  Odd cable counts (masked lanes, padding components of the joint rows), travel-limit flags,
+    one-step and fused launches, against the oracle."""
+    if mapping != "lane_per_cable":
+        pytest.skip("lane-per-cable only")
+    rng = np.random.default_rng(71)
+    full = pkg.eight_cable_model()
+    for keep, stages in (([0, 1, 2, 3, 4, 6], 1), ([0, 1, 2, 3, 4, 5, 6], 3), (list(range(8)), 3), ([0, 1, 2], 0), ([0, 1, 2, 3, 4], 0)):
+        m = pkg.Model(full.frame_anchors[keep], full.platform_anchors[keep])
+        m.travel_lower, m.travel_upper = -0.003, 0.003
+        B, n = 77, len(keep)
+        cfg = pkg.Config(model=m, batch=B, stages=stages)
+        eng, ora = pair(pkg, oracle, cfg, perturbed_poses(m, B, rng, 0.01, 0.03))
+        assert eng.mapping == "lane-per-cable"
+        eng.update(40), ora.update(40)
+        cmd = rng.uniform(-0.02, 0.02, (B, n)).astype(np.float32)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        eng.update(90), ora.update(90)
+        compare(eng, ora, where=f"lane-per-cable, n={n}, stages={stages}")
+        q = ora.joint_states()[0]
+        near = (np.abs(np.abs(q) - 0.003) < 2e-5).any(axis=1)
+        assert np.array_equal(eng.limit_state()[~near], ora.limit_state()[~near])
+        eng.update(30, 10), ora.update(30)
+        compare(eng, ora, where=f"lane-per-cable fused, n={n}")
+        eng.close()
 
 
 def test_c_example_matches_the_python_host(pkg, mapping, tmp_path):
