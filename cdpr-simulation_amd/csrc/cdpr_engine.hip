@@ -69,6 +69,7 @@ struct cdpr_engine {
   float* d_cable = nullptr;  // plain per-cable geometry, 7 rows of n
   size_t tstride = 0;
   GenPid gpid[2]{};
+  GenLayout glay{};          // rows of a Pid block: sized by the configured window length and cascade count
   // hipGraph cache: chains of identical steady-state launches (see run_steps)
   struct GraphEntry {
     void* kern;
@@ -677,7 +678,7 @@ int upload_home(cdpr_engine* h) {
     HIP_TRY(h, hipMemsetAsync(h->d_vel[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   }
-  if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows() * h->tstride * sizeof(float), h->stream));
+  if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows(h->glay) * h->tstride * sizeof(float), h->stream));
   if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157 (call count 0)
   if (h->d_target) HIP_TRY(h, hipMemsetAsync(h->d_target, 0, (size_t)h->stride * h->n * sizeof(float), h->stream));  // target 0 after Load
   HIP_TRY(h, wait_stream(h));
@@ -839,15 +840,17 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
   g.mode = h->mode;
   g.eps = (float)h->cfg.velocity_epsilon;
   g.dt = (float)h->cfg.dt;
+  g.lay = h->glay;
   g.pid[0] = h->gpid[0];
   g.pid[1] = h->gpid[1];
+  auto ctrl = (h->glay.nb <= 11) ? cdpr_general_ctrl_kernel<11> : cdpr_general_ctrl_kernel<kGenMaxBuf>;
   StepKernel plat = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysExt) : pick_ext_kernel(h->n, h->fk, h->td);
   const uint32_t total = h->batch * h->n;
   for (int k = 0; k < nsteps; ++k) {
     const bool first_world = (h->step == 0);
     g.first_world = first_world ? 1 : 0;
     g.now_step = (int)h->step;
-    hipLaunchKernelGGL(cdpr_general_ctrl_kernel, dim3((total + 255u) / 256u), dim3(256), 0, h->stream, g);
+    hipLaunchKernelGGL(ctrl, dim3((total + 255u) / 256u), dim3(256), 0, h->stream, g);
     a.flags = first_world ? kFlagFirstWorldStep : 0u;
     const double now = sim_time(h->step, h->cfg.dt);
     a.publish_mask = 0;
@@ -965,7 +968,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   };
   bool reset_pid = false;
   auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path)
-    return hipMemsetAsync(h->d_rec + h->tstride * (1 + (size_t)which * kGfRows), 0, (size_t)kGfRows * h->tstride * sizeof(float), h->stream);
+    return hipMemsetAsync(h->d_rec + h->tstride * (1 + (size_t)which * h->glay.rows()), 0, (size_t)h->glay.rows() * h->tstride * sizeof(float), h->stream);
   };
   if (h->per_robot) {
     // every robot has its own mode: commands (masked or not) are latched on the device, robot by robot
@@ -991,7 +994,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       la.mode = h->d_mode;
       la.pending = pending;
       la.latched = latched;
-      la.pid_block = h->d_rec + h->tstride * (1 + (size_t)which * kGfRows);
+      la.pid_block = h->d_rec + h->tstride * (1 + (size_t)which * h->glay.rows());
+      la.rows = h->glay.rows();
       la.tstride = h->tstride;
       la.batch = h->batch;
       la.n = h->n;
@@ -1374,7 +1378,10 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   if (h->general) {
     const size_t total = (size_t)h->batch * h->n;
     h->tstride = (total + 63) & ~(size_t)63;
-    if ((e = hipMalloc(&h->d_rec, gen_record_rows() * h->tstride * sizeof(float))) != hipSuccess) return fail("hipMalloc(rec)", e);
+    h->glay.nb = (int)std::max(cfg->velocity_pid.d_buffer_length, cfg->position_pid.d_buffer_length);
+    h->glay.ncas = (int)std::max(std::max(cfg->velocity_pid.p_filter.cascade, cfg->velocity_pid.d_filter.cascade),
+                                 std::max(cfg->position_pid.p_filter.cascade, cfg->position_pid.d_filter.cascade));
+    if ((e = hipMalloc(&h->d_rec, gen_record_rows(h->glay) * h->tstride * sizeof(float))) != hipSuccess) return fail("hipMalloc(rec)", e);
     if ((e = hipMalloc(&h->d_force, total * sizeof(float))) != hipSuccess) return fail("hipMalloc(force)", e);
     std::vector<float> cg((size_t)7 * h->n);
     for (uint32_t i = 0; i < h->n; ++i) {

@@ -22,7 +22,9 @@ constexpr int kGenMaxBuf = 32;   // CDPR_MAX_D_BUFFER
 constexpr int kGenMaxDeg = 4;    // CDPR_MAX_D_DEGREE
 constexpr int kGenMaxCas = 4;    // CDPR_MAX_CASCADE
 
-// fields of one Pid record (each a row of T floats)
+// fields of one Pid record (each a row of T floats).  The window and filter rows are sized by the CONFIGURED window
+// length and cascade count (GenLayout), not by the maxima: the shipped 11-sample window without cascades is 29 rows per
+// Pid (236 B per cable for both Pids and the hold position) instead of the 103 (828 B) a 32-sample / 4-cascade record takes.
 enum GenField : int {
   kGfWasLast = 0,  // Pid::mWasLastTime
   kGfLastStep,     // Pid::mLastTime as a world-step index
@@ -31,11 +33,18 @@ enum GenField : int {
   kGfCmd,
   kGfCount,        // samples pushed since reset (mDbufferLength - mDbufferMissing, saturating)
   kGfHead,         // ring index of the newest sample
-  kGfWinVal,       // kGenMaxBuf rows: mDbufferY
-  kGfWinStamp = kGfWinVal + kGenMaxBuf,           // kGenMaxBuf rows: mDbufferX as world-step indices
-  kGfPFilt = kGfWinStamp + kGenMaxBuf,            // kGenMaxCas x (x1 x2 y1 y2)
-  kGfDFilt = kGfPFilt + 4 * kGenMaxCas,
-  kGfRows = kGfDFilt + 4 * kGenMaxCas
+  kGfWinVal,       // nb rows: mDbufferY; then nb rows mDbufferX as world-step indices; then ncas x (x1 x2 y1 y2) for the P
+                   // input's cascade and the same for the D input's
+};
+
+// Row offsets inside one Pid block for a handle whose longest window is nb samples and deepest cascade ncas stages.
+struct GenLayout {
+  int nb, ncas;
+  __host__ __device__ int win_val() const { return kGfWinVal; }
+  __host__ __device__ int win_stamp() const { return kGfWinVal + nb; }
+  __host__ __device__ int p_filt() const { return kGfWinVal + 2 * nb; }
+  __host__ __device__ int d_filt() const { return kGfWinVal + 2 * nb + 4 * ncas; }
+  __host__ __device__ int rows() const { return kGfWinVal + 2 * nb + 8 * ncas; }
 };
 
 struct GenPid {
@@ -61,10 +70,11 @@ struct GenArgs {
   int first_world;      // t = 0: stepTime <= 0 -> force 0, nothing else (JFC.cpp:61-66)
   int now_step;
   float eps, dt;
+  GenLayout lay;        // row offsets of a Pid block
   GenPid pid[2];        // [0] position Pid, [1] velocity Pid
 };
 
-__host__ __device__ constexpr size_t gen_record_rows() { return 1 + 2 * (size_t)kGfRows; }
+__host__ __device__ inline size_t gen_record_rows(const GenLayout& l) { return 1 + 2 * (size_t)l.rows(); }
 
 struct GenRec {
   float* base;  // this thread's column of its Pid block
@@ -96,24 +106,47 @@ __device__ __forceinline__ float gen_cascade(GenRec& r, int first_row, int casca
   return out;
 }
 
-// Pid::derive + fitPolynomial (Pid.cpp:193-247) on the real stamps, fp64, centred and scaled time.
-__device__ __forceinline__ float gen_derive(const GenPid& p, GenRec& r, float value, int now_step, float dt) {
+// Pid::derive + fitPolynomial (Pid.cpp:193-247) on the real stamps, fp64, centred and scaled time.  NBMAX bounds the
+// window at compile time (11: the shipped length and everything below it; 32: the maximum): the window's 2 x nbuf rows
+// are loaded in ONE unrolled, predicated batch before anything is computed (with a run-time trip count every iteration
+// waited for its own two loads: 2 x 11 dependent round trips, most of the kernel's 13-20 us), and the power sums run over
+// registers.
+template <int NBMAX>
+__device__ __forceinline__ float gen_derive(const GenPid& p, GenRec& r, const GenLayout& lay, float value, int now_step, float dt) {
   const int nbuf = p.nbuf;
+  const int wv = lay.win_val(), ws = lay.win_stamp();
   int head = r.geti(kGfHead);
   int count = r.geti(kGfCount);
+  float y[NBMAX];
+  int t[NBMAX];
+#pragma unroll
+  for (int j = 0; j < NBMAX; ++j) {
+    y[j] = (j < nbuf) ? r.f(wv + j) : 0.f;
+    t[j] = (j < nbuf) ? r.geti(ws + j) : 0;
+  }
   head = (count == 0) ? 0 : ((head + 1 == nbuf) ? 0 : head + 1);
-  r.f(kGfWinVal + head) = value;
-  r.seti(kGfWinStamp + head, now_step);
+  r.f(wv + head) = value;
+  r.seti(ws + head, now_step);
   r.seti(kGfHead, head);
   if (count < nbuf) ++count;
   r.seti(kGfCount, count);
   if (count < nbuf) return 0.f;  // mDbufferMissing != 0 (Pid.cpp:200-203)
+#pragma unroll
+  for (int j = 0; j < NBMAX; ++j) {  // the sample just pushed, in registers too
+    y[j] = (j == head) ? value : y[j];
+    t[j] = (j == head) ? now_step : t[j];
+  }
 
   // oldest sample sits right after the head in the ring
   const int oldest = (head + 1 == nbuf) ? 0 : head + 1;
-  const double t_new = (double)now_step, t_old = (double)r.geti(kGfWinStamp + oldest);
+  int t_old_i = 0;
   double mean = 0.0;
-  for (int j = 0; j < nbuf; ++j) mean += (double)r.geti(kGfWinStamp + j);
+#pragma unroll
+  for (int j = 0; j < NBMAX; ++j) {
+    if (j < nbuf) mean += (double)t[j];
+    t_old_i = (j == oldest) ? t[j] : t_old_i;
+  }
+  const double t_new = (double)now_step, t_old = (double)t_old_i;
   mean /= (double)nbuf;
   double h = (t_new - t_old) / (double)(nbuf - 1);
   if (!(h > 0.0)) h = 1.0;
@@ -124,15 +157,18 @@ __device__ __forceinline__ float gen_derive(const GenPid& p, GenRec& r, float va
   for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) sx[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < kGenMaxDeg + 1; ++i) sb[i] = 0.0;
-  for (int j = 0; j < nbuf; ++j) {
-    const double x = ((double)r.geti(kGfWinStamp + j) - mean) * inv_h;
-    const double y = (double)r.f(kGfWinVal + j);
-    double pw = 1.0;
 #pragma unroll
-    for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) {  // powers beyond the fit's degree are summed too and never used
-      sx[i] += pw;
-      if (i < kGenMaxDeg + 1) sb[i] += pw * y;
-      pw *= x;
+  for (int j = 0; j < NBMAX; ++j) {
+    if (j < nbuf) {
+      const double x = ((double)t[j] - mean) * inv_h;
+      const double yy = (double)y[j];
+      double pw = 1.0;
+#pragma unroll
+      for (int i = 0; i < 2 * kGenMaxDeg + 1; ++i) {  // powers beyond the fit's degree are summed too and never used
+        sx[i] += pw;
+        if (i < kGenMaxDeg + 1) sb[i] += pw * yy;
+        pw *= x;
+      }
     }
   }
   // normal equations of the degree-(m-1) fit in the leading m x m block, identity rows below it: every index in the
@@ -173,7 +209,8 @@ struct GenTerms {
 };
 
 // Pid::update (Pid.cpp:122-191)
-__device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, float desired, float actual, int now_step,
+template <int NBMAX>
+__device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, const GenLayout& lay, float desired, float actual, int now_step,
                                                 float dt_step, GenTerms& t) {
   t.pi_written = t.d_written = t.desired_written = false;
   float cmd_out;
@@ -185,7 +222,7 @@ __device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, floa
     const float f_term = p.kf * desired;
     const float error = desired - actual;
     const float dt = (float)(now_step - r.geti(kGfLastStep)) * dt_step;
-    const float perr = gen_cascade(r, kGfPFilt, p.pcas, p.pa0, p.pa1, p.pa2, p.pb1, p.pb2, error);
+    const float perr = gen_cascade(r, lay.p_filt(), p.pcas, p.pa0, p.pa1, p.pa2, p.pb1, p.pb2, error);
     const float p_term = p.kp * perr;
     const float prev_ierr = r.f(kGfIerr);
     float ierr = fmaf(dt, error, prev_ierr);
@@ -202,8 +239,8 @@ __device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, floa
     }
     float derr = r.f(kGfDerr);
     if (dt > 0.f) {
-      const float derived = gen_derive(p, r, error, now_step, dt_step);
-      derr = gen_cascade(r, kGfDFilt, p.dcas, p.da0, p.da1, p.da2, p.db1, p.db2, derived);
+      const float derived = gen_derive<NBMAX>(p, r, lay, error, now_step, dt_step);
+      derr = gen_cascade(r, lay.d_filt(), p.dcas, p.da0, p.da1, p.da2, p.db1, p.db2, derived);
       r.f(kGfDerr) = derr;
       t.desired = desired;
       t.desired_written = true;
@@ -226,6 +263,7 @@ __device__ __forceinline__ float gen_pid_update(const GenPid& p, GenRec& r, floa
   return cmd_out;
 }
 
+template <int NBMAX>
 __global__ __launch_bounds__(256) void cdpr_general_ctrl_kernel(const GenArgs a) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t total = a.batch * a.n;
@@ -257,7 +295,7 @@ __global__ __launch_bounds__(256) void cdpr_general_ctrl_kernel(const GenArgs a)
 
   float* last_pos = a.rec + t;
   GenRec pos{a.rec + a.tstride * 1 + t, a.tstride};
-  GenRec vel{a.rec + a.tstride * (1 + (size_t)kGfRows) + t, a.tstride};
+  GenRec vel{a.rec + a.tstride * (1 + (size_t)a.lay.rows()) + t, a.tstride};
   GenTerms terms;
   terms.pi_written = terms.d_written = terms.desired_written = false;
   float force = 0.f;
@@ -266,14 +304,14 @@ __global__ __launch_bounds__(256) void cdpr_general_ctrl_kernel(const GenArgs a)
     const float vt = a.vel_cmd ? a.vel_cmd[t] : 0.f;
     if (fabsf(vt) > a.eps) {
       *last_pos = q;
-      force = gen_pid_update(a.pid[1], vel, vt, qd, a.now_step, a.dt, terms);
+      force = gen_pid_update<NBMAX>(a.pid[1], vel, a.lay, vt, qd, a.now_step, a.dt, terms);
     } else {
-      force = gen_pid_update(a.pid[0], pos, *last_pos, q, a.now_step, a.dt, terms);
+      force = gen_pid_update<NBMAX>(a.pid[0], pos, a.lay, *last_pos, q, a.now_step, a.dt, terms);
     }
   } else {  // Position (JFC.cpp:84-89)
     const float target = a.pos_cmd ? a.pos_cmd[t] : 0.f;
     *last_pos = q;
-    force = gen_pid_update(a.pid[0], pos, target, q, a.now_step, a.dt, terms);
+    force = gen_pid_update<NBMAX>(a.pid[0], pos, a.lay, target, q, a.now_step, a.dt, terms);
   }
   a.force[t] = force;
   if (a.dbg && i == 0) {  // `pid` topic: stale entries stay (Pid.cpp:139-142,158-168)
@@ -301,6 +339,7 @@ struct LatchArgs {
   size_t tstride;
   uint32_t batch, n;
   int new_mode;
+  int rows;              // rows of one Pid block (GenLayout::rows)
 };
 
 __global__ __launch_bounds__(256) void cdpr_latch_masked_kernel(const LatchArgs a) {
@@ -310,7 +349,7 @@ __global__ __launch_bounds__(256) void cdpr_latch_masked_kernel(const LatchArgs 
   if (a.mask && !a.mask[r]) return;
   a.latched[t] = a.pending[t];
   if ((int)a.mode[r] != a.new_mode) {
-    for (int row = 0; row < kGfRows; ++row) a.pid_block[(size_t)row * a.tstride + t] = 0.f;
+    for (int row = 0; row < a.rows; ++row) a.pid_block[(size_t)row * a.tstride + t] = 0.f;
   }
 }
 
