@@ -74,7 +74,7 @@ struct cdpr_engine {
   struct GraphEntry {
     void* kern;
     const float* cmd;
-    int steps_per_launch, launches;
+    int steps_per_launch, launches, start_slot;
     uint32_t flags;
     hipGraph_t graph;
     hipGraphExec_t exec;
@@ -1084,7 +1084,9 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   const uint32_t robots_per_block = h->lane_cable ? (h->n <= 4 ? 16u : 8u) : h->lane_pair ? 32u : 64u;
   const dim3 grid((h->batch + robots_per_block - 1u) / robots_per_block);
 
-  constexpr int kGraphChunk = 20;  // launches per captured graph (a multiple of the ring period 10)
+  constexpr int kGraphChunk = 10;  // launches per captured graph = one ring period: a chain ends on the ring slot it started from.
+                                   // (Ten, not more: a caller that refreshes its Joy batch every 10 steps - bench.py, the reference's
+                                   // 100 Hz publishers against the 1 kHz world - hands over 10 steps per call.)
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
@@ -1104,18 +1106,18 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
     // (measured on MI355X: 3.57 -> 3.41 us/step at 4 096 x 4 cables; at 65 536 x 8 cables the 15 us kernels already
     // hide the host launch and the replay's fixed cost makes it 2 % slower, so only small batches use it)
-    // (the ring position advances with every step, so a captured chain is only valid from the same position: chains
-    //  are captured and replayed from ring position 0 with the call count saturated (per-robot handles keep theirs on the device))
+    // (the ring position advances with every step, so a captured chain is only valid from the position it was captured at:
+    //  part of the cache key; the call count must be saturated (per-robot handles keep theirs on the device))
     if (record) a.obs = record + (size_t)done * image;
     const bool steady = !record && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && (h->per_robot || a.pid_calls == kCallSat) &&
-                        a.ring_slot == 0 && (10 % k == 0) && h->cfg.publish_period == 0.0 && (nsteps - done) >= kGraphChunk * k;
+                        h->cfg.publish_period == 0.0 && (nsteps - done) >= kGraphChunk * k;
     if (steady) {
       a.publish_mask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
       cdpr_engine::GraphEntry* ge = nullptr;
       for (auto& g : h->graphs)
-        if (g.kern == (void*)kern && g.cmd == a.cmd && g.steps_per_launch == k && g.flags == a.flags) ge = &g;
+        if (g.kern == (void*)kern && g.cmd == a.cmd && g.steps_per_launch == k && g.flags == a.flags && g.start_slot == a.ring_slot) ge = &g;
       if (!ge) {
-        cdpr_engine::GraphEntry g{(void*)kern, a.cmd, k, kGraphChunk, a.flags, nullptr, nullptr};
+        cdpr_engine::GraphEntry g{(void*)kern, a.cmd, k, kGraphChunk, a.ring_slot, a.flags, nullptr, nullptr};
         // any failure inside the capture: end it, drop the partial graph, stop using graphs on this handle and
         // fall through to the eager launches below (the stream must never be left capturing)
         bool captured = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -1123,7 +1125,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
           bool launched = true;
           for (int j = 0; j < kGraphChunk; ++j) {
             StepArgs aj = a;  // each node carries its own ring position
-            aj.ring_slot = (j * k) % kWin;
+            aj.ring_slot = (a.ring_slot + j * k) % kWin;
             set_weight_row(h, aj);
             hipLaunchKernelGGL(kern, grid, block, 0, h->stream, aj);
             launched = launched && (hipGetLastError() == hipSuccess);
@@ -1137,7 +1139,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
           h->use_graphs = false;
           continue;  // same `done`: this chunk is launched eagerly on the next pass
         }
-        if (h->graphs.size() >= 8) {  // tiny cache: drop the oldest
+        if (h->graphs.size() >= 16) {  // small cache (two Joy buffers x a few ring positions x step counts): drop the oldest
           (void)hipGraphExecDestroy(h->graphs.front().exec);
           (void)hipGraphDestroy(h->graphs.front().graph);
           h->graphs.erase(h->graphs.begin());
