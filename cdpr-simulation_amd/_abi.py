@@ -65,7 +65,7 @@ class ConfigStruct(C.Structure):
         ("effort_limit", C.c_double),
         ("velocity_limit", C.c_double),
         ("unilateral_cables", C.c_uint32),
-        ("reserved2_", C.c_uint32),
+        ("precision", C.c_uint32),
         ("velocity_pid", PidParams),
         ("position_pid", PidParams),
         ("velocity_epsilon", C.c_double),

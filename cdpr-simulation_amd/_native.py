@@ -19,7 +19,7 @@ EXPORTS = [
     "cdpr_set_velocity_command", "cdpr_set_position_command", "cdpr_set_velocity_command_device",
     "cdpr_set_position_command_device", "cdpr_bind_velocity_command_device", "cdpr_bind_position_command_device",
     "cdpr_set_velocity_command_masked", "cdpr_set_position_command_masked", "cdpr_update", "cdpr_update_fused", "cdpr_observable_image_bytes", "cdpr_update_record", "cdpr_decode_observables", "cdpr_synchronize", "cdpr_mapping", "cdpr_step_count",
-    "cdpr_get_joint_states", "cdpr_get_platform_state", "cdpr_get_observables", "cdpr_get_pid_debug", "cdpr_get_fk_state", "cdpr_get_td_state", "cdpr_get_limit_state",
+    "cdpr_get_joint_states", "cdpr_get_platform_state", "cdpr_get_observables", "cdpr_get_pid_debug", "cdpr_get_fk_state", "cdpr_get_td_state", "cdpr_get_limit_state", "cdpr_get_observables_f64", "cdpr_get_raw_state_f64", "cdpr_set_platform_state_f64",
     "cdpr_get_raw_state", "cdpr_rollout_velocity", "cdpr_rollout_velocity_launch", "cdpr_rollout_velocity_fetch",
     "cdpr_rollout_velocity_device", "cdpr_device_malloc", "cdpr_device_free", "cdpr_device_upload", "cdpr_device_download",
     "cdpr_profile_begin", "cdpr_profile_end", "cdpr_solve_ik", "cdpr_solve_fk", "cdpr_solve_td",
@@ -84,6 +84,9 @@ def lib():
     L.cdpr_get_fk_state.argtypes = [H, fp, fp, ip]
     L.cdpr_get_td_state.argtypes = [H, fp, ip]
     L.cdpr_get_limit_state.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.cdpr_get_observables_f64.argtypes = [C.c_void_p, dp, dp, dp, dp, dp]
+    L.cdpr_get_raw_state_f64.argtypes = [C.c_void_p, dp, dp]
+    L.cdpr_set_platform_state_f64.argtypes = [C.c_void_p, dp, dp]
     L.cdpr_rollout_velocity.argtypes = [H, C.c_int, C.c_int, C.c_void_p, fp, fp]
     L.cdpr_rollout_velocity_launch.argtypes = [H, C.c_int, C.c_int, C.c_void_p, fp]
     L.cdpr_rollout_velocity_fetch.argtypes = [H, fp]

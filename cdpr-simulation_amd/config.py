@@ -147,6 +147,7 @@ class Config:
     fkMaxIterations: int = 4
     fkLambda: float = 1e-9
     fkTolerance: float = 0.0
+    precision: int = 32  # 64: the step in the reference's own precision (one plain fp64 kernel; small batches; Engine.observables_f64)
     perRobotCommands: bool = False  # every robot has its own mode / Pid history: a Joy may reach some robots only ([NEW]: B plugin instances)
     tdFMin: float | None = None  # default: model.f_min
     tdFMax: float | None = None
@@ -236,6 +237,8 @@ class Config:
             raise ValueError("travel limits need lower < upper (lower == upper == 0: no limits, and then no stop)")
         if not 0 <= int(self.model.travel_stop) <= 64:
             raise ValueError("travel_stop (sweeps of the joint stop) must be in 0..64")
+        if int(self.precision) not in (0, 32, 64):
+            raise ValueError("precision must be 32 or 64")
         if self.stages & (_abi.STAGE_FK | _abi.STAGE_TD) and n < 6:
             raise ValueError("FK / tension distribution need at least 6 cables")
 
@@ -266,6 +269,7 @@ class Config:
         s.effort_limit = float(m.effort_limit)
         s.velocity_limit = float(m.velocity_limit)
         s.unilateral_cables = 1 if m.unilateral_cables else 0
+        s.precision = int(self.precision)
         s.passive_damping = float(m.passive_damping)
         s.leg_inertia = float(m.leg_inertia)
         s.cable_axial_mass = float(m.cable_axial_mass)

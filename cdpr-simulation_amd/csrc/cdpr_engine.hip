@@ -23,6 +23,7 @@
 #include "cdpr_step_kernel_pair.hpp"
 #include "cdpr_step_kernel_cable.hpp"
 #include "cdpr_general_ctrl.hpp"
+#include "cdpr_step_kernel_f64.hpp"
 #include "cdpr_solvers.hpp"
 
 using namespace cdpr;
@@ -125,6 +126,16 @@ struct cdpr_engine {
   float* d_roll_cost = nullptr;  // float[B][samples]
   size_t roll_cost_cap = 0;      // trajectories d_roll_cost can hold
   uint64_t roll_pending = 0;     // trajectories of the launched, not yet fetched rollout
+  // cdpr_config_t.precision = 64: the step in double (cdpr_step_kernel_f64.hpp); its own state, observables, tables
+  bool fp64 = false;
+  double* d_state64 = nullptr;
+  double* d_obs64 = nullptr;
+  double* d_geom64 = nullptr;    // [n][7]
+  double* d_wtab64 = nullptr;    // [velocity | position] x [10][12]
+  double* d_dbg64 = nullptr;
+  void* d_unpack64 = nullptr;    // read-out scratch of the fp64 getters (bytes)
+  size_t unpack64_cap = 0;
+  F64Args base64{};
   float* d_unpack = nullptr;     // read-out scratch (cdpr_get_*): robot-major copy of the requested fields, grow-only
   size_t unpack_cap = 0;
   std::string err;
@@ -219,6 +230,7 @@ std::string validate(const cdpr_config_t& c) {
     if (p->d_degree < 1 || p->d_degree > CDPR_MAX_D_DEGREE || p->d_degree >= p->d_buffer_length) return "d_degree out of range";
     if (p->p_filter.cascade > CDPR_MAX_CASCADE || p->d_filter.cascade > CDPR_MAX_CASCADE) return "filter cascade out of range";
   }
+  if (c.precision != 0 && c.precision != 32 && c.precision != 64) return "precision must be 32 (or 0) or 64";
   if (c.travel_lower > c.travel_upper) return "travel_lower must not exceed travel_upper";
   if (c.travel_stop && !(c.travel_lower < c.travel_upper)) return "travel_stop needs travel limits (travel_lower < travel_upper)";
   if (c.travel_stop > 64) return "travel_stop (sweeps of the joint stop) must be <= 64";
@@ -663,7 +675,29 @@ std::vector<float4> home_state(const cdpr_engine* h) {
   return s;
 }
 
+// fp64 handles: home state (platform at home, FK seed at home, controller rows zero), observables before the first publish
+int upload_home64(cdpr_engine* h) {
+  const size_t st = h->stride;
+  std::vector<double> s((size_t)f64_state_rows((int)h->n) * st, 0.0), o((size_t)f64_obs_rows((int)h->n) * st, 0.0);
+  for (uint32_t r = 0; r < h->stride; ++r)
+    for (int c = 0; c < 7; ++c) {
+      s[(size_t)c * st + r] = h->cfg.home_pose[c];
+      s[(size_t)(13 + c) * st + r] = h->cfg.home_pose[c];
+      o[(size_t)c * st + r] = h->cfg.home_pose[c];
+    }
+  HIP_TRY(h, hipMemcpyAsync(h->d_state64, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_obs64, o.data(), o.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->d_dbg64) HIP_TRY(h, hipMemsetAsync(h->d_dbg64, 0, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(double), h->stream));
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(h, hipMemsetAsync(h->d_vel[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
+  }
+  HIP_TRY(h, wait_stream(h));
+  return CDPR_OK;
+}
+
 int upload_home(cdpr_engine* h) {
+  if (h->fp64) return upload_home64(h);
   std::vector<float4> s = home_state(h);
   HIP_TRY(h, hipMemcpyAsync(h->d_state, s.data(), s.size() * sizeof(float4), hipMemcpyHostToDevice, h->stream));
   // observables before the first publish: the home pose, zeros elsewhere
@@ -701,6 +735,8 @@ void free_all(cdpr_engine* h) {
   for (int i = 0; i < 2; ++i)
     if (h->d_mask[i]) (void)hipFree(h->d_mask[i]);
   if (h->d_unpack) (void)hipFree(h->d_unpack);
+  for (void* p64 : {(void*)h->d_state64, (void*)h->d_obs64, (void*)h->d_geom64, (void*)h->d_wtab64, (void*)h->d_dbg64, h->d_unpack64})
+    if (p64) (void)hipFree(p64);
   if (h->h_pub) (void)hipHostFree(h->h_pub);
   if (h->h_pub_done) (void)hipHostFree(h->h_pub_done);
   if (h->d_pub_arrivals) (void)hipFree(h->d_pub_arrivals);
@@ -889,7 +925,7 @@ uint32_t step_block_threads(const cdpr_engine* h, int k) {
 // its argument buffers on the FIRST launch: measured ~1 ms), not the first cdpr_update: one launch of exactly that kernel
 // over one workgroup of home-state robots in a scratch buffer, which is then freed.  The handle's own state is not touched.
 int warm_first_launch(cdpr_engine* h) {
-  if (h->general) return CDPR_OK;
+  if (h->general || h->fp64) return CDPR_OK;
   if (const char* w = std::getenv("CDPR_NO_WARM_LAUNCH"))
     if (w[0] == '1') return CDPR_OK;
   const uint32_t rows = 64;
@@ -929,6 +965,124 @@ int warm_first_launch(cdpr_engine* h) {
   set_weight_row(h, a);
   hipLaunchKernelGGL(select_step_kernel(h, 1), dim3(1), dim3(step_block_threads(h, 1)), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, wait_stream(h));
+  return CDPR_OK;
+}
+
+using F64Kernel = void (*)(const F64Args);
+F64Kernel pick_f64_kernel(uint32_t n) {
+  switch (n) {
+    case 1: return cdpr_step_kernel_f64<1>;
+    case 2: return cdpr_step_kernel_f64<2>;
+    case 3: return cdpr_step_kernel_f64<3>;
+    case 4: return cdpr_step_kernel_f64<4>;
+    case 5: return cdpr_step_kernel_f64<5>;
+    case 6: return cdpr_step_kernel_f64<6>;
+    case 7: return cdpr_step_kernel_f64<7>;
+    case 8: return cdpr_step_kernel_f64<8>;
+  }
+  return nullptr;
+}
+
+void fill_pid64(const cdpr_pid_params_t& p, double dt, F64Args& k) {
+  k.kf = p.forward_gain; k.kp = p.p_gain; k.ki = p.i_gain; k.kd = p.d_gain;
+  k.imax = std::fabs(p.i_limit); k.imin = -std::fabs(p.i_limit);  // Pid.cpp:70-73 (abs -> fabs)
+  k.cmax = std::fabs(p.cmd_limit); k.cmin = -std::fabs(p.cmd_limit);
+  k.inv_dt = 1.0 / dt;
+  k.nbuf = (int)p.d_buffer_length;
+  k.clamp_cmd = k.cmax > k.cmin;
+}
+
+// precision = 64: the same host logic (commands are latched by run_steps before this is reached), the fp64 kernel
+int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
+  const uint32_t n = h->n;
+  if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller row
+    h->pid_calls = 0;
+    HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)11 * n * h->stride * sizeof(double), h->stream));
+  }
+  F64Args a = h->base64;
+  const bool vel = h->mode == kModeVelocity;
+  fill_pid64(vel ? h->cfg.velocity_pid : h->cfg.position_pid, h->cfg.dt, a);
+  a.cmd = vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
+  a.wtab = h->d_wtab64 + (vel ? 0 : kWin * (kWin + 2));
+  F64Kernel kern = pick_f64_kernel(n);
+  int done = 0;
+  while (done < nsteps) {
+    const int k = std::min(per_launch, nsteps - done);
+    a.nsteps = k;
+    a.flags = vel ? kFlagActualIsVelocity : 0u;
+    const bool first_world = (h->step == 0);
+    if (first_world) a.flags |= kFlagFirstWorldStep;
+    a.pid_calls = sat_pid_calls(h->pid_calls);
+    a.ring_slot = ring_slot_of(h->step);
+    a.publish_mask = 0;
+    for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
+      const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
+      if ((now - h->prev_publish) > h->cfg.publish_period) {
+        h->prev_publish = now;
+        a.publish_mask |= (1ull << j);
+      }
+    }
+    hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
+    HIP_TRY(h, hipGetLastError());
+    ++h->launches;
+    h->step += (uint64_t)k;
+    h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
+    done += k;
+  }
+  return CDPR_OK;
+}
+
+// rows [first_row, first_row + width) of a double row buffer -> robot-major host array (double, or float when as_float)
+int fetch_rows64(cdpr_engine* h, const double* rows, uint32_t first_row, uint32_t width, void* host_out, bool as_float) {
+  if (!host_out) return CDPR_OK;
+  const size_t count = (size_t)h->batch * width, bytes = count * (as_float ? sizeof(float) : sizeof(double));
+  if (h->unpack64_cap < bytes) {
+    HIP_TRY(h, wait_stream(h));
+    if (h->d_unpack64) (void)hipFree(h->d_unpack64);
+    h->d_unpack64 = nullptr;
+    h->unpack64_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_unpack64, bytes));
+    h->unpack64_cap = bytes;
+  }
+  Unpack64Args u{};
+  u.rows = rows;
+  u.out = h->d_unpack64;
+  u.stride = h->stride;
+  u.batch = h->batch;
+  u.width = width;
+  u.first_row = first_row;
+  u.as_float = as_float ? 1 : 0;
+  hipLaunchKernelGGL(cdpr_unpack64_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, h->stream, u);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(host_out, h->d_unpack64, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, wait_stream(h));
+  return CDPR_OK;
+}
+
+// the five observable arrays of an fp64 handle (any may be null), double or rounded to float
+int fetch_observables64(cdpr_engine* h, void* position, void* velocity, void* effort, void* pose7, void* twist6, bool as_float) {
+  const uint32_t n = h->n;
+  int rc = fetch_rows64(h, h->d_obs64, 16, n, position, as_float);
+  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 16 + n, n, velocity, as_float);
+  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 16 + 2 * n, n, effort, as_float);
+  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 0, 7, pose7, as_float);
+  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 7, 6, twist6, as_float);
+  return rc;
+}
+
+int set_platform_state64(cdpr_engine* h, const double* pose7, const double* twist6) {
+  const size_t st = h->stride;
+  std::vector<double> s((size_t)20 * st);
+  HIP_TRY(h, hipMemcpyAsync(s.data(), h->d_state64, s.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, wait_stream(h));
+  for (uint32_t r = 0; r < h->batch; ++r) {
+    if (pose7)
+      for (int c = 0; c < 7; ++c) s[(size_t)c * st + r] = s[(size_t)(13 + c) * st + r] = pose7[(size_t)r * 7 + c];  // the FK seed follows the spawn pose
+    if (twist6)
+      for (int c = 0; c < 6; ++c) s[(size_t)(7 + c) * st + r] = twist6[(size_t)r * 6 + c];
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->d_state64, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
@@ -1053,6 +1207,13 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   }
   if (int rc = mark_free()) return rc;
   if (h->general) return run_steps_general(h, nsteps);
+  if (h->fp64) {
+    if (record) {
+      h->err = "trajectory records are fp32-only";
+      return CDPR_ERR_UNSUPPORTED;
+    }
+    return run_steps_f64(h, nsteps, per_launch, reset_pid);
+  }
 
   if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller record; rare, so done outside the step kernel
     h->pid_calls = 0;
@@ -1192,6 +1353,8 @@ int fetch_fields(cdpr_engine* h, const float4* rows, const std::vector<std::pair
   if (h->unpack_cap < count) {
     HIP_TRY(h, wait_stream(h));
     if (h->d_unpack) (void)hipFree(h->d_unpack);
+  for (void* p64 : {(void*)h->d_state64, (void*)h->d_obs64, (void*)h->d_geom64, (void*)h->d_wtab64, (void*)h->d_dbg64, h->d_unpack64})
+    if (p64) (void)hipFree(p64);
     h->d_unpack = nullptr;
     h->unpack_cap = 0;
     HIP_TRY(h, hipMalloc(&h->d_unpack, count * sizeof(float)));
@@ -1276,6 +1439,12 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   // two Pids that fit different derivative windows, take the general controller path
   const bool pr_windows_differ = cfg->velocity_pid.d_buffer_length != cfg->position_pid.d_buffer_length || cfg->velocity_pid.d_degree != cfg->position_pid.d_degree;
   const bool general = !fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && (phys_cfg || pr_windows_differ));
+  if (cfg->precision == 64 && (general || cfg->per_robot_commands != 0 || phys_cfg)) {
+    g_create_error = "precision = 64 covers uniform-mode handles on the register-resident path only (no per_robot_commands, lumped legs, "
+                     "travel_stop, hold branch, cascades, long windows or cmd_limit 0): " +
+                     (general ? fast_path_obstacle(*cfg) : std::string("per-robot modes / optional physics"));
+    return CDPR_ERR_UNSUPPORTED;
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -1296,6 +1465,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
   h->general = general;
+  h->fp64 = cfg->precision == 64;
   h->per_robot = cfg->per_robot_commands != 0;
   h->phys = phys_cfg;
   {
@@ -1318,6 +1488,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     const bool split_case = !general && !h->phys && (cfg->stages & CDPR_STAGE_FK) && (cfg->stages & CDPR_STAGE_TD) && cfg->n_cables >= 6;
     if (mapping == CDPR_MAP_AUTO)
       mapping = (can_pair && !split_case && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
+    if (h->fp64) mapping = CDPR_MAP_LANE_PER_ROBOT;  // one plain kernel
     h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
     // one lane per cable: any cable count; not with the optional physics, per-robot modes or the general path (those
     // handles silently keep the lane-per-robot mapping, as the lane-pair request does where it cannot be served)
@@ -1359,8 +1530,59 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return fail("hipEventCreate", e);
   const size_t slot_bytes = (size_t)h->stride * sizeof(float4);
-  if ((e = hipMalloc(&h->d_state, slot_bytes * h->n_state)) != hipSuccess) return fail("hipMalloc(state)", e);
-  if ((e = hipMalloc(&h->d_obs, slot_bytes * h->n_obs)) != hipSuccess) return fail("hipMalloc(obs)", e);
+  if (h->fp64) {
+    const size_t row = (size_t)h->stride * sizeof(double);
+    if ((e = hipMalloc(&h->d_state64, row * f64_state_rows((int)h->n))) != hipSuccess) return fail("hipMalloc(state64)", e);
+    if ((e = hipMalloc(&h->d_obs64, row * f64_obs_rows((int)h->n))) != hipSuccess) return fail("hipMalloc(obs64)", e);
+    std::vector<double> g((size_t)h->n * 7), wt((size_t)2 * kWin * (kWin + 2), 0.0);
+    for (uint32_t i = 0; i < h->n; ++i) {
+      for (int k = 0; k < 3; ++k) {
+        g[(size_t)i * 7 + k] = cfg->frame_anchor[i][k];
+        g[(size_t)i * 7 + 3 + k] = cfg->platform_anchor[i][k];
+      }
+      g[(size_t)i * 7 + 6] = cfg->cable_ref_length[i];
+    }
+    const cdpr_pid_params_t* pids[2] = {&cfg->velocity_pid, &cfg->position_pid};
+    for (int t = 0; t < 2; ++t) {  // the rotated weight tables of fill_pid, in double
+      double w[CDPR_MAX_D_BUFFER], wpad[kWin + 1];
+      for (int j = 0; j <= kWin; ++j) wpad[j] = 0.0;
+      if (derivative_weights(pids[t]->d_buffer_length, pids[t]->d_degree, w) == CDPR_OK)
+        for (uint32_t j = 0; j < pids[t]->d_buffer_length; ++j) wpad[kWin + 1 - pids[t]->d_buffer_length + j] = w[j];
+      double* tab = &wt[(size_t)t * kWin * (kWin + 2)];
+      for (int ws = 0; ws < kWin; ++ws) {
+        for (int sl = 0; sl < kWin; ++sl) {
+          int j = ((ws - sl) % kWin + kWin) % kWin;
+          if (j == 0) j = kWin;
+          tab[ws * (kWin + 2) + sl] = wpad[kWin - j];
+        }
+        tab[ws * (kWin + 2) + kWin] = wpad[kWin];
+      }
+    }
+    if ((e = hipMalloc(&h->d_geom64, g.size() * sizeof(double))) != hipSuccess) return fail("hipMalloc(geom64)", e);
+    if ((e = hipMemcpy(h->d_geom64, g.data(), g.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(geom64)", e);
+    if ((e = hipMalloc(&h->d_wtab64, wt.size() * sizeof(double))) != hipSuccess) return fail("hipMalloc(wtab64)", e);
+    if ((e = hipMemcpy(h->d_wtab64, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(wtab64)", e);
+    if (h->dbg && (e = hipMalloc(&h->d_dbg64, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(double))) != hipSuccess) return fail("hipMalloc(dbg64)", e);
+    F64Args& b = h->base64;
+    memset(&b, 0, sizeof b);
+    b.state = h->d_state64; b.obs = h->d_obs64; b.dbg = h->d_dbg64; b.geom = h->d_geom64;
+    b.batch = h->batch; b.stride = h->stride;
+    b.fk = h->fk ? 1 : 0; b.td = h->td ? 1 : 0;
+    b.dt = cfg->dt; b.half_dt = 0.5 * cfg->dt; b.inv_mass = 1.0 / cfg->mass;
+    b.fgx = cfg->mass * cfg->gravity[0]; b.fgy = cfg->mass * cfg->gravity[1]; b.fgz = cfg->mass * cfg->gravity[2];
+    double inv6[6];
+    mat3_inverse_sym(cfg->inertia, inv6);
+    for (int i = 0; i < 6; ++i) { b.ib[i] = cfg->inertia[i]; b.ibinv[i] = inv6[i]; }
+    b.damping = cfg->joint_damping; b.effort = cfg->effort_limit; b.vel_limit = cfg->velocity_limit;
+    b.unilateral = cfg->unilateral_cables ? 1 : 0;
+    b.travel_on = (cfg->travel_lower != 0.0 || cfg->travel_upper != 0.0) ? 1 : 0;
+    b.travel_lo = cfg->travel_lower; b.travel_hi = cfg->travel_upper;
+    b.fk_lambda = cfg->fk_lambda; b.fk_tol = cfg->fk_tolerance; b.fk_iters = (int)cfg->fk_max_iterations;
+    b.td_min = cfg->td_f_min; b.td_max = cfg->td_f_max; b.td_mid = 0.5 * (cfg->td_f_min + cfg->td_f_max);
+  } else {
+    if ((e = hipMalloc(&h->d_state, slot_bytes * h->n_state)) != hipSuccess) return fail("hipMalloc(state)", e);
+    if ((e = hipMalloc(&h->d_obs, slot_bytes * h->n_obs)) != hipSuccess) return fail("hipMalloc(obs)", e);
+  }
   const size_t cmd_bytes = (size_t)h->stride * h->n * sizeof(float);
   for (int i = 0; i < 2; ++i) {
     if ((e = hipMalloc(&h->d_vel[i], cmd_bytes)) != hipSuccess) return fail("hipMalloc(cmd)", e);
@@ -1404,7 +1626,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     for (int i = 0; i < 2; ++i)
       if ((e = hipMalloc(&h->d_mask[i], h->batch)) != hipSuccess) return fail("hipMalloc(mask)", e);
   }
-  if (h->dbg)
+  if (h->dbg && !h->fp64)
     if ((e = hipMalloc(&h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float))) != hipSuccess)
       return fail("hipMalloc(dbg)", e);
   if (upload_home(h) != CDPR_OK || warm_first_launch(h) != CDPR_OK) {
@@ -1436,6 +1658,12 @@ int cdpr_reset(cdpr_handle_t h) {
 int cdpr_set_platform_state(cdpr_handle_t h, const float* pose7, const float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (h->fp64) {
+    std::vector<double> p, t;
+    if (pose7) p.assign(pose7, pose7 + (size_t)h->batch * 7);
+    if (twist6) t.assign(twist6, twist6 + (size_t)h->batch * 6);
+    return set_platform_state64(h, pose7 ? p.data() : nullptr, twist6 ? t.data() : nullptr);
+  }
   const int P = plat_slots(h->fk);
   std::vector<float4> s;
   int rc = fetch_slots(h, h->d_state, P, s);
@@ -1601,14 +1829,18 @@ int cdpr_update_fused(cdpr_handle_t h, int nsteps, int steps_per_launch) { retur
 
 int cdpr_observable_image_bytes(cdpr_handle_t h, size_t* bytes) {
   if (!h || !bytes) return CDPR_ERR_INVALID;
+  if (h->fp64) {
+    h->err = "observable images / trajectory records are fp32-only";
+    return CDPR_ERR_UNSUPPORTED;
+  }
   *bytes = (size_t)h->n_obs * h->stride * sizeof(float4);
   return CDPR_OK;
 }
 
 int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void* d_record, size_t record_bytes) {
   if (!h) return CDPR_ERR_INVALID;
-  if (h->general) {
-    h->err = "cdpr_update_record: not available on the general controller path";
+  if (h->general || h->fp64) {
+    h->err = "cdpr_update_record: not available on the general controller path or with precision = 64";
     return CDPR_ERR_UNSUPPORTED;
   }
   if (h->cfg.publish_period != 0.0) {
@@ -1686,6 +1918,7 @@ uint64_t cdpr_step_count(cdpr_handle_t h) { return h ? h->step : 0; }
 int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, float* effort) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (h->fp64) return fetch_observables64(h, position, velocity, effort, nullptr, nullptr, true);
   const int G = joint_groups((int)h->n);
   float* dst[3] = {position, velocity, effort};
   for (int f = 0; f < 3; ++f) {
@@ -1703,6 +1936,7 @@ int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, flo
 int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, float* effort, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (h->fp64) return fetch_observables64(h, position, velocity, effort, pose7, twist6, true);
   const uint32_t n = h->n, width = 3u * n + 13u;
   const size_t count = (size_t)h->batch * width;
   // lazy set-up, every allocation guarded on its own pointer (a failure half way leaves nothing to leak or to skip next
@@ -1728,6 +1962,8 @@ int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, floa
   if (!direct && h->unpack_cap < count) {
     HIP_TRY(h, wait_stream(h));
     if (h->d_unpack) (void)hipFree(h->d_unpack);
+  for (void* p64 : {(void*)h->d_state64, (void*)h->d_obs64, (void*)h->d_geom64, (void*)h->d_wtab64, (void*)h->d_dbg64, h->d_unpack64})
+    if (p64) (void)hipFree(p64);
     h->d_unpack = nullptr;
     h->unpack_cap = 0;
     HIP_TRY(h, hipMalloc(&h->d_unpack, count * sizeof(float)));
@@ -1802,13 +2038,46 @@ int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, floa
 int cdpr_get_platform_state(cdpr_handle_t h, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (h->fp64) return fetch_observables64(h, nullptr, nullptr, nullptr, pose7, twist6, true);
   return fetch_platform(h, h->d_obs, pose7, twist6);
 }
 
 int cdpr_get_raw_state(cdpr_handle_t h, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (h->fp64) {
+    int rc = fetch_rows64(h, h->d_state64, 0, 7, pose7, true);
+    return rc != CDPR_OK ? rc : fetch_rows64(h, h->d_state64, 7, 6, twist6, true);
+  }
   return fetch_platform(h, h->d_state, pose7, twist6);
+}
+
+static int need_fp64(cdpr_engine* h, const char* what) {
+  if (h->fp64) return CDPR_OK;
+  h->err = std::string(what) + ": the handle was not created with precision = 64";
+  return CDPR_ERR_UNSUPPORTED;
+}
+
+int cdpr_get_observables_f64(cdpr_handle_t h, double* position, double* velocity, double* effort, double* pose7, double* twist6) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (int rc = need_fp64(h, "cdpr_get_observables_f64")) return rc;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  return fetch_observables64(h, position, velocity, effort, pose7, twist6, false);
+}
+
+int cdpr_get_raw_state_f64(cdpr_handle_t h, double* pose7, double* twist6) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (int rc = need_fp64(h, "cdpr_get_raw_state_f64")) return rc;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  int rc = fetch_rows64(h, h->d_state64, 0, 7, pose7, false);
+  return rc != CDPR_OK ? rc : fetch_rows64(h, h->d_state64, 7, 6, twist6, false);
+}
+
+int cdpr_set_platform_state_f64(cdpr_handle_t h, const double* pose7, const double* twist6) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (int rc = need_fp64(h, "cdpr_set_platform_state_f64")) return rc;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  return set_platform_state64(h, pose7, twist6);
 }
 
 int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
@@ -1818,10 +2087,27 @@ int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
     return CDPR_ERR_UNSUPPORTED;
   }
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (h->fp64) {
+    std::vector<double> d((size_t)h->batch * CDPR_PID_DEBUG_AXES);
+    HIP_TRY(h, hipMemcpyAsync(d.data(), h->d_dbg64, d.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, wait_stream(h));
+    for (size_t i = 0; i < d.size(); ++i) axes9[i] = (float)d[i];
+    return CDPR_OK;
+  }
   HIP_TRY(h, hipMemcpyAsync(axes9, h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float), hipMemcpyDeviceToHost,
                             h->stream));
   HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
+}
+
+// fp64 handles: one observable row of doubles as int32 per robot (iteration count, flags)
+static int fetch_int_row64(cdpr_engine* h, uint32_t row, int32_t* out) {
+  if (!out) return CDPR_OK;
+  std::vector<double> d(h->batch);
+  int rc = fetch_rows64(h, h->d_obs64, row, 1, d.data(), false);
+  if (rc == CDPR_OK)
+    for (uint32_t b = 0; b < h->batch; ++b) out[b] = (int32_t)d[b];
+  return rc;
 }
 
 int cdpr_get_fk_state(cdpr_handle_t h, float* pose7, float* residual, int32_t* iterations) {
@@ -1831,6 +2117,11 @@ int cdpr_get_fk_state(cdpr_handle_t h, float* pose7, float* residual, int32_t* i
     return CDPR_ERR_UNSUPPORTED;
   }
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  if (h->fp64) {
+    int rc = fetch_rows64(h, h->d_state64, 13, 7, pose7, true);
+    if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 13, 1, residual, true);
+    return rc != CDPR_OK ? rc : fetch_int_row64(h, 14, iterations);
+  }
   // estimate: state slot 3 yzw + slot 4 xyzw; residual / iteration count: observable slot 3 y, z
   int rc = fetch_fields(h, h->d_state, {{3, 1}, {3, 2}, {3, 3}, {4, 0}, {4, 1}, {4, 2}, {4, 3}}, pose7);
   if (rc != CDPR_OK) return rc;
@@ -1847,7 +2138,7 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
   }
   int rc = cdpr_get_joint_states(h, nullptr, nullptr, tension);  // applied force == distributed tension
   if (rc != CDPR_OK) return rc;
-  rc = fetch_fields(h, h->d_obs, {{3, 3}}, infeasible, 1u);
+  rc = h->fp64 ? fetch_int_row64(h, 15, infeasible) : fetch_fields(h, h->d_obs, {{3, 3}}, infeasible, 1u);
   if (rc == CDPR_OK && infeasible)
     for (uint32_t b = 0; b < h->batch; ++b) infeasible[b] &= 1;  // the travel-limit mask shares the component (pack_flags)
   return rc;
@@ -1856,7 +2147,7 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
 int cdpr_get_limit_state(cdpr_handle_t h, uint32_t* cable_mask) {
   if (!h || !cable_mask) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  int rc = fetch_fields(h, h->d_obs, {{3, 3}}, cable_mask, 1u);
+  int rc = h->fp64 ? fetch_int_row64(h, 15, reinterpret_cast<int32_t*>(cable_mask)) : fetch_fields(h, h->d_obs, {{3, 3}}, cable_mask, 1u);
   if (rc == CDPR_OK)
     for (uint32_t b = 0; b < h->batch; ++b) cable_mask[b] >>= 1;  // bit 0 is the tension-distribution flag
   return rc;
@@ -1905,8 +2196,8 @@ static int rollout_check(cdpr_engine* h, int samples, int horizon, const void* d
     h->err = "rollout: samples, horizon >= 1 and the command buffer are required";
     return CDPR_ERR_INVALID;
   }
-  if (h->general) {
-    h->err = "rollout: not available on the general controller path";
+  if (h->general || h->fp64) {
+    h->err = "rollout: not available on the general controller path or with precision = 64";
     return CDPR_ERR_UNSUPPORTED;
   }
   if ((uint64_t)h->batch * (uint64_t)samples > (1ull << 30)) {

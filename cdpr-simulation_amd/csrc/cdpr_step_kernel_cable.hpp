@@ -21,7 +21,7 @@
 // (same address: one request) and written by lanes 0..4, one row each; observables likewise, joint rows by dword.
 //
 // Arithmetic: same formulas as the other mappings, but the sums over cables are tree reductions here, so results agree
-// with the other mappings to fp32 rounding, not bit for bit (tests compare with the oracle at the usual tolerances).
+// with the other mappings to fp32 rounding, not bit for bit (the parity tests run at the usual tolerances).
 #pragma once
 #include "cdpr_step_kernel.hpp"
 

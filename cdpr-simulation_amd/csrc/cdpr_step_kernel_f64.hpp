@@ -1,0 +1,477 @@
+// cdpr_step_kernel_f64.hpp — the step in the REFERENCE'S OWN PRECISION (gfx950, fp64): cdpr_config_t.precision = 64.
+//
+// The reference computes in double throughout (Pid.h members, Gazebo/ODE state); BASELINE.json's north-star allows fp32
+// "to a stated tolerance", and the fp32 kernels are what the throughput figures are quoted on.  This kernel is the
+// drop-in for callers who want the plugin's numbers instead: one robot (config 1) or a small batch, where the step is
+// pure latency anyway and MI355X's vector fp64 issues at the plain-fp32 rate.  Same step semantics (DESIGN.md
+// section 1), same Pid formulation as the fp32 fast path (the closed-form end-point least-squares derivative, weights in
+// double; ring position from the world step), one lane per robot, plain scalar double arithmetic (there is no packed
+// fp64), no role split, no LDS: clarity over speed.  It covers what the register-resident fp32 path covers for a
+// uniform-mode handle (IK, Pid, optional Newton-Raphson FK and tension distribution, SetForce limits, velocity limit,
+// unilateral cables, observables with publish decimation, travel-limit flags, world step, any number of steps per
+// launch); everything else (general controller path, per-robot modes, lumped legs, rollout, trajectory record) stays
+// fp32-only and cdpr_create refuses the combination.
+//
+// HBM layout (doubles, struct of arrays over the batch, row r of the state at state[r * stride + robot]):
+//   state: 0-6 pose (x y z qx qy qz qw) | 7-12 twist (v, w) | 13-19 FK estimate (pose7) | per cable i: 20 + 11 i + j,
+//          j = 0..9 the ring of the last ten errors, j = 10 the integral
+//   obs:   0-6 pose | 7-12 twist | 13 fk residual | 14 fk iterations | 15 flags (bit 0 TD infeasible, bits 1.. travel
+//          limits) | 16 + i joint position | 16 + n + i joint velocity | 16 + 2n + i effort
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cdpr_step_kernel.hpp"
+
+namespace cdpr {
+
+struct F64Args {
+  double* state;
+  double* obs;
+  const float* cmd;     // latched Joy.axes of the active mode, float[B][n] (float32 on the wire: sensor_msgs/Joy)
+  double* dbg;          // double[B][9] `pid` debug topic, or nullptr
+  const double* geom;   // [n][7]: ax ay az bx by bz l0
+  const double* wtab;   // [10][12]: weights pre-rotated per ring slot, as StepArgs::wtab
+  uint32_t batch, stride;
+  int nsteps;
+  uint32_t flags;       // StepFlags
+  uint64_t publish_mask;
+  int pid_calls, ring_slot;
+  int fk, td;           // stages
+  double dt, half_dt, inv_mass, fgx, fgy, fgz;
+  double ib[6], ibinv[6];
+  double damping, effort, vel_limit;
+  int unilateral, travel_on;
+  double travel_lo, travel_hi;
+  double fk_lambda, fk_tol;
+  int fk_iters;
+  double td_min, td_max, td_mid;
+  double kf, kp, ki, kd, imax, imin, cmax, cmin, inv_dt;
+  int nbuf, clamp_cmd;
+};
+
+__host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
+__host__ __device__ constexpr int f64_obs_rows(int n) { return 16 + 3 * n; }
+
+struct Rot64 {
+  double r00, r01, r02, r10, r11, r12, r20, r21, r22;
+};
+__device__ __forceinline__ Rot64 quat_to_rot64(double x, double y, double z, double w) {
+  Rot64 r;
+  r.r00 = 1.0 - 2.0 * (y * y + z * z);
+  r.r01 = 2.0 * (x * y - z * w);
+  r.r02 = 2.0 * (x * z + y * w);
+  r.r10 = 2.0 * (x * y + z * w);
+  r.r11 = 1.0 - 2.0 * (x * x + z * z);
+  r.r12 = 2.0 * (y * z - x * w);
+  r.r20 = 2.0 * (x * z - y * w);
+  r.r21 = 2.0 * (y * z + x * w);
+  r.r22 = 1.0 - 2.0 * (x * x + y * y);
+  return r;
+}
+
+// sin(x)/x and cos(x) for the half angle of a rotation increment.  The library's double sin / cos carry a Payne-Hanek
+// argument reduction that costs 2 KiB of scratch memory per lane whether it runs or not; a Newton step's half angle is
+// tiny, so: halve x until it is below 0.8 (never, in practice), Taylor series in x^2 to x^20 / x^21 (remainder < 1e-21
+// there), then undo the halvings with the double-angle formulas.
+__device__ __forceinline__ void sinc_cos64(double x, double& sinc, double& c) {
+  int halvings = 0;
+  while (x > 0.8 && halvings < 16) {
+    x *= 0.5;
+    ++halvings;
+  }
+  const double z = x * x;
+  // sin(x)/x = sum (-z)^k / (2k+1)!,  cos(x) = sum (-z)^k / (2k)!
+  double sc = 1.0 / 51090942171709440000.0;  // 1/21!
+  sc = sc * -z + 1.0 / 121645100408832000.0;  // 1/19!
+  sc = sc * -z + 1.0 / 355687428096000.0;     // 1/17!
+  sc = sc * -z + 1.0 / 1307674368000.0;       // 1/15!
+  sc = sc * -z + 1.0 / 6227020800.0;          // 1/13!
+  sc = sc * -z + 1.0 / 39916800.0;            // 1/11!
+  sc = sc * -z + 1.0 / 362880.0;              // 1/9!
+  sc = sc * -z + 1.0 / 5040.0;                // 1/7!
+  sc = sc * -z + 1.0 / 120.0;                 // 1/5!
+  sc = sc * -z + 1.0 / 6.0;                   // 1/3!
+  sc = sc * -z + 1.0;
+  double cc = 1.0 / 2432902008176640000.0;    // 1/20!
+  cc = cc * -z + 1.0 / 6402373705728000.0;    // 1/18!
+  cc = cc * -z + 1.0 / 20922789888000.0;      // 1/16!
+  cc = cc * -z + 1.0 / 87178291200.0;         // 1/14!
+  cc = cc * -z + 1.0 / 479001600.0;           // 1/12!
+  cc = cc * -z + 1.0 / 3628800.0;             // 1/10!
+  cc = cc * -z + 1.0 / 40320.0;               // 1/8!
+  cc = cc * -z + 1.0 / 720.0;                 // 1/6!
+  cc = cc * -z + 1.0 / 24.0;                  // 1/4!
+  cc = cc * -z + 0.5;                         // 1/2!
+  cc = cc * -z + 1.0;
+  double sn = sc * x;
+  for (int k = 0; k < halvings; ++k) {  // sin 2x = 2 s c, cos 2x = c^2 - s^2
+    const double s2 = 2.0 * sn * cc, c2 = cc * cc - sn * sn;
+    sn = s2;
+    cc = c2;
+    x *= 2.0;
+  }
+  sinc = (halvings == 0) ? sc : sn / x;
+  c = cc;
+}
+
+// q <- exp(theta / 2) (x) q, renormalised (world-frame rotation increment)
+__device__ __forceinline__ void quat_apply_rotvec64(double (&q)[4], double tx, double ty, double tz) {
+  const double a2 = tx * tx + ty * ty + tz * tz;
+  const double a = sqrt(a2);
+  double sinc, c;
+  sinc_cos64(0.5 * a, sinc, c);
+  const double k = 0.5 * sinc;  // sin(a/2) / a
+  const double dx = k * tx, dy = k * ty, dz = k * tz;
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  const double nw = c * w - dx * x - dy * y - dz * z;
+  const double nx = c * x + w * dx + dy * z - dz * y;
+  const double ny = c * y + w * dy + dz * x - dx * z;
+  const double nz = c * z + w * dz + dx * y - dy * x;
+  const double inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+  q[0] = nx * inv;
+  q[1] = ny * inv;
+  q[2] = nz * inv;
+  q[3] = nw * inv;
+}
+
+// One IK row (gen:113-118): l = p + R b - a, L = |l|, u = l / L, J row = [u, (R b) x u]
+__device__ __forceinline__ void ik_row64(const double* g, const Rot64& r, const double (&p)[3], double& L, double (&j)[6]) {
+  const double rbx = r.r00 * g[3] + r.r01 * g[4] + r.r02 * g[5];
+  const double rby = r.r10 * g[3] + r.r11 * g[4] + r.r12 * g[5];
+  const double rbz = r.r20 * g[3] + r.r21 * g[4] + r.r22 * g[5];
+  const double lx = p[0] + rbx - g[0], ly = p[1] + rby - g[1], lz = p[2] + rbz - g[2];
+  L = sqrt(lx * lx + ly * ly + lz * lz);
+  const double inv = 1.0 / L;
+  const double ux = lx * inv, uy = ly * inv, uz = lz * inv;
+  j[0] = ux;
+  j[1] = uy;
+  j[2] = uz;
+  j[3] = rby * uz - rbz * uy;
+  j[4] = rbz * ux - rbx * uz;
+  j[5] = rbx * uy - rby * ux;
+}
+
+// m x = g for the SPD 6x6 system whose lower triangle is given (g -> x), Cholesky
+__device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) {
+  double invd[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = m[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= m[j][k] * m[j][k];
+    invd[j] = 1.0 / sqrt(d);
+#pragma unroll
+    for (int i = j + 1; i < 6; ++i) {
+      double s = m[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) s -= m[i][k] * m[j][k];
+      m[i][j] = s * invd[j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double s = g[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= m[i][k] * g[k];
+    g[i] = s * invd[i];
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s = g[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= m[k][i] * g[k];
+    g[i] = s * invd[i];
+  }
+}
+
+// Per-cable scalars of a lane live in LDS columns (one column per lane), so the loops over the cables are real loops
+// with a run-time index: the structure matrix is never held as a whole, every stage rebuilds the rows it needs and
+// accumulates J^T J / J^T v on the fly.  (Fully unrolled, with both structure matrices in registers, the double
+// version of this kernel needed 512 registers and 2 KiB of scratch per lane.)
+template <int N>
+__global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
+  __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t r = blockIdx.x * 64u + lane;
+  if (r >= a.batch) return;  // no barrier below: lanes are independent, LDS columns are private
+  const size_t st = a.stride;
+  double* const S = a.state + r;
+  double p[3] = {S[0 * st], S[1 * st], S[2 * st]};
+  double q4[4] = {S[3 * st], S[4 * st], S[5 * st], S[6 * st]};
+  double v[3] = {S[7 * st], S[8 * st], S[9 * st]}, om[3] = {S[10 * st], S[11 * st], S[12 * st]};
+  double fkp[3] = {S[13 * st], S[14 * st], S[15 * st]};
+  double fkq[4] = {S[16 * st], S[17 * st], S[18 * st], S[19 * st]};
+  // the derivative ring stays in HBM / L2 (read by the FIR of every step, one slot written back)
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) {
+    c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
+    c_des[i][lane] = (double)a.cmd[(size_t)r * N + i];
+  }
+  const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
+  int calls = a.pid_calls;
+
+  for (int step = 0; step < a.nsteps; ++step) {
+    const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
+    const bool run_pid = !first_world && calls != 0;  // Pid.cpp:123-126: the first call since reset returns 0
+    const bool full = calls >= a.nbuf;
+    const int ring_slot = (a.ring_slot + step) % kWin;
+    const double* wt = a.wtab + ring_slot * (kWin + 2);
+    double dbg_p = 0.0, dbg_i = 0.0, dbg_d = 0.0;
+    // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
+    {
+      const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
+#pragma unroll 1
+      for (int i = 0; i < N; ++i) {
+        double L, j[6];
+        ik_row64(a.geom + i * 7, R, p, L, j);
+        const double q = a.geom[i * 7 + 6] - L;
+        const double qd = -(j[0] * v[0] + j[1] * v[1] + j[2] * v[2] + j[3] * om[0] + j[4] * om[1] + j[5] * om[2]);
+        c_len[i][lane] = L;
+        c_q[i][lane] = q;
+        c_qd[i][lane] = qd;
+        double force = 0.0;
+        if (run_pid) {
+          const double desired = c_des[i][lane];
+          const double error = desired - (actual_is_vel ? qd : q);
+          double acc = wt[kWin] * error;
+#pragma unroll
+          for (int k = 0; k < kWin; ++k) acc += wt[k] * S[(size_t)(20 + 11 * i + k) * st];
+          const double p_term = a.kp * error;
+          const double prev_ierr = c_ierr[i][lane];
+          double ie = prev_ierr + a.dt * error;
+          double i_term = a.ki * ie;
+          const double i_raw = i_term;
+          if (i_term > a.imax) {  // Pid.cpp:143-152
+            i_term = a.imax;
+            ie = i_term / a.ki;
+          } else if (i_term < a.imin) {
+            i_term = a.imin;
+            ie = i_term / a.ki;
+          }
+          const double derived = full ? acc * a.inv_dt : 0.0;
+          const double d_term = a.kd * derived;
+          const double cmd = a.kf * desired + p_term + i_term + d_term;
+          double out = a.clamp_cmd ? fmax(fmin(cmd, a.cmax), a.cmin) : cmd;  // Pid.cpp:175-177
+          if (out != cmd) {                                                    // Pid.cpp:181-184
+            ie = prev_ierr;
+            out += a.dt * error * a.ki;
+          }
+          c_ierr[i][lane] = ie;
+          force = out;
+          S[(size_t)(20 + 11 * i + ring_slot) * st] = error;  // after the FIR has read the slot's old content
+          if (i == 0) {
+            dbg_p = p_term;
+            dbg_i = i_raw;
+            dbg_d = d_term;
+          }
+        }
+        c_f[i][lane] = force;
+      }
+      if (!first_world) ++calls;
+    }
+    // ---- Newton-Raphson forward kinematics ([NEW] SURVEY 8(a) row 14)
+    double fk_res = 0.0;
+    int fk_it = 0, td_flag = 0;
+    if (a.fk) {
+      bool active = true;
+      for (int it = 0; it < a.fk_iters; ++it) {
+        const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
+        double m[6][6], g[6], rmax = 0.0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          g[x] = 0.0;
+#pragma unroll
+          for (int y = 0; y <= x; ++y) m[x][y] = (x == y) ? a.fk_lambda : 0.0;
+        }
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+          double L, j[6];
+          ik_row64(a.geom + i * 7, R, fkp, L, j);
+          const double res = c_len[i][lane] - L;
+          rmax = fmax(rmax, fabs(res));
+#pragma unroll
+          for (int x = 0; x < 6; ++x) {
+            g[x] += j[x] * res;
+#pragma unroll
+            for (int y = 0; y <= x; ++y) m[x][y] += j[x] * j[y];
+          }
+        }
+        active = active && !(rmax < a.fk_tol);
+        chol_solve64(m, g);
+        if (active) {
+          fkp[0] += g[0];
+          fkp[1] += g[1];
+          fkp[2] += g[2];
+          quat_apply_rotvec64(fkq, g[3], g[4], g[5]);
+          ++fk_it;
+        }
+      }
+      const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
+#pragma unroll 1
+      for (int i = 0; i < N; ++i) {
+        double L, j[6];
+        ik_row64(a.geom + i * 7, R, fkp, L, j);
+        fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
+      }
+    }
+    // ---- tension distribution ([NEW] SURVEY 8(a) row 15): T = Tm 1 + J (J^T J)^-1 J^T (f - Tm 1) with J at the FK
+    //      estimate (the true pose without FK), bounds; then the SetForce limits; c_f becomes the applied force
+    uint32_t lim = 0u;
+    {
+      double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      const Rot64 Rt = a.fk ? quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]) : quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
+      const double pt[3] = {a.fk ? fkp[0] : p[0], a.fk ? fkp[1] : p[1], a.fk ? fkp[2] : p[2]};
+      if (a.td) {
+        double m[6][6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+#pragma unroll
+          for (int y = 0; y <= x; ++y) m[x][y] = 0.0;
+        }
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+          double L, j[6];
+          ik_row64(a.geom + i * 7, Rt, pt, L, j);
+          const double df = c_f[i][lane] - a.td_mid;
+#pragma unroll
+          for (int x = 0; x < 6; ++x) {
+            g[x] += j[x] * df;
+#pragma unroll
+            for (int y = 0; y <= x; ++y) m[x][y] += j[x] * j[y];
+          }
+        }
+        chol_solve64(m, g);
+      }
+#pragma unroll 1
+      for (int i = 0; i < N; ++i) {
+        double applied = c_f[i][lane];
+        if (a.td) {
+          double L, j[6];
+          ik_row64(a.geom + i * 7, Rt, pt, L, j);
+          double t = a.td_mid;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) t += g[c] * j[c];
+          const double tc = fmax(fmin(t, a.td_max), a.td_min);
+          td_flag |= (tc != t) ? 1 : 0;
+          applied = tc;
+        }
+        const double qd = c_qd[i][lane], q = c_q[i][lane];
+        if (a.vel_limit > 0.0)  // Joint::SetForce velocity truncation [EXT]
+          applied = ((qd > a.vel_limit && applied > 0.0) || (qd < -a.vel_limit && applied < 0.0)) ? 0.0 : applied;
+        if (a.effort >= 0.0) applied = fmax(fmin(applied, a.effort), -a.effort);  // Joint::SetForce clamp (cube.sdf:438)
+        if (a.travel_on && (q < a.travel_lo || q > a.travel_hi)) lim |= 1u << i;
+        c_f[i][lane] = applied;
+      }
+    }
+    if (a.dbg) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
+      double* d = a.dbg + (size_t)r * 9;
+      if (run_pid) {
+        d[0] = dbg_p;
+        d[1] = dbg_i;
+        d[2] = dbg_d;
+        d[3] = c_des[0][lane];
+      }
+      d[4] = c_f[0][lane];
+    }
+    // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
+    if ((a.publish_mask >> step) & 1ull) {
+      double* const O = a.obs + r;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        O[(size_t)c * st] = p[c];
+        O[(size_t)(7 + c) * st] = v[c];
+        O[(size_t)(10 + c) * st] = om[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) O[(size_t)(3 + c) * st] = q4[c];
+      O[13 * st] = fk_res;
+      O[14 * st] = (double)fk_it;
+      O[15 * st] = (double)((uint32_t)td_flag | (lim << 1));
+#pragma unroll 1
+      for (int i = 0; i < N; ++i) {
+        O[(size_t)(16 + i) * st] = c_q[i][lane];
+        O[(size_t)(16 + N + i) * st] = c_qd[i][lane];
+        O[(size_t)(16 + 2 * N + i) * st] = c_f[i][lane];
+      }
+    }
+    // ---- world step to t_{k+1}: wrench = -J^T (applied - d qdot) + m g, semi-implicit Euler
+    {
+      double w[6] = {a.fgx, a.fgy, a.fgz, 0.0, 0.0, 0.0};
+      const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
+#pragma unroll 1
+      for (int i = 0; i < N; ++i) {
+        double L, j[6];
+        ik_row64(a.geom + i * 7, R, p, L, j);
+        double t = c_f[i][lane] - a.damping * c_qd[i][lane];
+        if (a.unilateral) t = fmax(t, 0.0);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) w[c] -= j[c] * t;
+      }
+      v[0] += a.dt * w[0] * a.inv_mass;
+      v[1] += a.dt * w[1] * a.inv_mass;
+      v[2] += a.dt * w[2] * a.inv_mass;
+      double tb[3] = {R.r00 * w[3] + R.r10 * w[4] + R.r20 * w[5], R.r01 * w[3] + R.r11 * w[4] + R.r21 * w[5], R.r02 * w[3] + R.r12 * w[4] + R.r22 * w[5]};
+      const double ob[3] = {R.r00 * om[0] + R.r10 * om[1] + R.r20 * om[2], R.r01 * om[0] + R.r11 * om[1] + R.r21 * om[2],
+                            R.r02 * om[0] + R.r12 * om[1] + R.r22 * om[2]};
+      const double io[3] = {a.ib[0] * ob[0] + a.ib[3] * ob[1] + a.ib[4] * ob[2], a.ib[3] * ob[0] + a.ib[1] * ob[1] + a.ib[5] * ob[2],
+                            a.ib[4] * ob[0] + a.ib[5] * ob[1] + a.ib[2] * ob[2]};
+      tb[0] -= ob[1] * io[2] - ob[2] * io[1];
+      tb[1] -= ob[2] * io[0] - ob[0] * io[2];
+      tb[2] -= ob[0] * io[1] - ob[1] * io[0];
+      const double ab[3] = {a.ibinv[0] * tb[0] + a.ibinv[3] * tb[1] + a.ibinv[4] * tb[2], a.ibinv[3] * tb[0] + a.ibinv[1] * tb[1] + a.ibinv[5] * tb[2],
+                            a.ibinv[4] * tb[0] + a.ibinv[5] * tb[1] + a.ibinv[2] * tb[2]};
+      om[0] += a.dt * (R.r00 * ab[0] + R.r01 * ab[1] + R.r02 * ab[2]);
+      om[1] += a.dt * (R.r10 * ab[0] + R.r11 * ab[1] + R.r12 * ab[2]);
+      om[2] += a.dt * (R.r20 * ab[0] + R.r21 * ab[1] + R.r22 * ab[2]);
+      p[0] += a.dt * v[0];
+      p[1] += a.dt * v[1];
+      p[2] += a.dt * v[2];
+      const double h = a.half_dt, x = q4[0], y = q4[1], z = q4[2], ww = q4[3];
+      const double nx = x + h * (ww * om[0] + om[1] * z - om[2] * y);
+      const double ny = y + h * (ww * om[1] + om[2] * x - om[0] * z);
+      const double nz = z + h * (ww * om[2] + om[0] * y - om[1] * x);
+      const double nw = ww - h * (om[0] * x + om[1] * y + om[2] * z);
+      const double inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+      q4[0] = nx * inv;
+      q4[1] = ny * inv;
+      q4[2] = nz * inv;
+      q4[3] = nw * inv;
+    }
+  }
+  // ---- store
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    S[(size_t)c * st] = p[c];
+    S[(size_t)(7 + c) * st] = v[c];
+    S[(size_t)(10 + c) * st] = om[c];
+    S[(size_t)(13 + c) * st] = fkp[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    S[(size_t)(3 + c) * st] = q4[c];
+    S[(size_t)(16 + c) * st] = fkq[c];
+  }
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) S[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
+}
+
+// Read-out of double rows into robot-major arrays (double or float), one thread per (robot, column)
+struct Unpack64Args {
+  const double* rows;
+  void* out;
+  uint32_t stride, batch, width, first_row;
+  int as_float;
+};
+__global__ __launch_bounds__(256) void cdpr_unpack64_kernel(const Unpack64Args a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= a.batch * a.width) return;
+  const uint32_t r = t / a.width, j = t - r * a.width;
+  const double v = a.rows[(size_t)(a.first_row + j) * a.stride + r];
+  if (a.as_float)
+    static_cast<float*>(a.out)[t] = (float)v;
+  else
+    static_cast<double*>(a.out)[t] = v;
+}
+
+}  // namespace cdpr

@@ -180,6 +180,28 @@ class Engine:
         self._check(lib().cdpr_get_observables(self._h, _fp(q), _fp(qd), _fp(e), _fp(p), _fp(t)))
         return q, qd, e, p, t
 
+    # -- handles created with Config.precision = 64: the same read-outs in double
+    @staticmethod
+    def _dp(a: Optional[np.ndarray]):
+        return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def observables_f64(self):
+        """position, velocity, effort [B, n], pose [B, 7], twist [B, 6] of the last published step, float64."""
+        q, qd, e = (np.empty((self.B, self.n), dtype=np.float64) for _ in range(3))
+        p, t = np.empty((self.B, 7), dtype=np.float64), np.empty((self.B, 6), dtype=np.float64)
+        self._check(lib().cdpr_get_observables_f64(self._h, self._dp(q), self._dp(qd), self._dp(e), self._dp(p), self._dp(t)))
+        return q, qd, e, p, t
+
+    def raw_state_f64(self) -> Tuple[np.ndarray, np.ndarray]:
+        p, t = np.empty((self.B, 7), dtype=np.float64), np.empty((self.B, 6), dtype=np.float64)
+        self._check(lib().cdpr_get_raw_state_f64(self._h, self._dp(p), self._dp(t)))
+        return p, t
+
+    def set_platform_state_f64(self, pose7=None, twist6=None) -> None:
+        p = None if pose7 is None else np.ascontiguousarray(pose7, dtype=np.float64).reshape(self.B, 7)
+        t = None if twist6 is None else np.ascontiguousarray(twist6, dtype=np.float64).reshape(self.B, 6)
+        self._check(lib().cdpr_set_platform_state_f64(self._h, self._dp(p), self._dp(t)))
+
     def raw_state(self) -> Tuple[np.ndarray, np.ndarray]:
         p, t = np.empty((self.B, 7), dtype=np.float32), np.empty((self.B, 6), dtype=np.float32)
         self._check(lib().cdpr_get_raw_state(self._h, _fp(p), _fp(t)))

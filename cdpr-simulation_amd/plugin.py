@@ -194,7 +194,9 @@ class CdprGazeboPlugin:
                 self._pub_pid(Joy(axes=eng.pid_debug(), header=Header(stamp=t)))
             if (t - self.mPreviousProcessingTime) > self.mPublishPeriod:
                 self.mPreviousProcessingTime = t
-                self._publish(t, *eng.observables())  # publishJointStates + publishPlatformState, one device round trip
+                # publishJointStates + publishPlatformState, one device round trip; float64 arrays (what the ROS messages
+                # carry, PLG.cpp:248-280) when the engine steps in the reference's precision
+                self._publish(t, *(eng.observables_f64() if int(self.config.precision) == 64 else eng.observables()))
 
     def _publish(self, t, q, qd, eff, pose, twist) -> None:
         self._pub_joint(JointState(name=list(self.mJointNames), position=q, velocity=qd, effort=eff, header=Header(stamp=t)))

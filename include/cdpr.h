@@ -114,7 +114,12 @@ typedef struct cdpr_config {
                                        +-limit further out [EXT Gazebo]; <= 0 disables (the contract's reduced model,
                                        and what a zero-initialised struct gets) */
   uint32_t unilateral_cables;       /* 1: a cable cannot push, axial force max(T, 0) ([NEW]; the reference has no slack model) */
-  uint32_t reserved2_;
+  uint32_t precision;               /* 0 or 32: fp32 kernels (what every throughput figure is quoted on).  64: the step in the
+                                       reference's own precision (Pid.h, Gazebo/ODE compute in double): one plain fp64 kernel for
+                                       uniform-mode handles (IK, Pid, FK, TD, limits, observables, world step; any steps per launch),
+                                       meant for one robot / small batches; read it out with the *_f64 getters.  Not with
+                                       per_robot_commands, the general controller path, the lumped legs, travel_stop, rollouts or
+                                       trajectory records (cdpr_create / the call return CDPR_ERR_UNSUPPORTED) */
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */
@@ -253,6 +258,12 @@ int cdpr_get_platform_state(cdpr_handle_t h, float *pose7, float *twist6);
  * (PLG.cpp:236-242 publishes jointStates and platformPose on every step): one gather launch into a pinned host image and
  * a completion word the host spins on, instead of five gather / copy / wait rounds. */
 int cdpr_get_observables(cdpr_handle_t h, float *position, float *velocity, float *effort, float *pose7, float *twist6);
+/* Handles created with cdpr_config_t.precision = 64: the same read-outs in double (the float getters work too and round).
+ * Any pointer may be NULL.  cdpr_get_raw_state_f64 = the current state (not decimated by publish_period);
+ * cdpr_set_platform_state_f64 = cdpr_set_platform_state without the rounding to float.  CDPR_ERR_UNSUPPORTED on fp32 handles. */
+int cdpr_get_observables_f64(cdpr_handle_t h, double *position, double *velocity, double *effort, double *pose7, double *twist6);
+int cdpr_get_raw_state_f64(cdpr_handle_t h, double *pose7, double *twist6);
+int cdpr_set_platform_state_f64(cdpr_handle_t h, const double *pose7, const double *twist6);
 /* Replaces the `pid` debug topic (PLG.cpp:193-194,223-227,233-235;
  * Pid.cpp:139-142,158-168): axes9[B][9] = P term, I term before clamp, D term,
  * desired, applied force of cable 0, then four unused zeros.  Needs

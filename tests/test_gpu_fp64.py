@@ -1,0 +1,173 @@
+"""cdpr_config_t.precision = 64: the step in the reference's own precision (cdpr_step_kernel_f64.hpp), through the C-ABI,
+against the fp64 oracle.  Both sides compute in double; they differ in the order of the sums and in the derivative's
+formulation (closed-form end-point weights here, a least-squares fit in centred time there), so the agreement is that of
+two double implementations: tolerances 1e-9 on pose / joint position, 1e-7 on rates, 2e-6 N on effort (the position Pid's
+D gain times 1/dt = 8e4 N s/m amplifies the last bits of the 1 ms window); measured values are printed by the tests'
+assertion messages when they fail and recorded in DESIGN.md section 4."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import perturbed_poses
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = {"pose": 1e-9, "twist": 1e-7, "q": 1e-9, "qd": 1e-7, "eff": 2e-6}
+
+
+def compare64(eng, ora, where, tol=TOL64):
+    gq, gqd, ge, gp, gt = eng.observables_f64()
+    op, ot = ora.platform_state()
+    oq, oqd, oe = ora.joint_states()
+    worst = {}
+    for name, g, o in (("pose", gp, op), ("twist", gt, ot), ("q", gq, oq), ("qd", gqd, oqd), ("eff", ge, oe)):
+        assert g.dtype == np.float64 and np.isfinite(g).all(), where
+        worst[name] = float(np.abs(g - o).max())
+        assert worst[name] <= tol[name], f"{where}: {name} differs from the oracle by {worst[name]:.3e} (tolerance {tol[name]:.1e})"
+    return worst
+
+
+def pair64(pkg, oracle, cfg, pose=None):
+    eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+    if pose is not None:
+        eng.set_platform_state_f64(pose7=pose), ora.set_platform_state(pose7=pose)
+    return eng, ora
+
+
+def test_config1_in_the_reference_precision(pkg, oracle):
+    """BASELINE config 1 (the shipped 4-cable robot under sinevelocitytest, 3 000 steps of 1 ms) in double: the facade's
+    drop-in case.  Five orders of magnitude closer to the oracle than the fp32 kernels (pose 6e-7 there)."""
+    cfg = pkg.Config(batch=1, precision=64)
+    eng, ora = pair64(pkg, oracle, cfg)
+    gen = pkg.stimulus.sine_velocity(4)
+    worst = {}
+    for k in range(300):
+        cmd = next(gen)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        eng.update(10), ora.update(10)
+        if k % 20 == 19:
+            w = compare64(eng, ora, f"step {10 * (k + 1)}")
+            worst = {n: max(worst.get(n, 0.0), v) for n, v in w.items()}
+    assert eng.step_count == 3000
+    print("fp64 config 1, worst over the trajectory:", worst)
+    # the float getters of the same handle round the doubles
+    q32, qd32, e32 = eng.joint_states()
+    q64, qd64, e64, p64, t64 = eng.observables_f64()
+    assert np.array_equal(q32, q64.astype(np.float32)) and np.array_equal(e32, e64.astype(np.float32))
+    assert np.array_equal(eng.platform_state()[0], p64.astype(np.float32))
+
+
+@pytest.mark.parametrize("stages", [0, 3])
+def test_eight_cable_batch_modes_and_fused_launches(pkg, oracle, stages):
+    """8 cables, with and without FK + TD, ragged batch, both modes with Pid resets in between, position commands,
+    fused launches (bit-identical to one-step launches: same kernel, state in registers / LDS between the steps)."""
+    B = 70
+    rng = np.random.default_rng(81 + stages)
+    model = pkg.eight_cable_model()
+    cfg = pkg.Config(model=model, batch=B, stages=stages, precision=64)
+    pose = perturbed_poses(model, B, rng, 0.03, 0.05)
+    eng, ora = pair64(pkg, oracle, cfg, pose)
+    twin = pkg.Engine(cfg, 0)
+    twin.set_platform_state_f64(pose7=pose)
+    v = rng.uniform(-0.03, 0.03, (B, 8)).astype(np.float32)
+    p = rng.uniform(-0.003, 0.003, (B, 8)).astype(np.float32)
+    for e in (eng, ora, twin):
+        e.update(12)
+        e.set_velocity_command(v)
+    eng.update(60), ora.update(60), twin.update(60, 15)
+    compare64(eng, ora, "velocity mode")
+    for e in (eng, ora, twin):
+        e.set_position_command(p)
+    eng.update(45), ora.update(45), twin.update(45, 9)
+    compare64(eng, ora, "position mode")
+    for e in (eng, ora, twin):
+        e.set_velocity_command(-v)
+        e.set_position_command(p[0])  # both kinds before one update; a broadcast row
+    eng.update(30), ora.update(30), twin.update(30, 30)
+    compare64(eng, ora, "both kinds in one update")
+    for x, y in zip(eng.observables_f64() + eng.raw_state_f64(), twin.observables_f64() + twin.raw_state_f64()):
+        assert np.array_equal(x, y)
+    if stages & 1:
+        gp, gr, gi = eng.fk_state()
+        op, orr, oi = ora.fk_state()
+        assert np.array_equal(gi, oi) and np.abs(gp - op).max() < 1e-6 and gr.max() < 1e-12  # fk_state reads out as float
+    if stages & 2:
+        gt, gf = eng.td_state()
+        ot, of = ora.td_state()
+        assert np.array_equal(gf, of) and np.abs(gt - ot).max() < 1e-4
+    eng.reset(), ora.reset()
+    eng.update(25), ora.update(25)
+    compare64(eng, ora, "after reset")
+
+
+def test_fp64_limits_decimation_and_debug_topic(pkg, oracle):
+    """Travel-limit flags, publishPeriod decimation, the `pid` debug topic, velocity limit and unilateral cables on the
+    fp64 kernel."""
+    rng = np.random.default_rng(83)
+    model = pkg.eight_cable_model()
+    model.travel_lower, model.travel_upper = -0.003, 0.003
+    model.velocity_limit, model.unilateral_cables = 0.03, True
+    B = 40
+    cfg = pkg.Config(model=model, batch=B, stages=3 | pkg._abi.STAGE_PID_DEBUG, precision=64, publishPeriod=0.0035)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.01, 0.03))
+    jac = oracle.ik(cfg.to_struct(), model.home_pose())[3]
+    tw = np.concatenate([rng.uniform(-0.05, 0.05, (B, 3)), rng.uniform(-0.2, 0.2, (B, 3))], axis=1)
+    cmd = (-(jac @ tw.T).T).astype(np.float32)
+    for e in (eng, ora):
+        e.update(9)
+        e.set_velocity_command(cmd)
+    for k in range(10):
+        eng.update(17), ora.update(17)
+        compare64(eng, ora, f"block {k}", tol=dict(TOL64, eff=1e-5))
+        q = ora.joint_states()[0]
+        near = (np.abs(np.abs(q) - 0.003) < 1e-9).any(axis=1)
+        assert np.array_equal(eng.limit_state()[~near], ora.limit_state()[~near])
+        assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 1e-4  # the topic is float32 (sensor_msgs/Joy)
+    assert (eng.limit_state() != 0).any()
+
+
+def test_fp64_facade_publishes_doubles(pkg, oracle):
+    """The drop-in surface with precision = 64: jointStates / platformPose carry float64 arrays (as the ROS messages of the
+    reference do, PLG.cpp:248-280) that match the oracle to double accuracy."""
+    cfg = pkg.Config(batch=1, precision=64)
+    plug = pkg.CdprGazeboPlugin()
+    plug.Load(cfg)
+    got = {"joint": [], "platform": []}
+    plug.bus.subscribe("jointStates", got["joint"].append)
+    plug.bus.subscribe("platformPose", got["platform"].append)
+    ora = oracle.OracleSim(cfg.to_struct())
+    gen = pkg.stimulus.sine_velocity(4)
+    for k in range(20):
+        cmd = next(gen)
+        plug.bus.publish("jointVelocities", pkg.Joy(axes=cmd))
+        ora.set_velocity_command(cmd)
+        plug.update(10), ora.update(10)
+    assert len(got["joint"]) == 199
+    js, ps = got["joint"][-1], got["platform"][-1]
+    assert js.position.dtype == np.float64 and ps.pose.position.dtype == np.float64
+    oq, oqd, oe = ora.joint_states()
+    op, ot = ora.platform_state()
+    assert np.abs(js.effort - oe).max() < TOL64["eff"] and np.abs(js.position - oq).max() < TOL64["q"]
+    assert np.abs(ps.pose.position - op[:, :3]).max() < TOL64["pose"] and np.abs(ps.velocity.angular - ot[:, 3:]).max() < TOL64["twist"]
+
+
+def test_fp64_refuses_what_it_does_not_cover(pkg):
+    for kw in (dict(perRobotCommands=True), dict(velocityEpsilon=0.01)):
+        with pytest.raises(pkg.CdprError) as ei:
+            pkg.Engine(pkg.Config(batch=4, precision=64, **kw), 0)
+        assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+    lumped = pkg.cube_model()
+    lumped.passive_damping = 0.01
+    with pytest.raises(pkg.CdprError):
+        pkg.Engine(pkg.Config(model=lumped, batch=4, precision=64), 0)
+    eng = pkg.Engine(pkg.Config(model=pkg.eight_cable_model(), batch=4, stages=3, precision=64), 0)
+    with pytest.raises(pkg.CdprError) as ei:
+        eng.rollout_velocity(np.zeros((4, 3, 2, 8), np.float32), np.zeros((4, 3), np.float32))
+    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+    with pytest.raises(pkg.CdprError):
+        eng.update_record(5, 5)
+    plain = pkg.Engine(pkg.Config(batch=2), 0)
+    with pytest.raises(pkg.CdprError) as ei:
+        plain.observables_f64()
+    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+    with pytest.raises(ValueError):
+        pkg.Config(batch=1, precision=16).to_struct()
