@@ -1,9 +1,9 @@
 """cdpr_config_t.precision = 64: the step in the reference's own precision (cdpr_step_kernel_f64.hpp), through the C-ABI,
 against the fp64 oracle.  Both sides compute in double; they differ in the order of the sums and in the derivative's
 formulation (closed-form end-point weights here, a least-squares fit in centred time there), so the agreement is that of
-two double implementations: tolerances 1e-9 on pose / joint position, 1e-7 on rates, 2e-6 N on effort (the position Pid's
-D gain times 1/dt = 8e4 N s/m amplifies the last bits of the 1 ms window); measured values are printed by the tests'
-assertion messages when they fail and recorded in DESIGN.md section 4."""
+two double implementations.  Measured on MI355X over this module: pose 8.3e-16, twist 5.1e-14, joint position 6.7e-16,
+joint velocity 3.9e-14, effort 1.2e-11 N (the position Pid's D gain times 1/dt = 8e4 N s/m amplifies the last bits of the
+1 ms window); config 1 over 3 000 steps: pose 1.7e-16, effort 7.3e-14.  Tolerances: two orders above that."""
 import numpy as np
 import pytest
 
@@ -11,7 +11,8 @@ from test_gpu_parity import perturbed_poses
 
 pytestmark = pytest.mark.gpu
 
-TOL64 = {"pose": 1e-9, "twist": 1e-7, "q": 1e-9, "qd": 1e-7, "eff": 2e-6}
+TOL64 = {"pose": 1e-13, "twist": 5e-12, "q": 1e-13, "qd": 5e-12, "eff": 1e-9}
+WORST = {}
 
 
 def compare64(eng, ora, where, tol=TOL64):
@@ -23,6 +24,7 @@ def compare64(eng, ora, where, tol=TOL64):
         assert g.dtype == np.float64 and np.isfinite(g).all(), where
         worst[name] = float(np.abs(g - o).max())
         assert worst[name] <= tol[name], f"{where}: {name} differs from the oracle by {worst[name]:.3e} (tolerance {tol[name]:.1e})"
+        WORST[name] = max(WORST.get(name, 0.0), worst[name])
     return worst
 
 
@@ -117,7 +119,7 @@ def test_fp64_limits_decimation_and_debug_topic(pkg, oracle):
         e.set_velocity_command(cmd)
     for k in range(10):
         eng.update(17), ora.update(17)
-        compare64(eng, ora, f"block {k}", tol=dict(TOL64, eff=1e-5))
+        compare64(eng, ora, f"block {k}")
         q = ora.joint_states()[0]
         near = (np.abs(np.abs(q) - 0.003) < 1e-9).any(axis=1)
         assert np.array_equal(eng.limit_state()[~near], ora.limit_state()[~near])
@@ -171,3 +173,7 @@ def test_fp64_refuses_what_it_does_not_cover(pkg):
     assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
     with pytest.raises(ValueError):
         pkg.Config(batch=1, precision=16).to_struct()
+
+
+def test_zz_report_measured_agreement():
+    print("fp64 kernel vs fp64 oracle, worst over this module:", {k: f"{v:.2e}" for k, v in WORST.items()})
