@@ -75,6 +75,30 @@ def lib():
     return _lib
 
 
+_threads_default = None
+
+
+def _default_threads():
+    """CPUs this process may use: the affinity mask capped by the cgroup CPU quota."""
+    global _threads_default
+    if _threads_default is None:
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+        except Exception:
+            try:
+                q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / p + 0.5)))
+            except Exception:
+                pass
+        _threads_default = max(1, min(n, lib().orc_max_threads()))
+    return _threads_default
+
+
 def _dp(a):
     return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -128,15 +152,23 @@ class OracleSim:
     def set_position_command(self, axes, mask=None):
         return self._cmd(lib().orc_set_position_command, lib().orc_set_position_command_masked, axes, mask)
 
+    def _threads(self, nthreads, units):
+        """OpenMP threads for a call over `units` independent robots / trajectories when the caller names none: never more
+        than the CPUs this process may really use (on the GPU box `nproc` says 256 while the cgroup grants 16: a parallel
+        region of 256 threads on 16 CPUs costs ~100 ms per call) and not more than a thread per 16 units."""
+        if nthreads and nthreads > 0:
+            return int(nthreads)
+        return max(1, min(_default_threads(), (int(units) + 15) // 16))
+
     def update(self, nsteps=1, nthreads=0):
-        return lib().orc_update(self._h, int(nsteps), int(nthreads))
+        return lib().orc_update(self._h, int(nsteps), self._threads(nthreads, self.B))
 
     def rollout_velocity(self, commands, ref_position, nthreads=0):
         c = np.ascontiguousarray(commands, dtype=np.float32)
         H, S = int(c.shape[1]), int(c.shape[2])
         ref = np.ascontiguousarray(ref_position, dtype=np.float64).reshape(self.B, 3)
         cost = np.empty((self.B, S))
-        lib().orc_rollout_velocity(self._h, S, H, c.ctypes.data_as(C.POINTER(C.c_float)), _dp(ref), _dp(cost), int(nthreads))
+        lib().orc_rollout_velocity(self._h, S, H, c.ctypes.data_as(C.POINTER(C.c_float)), _dp(ref), _dp(cost), self._threads(nthreads, self.B * S))
         return cost
 
     @property
