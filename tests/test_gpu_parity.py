@@ -14,23 +14,12 @@ pytestmark = pytest.mark.gpu
 TOL = {"pose": 1e-5, "twist": 2e-4, "q": 1e-5, "qd": 2e-4, "eff": 2e-2}
 
 
-# what runs under the lane-per-cable mapping too (one lane per cable, 8 lanes per robot: cdpr_step_kernel_cable.hpp)
-CABLE_MAPPING_TESTS = {
-    "test_config1_sine_velocity_trajectory", "test_position_hold_from_load", "test_first_steps_match_exactly_in_structure",
-    "test_config2_random_batch_four_cable", "test_config3_eight_cable_stage_combinations", "test_mode_switching_resets_the_right_pid",
-    "test_saturation_and_anti_windup", "test_publish_period_decimation", "test_pid_debug_topic", "test_reset_restores_load_state",
-    "test_random_call_sequences_stay_on_the_oracle", "test_randomised_model_and_controller_parameters", "test_trajectory_record_keeps_every_published_step",
-    "test_bound_command_buffers_are_used_in_place", "test_cable_mapping_runs_on_the_same_state_as_the_others",
-}
-
-
 @pytest.fixture(autouse=True, params=["lane_per_robot", "lane_pair", "lane_per_cable"])
 def mapping(request, monkeypatch):
-    """Every test runs under the wavefront mappings (CDPR_MAPPING overrides CDPR_MAP_AUTO at cdpr_create): one lane per
-    robot, two lanes per robot (n = 4 or 8; other cable counts and the general controller path fall back to one lane
-    per robot by themselves), and - for the tests of CABLE_MAPPING_TESTS - one lane per cable."""
-    if request.param == "lane_per_cable" and request.node.originalname not in CABLE_MAPPING_TESTS:
-        pytest.skip("not part of the lane-per-cable selection")
+    """Every test runs under the three wavefront mappings (CDPR_MAPPING overrides CDPR_MAP_AUTO at cdpr_create): one lane
+    per robot, two lanes per robot (n = 4 or 8), one lane per cable (8 lanes per robot, cdpr_step_kernel_cable.hpp).  Handles
+    a mapping cannot serve (other cable counts for the pair mapping; the general controller path, per-robot modes, the
+    optional physics for both) fall back to one lane per robot by themselves; tests of such paths run once (`once`)."""
     monkeypatch.setenv("CDPR_MAPPING", {"lane_per_robot": "1", "lane_pair": "2", "lane_per_cable": "3"}[request.param])
     return request.param
 
