@@ -6,6 +6,8 @@
              (one device twice on a 1-GPU lease), the auto-selected low-register kernel at 131 072 robots, and
              `bench.py --gpus 2` as its own launcher
   config 5   512 x 128 x 64 MPC rollout (one GPU's share)
+  configs 4 and 5 AS SPECIFIED (524 288 robots in eight shards of 65 536; 4 096 x 128 x 64 in eight shards of 512) through
+             ShardedEngine, on however many devices the box has (eight shards on the one device of a 1-GPU lease)
 
 At these sizes the oracle only checks a slice (robots are independent, so a slice of the batch is its own problem);
 the rest of the batch is covered by size-independent properties: duplicates stay bit-identical, a permutation of the
@@ -160,6 +162,75 @@ def test_sharded_engine_against_the_oracle(pkg, oracle, monkeypatch):
     ref = pose[:, :3] + np.float32([0.0, 0.0, 0.01])
     gc, oc = many.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref.astype(np.float64))
     assert np.abs(gc - oc).max() < 1e-6 + 2e-4 * np.abs(oc).max()
+    many.close()
+
+
+def test_config4_as_specified_eight_shards(pkg, oracle, monkeypatch):
+    """BASELINE config 4 at its stated size and placement - 524 288 x 8-cable robots in eight contiguous shards of 65 536,
+    one handle each, nothing exchanged - on however many devices the box has (all eight shards on device 0 of a 1-GPU
+    lease: what eight GPUs run side by side runs back to back here).  Each shard's 65 536 x 8 launch is the role-split
+    headline kernel; slices out of three different shards against the oracle, duplicates bit-identical across shards."""
+    from cdpr_simulation_amd._native import lib
+
+    monkeypatch.setenv("CDPR_MAPPING", "1")
+    ndev = max(lib().cdpr_device_count(), 1)
+    devices = [d % ndev for d in range(8)]
+    B, per = 524288, 65536
+    rng = np.random.default_rng(1240)
+    model = pkg.eight_cable_model()
+    pose = perturbed_poses(model, B, rng).astype(np.float32)
+    cmd = rng.uniform(-0.04, 0.04, (B, 8)).astype(np.float32)
+    pose[7 * per:] = pose[:per]  # shard 7 repeats shard 0
+    cmd[7 * per:] = cmd[:per]
+    many = pkg.ShardedEngine(pkg.Config(model=model, batch=B, stages=3), devices=devices)
+    assert [hi - lo for lo, hi in many.spans] == [per] * 8
+    many.set_platform_state(pose7=pose)
+    many.update(15)
+    assert many.set_velocity_command(cmd) == 0
+    many.update(45)
+    got = many.platform_state() + many.joint_states()
+    assert all(np.isfinite(x).all() for x in got)
+    for x in got:
+        assert np.array_equal(x[:per], x[7 * per:])
+    for sl in (slice(64, 192), slice(3 * per + 576, 3 * per + 704), slice(6 * per + per - 128, 7 * per)):
+        check_slice(pkg, oracle, dict(model=model, stages=3), sl, pose, [(15, None), (45, cmd)], got)
+    many.close()
+
+
+def test_config5_as_specified_eight_shards(pkg, oracle, monkeypatch):
+    """BASELINE config 5 at its stated size: 4 096 robots x 128 sampled sequences x 64-step horizon (33.5 M state-steps per
+    rollout), fanned out over eight shards of 512 robots (ShardedEngine.rollout_velocity: launch on every shard, then
+    fetch), on however many devices the box has.  Nominal + N(0, 0.01^2) commands per robot and step as SURVEY 8(d)
+    states; the sample axis is tiled from 16 drawn samples so that the 1 GiB command tensor is cheap to make - identical
+    samples must give identical costs; eight robots out of four shards against the oracle."""
+    from cdpr_simulation_amd._native import lib
+
+    monkeypatch.setenv("CDPR_MAPPING", "1")
+    ndev = max(lib().cdpr_device_count(), 1)
+    devices = [d % ndev for d in range(8)]
+    B, S, H, n = 4096, 128, 64, 8
+    rng = np.random.default_rng(1236)
+    model = pkg.eight_cable_model()
+    cfg_kwargs = dict(model=model, stages=3)
+    pose = perturbed_poses(model, B, rng).astype(np.float32)
+    many = pkg.ShardedEngine(pkg.Config(batch=B, **cfg_kwargs), devices=devices)
+    assert [hi - lo for lo, hi in many.spans] == [512] * 8
+    many.set_platform_state(pose7=pose)
+    many.update(20)
+    base = rng.uniform(-0.03, 0.03, (B, H, 1, n)) + rng.normal(0.0, 0.01, (B, H, 16, n))
+    cmds = np.tile(base.astype(np.float32), (1, 1, S // 16, 1))
+    assert cmds.shape == (B, H, S, n)
+    ref = pose[:, :3] + np.float32([0.0, 0.0, 0.01])
+    cost = many.rollout_velocity(cmds, ref)
+    assert cost.shape == (B, S) and np.isfinite(cost).all() and (cost > 0).all()
+    for k in range(1, S // 16):
+        assert np.array_equal(cost[:, :16], cost[:, 16 * k:16 * (k + 1)])
+    pick = np.array([3, 511, 512, 1500, 2047, 2048, 3333, 4095])
+    ora = oracle.OracleSim(pkg.Config(batch=len(pick), **cfg_kwargs).to_struct(), oracle.DERIV_EXACT)
+    ora.set_platform_state(pose7=pose[pick].astype(np.float64))
+    ora.update(20)
+    oc = ora.rollout_velocity(cmds[pick][:, :, :16], ref[pick].astype(np.float64))
+    assert np.abs(cost[pick][:, :16] - oc).max() < 1e-6 + 2e-4 * np.abs(oc).max()
     many.close()
 
 
