@@ -46,6 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0  # what a plain row-copy kernel reaches on this part (scripts/micro/rowcopy.hip): the practical ceiling
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide
 # flop per state-step counted from the gfx950 ISA of the shipped kernels
 FLOP_PER_STATE_STEP = {8: 6325, 4: 648}
@@ -597,6 +598,8 @@ def main():
                 # rewrites 6 controller rows per step where the contract's accounting assumes 24
                 "traffic_GBps": (traffic / launch_s / 1e9) if traffic else None,
                 "traffic_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                # ... and against what a plain copy kernel reaches on this part: how much of the practical ceiling the launch uses
+                "traffic_frac_of_copy_rate": (traffic / launch_s / 1e9 / HBM_COPY_GBS) if traffic else None,
                 "limiter": "instruction issue of the one wave that carries a robot's serial chain (5 cycles per vector instruction, DESIGN.md section 4), not HBM bandwidth",
             },
         }

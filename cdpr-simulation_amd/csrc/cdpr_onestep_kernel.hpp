@@ -527,7 +527,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
       for (int k = 0; k < NP; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
       fk_res = fmaxf(rm.x, rm.y);
     }
-    if (live) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+    if (live) store_slot_aux<CDPR_SPLIT_PLAT_AUX>(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
     CDPR_SPLIT_STAMP(1);
     // the tension distribution's matrix and its factor need no forces: done while the controller wave may still be busy
     v2f td_l[6][3];
@@ -759,10 +759,10 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     integrate(a, s, w);
   }
   if (live) {
-    CDPR_STORE_STATE(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
-    CDPR_STORE_STATE(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
-    CDPR_STORE_STATE(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
-    CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
+    store_slot_aux<CDPR_SPLIT_PLAT_AUX>(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
+    store_slot_aux<CDPR_SPLIT_PLAT_AUX>(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
+    store_slot_aux<CDPR_SPLIT_PLAT_AUX>(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
+    store_slot_aux<CDPR_SPLIT_PLAT_AUX>(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
   }
   CDPR_CTL_STAMP(6);
 }

@@ -718,6 +718,22 @@ CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, co
 #endif
 }
 
+// Row store with the cache policy as a template argument (experiments on single rows; see CDPR_STORE_AUX for the values)
+template <int AUX>
+CDPR_DEV void store_slot_aux(float4* base, size_t stride, int slot, uint32_t off, const float4& v) {
+  if constexpr (AUX == 0) {
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(base + (size_t)slot * stride) + off) = v;
+  } else {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)slot * stride, 0, (int)(stride * sizeof(float4)), 0x00020000);
+    const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+                     __builtin_bit_cast(unsigned, v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off, 0, AUX);
+  }
+}
+#ifndef CDPR_SPLIT_PLAT_AUX
+#define CDPR_SPLIT_PLAT_AUX CDPR_STORE_AUX  // cache policy of the role-split kernel's platform-row stores (the rows the NEXT launch reads first)
+#endif
+
 // win[k][slot] = e[k] for a wave-uniform ring slot, written as per-slot selects: a switch (or if-chain) over the
 // slot gets merged by LLVM into ONE store through a run-time index into the register array, which sends the
 // whole window to scratch memory (seen in the ISA: 256 B of scratch per lane); selects keep everything in VGPRs.
