@@ -1484,7 +1484,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     // FK + TD handles: the role-split kernel (cdpr_split_kernel: two waves per 64 robots with different roles) beats both
     // mappings up to one robot per hardware lane (profiles/r02o_split_kernel_batch_scan.txt, us/step pair or one-wave ->
     // split: 4 096: 7.6 -> 7.2; 16 384: 8.4 -> 7.7; 32 768: 9.7 -> 9.1; 49 152: 10.8 -> 9.7; 65 536: 11.9 -> 10.9), so AUTO
-    // keeps those on the lane-per-robot mapping; above ~82 000 robots the low-register kernel takes over (below)
+    // keeps those on the lane-per-robot mapping; above ~90 000 robots the low-register kernel takes over (below)
     const bool split_case = !general && !h->phys && (cfg->stages & CDPR_STAGE_FK) && (cfg->stages & CDPR_STAGE_TD) && cfg->n_cables >= 6;
     if (mapping == CDPR_MAP_AUTO)
       mapping = (can_pair && !split_case && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
@@ -1496,7 +1496,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
     // Measured (scripts/ab_bench.py with CDPR_LOWREG=0|1, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
     // 131 072: 29.9 -> 27.0; 196 608: 41.2 -> 36.3; 524 288: 89.9 -> 79.0 (6.6e9 state-steps/s)
-    h->lowreg = !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 81920u;
+    h->lowreg = !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 90112u;  // crossover measured: profiles/r03j_cliff_scan.txt
     if (const char* lr = std::getenv("CDPR_LOWREG"))
       h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
   }
