@@ -1858,6 +1858,10 @@ int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void* 
 int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position, float* velocity, float* effort,
                             float* pose7, float* twist6) {
   if (!h || !image) return CDPR_ERR_INVALID;
+  if (h->fp64) {
+    h->err = "observable images / trajectory records are fp32-only";
+    return CDPR_ERR_UNSUPPORTED;
+  }
   const float4* o = static_cast<const float4*>(image);
   const size_t st = h->stride;
   const int G = joint_groups((int)h->n);
