@@ -1173,6 +1173,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       touched[1] = true;
     }
     if (int rc = mark_free()) return rc;
+    touched[0] = touched[1] = false;  // recorded; nothing below latches on a per-robot handle
     if (h->general) return run_steps_general(h, nsteps);
   }
   if (h->vel_pending) {
@@ -1300,7 +1301,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
           h->use_graphs = false;
           continue;  // same `done`: this chunk is launched eagerly on the next pass
         }
-        if (h->graphs.size() >= 16) {  // small cache (two Joy buffers x a few ring positions x step counts): drop the oldest
+        if (h->graphs.size() >= 32) {  // small cache (two Joy buffers x a few ring positions x step counts): drop the oldest
           (void)hipGraphExecDestroy(h->graphs.front().exec);
           (void)hipGraphDestroy(h->graphs.front().graph);
           h->graphs.erase(h->graphs.begin());
