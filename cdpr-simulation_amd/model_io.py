@@ -3,6 +3,9 @@
 * `load_yaml`  — the upstream `cdpr` package layout that `sdf/cube.yaml` uses (cube.yaml:1-29): `points: [{frame,
   platform}]`, `platform: {mass, inertia, position: {xyz, rpy}}`, `joints: {actuated: {damping, effort, min}}`.
   Any cable count 1..8, so an 8-cable robot is data, not code.
+* `load_launch` — the roslaunch file that starts the reference (`launch/cdpr_gazebo.launch`): the controller parameters
+  under the `cdpr_gazebo_simulator` node (launch:17-39, the keys `CdprGazeboPlugin::Load` reads, PLG.h:32-54), the spawn
+  pose of the model (`-x -y -z -R -P -Y`, launch:16) and the SDF / YAML files it names.
 * `load_sdf`   — the SDF that `gen_cdpr.py` emits and Gazebo loads (`sdf/cube.sdf`): the platform link's pose and
   inertial (cube.sdf:309-342), the frame-side anchor = pose of link `virt_X<i>` (gen_cdpr.py:140-150 puts it at the
   frame attach point), the platform-side anchor = pose of link `virt_Xpf<i>` at spawn, damping / effort of the
@@ -150,3 +153,43 @@ def load_sdf(path_or_text: str, f_min: float = 5.0, lumped_links: bool = False, 
         travel_stop=int(travel_stop) if lower < upper else 0,
         **lumped,
     )
+
+
+def load_launch(path_or_text: str):
+    """Read the reference's roslaunch file (launch/cdpr_gazebo.launch).  Returns a dict:
+      params      {"/cdpr_gazebo_simulator/<key>": value}: what the plugin reads from the parameter server (PLG.cpp:57,102-138);
+                  feed it to `Config.from_launch_params`
+      frame_pose  [x, y, z, qx, qy, qz, qw] of the spawned model (the `-x -y -z -R -P -Y` of the spawn_model node,
+                  launch:16) = `CdprGazeboPlugin.Load(config, frame_pose=...)`
+      sdf_file, model_yaml   the files the launch names (`$(find pkg)/` prefixes kept as written), or None
+    Only this file's own `<param>` tags count (commented-out alternatives, launch:40-46, are comments to XML too)."""
+    from .config import LAUNCH_PARAM_PREFIX
+
+    text = open(path_or_text).read() if "<" not in path_or_text else path_or_text
+    root = ET.fromstring(text)
+    out = {"params": {}, "frame_pose": [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0], "sdf_file": None, "model_yaml": None}
+    for node in root.iter("node"):
+        if node.get("type") != "spawn_model":
+            continue
+        ns = "/" + node.get("name", "").strip("/") + "/"
+        for prm in node.findall("param"):
+            raw = prm.get("value", "")
+            try:
+                val = int(raw)
+            except ValueError:
+                val = float(raw)
+            out["params"][(LAUNCH_PARAM_PREFIX if ns == LAUNCH_PARAM_PREFIX else ns) + prm.get("name")] = val
+        argstr = node.get("args", "")
+        m = re.search(r"-file\s+((?:\$\([^)]*\)|\S)+)", argstr)  # a roslaunch substitution `$(find pkg)` contains a blank
+        if m:
+            out["sdf_file"] = m.group(1)
+        args = argstr.split()
+        spawn = {"-x": 0.0, "-y": 0.0, "-z": 0.0, "-R": 0.0, "-P": 0.0, "-Y": 0.0}
+        for i, tok in enumerate(args[:-1]):
+            if tok in spawn:
+                spawn[tok] = float(args[i + 1])
+        out["frame_pose"] = [spawn["-x"], spawn["-y"], spawn["-z"]] + [float(v) for v in rpy_to_quat(spawn["-R"], spawn["-P"], spawn["-Y"])]
+    for rp in root.iter("rosparam"):
+        if rp.get("command") == "load" and rp.get("file"):
+            out["model_yaml"] = rp.get("file")
+    return out

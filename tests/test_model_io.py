@@ -143,3 +143,41 @@ def test_reference_sdf_lumped_link_terms(pkg):
     assert plain.passive_damping == plain.leg_inertia == plain.anchor_point_mass == 0.0  # off by default: the contract's reduced model
     s = pkg.Config(model=m).to_struct()
     assert (s.passive_damping, s.leg_inertia, s.cable_axial_mass, s.anchor_point_mass, s.anchor_inertia) == (0.01, m.leg_inertia, 0.001, m.anchor_point_mass, 0.001)
+
+
+LAUNCH_TEXT = """<?xml version="1.0"?>
+<launch>
+  <node name="cdpr_gazebo_simulator" pkg="gazebo_ros" type="spawn_model" respawn="false" output="screen"
+        args="-sdf -model cube -file $(find cdpr_gazebo)/sdf/cube.sdf -x 0.1 -y -0.2 -z 0.3 -R 0.0 -P 0.0 -Y 1.5707963267948966">
+    <param name="publishPeriod"              value="0.002" />
+    <param name="velocityEpsilon"            value="-0.001" />
+    <param name="velocityControllerP"        value="150"/>
+    <param name="velocityControllerDbuffer"  value="9"/>
+    <param name="positionControllerD"        value="40.5" />
+<!-- an alternative tuning, commented out as in the reference's launch file>
+    <param name="positionControllerP" value="20.0" />
+    <param name="positionControllerMaxCmd" value="1.0" /-->
+  </node>
+  <rosparam file="$(find cdpr_gazebo)/sdf/cube.yaml" command="load" ns="model"/>
+</launch>"""
+
+
+def test_launch_file_loader(pkg):
+    """launch/cdpr_gazebo.launch layout: controller parameters under the spawn_model node, spawn pose, file names."""
+    d = pkg.load_launch(LAUNCH_TEXT)
+    assert d["sdf_file"].endswith("sdf/cube.sdf") and d["model_yaml"].endswith("sdf/cube.yaml")
+    assert d["params"]["/cdpr_gazebo_simulator/velocityControllerP"] == 150 and d["params"]["/cdpr_gazebo_simulator/positionControllerD"] == 40.5
+    assert "/cdpr_gazebo_simulator/positionControllerMaxCmd" not in d["params"]  # inside the XML comment
+    cfg = pkg.Config.from_launch_params(d["params"])
+    assert (cfg.publishPeriod, cfg.velocityController.pGain, cfg.velocityController.dBufferLength, cfg.positionController.dGain) == (0.002, 150.0, 9, 40.5)
+    assert cfg.positionController.pGain == 200.0  # untouched keys keep the shipped defaults
+    assert np.allclose(d["frame_pose"][:3], [0.1, -0.2, 0.3]) and np.allclose(d["frame_pose"][3:], [0, 0, np.sqrt(0.5), np.sqrt(0.5)])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree only exists in the build container")
+def test_reference_launch_file_gives_the_shipped_configuration(pkg):
+    """The reference's own launch file (launch/cdpr_gazebo.launch:16-39) loads to exactly the defaults `Config()` carries."""
+    d = pkg.load_launch(os.path.join(REF, "..", "launch", "cdpr_gazebo.launch"))
+    assert len(d["params"]) == 23  # PLG.h:32-54: publishPeriod, velocityEpsilon, 14 velocity-controller and 7 position-controller keys
+    assert pkg.Config.from_launch_params(d["params"]).launch_params() == pkg.Config().launch_params()
+    assert d["frame_pose"] == [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0] and d["sdf_file"].endswith("sdf/cube.sdf")
