@@ -165,6 +165,52 @@ def test_sharded_engine_against_the_oracle(pkg, oracle, monkeypatch):
     many.close()
 
 
+@pytest.mark.parametrize("B", [65536, 131072])
+def test_per_robot_handles_at_full_size(pkg, oracle, monkeypatch, B):
+    """Per-robot command arrival at the headline size and beyond: 65 536 robots run the PR role-split kernel with every
+    SIMD hosting two waves, 131 072 the PR low-register kernel (auto-selected).  A third of the robots stays in Position
+    mode, a third gets velocity Joys, a third is switched back and forth (Pids reset at different world steps); three
+    slices against the oracle, which is B independent JointForceCalculator sets by construction."""
+    monkeypatch.setenv("CDPR_MAPPING", "1")
+    rng = np.random.default_rng(1241)
+    model = pkg.eight_cable_model()
+    kw = dict(model=model, stages=3, perRobotCommands=True)
+    pose = perturbed_poses(model, B, rng, 0.03, 0.05).astype(np.float32)
+    grp = (np.arange(B) // 7) % 3
+    v1 = rng.uniform(-0.03, 0.03, (B, 8)).astype(np.float32)
+    v2 = rng.uniform(-0.03, 0.03, (B, 8)).astype(np.float32)
+    p1 = rng.uniform(-0.003, 0.003, (B, 8)).astype(np.float32)
+    eng = pkg.Engine(pkg.Config(batch=B, **kw), 0)
+    eng.set_platform_state(pose7=pose)
+    slices = (slice(0, 128), slice(B // 2 - 64, B // 2 + 64), slice(B - 128, B))
+    oras = []
+    for sl in slices:
+        o = oracle.OracleSim(pkg.Config(batch=sl.stop - sl.start, **kw).to_struct(), oracle.DERIV_EXACT)
+        o.set_platform_state(pose7=pose[sl].astype(np.float64))
+        oras.append(o)
+
+    def both(fn):
+        fn(eng, slice(0, B))
+        for o, sl in zip(oras, slices):
+            fn(o, sl)
+
+    both(lambda e, sl: e.update(11))
+    both(lambda e, sl: e.set_velocity_command(v1[sl], mask=(grp >= 1)[sl]))
+    both(lambda e, sl: e.update(37))
+    both(lambda e, sl: e.set_position_command(p1[sl], mask=(grp == 2)[sl]))
+    both(lambda e, sl: e.update(23))
+    both(lambda e, sl: (e.set_velocity_command(v2[sl], mask=(grp == 2)[sl]), e.set_velocity_command(v2[sl], mask=(grp == 1)[sl])))
+    both(lambda e, sl: e.update(40))
+    got = eng.platform_state() + eng.joint_states()
+    assert all(np.isfinite(x).all() for x in got)
+    for o, sl in zip(oras, slices):
+        ref = o.platform_state() + o.joint_states()
+        for name, g, r in zip(("pose", "twist", "q", "qd", "eff"), got, ref):
+            err = float(np.abs(g[sl] - r).max())
+            assert err <= TOL[name], f"B={B}, robots {sl}: {name} differs from the oracle by {err:.3e}"
+    eng.close()
+
+
 def test_config4_as_specified_eight_shards(pkg, oracle, monkeypatch):
     """BASELINE config 4 at its stated size and placement - 524 288 x 8-cable robots in eight contiguous shards of 65 536,
     one handle each, nothing exchanged - on however many devices the box has (all eight shards on device 0 of a 1-GPU
