@@ -131,7 +131,8 @@ typedef struct cdpr_config {
   uint32_t fk_max_iterations;       /* Newton-Raphson iteration cap */
   uint32_t per_robot_commands;      /* 1: every robot has its own JointForceCalculator mode and Pid call history, as B
                                        independent plugin instances have (PLG.cpp:206-219 runs per model): a Joy may reach
-                                       some robots only (cdpr_set_*_command_masked).  Selects the general controller path.
+                                       some robots only (cdpr_set_*_command_masked).  Runs on the same register-resident kernels as a uniform handle
+                                       (mode and Pid call count per lane), unless the configuration needs the general controller path.
                                        0: a Joy batch always addresses every robot (mode uniform over the batch) */
   double fk_lambda;                 /* Levenberg damping added to the diagonal of J^T J */
   double fk_tolerance;              /* stop when max_i |L*_i - L_i| < tol; 0 = always run the cap */

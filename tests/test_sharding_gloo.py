@@ -38,8 +38,10 @@ if ctx.rank == 1:
 ctx.fast_barrier()  # shared-memory spin barrier: rank 0 must sit here until rank 1 arrives
 open(os.path.join({out!r}, f"wait{{ctx.rank}}.txt"), "w").write(repr((time.perf_counter() - t1, ctx._spin is not None, ctx._spin.path if ctx._spin else "")))
 np.save(os.path.join({out!r}, f"shard{{ctx.rank}}.npy"), sim.raw_state()[0])
+gathered = ctx.gather_over_ranks([float(ctx.rank) + 0.5, float(hi - lo)])  # every rank's own figures, indexed by rank
 if ctx.rank == 0:
     open(os.path.join({out!r}, "elapsed.txt"), "w").write(repr(elapsed))
+    open(os.path.join({out!r}, "gathered.txt"), "w").write(repr(gathered))
 ctx.close()
 """
 
@@ -68,6 +70,7 @@ def test_two_rank_sharding_matches_unsharded(tmp_path, pkg, oracle):
     waited1, spin1, _ = eval((tmp_path / "wait1.txt").read_text())
     assert spin0 and spin1 and waited0 >= 0.29 and waited1 < waited0 + 0.05  # the fast barrier really holds rank 0 back
     assert not os.path.exists(path0)  # and its /dev/shm file is removed at close
+    assert eval((tmp_path / "gathered.txt").read_text()) == [[0.5, 5.0], [1.5, 5.0]]  # per-rank figures, indexed by rank
 
 
 FALLBACK_WORKER = r"""
