@@ -327,6 +327,8 @@ def test_bench_gpus_8_on_the_one_gpu():
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CDPR_MAPPING", "CDPR_LOWREG"):
         env.pop(k, None)
+    # the first `import torch` on a fresh box pages the image in (a minute or two): do that once here, outside the clock
+    subprocess.run([sys.executable, "-c", "import torch, scipy.spatial.transform"], env=env, capture_output=True, timeout=900)
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "50", "--warmup", "10", "--batch", "4096",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
