@@ -52,6 +52,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide
 FLOP_PER_STATE_STEP = {8: 6325, 4: 648}
 METRIC = "CDPR sim-steps/sec (whole node), 65 536 parallel 8-cable robots, 1 ms dt"
 CONFIGS = {2: dict(batch=4096, cables=4), 3: dict(batch=65536, cables=8)}
+FUSED_WARM, FUSED_LAUNCHES = 3, 30  # the fused leg's own schedule: untimed / minimum timed launches of 10 steps each
 ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
 
 
@@ -208,31 +209,101 @@ def parity_check(pkg, cfg_kwargs, pose, command, refresh, total_steps, got, slic
     }
 
 
-def rank_cpu_set(local_rank, local_world, cpus=None):
-    """Cores rank `local_rank` of `local_world` pins itself to: an equal, contiguous share of the CPUs this process may
-    run on (disjoint between ranks, so that eight launch loops never meet on one core).  None when there is nothing to
-    split (one rank, or fewer CPUs than ranks)."""
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> {0, 1, 2, 3, 8, 10, 11} (the kernel's cpulist format)."""
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_nodes(sysfs="/sys"):
+    """NUMA node of every GPU in HIP ordinal order, from sysfs alone (nothing here touches the GPU runtime): the KFD
+    topology lists the GPU nodes in the order HIP enumerates them (`simd_count` > 0), each with its PCI address
+    (`domain`, `location_id` = bus << 8 | device << 3 | function), and /sys/bus/pci/devices/<address>/numa_node (the
+    device directory /sys/class/drm/card*/device links to) says which socket's memory controller it hangs off.
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES given as plain index lists re-map the ordinals.  [] when the tree is
+    not there (no amdgpu driver, a container that hides it) or a property cannot be read."""
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        ids = sorted(int(d) for d in os.listdir(base) if d.isdigit())
+    except OSError:
+        return []
+    nodes = []
+    for i in ids:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(base, str(i), "properties")) if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue  # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            addr = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+            numa = int(open(os.path.join(sysfs, "bus", "pci", "devices", addr, "numa_node")).read().strip())
+            nodes.append(numa)
+        except (OSError, KeyError, ValueError):
+            return []
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):  # ROCR filters first, HIP indexes what is left
+        sel = os.environ.get(var)
+        if sel:
+            try:
+                nodes = [nodes[int(x)] for x in sel.split(",") if x.strip() != ""]
+            except (ValueError, IndexError):
+                return []  # UUIDs or something else this reader does not follow: no topology claim
+    return nodes
+
+
+def numa_cpus(node, sysfs="/sys"):
+    try:
+        return parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+    except (OSError, ValueError):
+        return set()
+
+
+def rank_cpu_set(local_rank, local_world, cpus=None, gpu_nodes=None, sysfs="/sys"):
+    """Cores rank `local_rank` of `local_world` pins itself to, disjoint between ranks (eight launch loops never meet on one
+    core).  With the GPUs' NUMA nodes known (gpu_numa_nodes): rank r drives GPU r % len(gpu_nodes), so it takes an equal
+    share of the allowed CPUs of THAT GPU's node, split among the ranks that share the node - a launch loop that issues a
+    kernel every 10 us from the far socket pays the inter-socket hop on every doorbell and every completion poll.  Without
+    (no sysfs, one node, a node without allowed CPUs): the r-th of `local_world` equal, contiguous shares of the allowed
+    CPUs, as before.  Returns (cpu set or None, numa node or None)."""
     cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
-    per = len(cpus) // max(local_world, 1)
-    if local_world <= 1 or per < 1:
-        return None
-    return set(cpus[local_rank * per:(local_rank + 1) * per])
+    if local_world <= 1:
+        return None, None
+    if gpu_nodes:
+        node_of = [gpu_nodes[r % len(gpu_nodes)] for r in range(local_world)]
+        mine = node_of[local_rank]
+        peers = [r for r in range(local_world) if node_of[r] == mine]
+        local = sorted(set(cpus) & numa_cpus(mine, sysfs)) if mine >= 0 else []
+        per = len(local) // len(peers)
+        if per >= 1 and all(len(set(cpus) & numa_cpus(nd, sysfs)) >= node_of.count(nd) for nd in set(node_of) if nd >= 0) and min(node_of) >= 0:
+            k = peers.index(local_rank)
+            return set(local[k * per:(k + 1) * per]), mine
+    per = len(cpus) // local_world
+    if per < 1:
+        return None, None
+    return set(cpus[local_rank * per:(local_rank + 1) * per]), None
 
 
-def host_placement(local_rank, local_world):
+def host_placement(local_rank, local_world, sysfs="/sys"):
     """Called by every rank BEFORE anything touches the GPU (the runtime's helper threads inherit the mask): pin to
-    rank_cpu_set, and when the cgroup grants fewer than 2 CPUs' worth of time per rank, make every wait of the library
-    a blocking one (CDPR_SYNC_SPIN_US=0): a launch loop and a polling wait per rank would otherwise starve each other and
-    show up as "poor scaling".  Returns what was done, for the JSON line."""
-    info = {"cpus_effective": effective_cpu_count(), "pinned": None, "blocking_waits": False}
+    rank_cpu_set (cores of the rank's own GPU's NUMA node where sysfs tells), and when the cgroup grants fewer than 2
+    CPUs' worth of time per rank, make every wait of the library a blocking one (CDPR_SYNC_SPIN_US=0): a launch loop and
+    a polling wait per rank would otherwise starve each other and show up as "poor scaling".  Returns what was done, for
+    the JSON line."""
+    info = {"cpus_effective": effective_cpu_count(), "pinned": None, "numa_node": None, "blocking_waits": False}
     if local_world <= 1:
         return info
     if os.environ.get("CDPR_BENCH_NO_PIN") != "1" and hasattr(os, "sched_setaffinity"):
-        mine = rank_cpu_set(local_rank, local_world)
+        gpu_nodes = gpu_numa_nodes(sysfs)
+        info["gpu_numa_nodes"] = gpu_nodes or None
+        mine, node = rank_cpu_set(local_rank, local_world, gpu_nodes=gpu_nodes, sysfs=sysfs)
         if mine:
             try:
                 os.sched_setaffinity(0, mine)
                 info["pinned"] = [min(mine), max(mine), len(mine)]
+                info["numa_node"] = node
             except OSError:
                 pass
     info["cpus_per_rank"] = info["cpus_effective"] / local_world
@@ -335,7 +406,8 @@ def main():
     from cdpr_simulation_amd.sharding import RankContext
 
     # host placement first: nothing has touched the GPU yet, so the runtime's threads inherit this rank's core set
-    placement = host_placement(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    placement = host_placement(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))),
+                               sysfs=os.environ.get("CDPR_BENCH_SYSFS", "/sys"))
 
     # torch.distributed (RCCL) only provides the rendezvous: barrier + max over ranks. No data-path collective.
     ctx = RankContext.from_env(backend=os.environ.get("CDPR_BENCH_BACKEND", "nccl"))
@@ -351,10 +423,10 @@ def main():
         ctx.fast_barrier()
         mine = time.perf_counter() - t0
         elapsed = ctx.max_over_ranks(mine)
-        per_rank = ctx.gather_over_ranks([mine, float(len(os.sched_getaffinity(0)))])
+        per_rank = ctx.gather_over_ranks([mine, float(len(os.sched_getaffinity(0))), float(-1 if placement.get("numa_node") is None else placement["numa_node"])])
         if rank == 0:
             emit(json.dumps({"metric": METRIC, "value": 0.0, "placement": placement,
-                             "per_rank": [{"rank": i, "elapsed_s": v[0], "cpus": int(v[1])} for i, v in enumerate(per_rank)], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
+                             "per_rank": [{"rank": i, "elapsed_s": v[0], "cpus": int(v[1]), "placement": {"numa_node": None if v[2] < 0 else int(v[2])}} for i, v in enumerate(per_rank)], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
                              "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                              "config": {"workload": "dry run: rank plumbing only, no GPU work"}}))
@@ -417,7 +489,9 @@ def main():
     elapsed_mine = time.perf_counter() - t0
     elapsed = ctx.max_over_ranks(elapsed_mine)
     # every rank's own figures, so that a straggler shows next to the max-over-ranks value
-    per_rank = ctx.gather_over_ranks([elapsed_mine, ev_ms * 1e3 / max(launches, 1), float(device)])
+    per_rank = ctx.gather_over_ranks([elapsed_mine, ev_ms * 1e3 / max(launches, 1), float(device),
+                                      float(-1 if placement.get("numa_node") is None else placement["numa_node"]),
+                                      float(placement["pinned"][0] if placement.get("pinned") else -1), float(placement["pinned"][2] if placement.get("pinned") else 0)])
 
     pose_end, twist_end = eng.platform_state()
     joint_end = eng.joint_states()
@@ -436,17 +510,23 @@ def main():
     if args.steps_per_launch == 1 and not args.no_secondary:
         # (a) same workload with the 10 steps of each command hold fused into one launch: state stays on chip
         #     between the steps, observables are still written every step
+        # A schedule of its own, whatever --steps says (the driver's --steps 20 used to leave this leg two cold launches):
+        # FUSED_WARM launches untimed, then FUSED_LAUNCHES (or --steps / 10, if that is more, up to 200) timed.
         spl = refresh
-        steps2 = max((min(args.steps, 2000) // refresh) * refresh, refresh)
+        launches_timed = max(FUSED_LAUNCHES, min(args.steps, 2000) // refresh)
+        steps2 = launches_timed * refresh
         start = args.warmup + args.steps
-        sched2 = [eng.device_upload(command((start + j * refresh) // refresh)) for j in range(steps2 // refresh)]
+        sched2 = [eng.device_upload(command((start + j * refresh) // refresh)) for j in range(FUSED_WARM + launches_timed)]
         image = eng.observable_image_bytes()
         d_rec = eng.device_upload(np.zeros(image * refresh, dtype=np.uint8))  # trajectory record of one command hold
+        for j in range(FUSED_WARM):
+            eng.bind_velocity_command_device(sched2[j], count)
+            eng.update_record_device(refresh, spl, d_rec, image * refresh)
         barrier()
         edge()
         eng.profile_begin()
         t0 = time.perf_counter()
-        for j in range(steps2 // refresh):
+        for j in range(FUSED_WARM, FUSED_WARM + launches_timed):
             eng.bind_velocity_command_device(sched2[j], count)
             eng.update_record_device(refresh, spl, d_rec, image * refresh)  # every step's observables stay in HBM
         ms2, launches2 = eng.profile_end()
@@ -460,6 +540,8 @@ def main():
         v2 = world * args.batch * steps2 / el2
         secondary["fused"] = {
             "steps_per_launch": spl,
+            "launches_timed": launches_timed,
+            "launches_warmup": FUSED_WARM,
             "value": v2,
             "unit": "state-steps/s",
             "kernel_us": ms2 * 1e3 / max(launches2, 1),
@@ -580,7 +662,14 @@ def main():
                 "rendezvous": ctx.backend_name(),  # "none" (one rank), "nccl" (= RCCL) or "gloo": barrier + max only, no data-path collective
             },
             "roofline": {
-                "bound": "hbm",
+                # what limits the launch, and the tighter of the two roofs it is priced against (frozen in round 4: these
+                # keys keep their meaning from here on)
+                "bound": "valu-issue",
+                "roof": "hbm",
+                "frac_definition": "achieved / peak with achieved = algorithmic bytes per launch (SURVEY.md 8(d): 4*(39+28n) B per "
+                                   "state-step x robots x steps of one launch) / the step kernel's average launch duration by HIP events "
+                                   "on the engine's stream over the timed region; frac_wall = the same bytes by the wall clock "
+                                   "(BASELINE.md section 3); traffic_frac = measured HBM bytes (rocprofv3 PMC) / the same duration",
                 # algorithmic bytes per launch (4 (39 + 28 n) B per state-step x the robots and steps of one
                 # launch) / the kernel's average launch duration, HIP events on the engine's stream over the timed region
                 "achieved": achieved_kernel,
@@ -610,7 +699,8 @@ def main():
         out["parity_check"] = parity
         out["placement"] = placement
         out["per_rank"] = [{"rank": i, "value": args.batch * args.steps / v[0], "ms_per_step": v[0] / args.steps * 1e3, "kernel_us": v[1],
-                            "device": int(v[2])} for i, v in enumerate(per_rank)]
+                            "device": int(v[2]), "placement": {"numa_node": None if v[3] < 0 else int(v[3]), "first_cpu": None if v[4] < 0 else int(v[4]),
+                                                                "cpus": int(v[5])}} for i, v in enumerate(per_rank)]
         out.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, args.cpu_seconds)

@@ -5,7 +5,7 @@ loader and the function prototypes are in `_native.py`.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_CABLES = 8
 MAX_D_BUFFER = 32
 MAX_D_DEGREE = 4

@@ -62,6 +62,8 @@ struct cdpr_engine {
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
   bool split = false;       // FK + TD one-step launches use cdpr_split_kernel (estimator wave + controller wave per 64 robots)
+  uint32_t chunk = 0;       // > 0: a step over the batch is issued as back-to-back launches over contiguous blocks of at most
+                            // this many robots (batches between one and ~5 robots per hardware lane: see cdpr_create)
   bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
   // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
   bool general = false;
@@ -84,29 +86,31 @@ struct cdpr_engine {
   bool use_graphs = true;
   float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
   float* d_pos[2] = {nullptr, nullptr};
+  float* d_frc[2] = {nullptr, nullptr};  // force commands (cdpr_set_force_command; JFC.h:92-95)
   // zero-copy commands (cdpr_bind_*_command_device): a caller-owned device buffer takes the place of d_*[0] / d_*[1]
   const float* ext_vel[2] = {nullptr, nullptr};
   const float* ext_pos[2] = {nullptr, nullptr};
+  const float* ext_frc[2] = {nullptr, nullptr};
   // per-robot command arrival (cfg.per_robot_commands): every robot has its own mode; general controller path only
   bool per_robot = false;
   uint8_t* d_mode = nullptr;        // uint8[B]: 1 = Position, 2 = Velocity; on the register-resident path also the robot's
                                     // Pid call count in bits 2-7 (StepArgs::meta)
   float* d_target = nullptr;        // per-robot handles on the register-resident path: float[B][n], every robot's ACTIVE target row
-  uint8_t* d_mask[2] = {nullptr, nullptr};  // pending masks of the velocity / position command, uint8[B]
-  bool vel_masked = false, pos_masked = false;  // the pending command came with a mask
+  uint8_t* d_mask[3] = {nullptr, nullptr, nullptr};  // pending masks of the velocity / position / force command, uint8[B]
+  bool vel_masked = false, pos_masked = false, frc_masked = false;  // the pending command came with a mask
   // Host-side Joy batches travel on their own stream (cdpr_set_*_command with a host pointer): the caller's rows go into
   // one of two pinned staging buffers per kind and from there to the PENDING device buffer while earlier launches still
-  // run; the call returns without waiting.  kind 0 = velocity, 1 = position.
+  // run; the call returns without waiting.  kind 0 = velocity, 1 = position, 2 = force.
   hipStream_t copy_stream = nullptr;
-  float* h_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-  hipEvent_t stage_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // the copy out of that staging buffer has completed
-  bool stage_ev_set[2][2] = {{false, false}, {false, false}};
-  int stage_idx[2] = {0, 0};
-  hipEvent_t ready_wait[2] = {nullptr, nullptr};  // event the compute stream has to pass before it touches the pending buffer
-  hipEvent_t free_ev[2] = {nullptr, nullptr};     // every launch that read what is now the pending buffer has completed
-  bool free_ev_set[2] = {false, false};
-  bool vel_pending = false, pos_pending = false;
-  bool have_vel = false, have_pos = false;  // a command of that kind has been latched since Load
+  float* h_stage[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  hipEvent_t stage_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // the copy out of that staging buffer has completed
+  bool stage_ev_set[3][2] = {{false, false}, {false, false}, {false, false}};
+  int stage_idx[3] = {0, 0, 0};
+  hipEvent_t ready_wait[3] = {nullptr, nullptr, nullptr};  // event the compute stream has to pass before it touches the pending buffer
+  hipEvent_t free_ev[3] = {nullptr, nullptr, nullptr};     // every launch that read what is now the pending buffer has completed
+  bool free_ev_set[3] = {false, false, false};
+  bool vel_pending = false, pos_pending = false, frc_pending = false;
+  bool have_vel = false, have_pos = false, have_frc = false;  // a command of that kind has been latched since Load
   int mode = kModePosition;
   uint64_t step = 0;
   double prev_publish = 0.0;
@@ -691,6 +695,7 @@ int upload_home64(cdpr_engine* h) {
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(h, hipMemsetAsync(h->d_vel[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_frc[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   }
   HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
@@ -711,6 +716,7 @@ int upload_home(cdpr_engine* h) {
   for (int i = 0; i < 2; ++i) {  // latched and pending Joy buffers: target 0 after Load / reset
     HIP_TRY(h, hipMemsetAsync(h->d_vel[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_frc[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   }
   if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows(h->glay) * h->tstride * sizeof(float), h->stream));
   if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157 (call count 0)
@@ -732,7 +738,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_cable) (void)hipFree(h->d_cable);
   if (h->d_mode) (void)hipFree(h->d_mode);
   if (h->d_target) (void)hipFree(h->d_target);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if (h->d_mask[i]) (void)hipFree(h->d_mask[i]);
   if (h->d_unpack) (void)hipFree(h->d_unpack);
   for (void* p64 : {(void*)h->d_state64, (void*)h->d_obs64, (void*)h->d_geom64, (void*)h->d_wtab64, (void*)h->d_dbg64, h->d_unpack64})
@@ -745,13 +751,14 @@ void free_all(cdpr_engine* h) {
   for (int i = 0; i < 2; ++i) {
     if (h->d_vel[i]) (void)hipFree(h->d_vel[i]);
     if (h->d_pos[i]) (void)hipFree(h->d_pos[i]);
+    if (h->d_frc[i]) (void)hipFree(h->d_frc[i]);
   }
   for (auto& g : h->graphs) {
     (void)hipGraphExecDestroy(g.exec);
     (void)hipGraphDestroy(g.graph);
   }
   if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     for (int i = 0; i < 2; ++i) {
       if (h->h_stage[k][i]) (void)hipHostFree(h->h_stage[k][i]);
       if (h->stage_ev[k][i]) (void)hipEventDestroy(h->stage_ev[k][i]);
@@ -766,10 +773,10 @@ void free_all(cdpr_engine* h) {
 }
 
 void engine_reset_host(cdpr_engine* h) {
-  h->vel_pending = h->pos_pending = false;
-  h->vel_masked = h->pos_masked = false;
-  h->ext_vel[0] = h->ext_vel[1] = h->ext_pos[0] = h->ext_pos[1] = nullptr;
-  h->have_vel = h->have_pos = false;
+  h->vel_pending = h->pos_pending = h->frc_pending = false;
+  h->vel_masked = h->pos_masked = h->frc_masked = false;
+  h->ext_vel[0] = h->ext_vel[1] = h->ext_pos[0] = h->ext_pos[1] = h->ext_frc[0] = h->ext_frc[1] = nullptr;
+  h->have_vel = h->have_pos = h->have_frc = false;
   h->mode = kModePosition;  // PLG.cpp:153-157: Position mode, target 0 after operator= -> reset()
   h->step = 0;
   h->pid_calls = 0;
@@ -780,7 +787,7 @@ void engine_reset_host(cdpr_engine* h) {
 // in any other way than latching it (device-side staging, masked merges, resets).
 static int drain_copy_stream(cdpr_engine* h) {
   if (h->copy_stream) HIP_TRY(h, hipStreamSynchronize(h->copy_stream));
-  h->ready_wait[0] = h->ready_wait[1] = nullptr;
+  h->ready_wait[0] = h->ready_wait[1] = h->ready_wait[2] = nullptr;
   return CDPR_OK;
 }
 
@@ -807,7 +814,7 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
     return CDPR_OK;
   }
   // host source: rows -> pinned staging -> pending device buffer on the copy stream, no wait for the launches in flight
-  const int kind = (dst == h->d_vel[1]) ? 0 : 1;
+  const int kind = (dst == h->d_vel[1]) ? 0 : (dst == h->d_pos[1]) ? 1 : 2;
   if (!h->copy_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
   const int idx = (h->stage_idx[kind] ^= 1);
   if (!h->h_stage[kind][idx]) {
@@ -868,6 +875,7 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
   g.cable = h->d_cable;
   g.vel_cmd = h->have_vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : nullptr;
   g.pos_cmd = h->have_pos ? (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]) : nullptr;
+  g.frc_cmd = h->have_frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0]) : nullptr;
   g.mode_arr = h->per_robot ? h->d_mode : nullptr;
   g.rec = h->d_rec;
   g.tstride = h->tstride;
@@ -1001,16 +1009,17 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
     HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)11 * n * h->stride * sizeof(double), h->stream));
   }
   F64Args a = h->base64;
-  const bool vel = h->mode == kModeVelocity;
+  const bool vel = h->mode == kModeVelocity, frc = h->mode == kModeForce;
   fill_pid64(vel ? h->cfg.velocity_pid : h->cfg.position_pid, h->cfg.dt, a);
-  a.cmd = vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
+  a.cmd = frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0])
+              : vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
   a.wtab = h->d_wtab64 + (vel ? 0 : kWin * (kWin + 2));
   F64Kernel kern = pick_f64_kernel(n);
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
     a.nsteps = k;
-    a.flags = vel ? kFlagActualIsVelocity : 0u;
+    a.flags = vel ? kFlagActualIsVelocity : (frc ? kFlagForceMode : 0u);
     const bool first_world = (h->step == 0);
     if (first_world) a.flags |= kFlagFirstWorldStep;
     a.pid_calls = sat_pid_calls(h->pid_calls);
@@ -1087,6 +1096,27 @@ int set_platform_state64(cdpr_engine* h, const double* pose7, const double* twis
   return CDPR_OK;
 }
 
+// One step-kernel launch over the whole batch, or (h->chunk) the same launch cut into contiguous blocks of robots issued
+// back to back on the handle's stream: every pointer that is indexed by robot moves to the block's first robot, the row
+// stride stays.  Robots are independent, so the results are bit-identical to the single launch (tested).
+void launch_step(cdpr_engine* h, StepKernel kern, uint32_t robots_per_block, dim3 block, const StepArgs& a) {
+  const uint32_t B = a.batch;
+  const uint32_t chunk = (h->chunk && B > h->chunk) ? h->chunk : B;
+  const uint32_t pieces = (B + chunk - 1u) / chunk;
+  const uint32_t each = (((B + pieces - 1u) / pieces) + 63u) & ~63u;  // balanced, whole wavefronts
+  for (uint32_t first = 0; first < B; first += each) {
+    StepArgs c = a;
+    c.batch = std::min(each, B - first);
+    c.state = a.state + first;
+    c.obs = a.obs + first;
+    if (a.cmd) c.cmd = a.cmd + (size_t)first * h->n;
+    if (a.dbg) c.dbg = a.dbg + (size_t)first * CDPR_PID_DEBUG_AXES;
+    if (a.meta) c.meta = a.meta + first;
+    hipLaunchKernelGGL(kern, dim3((c.batch + robots_per_block - 1u) / robots_per_block), block, 0, h->stream, c);
+    ++h->launches;
+  }
+}
+
 int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullptr) {
   if (!h) return CDPR_ERR_INVALID;
   if (nsteps < 0 || per_launch < 1 || per_launch > 64) {
@@ -1097,8 +1127,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
 
   // --- PLG.cpp:206-219: latch pending commands, velocity first, then position
-  const bool latch_kind[2] = {h->vel_pending, h->pos_pending};
-  for (int k = 0; k < 2; ++k) {
+  const bool latch_kind[3] = {h->vel_pending, h->pos_pending, h->frc_pending};
+  for (int k = 0; k < 3; ++k) {
     if (latch_kind[k] && h->ready_wait[k]) {  // a host Joy batch is (or was) on its way on the copy stream
       HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ready_wait[k], 0));
       h->ready_wait[k] = nullptr;
@@ -1110,9 +1140,9 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   // on EVERY such latch once a copy stream exists, however the latched command itself arrived (host, _device or masked):
   // a stale event from an earlier host batch would let the copy run into launches that still read the buffer.  Bound
   // commands swap nothing and handles that never saw a host batch have no copy stream: no event, no device time.
-  bool touched[2] = {false, false};
+  bool touched[3] = {false, false, false};
   auto mark_free = [&]() -> int {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
       if (!touched[k] || !h->copy_stream) continue;
       if (!h->free_ev[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->free_ev[k], hipEventDisableTiming));
       HIP_TRY(h, hipEventRecord(h->free_ev[k], h->stream));
@@ -1138,7 +1168,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         lf.batch = h->batch;
         lf.n = h->n;
         lf.hot_rows = (uint32_t)((cable_pairs((int)h->n) + 1) / 2);
-        lf.new_mode = (new_mode == kModeVelocity) ? kMetaVelocity : kMetaPosition;
+        lf.new_mode = (new_mode == kModeVelocity) ? kMetaVelocity : (new_mode == kModePosition) ? kMetaPosition : kMetaForce;
         hipLaunchKernelGGL(cdpr_latch_fast_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, lf);
         HIP_TRY(h, hipGetLastError());
         return CDPR_OK;
@@ -1148,7 +1178,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       la.mode = h->d_mode;
       la.pending = pending;
       la.latched = latched;
-      la.pid_block = h->d_rec + h->tstride * (1 + (size_t)which * h->glay.rows());
+      la.pid_block = which < 0 ? nullptr : h->d_rec + h->tstride * (1 + (size_t)which * h->glay.rows());
       la.rows = h->glay.rows();
       la.tstride = h->tstride;
       la.batch = h->batch;
@@ -1172,8 +1202,14 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       h->have_pos = true;
       touched[1] = true;
     }
+    if (h->frc_pending) {  // [NEW] ordering: after the two Joy topics (the reference has no force callback)
+      if (int rc = latch(h->d_frc[1], h->d_frc[0], h->frc_masked ? h->d_mask[2] : nullptr, -1, kModeForce)) return rc;
+      h->frc_pending = h->frc_masked = false;
+      h->have_frc = true;
+      touched[2] = true;
+    }
     if (int rc = mark_free()) return rc;
-    touched[0] = touched[1] = false;  // recorded; nothing below latches on a per-robot handle
+    touched[0] = touched[1] = touched[2] = false;  // recorded; nothing below latches on a per-robot handle
     if (h->general) return run_steps_general(h, nsteps);
   }
   if (h->vel_pending) {
@@ -1205,6 +1241,19 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     reset_pid = (h->mode != kModePosition);  // JFC.cpp:101-103 (fast path: the single record now belongs to the position Pid)
     if (h->general && reset_pid) HIP_TRY(h, reset_block(0));
     h->mode = kModePosition;
+  }
+  if (h->frc_pending) {  // setForce (JFC.h:92-95): mode Force, no Pid is reset.  [NEW] ordering: after the two Joy topics
+    if (h->ext_frc[1]) {
+      h->ext_frc[0] = h->ext_frc[1];
+      h->ext_frc[1] = nullptr;
+    } else {
+      std::swap(h->d_frc[0], h->d_frc[1]);
+      h->ext_frc[0] = nullptr;
+      touched[2] = true;
+    }
+    h->frc_pending = false;
+    h->have_frc = true;
+    h->mode = kModeForce;
   }
   if (int rc = mark_free()) return rc;
   if (h->general) return run_steps_general(h, nsteps);
@@ -1239,6 +1288,9 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   } else if (h->mode == kModeVelocity) {
     copy_pid(h->pid_vel, a);
     a.cmd = h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0];
+  } else if (h->mode == kModeForce) {
+    copy_pid(h->pid_pos, a);  // unused: no Pid runs in Force mode
+    a.cmd = h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0];
   } else {
     copy_pid(h->pid_pos, a);
     a.cmd = h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0];  // all zeros until the first jointPositions message: target 0 (PLG.cpp:153-157)
@@ -1253,7 +1305,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
     a.nsteps = k;
-    a.flags = (!h->per_robot && h->mode == kModeVelocity ? kFlagActualIsVelocity : 0u);
+    a.flags = h->per_robot ? 0u : (h->mode == kModeVelocity ? kFlagActualIsVelocity : h->mode == kModeForce ? kFlagForceMode : 0u);
     const bool first_world = (h->step == 0);
     if (first_world) a.flags |= kFlagFirstWorldStep;
     // the kernel uses calls != 0 and calls >= nbuf (<= 11): the count saturates, and the ring position follows the world
@@ -1271,7 +1323,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // (the ring position advances with every step, so a captured chain is only valid from the position it was captured at:
     //  part of the cache key; the call count must be saturated (per-robot handles keep theirs on the device))
     if (record) a.obs = record + (size_t)done * image;
-    const bool steady = !record && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && (h->per_robot || a.pid_calls == kCallSat) &&
+    const bool steady = !record && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && (h->per_robot || a.pid_calls == kCallSat || h->mode == kModeForce) &&
                         h->cfg.publish_period == 0.0 && (nsteps - done) >= kGraphChunk * k;
     if (steady) {
       a.publish_mask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -1313,7 +1365,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       const int steps = kGraphChunk * k;
       h->launches += kGraphChunk;
       h->step += (uint64_t)steps;
-      h->pid_calls = sat_pid_calls(h->pid_calls + steps);
+      if (h->mode != kModeForce) h->pid_calls = sat_pid_calls(h->pid_calls + steps);  // (no Pid call in Force mode)
       h->prev_publish = sim_time(h->step - 1, h->cfg.dt);
       done += steps;
       continue;
@@ -1327,11 +1379,10 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         a.publish_mask |= (1ull << j);
       }
     }
-    hipLaunchKernelGGL(kern, grid, block, 0, h->stream, a);
+    launch_step(h, kern, robots_per_block, block, a);
     HIP_TRY(h, hipGetLastError());
-    ++h->launches;
     h->step += (uint64_t)k;
-    h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
+    if (h->mode != kModeForce) h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
     done += k;
   }
   if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
@@ -1354,8 +1405,6 @@ int fetch_fields(cdpr_engine* h, const float4* rows, const std::vector<std::pair
   if (h->unpack_cap < count) {
     HIP_TRY(h, wait_stream(h));
     if (h->d_unpack) (void)hipFree(h->d_unpack);
-  for (void* p64 : {(void*)h->d_state64, (void*)h->d_obs64, (void*)h->d_geom64, (void*)h->d_wtab64, (void*)h->d_dbg64, h->d_unpack64})
-    if (p64) (void)hipFree(p64);
     h->d_unpack = nullptr;
     h->unpack_cap = 0;
     HIP_TRY(h, hipMalloc(&h->d_unpack, count * sizeof(float)));
@@ -1475,8 +1524,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     // (16.4 vs 15.7 us/step: the duplicated 6x6 solves cost more than the second wave per SIMD hides), so AUTO
     // takes the pair mapping up to 32 768 robots at n = 8 (32 768: 9.5 vs 10.5 us/step; 49 152: 13.6 vs 11.2) and up
     // to 65 536 at n = 4 (65 536: 4.9 vs 5.2; 131 072: 8.5 vs 8.1).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
-    const bool travel_on = cfg->travel_lower != 0.0 || cfg->travel_upper != 0.0;  // the lane-pair kernel has no travel-limit flag
-    const bool can_pair = !general && !h->phys && !h->per_robot && !travel_on && (cfg->n_cables == 4 || cfg->n_cables == 8);
+    const bool can_pair = !general && !h->phys && !h->per_robot && (cfg->n_cables == 4 || cfg->n_cables == 8);
     uint32_t mapping = cfg->mapping;
     if (mapping == CDPR_MAP_AUTO) {
       const char* mv = std::getenv("CDPR_MAPPING");
@@ -1490,16 +1538,38 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     if (mapping == CDPR_MAP_AUTO)
       mapping = (can_pair && !split_case && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
     if (h->fp64) mapping = CDPR_MAP_LANE_PER_ROBOT;  // one plain kernel
+    // a mapping the CONFIGURATION asks for by name is served or refused; the CDPR_MAPPING environment override (A/B runs over
+    // whole test suites) keeps falling back to one lane per robot where the requested mapping does not exist
+    const bool can_cable = !general && !h->phys && !h->per_robot;
+    if (!h->fp64 && ((cfg->mapping == CDPR_MAP_LANE_PAIR && !can_pair) || (cfg->mapping == CDPR_MAP_LANE_PER_CABLE && !can_cable))) {
+      g_create_error = std::string(cfg->mapping == CDPR_MAP_LANE_PAIR ? "CDPR_MAP_LANE_PAIR" : "CDPR_MAP_LANE_PER_CABLE") +
+                       " is not available with the general controller path, the optional physics terms or per_robot_commands" +
+                       (cfg->mapping == CDPR_MAP_LANE_PAIR ? " (and needs 4 or 8 cables)" : "") + "; use CDPR_MAP_AUTO or CDPR_MAP_LANE_PER_ROBOT";
+      delete h;
+      return CDPR_ERR_UNSUPPORTED;
+    }
     h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
     // one lane per cable: any cable count; not with the optional physics, per-robot modes or the general path (those
     // handles silently keep the lane-per-robot mapping, as the lane-pair request does where it cannot be served)
-    h->lane_cable = (mapping == CDPR_MAP_LANE_PER_CABLE) && !general && !h->phys && !h->per_robot;
+    h->lane_cable = (mapping == CDPR_MAP_LANE_PER_CABLE) && can_cable;
     // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
     // Measured (scripts/ab_bench.py with CDPR_LOWREG=0|1, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
     // 131 072: 29.9 -> 27.0; 196 608: 41.2 -> 36.3; 524 288: 89.9 -> 79.0 (6.6e9 state-steps/s)
     h->lowreg = !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 90112u;  // crossover measured: profiles/r03j_cliff_scan.txt
     if (const char* lr = std::getenv("CDPR_LOWREG"))
       h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
+    // Between one and a few robots per hardware lane a single launch is a bulk-synchronous load -> compute -> store in which
+    // the co-resident waves of a SIMD start together: their memory phases coincide and their compute phases coincide, so
+    // two waves per SIMD cost 2.1-2.7x one (rocprofv3 PMC at 65 536 / 98 304 / 131 072 / 196 608: the vector pipes are busy
+    // 45 % of the launch at one AND at two waves per SIMD, profiles/r04a_cliff_pmc.txt).  The same step issued as back-to-back
+    // launches over blocks of <= 65 536 robots, each at the role-split kernel's operating point, is never slower there.
+    const uint32_t kChunkRobots = 65536u, kChunkMaxBatch = 393216u;
+    if (split_case && !h->lane_pair && !h->lane_cable && cfg->batch > kChunkRobots && cfg->batch <= kChunkMaxBatch) h->chunk = kChunkRobots;
+    if (const char* ck = std::getenv("CDPR_CHUNK")) {  // A/B: 0 = never, N = blocks of at most N robots whatever the batch
+      const long v = std::atol(ck);
+      h->chunk = (v > 0 && !general && !h->fp64 && !h->lane_pair && !h->lane_cable) ? (uint32_t)((v + 63) & ~63L) : 0u;
+    }
+    if (h->chunk && !std::getenv("CDPR_LOWREG")) h->lowreg = false;  // every block runs at <= 65 536 robots: the role-split kernel's range
   }
   // second-generation one-step kernel: wins wherever there is a Newton stage to hide the controller rows under, and
   // without one from ~32 768 robots on (65 536 x 8, no FK: 6.3 vs 7.0 us/step); small batches without FK are pure
@@ -1588,8 +1658,10 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   for (int i = 0; i < 2; ++i) {
     if ((e = hipMalloc(&h->d_vel[i], cmd_bytes)) != hipSuccess) return fail("hipMalloc(cmd)", e);
     if ((e = hipMalloc(&h->d_pos[i], cmd_bytes)) != hipSuccess) return fail("hipMalloc(cmd)", e);
+    if ((e = hipMalloc(&h->d_frc[i], cmd_bytes)) != hipSuccess) return fail("hipMalloc(cmd)", e);
     (void)hipMemset(h->d_vel[i], 0, cmd_bytes);
     (void)hipMemset(h->d_pos[i], 0, cmd_bytes);
+    (void)hipMemset(h->d_frc[i], 0, cmd_bytes);
   }
   if ((e = hipMalloc(&h->d_wtab, sizeof wtab_host)) != hipSuccess) return fail("hipMalloc(wtab)", e);
   if ((e = hipMemcpy(h->d_wtab, wtab_host, sizeof wtab_host, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(wtab)", e);
@@ -1624,7 +1696,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   if (h->per_robot) {
     if (!h->general && (e = hipMalloc(&h->d_target, cmd_bytes)) != hipSuccess) return fail("hipMalloc(target)", e);
     if ((e = hipMalloc(&h->d_mode, h->batch)) != hipSuccess) return fail("hipMalloc(mode)", e);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
       if ((e = hipMalloc(&h->d_mask[i], h->batch)) != hipSuccess) return fail("hipMalloc(mask)", e);
   }
   if (h->dbg && !h->fp64)
@@ -1651,7 +1723,7 @@ int cdpr_reset(cdpr_handle_t h) {
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   if (int rc = drain_copy_stream(h)) return rc;
   HIP_TRY(h, wait_stream(h));
-  h->free_ev_set[0] = h->free_ev_set[1] = false;
+  h->free_ev_set[0] = h->free_ev_set[1] = h->free_ev_set[2] = false;
   engine_reset_host(h);
   return upload_home(h);
 }
@@ -1705,9 +1777,9 @@ static int stage_masked(cdpr_engine* h, int which, const float* axes, size_t cou
   if (count != n * B && count != n) return CDPR_IGNORED;  // PLG.cpp:68-73,77-82
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   if (int rc = drain_copy_stream(h)) return rc;
-  float* pending = which == 0 ? h->d_vel[1] : h->d_pos[1];
-  bool& is_pending = which == 0 ? h->vel_pending : h->pos_pending;
-  bool& masked = which == 0 ? h->vel_masked : h->pos_masked;
+  float* pending = which == 0 ? h->d_vel[1] : which == 1 ? h->d_pos[1] : h->d_frc[1];
+  bool& is_pending = which == 0 ? h->vel_pending : which == 1 ? h->pos_pending : h->frc_pending;
+  bool& masked = which == 0 ? h->vel_masked : which == 1 ? h->pos_masked : h->frc_masked;
   // merge with a command of the same kind that is already pending: rows and mask bits of the robots addressed now
   std::vector<float> rows(n * B);
   std::vector<uint8_t> mask(B, 0);
@@ -1752,6 +1824,37 @@ int cdpr_set_position_command(cdpr_handle_t h, const float* axes, size_t count) 
     h->ext_pos[1] = nullptr;
   }
   return rc;
+}
+
+int cdpr_set_force_command(cdpr_handle_t h, const float* axes, size_t count) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = stage_command(h, h->d_frc[1], axes, count, false);
+  if (rc == CDPR_OK) {
+    h->frc_pending = true;
+    h->frc_masked = false;
+    h->ext_frc[1] = nullptr;
+  }
+  return rc;
+}
+
+int cdpr_set_force_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
+  if (!h) return CDPR_ERR_INVALID;
+  int rc = stage_command(h, h->d_frc[1], d_axes, count, true);
+  if (rc == CDPR_OK) {
+    h->frc_pending = true;
+    h->frc_masked = false;
+    h->ext_frc[1] = nullptr;
+  }
+  return rc;
+}
+
+int cdpr_set_force_command_masked(cdpr_handle_t h, const float* axes, size_t count, const uint8_t* robot_mask) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (!axes) {
+    h->err = "null command buffer";
+    return CDPR_ERR_INVALID;
+  }
+  return stage_masked(h, 2, axes, count, robot_mask);
 }
 
 int cdpr_set_velocity_command_masked(cdpr_handle_t h, const float* axes, size_t count, const uint8_t* robot_mask) {
@@ -1809,11 +1912,18 @@ static int bind_command(cdpr_engine* h, int which, const float* d_axes, size_t c
   if (which == 0) {
     h->ext_vel[1] = d_axes;
     h->vel_pending = true;
-  } else {
+  } else if (which == 1) {
     h->ext_pos[1] = d_axes;
     h->pos_pending = true;
+  } else {
+    h->ext_frc[1] = d_axes;
+    h->frc_pending = true;
   }
   return CDPR_OK;
+}
+
+int cdpr_bind_force_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
+  return h ? bind_command(h, 2, d_axes, count) : CDPR_ERR_INVALID;
 }
 
 int cdpr_bind_velocity_command_device(cdpr_handle_t h, const float* d_axes, size_t count) {
@@ -1967,8 +2077,6 @@ int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, floa
   if (!direct && h->unpack_cap < count) {
     HIP_TRY(h, wait_stream(h));
     if (h->d_unpack) (void)hipFree(h->d_unpack);
-  for (void* p64 : {(void*)h->d_state64, (void*)h->d_obs64, (void*)h->d_geom64, (void*)h->d_wtab64, (void*)h->d_dbg64, h->d_unpack64})
-    if (p64) (void)hipFree(p64);
     h->d_unpack = nullptr;
     h->unpack_cap = 0;
     HIP_TRY(h, hipMalloc(&h->d_unpack, count * sizeof(float)));

@@ -61,6 +61,7 @@ struct GenArgs {
   const float* cable;   // plain per-cable geometry: ax ay az bx by bz l0, 7 rows of n
   const float* vel_cmd; // latched jointVelocities, float[B][n] (or nullptr)
   const float* pos_cmd; // latched jointPositions, float[B][n] (or nullptr -> target 0)
+  const float* frc_cmd; // latched force command (setForce, JFC.h:92-95), float[B][n] (or nullptr -> 0)
   float* rec;           // [last_pos row][pos Pid block][vel Pid block], rows of `tstride` floats
   size_t tstride;
   float* force;         // out: raw force per cable, float[B][n]
@@ -300,7 +301,10 @@ __global__ __launch_bounds__(256) void cdpr_general_ctrl_kernel(const GenArgs a)
   terms.pi_written = terms.d_written = terms.desired_written = false;
   float force = 0.f;
   const int mode = a.mode_arr ? (int)a.mode_arr[r] : a.mode;
-  if (mode == 2) {  // Velocity (JFC.cpp:71-83)
+  if (mode == 0) {  // Force (JFC.cpp:67-70)
+    *last_pos = q;
+    force = a.frc_cmd ? a.frc_cmd[t] : 0.f;
+  } else if (mode == 2) {  // Velocity (JFC.cpp:71-83)
     const float vt = a.vel_cmd ? a.vel_cmd[t] : 0.f;
     if (fabsf(vt) > a.eps) {
       *last_pos = q;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void cdpr_latch_masked_kernel(const LatchArgs 
   const uint32_t r = t / a.n;
   if (a.mask && !a.mask[r]) return;
   a.latched[t] = a.pending[t];
-  if ((int)a.mode[r] != a.new_mode) {
+  if (a.pid_block && (int)a.mode[r] != a.new_mode) {  // (setForce resets no Pid: pid_block is null)
     for (int row = 0; row < a.rows; ++row) a.pid_block[(size_t)row * a.tstride + t] = 0.f;
   }
 }
@@ -375,7 +379,9 @@ __global__ __launch_bounds__(256) void cdpr_latch_fast_kernel(const LatchFastArg
   if (a.mask && !a.mask[r]) return;
   for (uint32_t i = 0; i < a.n; ++i) a.target[(size_t)r * a.n + i] = a.pending[(size_t)r * a.n + i];
   uint32_t m = a.meta[r];
-  if ((m & kMetaModeMask) != a.new_mode) {
+  if (a.new_mode == kMetaForce) {  // setForce (JFC.h:92-95) resets nothing; leaving Force mode resets the Pid entered
+    m = (m & ~kMetaModeMask) | kMetaForce;
+  } else if ((m & kMetaModeMask) != a.new_mode) {
     for (uint32_t g = 0; g < a.hot_rows; ++g) a.hot[(size_t)g * a.stride + r] = make_float4(0.f, 0.f, 0.f, 0.f);
     m = a.new_mode;  // call count 0
   }

@@ -41,9 +41,9 @@ CDPR_DEV void row_to_lds(const float4* src, float4* dst_row) {
 // just reset (calls == 0: "first call returns 0", Pid.cpp:123-126) keeps force 0 and its integral.
 template <int NP, bool PR = false>
 CDPR_DEV void pid_pairs(const StepArgs& a, int calls, bool is_vel, const v2f (&desired)[NP], const v2f (&actual)[NP], const v2f (&win)[NP][kWin],
-                        v2f (&ierr)[NP], v2f (&f)[NP], v2f (&e_new)[NP], float& dbg_p, float& dbg_i, float& dbg_d) {
+                        v2f (&ierr)[NP], v2f (&f)[NP], v2f (&e_new)[NP], float& dbg_p, float& dbg_i, float& dbg_d, bool is_force = false) {
   const PidCoef c = pid_coef<PR>(a, is_vel);
-  const bool run = !PR || calls != 0;
+  const bool run = (!PR || calls != 0) && !is_force;  // is_force (PR only): the robot is driven open loop (JFC.cpp:67-70)
   const bool full = calls >= c.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
   // the host put the weights of this launch's ring position (StepArgs::ring_slot) into the arguments; on per-robot handles
   // both Pids fit the same window (same length and degree: cdpr_create sends anything else down the general path), so
@@ -80,7 +80,7 @@ CDPR_DEV void pid_pairs(const StepArgs& a, int calls, bool is_vel, const v2f (&d
     out.x = (out.x != cmd.x) ? bumped.x : out.x;
     out.y = (out.y != cmd.y) ? bumped.y : out.y;
     ierr[k] = run ? ie : prev_ierr;
-    f[k] = run ? out : splat(0.f);
+    f[k] = run ? out : (is_force ? desired[k] : splat(0.f));
     e_new[k] = error[k];
     if (k == 0) {
       dbg_p = p_term.x;
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
 #pragma unroll
   for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
   const float* cp = a.cmd + (size_t)rr * N;  // never null: before the first Joy the latched buffer holds zeros
-  if (!kCmdLds) {
+  const bool force_mode = (a.flags & kFlagForceMode) != 0u;  // UpdateMode::Force (JFC.cpp:67-70): no Pid, no controller rows
+  if (!kCmdLds || force_mode) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       if (i & 1)
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
   //      are in registers: hipcc drains every outstanding VMEM operation (vmcnt(0)) at the first use of an ordinary
   //      load's result while an LDS-DMA is pending, so the DMA must not be pending yet when the platform rows are used.
   const bool first_world = (a.flags & kFlagFirstWorldStep) != 0u;
-  const bool run_pid = !first_world && a.pid_calls != 0;  // wave-uniform (Pid.cpp:123-126: the first call returns 0)
+  const bool run_pid = !first_world && !force_mode && a.pid_calls != 0;  // wave-uniform (Pid.cpp:123-126: the first call returns 0)
   {
     // every ordinary load issued so far is consumed here (data dependence: no use of one can sink below the DMA issue)
     float keep = (s.px + s.qy) + (s.vy + s.wz) + fkqw;
@@ -290,6 +291,11 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
         CDPR_STORE_STATE(a.state, st, P + 5 * NP + g, woff, make_float4(ierr[2 * g].x, ierr[2 * g].y, ierr[k1].x, ierr[k1].y));
       }
     }
+  }
+
+  if (force_mode && !first_world) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) f[k] = desired[k];
   }
 
   CDPR_STAMP(5);
@@ -663,7 +669,11 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   if (PR) meta = a.meta[rr];
   const int calls = PR ? (int)(meta >> kMetaCallShift) : a.pid_calls;
   if (PR && live && !first_world) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)min(calls + 1, (int)kMetaCallMax) << kMetaCallShift));
-  if (!first_world && (PR || calls != 0)) {
+  const bool force_mode = !PR && (a.flags & kFlagForceMode) != 0u;  // UpdateMode::Force on a uniform handle (JFC.cpp:67-70)
+  if (force_mode && !first_world) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) f[k] = desired[k];
+  } else if (!first_world && (PR || calls != 0)) {
     v2f win[NP][kWin];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -678,8 +688,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
 #pragma unroll
     for (int k = 0; k < NP; ++k) actual[k] = actual_is_vel ? qd[k] : q[k];
     const int ring_slot = a.ring_slot;
-    pid_pairs<NP, PR>(a, calls, actual_is_vel, desired, actual, win, ierr, f, e_new, dbg_p, dbg_i, dbg_d);
-    dbg_wrote = !PR || calls != 0;
+    const bool is_force = PR && (meta & kMetaModeMask) == kMetaForce;
+    pid_pairs<NP, PR>(a, calls, actual_is_vel, desired, actual, win, ierr, f, e_new, dbg_p, dbg_i, dbg_d, is_force);
+    dbg_wrote = (!PR || calls != 0) && !is_force;
     if (live) {
 #pragma unroll
       for (int m = 0; m < 5; ++m) {

@@ -52,6 +52,8 @@ enum StepFlags : uint32_t {
   kFlagFirstWorldStep = 1u << 0,    // JFC.cpp:61-66: stepTime <= 0 at t = 0 -> force 0, no Pid call
   kFlagRolloutResetPid = 1u << 1,   // rollout entered from Position mode: setVelocityTarget resets the Pid (JFC.cpp:113-115)
   kFlagActualIsVelocity = 1u << 2,  // velocity mode: Pid sees joint velocity (JFC.cpp:76), else position (JFC.cpp:88)
+  kFlagForceMode = 1u << 3,         // UpdateMode::Force (JFC.cpp:67-70): force = the commanded force, no Pid runs (uniform handles;
+                                    // per-robot handles carry the mode per lane: meta mode bits 0)
 };
 
 // One Pid's parameters as the kernels take them (Pid.cpp:64-73); see the "active Pid" fields of StepArgs.
@@ -453,7 +455,7 @@ CDPR_DEV PidCoef pid_coef(const StepArgs& a, bool is_vel) {
   return c;
 }
 constexpr uint32_t kMetaModeMask = 3u, kMetaCallShift = 2u, kMetaCallMax = 63u;
-constexpr uint32_t kMetaPosition = 1u, kMetaVelocity = 2u;  // JFC.h:35-37
+constexpr uint32_t kMetaForce = 0u, kMetaPosition = 1u, kMetaVelocity = 2u;  // JFC.h:35-37
 
 struct Platform {
   float px, py, pz, qx, qy, qz, qw;
@@ -977,11 +979,16 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
     if (EXT) {
 #pragma unroll
       for (int k = 0; k < NP; ++k) f[k] = first_world ? splat(0.f) : desired[k];
+    } else if (!first_world && !PR && (a.flags & kFlagForceMode)) {
+      // UpdateMode::Force (JFC.cpp:67-70): the commanded force goes out as it is, no Pid is called
+#pragma unroll
+      for (int k = 0; k < NP; ++k) f[k] = desired[k];
     } else if (!first_world) {
       // PR: every lane runs the arithmetic, a robot whose Pid has just been reset (calls == 0) keeps force 0 and its integral
       if (PR || calls != 0) {  // not the first call since reset (Pid.cpp:123-126: that one returns 0)
         const PidCoef c = pid_coef<PR>(a, actual_is_vel);
-        const bool run = !PR || calls != 0;
+        const bool is_force = PR && (meta & kMetaModeMask) == kMetaForce;  // this robot is driven open loop (JFC.cpp:67-70)
+        const bool run = (!PR || calls != 0) && !is_force;
         const bool full = calls >= c.nbuf;  // derive(): 0 until the window holds nbuf samples (Pid.cpp:200-203)
         ring_slot = (a.ring_slot + step) % kWin;  // the oldest sample sits there and is overwritten below
         // weights pre-rotated for this ring position (scalar loads); per-robot handles: both Pids fit the same window
@@ -1019,7 +1026,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
           out.x = (out.x != cmd.x) ? bumped.x : out.x;
           out.y = (out.y != cmd.y) ? bumped.y : out.y;
           ierr[k] = run ? ie : prev_ierr;
-          f[k] = run ? out : splat(0.f);
+          f[k] = run ? out : (is_force ? desired[k] : splat(0.f));
           e_new[k] = error[k];
           if (k == 0) {
             dbg_p = p_term.x;

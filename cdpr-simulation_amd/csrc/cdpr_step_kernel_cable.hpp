@@ -149,7 +149,9 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_cable(const StepArgs a
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
     int ring_slot = -1;
     float e_new = 0.f;
-    if (!first_world) {
+    if (!first_world && (a.flags & kFlagForceMode)) {
+      f = desired;  // UpdateMode::Force (JFC.cpp:67-70): no Pid
+    } else if (!first_world) {
       if (calls != 0) {  // not the first call since reset (Pid.cpp:123-126: that one returns 0)
         const bool full = calls >= a.nbuf;
         ring_slot = (a.ring_slot + step) % kWin;

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 
   for (int step = 0; step < a.nsteps; ++step) {
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
-    const bool run_pid = !first_world && calls != 0;  // Pid.cpp:123-126: the first call since reset returns 0
+    const bool force_mode = (a.flags & kFlagForceMode) != 0u;      // UpdateMode::Force (JFC.cpp:67-70): no Pid
+    const bool run_pid = !first_world && !force_mode && calls != 0;  // Pid.cpp:123-126: the first call since reset returns 0
     const bool full = calls >= a.nbuf;
     const int ring_slot = (a.ring_slot + step) % kWin;
     const double* wt = a.wtab + ring_slot * (kWin + 2);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         c_len[i][lane] = L;
         c_q[i][lane] = q;
         c_qd[i][lane] = qd;
-        double force = 0.0;
+        double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
         if (run_pid) {
           const double desired = c_des[i][lane];
           const double error = desired - (actual_is_vel ? qd : q);

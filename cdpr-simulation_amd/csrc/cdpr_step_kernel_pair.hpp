@@ -153,7 +153,10 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
     bool dbg_wrote = false;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
     int ring_slot = -1;
-    if (!first_world) {
+    if (!first_world && (a.flags & kFlagForceMode)) {  // UpdateMode::Force (JFC.cpp:67-70): no Pid
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) f[k] = desired[k];
+    } else if (!first_world) {
       if (calls != 0) {
         const bool full = calls >= a.nbuf;
         ring_slot = (a.ring_slot + step) % kWin;
@@ -317,13 +320,25 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
     CDPR_STAMP(5);
     // ---- observables of step t_k: lane 0 writes the platform rows, each lane its own joint group
     float4* const obs = a.obs + (size_t)step * a.obs_step_stride;
+    // travel-limit flags (cube.sdf:436-437): each lane tests its own cables, the two halves meet through the partner exchange
+    uint32_t limit_mask = 0u;
+    if (a.travel_on) {
+      uint32_t mine = 0u;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        mine |= (q[k].x < a.travel_lo || q[k].x > a.travel_hi) ? (1u << (2 * k)) : 0u;
+        mine |= (q[k].y < a.travel_lo || q[k].y > a.travel_hi) ? (1u << (2 * k + 1)) : 0u;
+      }
+      mine <<= par * NL;
+      limit_mask = mine | __float_as_uint(partner(__uint_as_float(mine)));
+    }
     if (((a.publish_mask >> step) & 1ull) && live) {
       if (par == 0u) {
         store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
         store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
       } else {
         store_slot(obs, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
-        store_slot(obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, (float)td_flag));
+        store_slot(obs, st, 3, woff, make_float4(s.wz, fk_res, (float)fk_it, pack_flags(td_flag, limit_mask)));
       }
       if (NL == 4) {  // n = 8: group g = this lane's four cables
         float4* orow = obs + (size_t)(4 + par) * st + r;

@@ -95,6 +95,17 @@ class Engine:
     def set_position_command(self, axes, mask=None) -> int:
         return self._command(lib().cdpr_set_position_command, lib().cdpr_set_position_command_masked, axes, mask)
 
+    def set_force_command(self, axes, mask=None) -> int:
+        """JointForceCalculator::setForce on every joint (JFC.h:92-95): open-loop forces, held until another command of
+        any kind arrives; no Pid runs (JFC.cpp:67-70).  Latched after a pending velocity / position command."""
+        return self._command(lib().cdpr_set_force_command, lib().cdpr_set_force_command_masked, axes, mask)
+
+    def set_force_command_device(self, dptr: int, count: int) -> int:
+        return self._check(lib().cdpr_set_force_command_device(self._h, C.c_void_p(dptr), count))
+
+    def bind_force_command_device(self, dptr: int, count: int) -> int:
+        return self._check(lib().cdpr_bind_force_command_device(self._h, C.c_void_p(dptr), count))
+
     def bind_velocity_command_device(self, dptr: int, count: int) -> int:
         """Zero-copy: the device buffer float[B][n] at dptr is the latched Joy batch from the next update on; it must stay
         valid and unchanged until another velocity command has been latched."""

@@ -155,6 +155,14 @@ class CdprGazeboPlugin:
             self.mPositionCommand = aMsg
             self.mPositionCommandReceived = True
 
+    # ---- JointForceCalculator::setForce (JFC.h:92-95) on every joint.  No topic of the reference plugin reaches it
+    #      (UpdateMode::Force is the mode a calculator is constructed in, JFC.h:42, and dead code from Load on); a caller
+    #      that computes its own tensions (tension distribution, MPC) drives the joints open loop through this.
+    def setForce(self, aMsg: Joy) -> None:
+        if self._accepts(aMsg):
+            self.mForceCommand = aMsg
+            self.mForceCommandReceived = True
+
     # ---- PLG.cpp:202-246 (+ the world step)
     def update(self, nsteps: int = 1) -> None:
         """`nsteps` Gazebo world iterations under the commands latched now.  Every step whose stamp passes the
@@ -170,6 +178,9 @@ class CdprGazeboPlugin:
         if self.mPositionCommandReceived:
             eng.set_position_command(self.mPositionCommand.axes, mask=self.mPositionCommand.robots)
             self.mPositionCommandReceived = False
+        if getattr(self, "mForceCommandReceived", False):  # [NEW] ordering: after the two Joy topics
+            eng.set_force_command(self.mForceCommand.axes, mask=self.mForceCommand.robots)
+            self.mForceCommandReceived = False
         first = eng.step_count
         dt = self.config.dt
         debug = bool(self.config.stages & _abi.STAGE_PID_DEBUG)

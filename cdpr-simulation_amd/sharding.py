@@ -75,6 +75,9 @@ class ShardedEngine:
     def set_position_command(self, axes, mask=None):
         return self._command("set_position_command", axes, mask)
 
+    def set_force_command(self, axes, mask=None):
+        return self._command("set_force_command", axes, mask)
+
     def update(self, nsteps=1, steps_per_launch=1):
         for e in self.engines:  # asynchronous: all devices run concurrently
             e.update(nsteps, steps_per_launch)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CDPR_ABI_VERSION 3u
+#define CDPR_ABI_VERSION 4u
 #define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
 #define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
 #define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
@@ -222,6 +222,20 @@ int cdpr_bind_position_command_device(cdpr_handle_t h, const float *d_axes, size
  * broadcast to the masked robots.  Needs cdpr_config_t.per_robot_commands = 1, else CDPR_ERR_UNSUPPORTED. */
 int cdpr_set_velocity_command_masked(cdpr_handle_t h, const float *axes, size_t count, const uint8_t *robot_mask);
 int cdpr_set_position_command_masked(cdpr_handle_t h, const float *axes, size_t count, const uint8_t *robot_mask);
+
+/* Replaces JointForceCalculator::setForce (JFC.h:92-95; UpdateMode::Force, JFC.h:35-42, JFC.cpp:67-70): the joints are
+ * driven open loop, force_i = axes[i], held until another command arrives: `mLastPosition = joint position; force =
+ * mForce`, no Pid runs.  This is the mode a JointForceCalculator is constructed in (JFC.h:42); the shipped plugin never
+ * calls setForce (no topic reaches it), a tension-distribution / MPC caller does.  Same count rules as the two Joy
+ * callbacks (n*B or n, anything else CDPR_IGNORED).  Latched at the next cdpr_update AFTER a pending velocity and a
+ * pending position command ([NEW] ordering: the reference has no force callback to order against; the last setter
+ * wins).  setForce resets no Pid; leaving Force mode through a velocity / position command resets the Pid of the mode
+ * entered (JFC.cpp:99-119), as from any other mode.  The optional stages still apply: tension distribution redistributes
+ * the commanded forces, SetForce limits clamp them.  _masked needs per_robot_commands = 1. */
+int cdpr_set_force_command(cdpr_handle_t h, const float *axes, size_t count);
+int cdpr_set_force_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
+int cdpr_bind_force_command_device(cdpr_handle_t h, const float *d_axes, size_t count);
+int cdpr_set_force_command_masked(cdpr_handle_t h, const float *axes, size_t count, const uint8_t *robot_mask);
 
 /* Replaces nsteps x { CdprGazeboPlugin::update (PLG.cpp:202-246) followed by
  * the Gazebo/ODE world step }.  Asynchronous: returns once the work is queued

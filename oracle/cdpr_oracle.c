@@ -323,6 +323,12 @@ static void jfc_set_velocity_target(orc_jfc *j, double target) {
   j->mode = MODE_VELOCITY;
 }
 
+static void jfc_set_force(orc_jfc *j, double force) {
+  /* JFC.h:92-95 */
+  j->force = force;
+  j->mode = MODE_FORCE;
+}
+
 static void jfc_init(orc_jfc *j, const cdpr_config_t *cfg, int deriv_mode, double joint_position) {
   /* PLG.cpp:153-157: construct, setPositionTarget(joint->Position()), then copy-assign
    * into the slot; operator= (JFC.cpp:38-51) copies the mode and calls reset()
@@ -582,7 +588,9 @@ struct orc_sim {
   double prev_publish;
   orc_robot *rob;
   float *vel_cmd, *pos_cmd; /* latched Joy.axes, float32 on the wire */
+  float *frc_cmd;           /* force command (JointForceCalculator::setForce, JFC.h:92-95): no topic of the plugin reaches it */
   unsigned char *vel_received, *pos_received; /* per robot: a Joy arrived since the last update() (PLG.cpp:206,213) */
+  unsigned char *frc_received;
   double ib[9], ib_inv[9]; /* body inertia and its inverse */
 };
 
@@ -619,9 +627,11 @@ orc_sim *orc_create(const cdpr_config_t *cfg, int deriv_mode) {
   s->rob = (orc_robot *)malloc(sizeof(orc_robot) * cfg->batch);
   s->vel_cmd = (float *)calloc(cfg->batch * cfg->n_cables, sizeof(float));
   s->pos_cmd = (float *)calloc(cfg->batch * cfg->n_cables, sizeof(float));
+  s->frc_cmd = (float *)calloc(cfg->batch * cfg->n_cables, sizeof(float));
   s->vel_received = (unsigned char *)calloc(cfg->batch, 1);
   s->pos_received = (unsigned char *)calloc(cfg->batch, 1);
-  if (!s->rob || !s->vel_cmd || !s->pos_cmd || !s->vel_received || !s->pos_received) {
+  s->frc_received = (unsigned char *)calloc(cfg->batch, 1);
+  if (!s->rob || !s->vel_cmd || !s->pos_cmd || !s->frc_cmd || !s->vel_received || !s->pos_received || !s->frc_received) {
     orc_destroy(s);
     return NULL;
   }
@@ -638,8 +648,10 @@ void orc_destroy(orc_sim *s) {
   free(s->rob);
   free(s->vel_cmd);
   free(s->pos_cmd);
+  free(s->frc_cmd);
   free(s->vel_received);
   free(s->pos_received);
+  free(s->frc_received);
   free(s);
 }
 
@@ -648,6 +660,7 @@ void orc_reset(orc_sim *s) {
   s->prev_publish = 0.0; /* PLG.cpp:59 */
   memset(s->vel_received, 0, s->cfg.batch);
   memset(s->pos_received, 0, s->cfg.batch);
+  memset(s->frc_received, 0, s->cfg.batch);
   for (uint64_t b = 0; b < s->cfg.batch; ++b) robot_reset(s, &s->rob[b]);
 }
 
@@ -681,6 +694,13 @@ int orc_set_velocity_command(orc_sim *s, const float *axes, size_t count) {
 }
 int orc_set_position_command(orc_sim *s, const float *axes, size_t count) {
   return latch(s, s->pos_cmd, axes, count, s->pos_received, NULL);
+}
+/* JointForceCalculator::setForce for every joint (JFC.h:92-95); same length rule as the Joy callbacks */
+int orc_set_force_command(orc_sim *s, const float *axes, size_t count) {
+  return latch(s, s->frc_cmd, axes, count, s->frc_received, NULL);
+}
+int orc_set_force_command_masked(orc_sim *s, const float *axes, size_t count, const unsigned char *mask) {
+  return latch(s, s->frc_cmd, axes, count, s->frc_received, mask);
 }
 int orc_set_velocity_command_masked(orc_sim *s, const float *axes, size_t count, const unsigned char *mask) {
   return latch(s, s->vel_cmd, axes, count, s->vel_received, mask);
@@ -964,7 +984,10 @@ int orc_update(orc_sim *s, int nsteps, int nthreads) {
       for (unsigned i = 0; i < n; ++i) jfc_set_velocity_target(&r->jfc[i], (double)s->vel_cmd[b * n + i]);
     if (s->pos_received[b])
       for (unsigned i = 0; i < n; ++i) jfc_set_position_target(&r->jfc[i], (double)s->pos_cmd[b * n + i]);
-    s->vel_received[b] = s->pos_received[b] = 0;
+    /* [NEW] ordering: a force command (no callback of the reference reaches setForce) is applied after the two Joy topics */
+    if (s->frc_received[b])
+      for (unsigned i = 0; i < n; ++i) jfc_set_force(&r->jfc[i], (double)s->frc_cmd[b * n + i]);
+    s->vel_received[b] = s->pos_received[b] = s->frc_received[b] = 0;
     for (int k = 0; k < nsteps; ++k) robot_step(s, r, step0 + (uint64_t)k, pub[k]);
   }
   (void)nthreads;

@@ -90,6 +90,8 @@ void orc_reset(orc_sim *s);
 int orc_set_platform_state(orc_sim *s, const double *pose7, const double *twist6);
 int orc_set_velocity_command(orc_sim *s, const float *axes, size_t count); /* PLG.cpp:67-74 */
 int orc_set_position_command(orc_sim *s, const float *axes, size_t count); /* PLG.cpp:76-83 */
+int orc_set_force_command(orc_sim *s, const float *axes, size_t count);    /* JFC.h:92-95 setForce on every joint */
+int orc_set_force_command_masked(orc_sim *s, const float *axes, size_t count, const unsigned char *mask);
 /* the same callbacks reaching only the robots with mask[b] != 0: B independent plugin instances, some of which got no message */
 int orc_set_velocity_command_masked(orc_sim *s, const float *axes, size_t count, const unsigned char *mask);
 int orc_set_position_command_masked(orc_sim *s, const float *axes, size_t count, const unsigned char *mask);

@@ -42,6 +42,8 @@ def lib():
         L.orc_set_velocity_command.argtypes = [C.c_void_p, fp, C.c_size_t]
         L.orc_set_position_command.argtypes = [C.c_void_p, fp, C.c_size_t]
         L.orc_set_velocity_command_masked.argtypes = [C.c_void_p, fp, C.c_size_t, C.POINTER(C.c_uint8)]
+        L.orc_set_force_command.argtypes = [C.c_void_p, fp, C.c_size_t]
+        L.orc_set_force_command_masked.argtypes = [C.c_void_p, fp, C.c_size_t, C.POINTER(C.c_uint8)]
         L.orc_set_position_command_masked.argtypes = [C.c_void_p, fp, C.c_size_t, C.POINTER(C.c_uint8)]
         L.orc_update.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_rollout_velocity.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, dp, dp, C.c_int]
@@ -151,6 +153,10 @@ class OracleSim:
 
     def set_position_command(self, axes, mask=None):
         return self._cmd(lib().orc_set_position_command, lib().orc_set_position_command_masked, axes, mask)
+
+    def set_force_command(self, axes, mask=None):
+        """JointForceCalculator::setForce on every joint (JFC.h:92-95)."""
+        return self._cmd(lib().orc_set_force_command, lib().orc_set_force_command_masked, axes, mask)
 
     def _threads(self, nthreads, units):
         """OpenMP threads for a call over `units` independent robots / trajectories when the caller names none: never more

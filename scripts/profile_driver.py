@@ -8,6 +8,8 @@
   perrobot   65 536 x 8, all stages, one launch per step on a per_robot_commands handle: a third of the robots in
              Position mode, the rest in Velocity mode with Pids reset at two different times (PR split kernel)
   perrobot_general  16 384 x 8 per-robot handle forced onto the general controller path (velocityEpsilon = 0)
+  scan_<B>_<split|lowreg|auto>  <B> x 8, all stages, one launch per step, with the role-split kernel (CDPR_LOWREG=0), the
+             low-register kernel (CDPR_LOWREG=1) or whatever CDPR_MAP_AUTO picks: the 65 536 < B < 200 000 range
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +20,16 @@ import bench
 
 case = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-if case in ("fused", "onestep", "lowreg"):
+if case.startswith("scan_"):
+    _, b_, kind = case.split("_")
+    if kind != "auto":
+        os.environ["CDPR_LOWREG"] = "1" if kind == "lowreg" else "0"
+    B = int(b_)
+    model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 10)
+    eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3), 0)
+    eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
+    eng.update(reps * 2); eng.synchronize()
+elif case in ("fused", "onestep", "lowreg"):
     B = 524288 if case == "lowreg" else 65536
     model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 10)
     eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3), 0)

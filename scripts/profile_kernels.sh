@@ -14,5 +14,6 @@ for CASE in "$@"; do
   done
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD --output-format csv -d $OUT/pmc_SQ -- python3 $ROOT/scripts/profile_driver.py $CASE 40 > $OUT/pmc_SQ.log 2>&1
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_MFMA -- python3 $ROOT/scripts/profile_driver.py $CASE 40 > $OUT/pmc_MFMA.log 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d $OUT/pmc_L2 -- python3 $ROOT/scripts/profile_driver.py $CASE 40 > $OUT/pmc_L2.log 2>&1
   python3 $ROOT/scripts/summarize_profile.py $OUT ${TAG}_$CASE > $OUT/summary.log 2>&1
 done

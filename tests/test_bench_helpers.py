@@ -95,9 +95,9 @@ def test_rank_cpu_sets_are_disjoint_and_cover_equal_shares():
     import bench
 
     cpus = list(range(3, 35))  # 32 CPUs, not starting at 0
-    sets = [bench.rank_cpu_set(r, 8, cpus) for r in range(8)]
+    sets = [bench.rank_cpu_set(r, 8, cpus)[0] for r in range(8)]
     assert all(len(s) == 4 for s in sets) and len(set().union(*sets)) == 32
-    assert bench.rank_cpu_set(0, 1, cpus) is None and bench.rank_cpu_set(0, 64, cpus) is None
+    assert bench.rank_cpu_set(0, 1, cpus) == (None, None) and bench.rank_cpu_set(0, 64, cpus) == (None, None)
     assert [sl for sl in bench.parity_slices(65536)] == [slice(0, 64), slice(65472, 65536)]
     assert bench.parity_slices(40) == [slice(0, 40)]
 
@@ -154,3 +154,114 @@ def test_modelled_traffic_matches_the_measured_bytes():
     assert abs(bench.modelled_traffic_bytes(8, True, 65536) / measured["n8_b65536_spl1"] - 1) < 0.01
     assert abs(bench.modelled_traffic_bytes(8, True, 524288) / measured["n8_b524288_spl1"] - 1) < 0.01
     assert abs(bench.modelled_traffic_bytes(4, False, 4096) / measured["n4_b4096_spl1"] - 1) < 0.06  # 64 waves: per-launch constants show
+
+
+def test_traffic_table_is_not_older_than_the_newest_pmc_summary():
+    """profiles/traffic.json's headline entry must come from the NEWEST profiles/*_bench_pmc_summary.json (round tags sort:
+    r02final4 < r03final < r04a < r04final) and equal that summary's figure: scripts/profile_gpu.sh rewrites the table from
+    the PMC pass it has just run (scripts/update_traffic.py), and nobody may forget to copy it."""
+    import glob
+    import json
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import update_traffic
+
+    table = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc_summary.json")), key=os.path.basename)[-1]
+    src = table["_sources"]["n8_b65536_spl1"]
+    assert os.path.basename(src["file"]) == os.path.basename(newest), f"traffic.json quotes {src['file']}, newest PMC summary is {newest}"
+    name, total = update_traffic.dominant_step_kernel(json.load(open(newest)))
+    assert abs(total - table["n8_b65536_spl1"]) < 1.0 and name == src["kernel"]
+    for key, s_ in table["_sources"].items():
+        assert os.path.exists(os.path.join(ROOT, s_["file"])), f"{key}: source {s_['file']} is not in profiles/"
+
+
+def _fake_sysfs(root, gpus, nodes):
+    """A sysfs tree as an 8-GPU two-socket node shows it: KFD topology nodes (CPU nodes first, simd_count 0), one PCI device
+    directory per GPU with its numa_node, one cpulist per NUMA node.  gpus = [(bus, numa_node)], nodes = {node: cpulist}."""
+    topo = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    for i in range(len(nodes)):
+        os.makedirs(os.path.join(topo, str(i)))
+        open(os.path.join(topo, str(i), "properties"), "w").write("cpu_cores_count 48\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for g, (bus, numa) in enumerate(gpus):
+        d = os.path.join(topo, str(len(nodes) + g))
+        os.makedirs(d)
+        open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\ndrm_render_minor {128 + g}\n")
+        pci = os.path.join(root, "bus", "pci", "devices", f"0000:{bus:02x}:00.0")
+        os.makedirs(pci)
+        open(os.path.join(pci, "numa_node"), "w").write(f"{numa}\n")
+    for node, cpulist in nodes.items():
+        d = os.path.join(root, "devices", "system", "node", f"node{node}")
+        os.makedirs(d)
+        open(os.path.join(d, "cpulist"), "w").write(cpulist + "\n")
+
+
+def test_rank_placement_follows_the_gpus_numa_nodes(tmp_path, monkeypatch):
+    """Topology-aware pinning: rank r drives GPU r, so it takes cores of THAT GPU's NUMA node (an equal share among the
+    ranks sharing the node), read from sysfs by PCI address; the contiguous split remains where sysfs says nothing."""
+    import bench
+
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    root = str(tmp_path / "sys")
+    # GPUs 0-3 hang off socket 1, GPUs 4-7 off socket 0 (the inverse of the contiguous split's assumption); hyper-threads
+    # of a socket are listed in two ranges, as on real two-socket boxes
+    gpus = [(0x05, 1), (0x15, 1), (0x65, 1), (0x75, 1), (0x85, 0), (0x95, 0), (0xE5, 0), (0xF5, 0)]
+    _fake_sysfs(root, gpus, {0: "0-47,96-143", 1: "48-95,144-191"})
+    assert bench.parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    assert bench.gpu_numa_nodes(root) == [1, 1, 1, 1, 0, 0, 0, 0]
+    allowed = set(range(192))
+    sets = [bench.rank_cpu_set(r, 8, allowed, bench.gpu_numa_nodes(root), root) for r in range(8)]
+    node1, node0 = bench.numa_cpus(1, root), bench.numa_cpus(0, root)
+    for r, (cpus, node) in enumerate(sets):
+        assert node == (1 if r < 4 else 0) and len(cpus) == 24 and cpus <= (node1 if r < 4 else node0)
+    assert len(set().union(*(c for c, _ in sets))) == 192  # disjoint, everything used
+    # a cgroup / taskset that leaves only some cores: shares come out of what is allowed on the right node
+    some = set(range(40, 60)) | set(range(150, 160))
+    c0, n0 = bench.rank_cpu_set(0, 8, some, bench.gpu_numa_nodes(root), root)
+    c7, n7 = bench.rank_cpu_set(7, 8, some, bench.gpu_numa_nodes(root), root)
+    assert n0 == 1 and c0 <= node1 & some and n7 == 0 and c7 <= node0 & some and not (c0 & c7)
+    # visible-device lists re-map the ordinals
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,0,1")
+    assert bench.gpu_numa_nodes(root) == [0, 0, 1, 1]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")
+    assert bench.gpu_numa_nodes(root) == []
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # no sysfs / numa_node -1 (single-socket box, VM): the contiguous split
+    assert bench.gpu_numa_nodes(str(tmp_path / "nothing")) == []
+    cpus, node = bench.rank_cpu_set(3, 8, set(range(32)), [], root)
+    assert node is None and cpus == {12, 13, 14, 15}
+    cpus, node = bench.rank_cpu_set(3, 8, set(range(32)), [-1] * 8, root)
+    assert node is None and cpus == {12, 13, 14, 15}
+    # a node none of whose CPUs are allowed: no half-NUMA placement, the contiguous split for everybody
+    cpus, node = bench.rank_cpu_set(0, 8, set(range(0, 40)), bench.gpu_numa_nodes(root), root)
+    assert node is None and cpus == set(range(0, 5))
+
+
+def test_bench_dry_run_reports_the_numa_node_of_every_rank(tmp_path):
+    """`bench.py --gpus 8 --dry-run` against a fake two-socket sysfs (CDPR_BENCH_SYSFS): placement.numa_node per rank in
+    per_rank, the ranks of GPUs 0-3 on node 1, the rest on node 0 - whatever CPUs this box really has (the fake nodes are
+    built from them)."""
+    import json
+    import subprocess
+
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 8:
+        import pytest
+
+        pytest.skip("fewer than 8 CPUs")
+    half = len(allowed) // 2
+    fmt = lambda cs: ",".join(str(c) for c in cs)  # noqa: E731
+    root = str(tmp_path / "sys")
+    gpus = [(0x05, 1), (0x15, 1), (0x65, 1), (0x75, 1), (0x85, 0), (0x95, 0), (0xE5, 0), (0xF5, 0)]
+    _fake_sysfs(root, gpus, {0: fmt(allowed[:half]), 1: fmt(allowed[half:])})
+    env = dict(os.environ, CDPR_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1", CDPR_BENCH_SYSFS=root)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.splitlines()[0])
+    assert [p["placement"]["numa_node"] for p in out["per_rank"]] == [1, 1, 1, 1, 0, 0, 0, 0]
+    assert out["placement"]["gpu_numa_nodes"] == [1, 1, 1, 1, 0, 0, 0, 0] and out["placement"]["numa_node"] == 1
+    assert all(p["cpus"] == half // 4 for p in out["per_rank"])

@@ -237,3 +237,43 @@ def test_travel_stop_holds_the_joint_at_its_limit_and_only_removes_energy(pkg, o
             t = t + minv @ jac[i] * lam
     assert np.abs(got - t).max() < 1e-13
     assert 0.5 * got @ got <= 0.5 * twist0 @ twist0 + 1e-15
+
+
+def test_force_mode_holds_the_platform_at_the_survey_tension(pkg, oracle):
+    """UpdateMode::Force (JFC.cpp:67-70, JFC.h:92-95) through the oracle's entry point: the static tension of SURVEY 8(a)
+    row 13 on all four cables keeps the home pose (joint rates are zero there, so the damping adds nothing); step 0
+    applies force 0 whatever the mode (stepTime = 0, JFC.cpp:61-66), which costs one step of free fall."""
+    cfg = pkg.Config(batch=1)
+    sim = oracle.OracleSim(cfg.to_struct())
+    jac = oracle.ik(cfg.to_struct(), cfg.model.home_pose())[3]
+    t0 = 9.8 / (-jac[:, 2].sum())
+    assert abs(t0 - 3.965671444) < 1e-9
+    sim.set_force_command(np.full(4, t0, np.float32))
+    sim.update(1)
+    assert np.all(sim.joint_states()[2] == 0.0)
+    sim.update(1)
+    assert np.allclose(sim.joint_states()[2], np.float32(t0), rtol=0, atol=0)  # the command as it is, float32 on the wire
+    # one step of free fall, then (nearly) balanced: the platform drifts by the velocity it picked up, no faster
+    sim.update(100)
+    pose, twist = sim.raw_state()
+    assert abs(twist[0, 2]) < 9.8e-3 * 1.01 and abs(pose[0, 2] - 0.3) < 1.1e-3
+    assert sim.set_force_command(np.zeros(3, np.float32)) == 1  # wrong length: dropped (the Joy callbacks' rule)
+
+
+def test_leaving_force_mode_resets_the_pid_entered(pkg, oracle):
+    """setForce resets nothing (JFC.h:92-95); setVelocityTarget from Force mode resets the velocity Pid (JFC.cpp:113-115):
+    its first call returns 0 (Pid.cpp:123-126)."""
+    cfg = pkg.Config(batch=1)
+    sim = oracle.OracleSim(cfg.to_struct())
+    v = np.full(4, 0.02, np.float32)
+    sim.set_velocity_command(v)
+    sim.update(30)
+    assert np.all(sim.joint_states()[2] != 0.0)
+    sim.set_force_command(np.full(4, 4.0, np.float32))
+    sim.update(5)
+    assert np.all(sim.joint_states()[2] == 4.0)
+    sim.set_velocity_command(v)
+    sim.update(1)
+    assert np.all(sim.joint_states()[2] == 0.0)  # first Pid call after the reset
+    sim.update(1)
+    assert np.all(sim.joint_states()[2] != 0.0)
