@@ -18,12 +18,8 @@
 #include <vector>
 
 #include "../../include/cdpr.h"
-#include "cdpr_step_kernel.hpp"
-#include "cdpr_onestep_kernel.hpp"
-#include "cdpr_step_kernel_pair.hpp"
-#include "cdpr_step_kernel_cable.hpp"
-#include "cdpr_general_ctrl.hpp"
-#include "cdpr_step_kernel_f64.hpp"
+#include "cdpr_kernels.hpp"
+#include "cdpr_latch.hpp"
 #include "cdpr_solvers.hpp"
 
 using namespace cdpr;
@@ -65,14 +61,14 @@ struct cdpr_engine {
   uint32_t chunk = 0;       // > 0: a step over the batch is issued as back-to-back launches over contiguous blocks of at most
                             // this many robots (batches between one and ~5 robots per hardware lane: see cdpr_create)
   bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
-  // general controller path (hold branch, cascades, long windows): see cdpr_general_ctrl.hpp
+  // general controller path (hold branch, cascades, long windows): see cdpr_general_step.hpp
   bool general = false;
-  float* d_rec = nullptr;    // [last_pos][position Pid block][velocity Pid block]
-  float* d_force = nullptr;  // raw forces handed from the controller kernel to the platform kernel
-  float* d_cable = nullptr;  // plain per-cable geometry, 7 rows of n
-  size_t tstride = 0;
+  float* d_rec = nullptr;    // record rows: [mLastPosition per cable][position Pid rows][velocity Pid rows], one column per robot
+  float* d_gwtab = nullptr;  // FIR weights by ring head, [pid][head][slot]
   GenPid gpid[2]{};
   GenLayout glay{};          // rows of a Pid block: sized by the configured window length and cascade count
+  float* d_roll_rec = nullptr;   // MPC rollout on the general path: every trajectory's private copy of the records
+  size_t roll_rec_cols = 0;      // columns d_roll_rec can hold
   // hipGraph cache: chains of identical steady-state launches (see run_steps)
   struct GraphEntry {
     void* kern;
@@ -341,6 +337,10 @@ void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   k.split_swap = 0x9;  // measured on MI355X (65 536 x 8): masks 0 .. 0xf8 give 10.8-11.3 us/step, 0x9 the best; bits 8-9 (the
                        // workgroups that share a CU) make it 12.8: the dispatcher already alternates the SIMD pairs there
   if (const char* sw = std::getenv("CDPR_SPLIT_SWAP")) k.split_swap = (uint32_t)strtoul(sw, nullptr, 0);
+  k.stagger_sleeps = 0;
+  k.stagger_period = 1024;  // one wave slot on each of the chip's 1 024 SIMDs
+  if (const char* sg = std::getenv("CDPR_STAGGER")) k.stagger_sleeps = (uint32_t)strtoul(sg, nullptr, 0);
+  if (const char* sp = std::getenv("CDPR_STAGGER_PERIOD")) k.stagger_period = std::max(1u, (uint32_t)strtoul(sp, nullptr, 0));
   k.fk_lambda = (float)c.fk_lambda;
   k.fk_tol = (float)c.fk_tolerance;
   k.fk_iters = (int)c.fk_max_iterations;
@@ -355,6 +355,7 @@ void fill_gen_pid(const cdpr_pid_params_t& p, GenPid& g) {
   g.cmax = (float)std::fabs(p.cmd_limit); g.cmin = -(float)std::fabs(p.cmd_limit);
   g.nbuf = (int)p.d_buffer_length; g.degree = (int)p.d_degree;
   g.pcas = (int)p.p_filter.cascade; g.dcas = (int)p.d_filter.cascade;
+  g.clamp = g.cmax > g.cmin ? 1 : 0;
   auto biquad = [](const cdpr_filter_params_t& f, float& a0, float& a1, float& a2, float& b1, float& b2) {
     // BiQuad::SetFc(fc, fs = 1.0, q), Filter.h:130-140
     const double k = std::tan(M_PI * f.rel_cutoff / 1.0);
@@ -365,57 +366,6 @@ void fill_gen_pid(const cdpr_pid_params_t& p, GenPid& g) {
   g.pa0 = g.pa1 = g.pa2 = g.pb1 = g.pb2 = g.da0 = g.da1 = g.da2 = g.db1 = g.db2 = 0.f;
   if (g.pcas) biquad(p.p_filter, g.pa0, g.pa1, g.pa2, g.pb1, g.pb2);
   if (g.dcas) biquad(p.d_filter, g.da0, g.da1, g.da2, g.db1, g.db2);
-}
-
-using StepKernel = void (*)(const StepArgs);
-
-template <int N>
-StepKernel pick_ext_stage(bool fk, bool td) {
-  if constexpr (N >= 6) {
-    if (fk && td) return cdpr_step_kernel<N, true, true, true, true>;
-    if (fk) return cdpr_step_kernel<N, true, false, true, true>;
-    if (td) return cdpr_step_kernel<N, false, true, true, true>;
-  }
-  return cdpr_step_kernel<N, false, false, true, true>;
-}
-
-StepKernel pick_ext_kernel(uint32_t n, bool fk, bool td) {
-  switch (n) {
-    case 1: return pick_ext_stage<1>(fk, td);
-    case 2: return pick_ext_stage<2>(fk, td);
-    case 3: return pick_ext_stage<3>(fk, td);
-    case 4: return pick_ext_stage<4>(fk, td);
-    case 5: return pick_ext_stage<5>(fk, td);
-    case 6: return pick_ext_stage<6>(fk, td);
-    case 7: return pick_ext_stage<7>(fk, td);
-    case 8: return pick_ext_stage<8>(fk, td);
-  }
-  return nullptr;
-}
-
-template <int N, bool SINGLE>
-StepKernel pick_stage(bool fk, bool td) {
-  if constexpr (N >= 6) {
-    if (fk && td) return cdpr_step_kernel<N, true, true, SINGLE>;
-    if (fk) return cdpr_step_kernel<N, true, false, SINGLE>;
-    if (td) return cdpr_step_kernel<N, false, true, SINGLE>;
-  }
-  return cdpr_step_kernel<N, false, false, SINGLE>;
-}
-
-template <bool SINGLE>
-StepKernel pick_kernel(uint32_t n, bool fk, bool td) {
-  switch (n) {
-    case 1: return pick_stage<1, SINGLE>(fk, td);
-    case 2: return pick_stage<2, SINGLE>(fk, td);
-    case 3: return pick_stage<3, SINGLE>(fk, td);
-    case 4: return pick_stage<4, SINGLE>(fk, td);
-    case 5: return pick_stage<5, SINGLE>(fk, td);
-    case 6: return pick_stage<6, SINGLE>(fk, td);
-    case 7: return pick_stage<7, SINGLE>(fk, td);
-    case 8: return pick_stage<8, SINGLE>(fk, td);
-  }
-  return nullptr;
 }
 
 // Cable geometry as the kernel wants it in LDS: per cable pair
@@ -442,181 +392,6 @@ std::vector<float> geom_pairs(const cdpr_config_t& c) {
     }
   }
   return g;
-}
-
-template <int N, bool SINGLE>
-StepKernel pick_pair_stage(bool fk, bool td) {
-  if constexpr (N >= 6) {
-    if (fk && td) return cdpr_step_kernel_pair<N, true, true, SINGLE>;
-    if (fk) return cdpr_step_kernel_pair<N, true, false, SINGLE>;
-    if (td) return cdpr_step_kernel_pair<N, false, true, SINGLE>;
-  }
-  return cdpr_step_kernel_pair<N, false, false, SINGLE>;
-}
-
-template <bool SINGLE>
-StepKernel pick_pair_kernel(uint32_t n, bool fk, bool td) {
-  return n == 4 ? pick_pair_stage<4, SINGLE>(fk, td) : pick_pair_stage<8, SINGLE>(fk, td);
-}
-
-// one lane per cable (cdpr_step_kernel_cable.hpp): one kernel for any number of steps per launch
-template <int N>
-StepKernel pick_cable_stage(bool fk, bool td) {
-  if constexpr (N >= 6) {
-    if (fk && td) return cdpr_step_kernel_cable<N, true, true>;
-    if (fk) return cdpr_step_kernel_cable<N, true, false>;
-    if (td) return cdpr_step_kernel_cable<N, false, true>;
-  }
-  return cdpr_step_kernel_cable<N, false, false>;
-}
-StepKernel pick_cable_kernel(uint32_t n, bool fk, bool td) {
-  switch (n) {
-    case 1: return pick_cable_stage<1>(fk, td);
-    case 2: return pick_cable_stage<2>(fk, td);
-    case 3: return pick_cable_stage<3>(fk, td);
-    case 4: return pick_cable_stage<4>(fk, td);
-    case 5: return pick_cable_stage<5>(fk, td);
-    case 6: return pick_cable_stage<6>(fk, td);
-    case 7: return pick_cable_stage<7>(fk, td);
-    case 8: return pick_cable_stage<8>(fk, td);
-  }
-  return nullptr;
-}
-
-// second-generation one-step kernel (controller rows staged through LDS, cdpr_onestep_kernel.hpp)
-template <int N>
-StepKernel pick_onestep_stage(bool fk, bool td) {
-  if constexpr (N >= 6) {
-    if (fk && td) return cdpr_onestep_kernel<N, true, true>;
-    if (fk) return cdpr_onestep_kernel<N, true, false>;
-    if (td) return cdpr_onestep_kernel<N, false, true>;
-  }
-  return cdpr_onestep_kernel<N, false, false>;
-}
-
-StepKernel pick_onestep_kernel(uint32_t n, bool fk, bool td) {
-  switch (n) {
-    case 1: return pick_onestep_stage<1>(fk, td);
-    case 2: return pick_onestep_stage<2>(fk, td);
-    case 3: return pick_onestep_stage<3>(fk, td);
-    case 4: return pick_onestep_stage<4>(fk, td);
-    case 5: return pick_onestep_stage<5>(fk, td);
-    case 6: return pick_onestep_stage<6>(fk, td);
-    case 7: return pick_onestep_stage<7>(fk, td);
-    case 8: return pick_onestep_stage<8>(fk, td);
-  }
-  return nullptr;
-}
-
-// lumped-leg physics (PHYS = true): one generic stepping kernel (any steps per launch), the platform kernel of the
-// general controller path, the MPC rollout
-enum PhysKind { kPhysStep, kPhysExt, kPhysRollout };
-template <int N, bool FK, bool TD>
-StepKernel phys_variant(int kind) {
-  if (kind == kPhysExt) return cdpr_step_kernel<N, FK, TD, true, true, false, false, true>;
-  if (kind == kPhysRollout) return cdpr_step_kernel<N, FK, TD, false, false, true, false, true>;
-  return cdpr_step_kernel<N, FK, TD, false, false, false, false, true>;
-}
-template <int N>
-StepKernel pick_phys_stage(bool fk, bool td, int kind) {
-  if constexpr (N >= 6) {
-    if (fk && td) return phys_variant<N, true, true>(kind);
-    if (fk) return phys_variant<N, true, false>(kind);
-    if (td) return phys_variant<N, false, true>(kind);
-  }
-  return phys_variant<N, false, false>(kind);
-}
-StepKernel pick_phys_kernel(uint32_t n, bool fk, bool td, int kind) {
-  switch (n) {
-    case 1: return pick_phys_stage<1>(fk, td, kind);
-    case 2: return pick_phys_stage<2>(fk, td, kind);
-    case 3: return pick_phys_stage<3>(fk, td, kind);
-    case 4: return pick_phys_stage<4>(fk, td, kind);
-    case 5: return pick_phys_stage<5>(fk, td, kind);
-    case 6: return pick_phys_stage<6>(fk, td, kind);
-    case 7: return pick_phys_stage<7>(fk, td, kind);
-    case 8: return pick_phys_stage<8>(fk, td, kind);
-  }
-  return nullptr;
-}
-
-StepKernel pick_split_kernel(uint32_t n) {
-  switch (n) {
-    case 6: return cdpr_split_kernel<6>;
-    case 7: return cdpr_split_kernel<7>;
-    case 8: return cdpr_split_kernel<8>;
-  }
-  return nullptr;
-}
-
-// one-step kernels compiled for two waves per SIMD (FK on, n >= 6): see LOWREG in cdpr_step_kernel.hpp
-StepKernel pick_lowreg_kernel(uint32_t n, bool td) {
-  switch (n) {
-    case 6: return td ? cdpr_step_kernel<6, true, true, true, false, false, true> : cdpr_step_kernel<6, true, false, true, false, false, true>;
-    case 7: return td ? cdpr_step_kernel<7, true, true, true, false, false, true> : cdpr_step_kernel<7, true, false, true, false, false, true>;
-    case 8: return td ? cdpr_step_kernel<8, true, true, true, false, false, true> : cdpr_step_kernel<8, true, false, true, false, false, true>;
-  }
-  return nullptr;
-}
-
-template <int N>
-StepKernel pick_rollout_stage(bool fk, bool td) {
-  if constexpr (N >= 6) {
-    if (fk && td) return cdpr_step_kernel<N, true, true, false, false, true>;
-    if (fk) return cdpr_step_kernel<N, true, false, false, false, true>;
-    if (td) return cdpr_step_kernel<N, false, true, false, false, true>;
-  }
-  return cdpr_step_kernel<N, false, false, false, false, true>;
-}
-
-StepKernel pick_rollout_kernel(uint32_t n, bool fk, bool td) {
-  switch (n) {
-    case 1: return pick_rollout_stage<1>(fk, td);
-    case 2: return pick_rollout_stage<2>(fk, td);
-    case 3: return pick_rollout_stage<3>(fk, td);
-    case 4: return pick_rollout_stage<4>(fk, td);
-    case 5: return pick_rollout_stage<5>(fk, td);
-    case 6: return pick_rollout_stage<6>(fk, td);
-    case 7: return pick_rollout_stage<7>(fk, td);
-    case 8: return pick_rollout_stage<8>(fk, td);
-  }
-  return nullptr;
-}
-
-// per-robot handles on the register-resident path (PR = true): the first-generation kernel in every shape (one step, several
-// steps, low-register, rollout) and the role-split kernel for FK + TD one-step launches
-template <int N, bool SINGLE, bool ROLLOUT, bool LOWREG>
-StepKernel pick_pr_stage(bool fk, bool td) {
-  if constexpr (N >= 6) {
-    if (fk && td) return cdpr_step_kernel<N, true, true, SINGLE, false, ROLLOUT, LOWREG, false, true>;
-    if (fk) return cdpr_step_kernel<N, true, false, SINGLE, false, ROLLOUT, LOWREG, false, true>;
-    if constexpr (!LOWREG)
-      if (td) return cdpr_step_kernel<N, false, true, SINGLE, false, ROLLOUT, false, false, true>;
-  }
-  if constexpr (!LOWREG) return cdpr_step_kernel<N, false, false, SINGLE, false, ROLLOUT, false, false, true>;
-  return nullptr;
-}
-template <bool SINGLE, bool ROLLOUT, bool LOWREG = false>
-StepKernel pick_pr_kernel(uint32_t n, bool fk, bool td) {
-  switch (n) {
-    case 1: return pick_pr_stage<1, SINGLE, ROLLOUT, LOWREG>(fk, td);
-    case 2: return pick_pr_stage<2, SINGLE, ROLLOUT, LOWREG>(fk, td);
-    case 3: return pick_pr_stage<3, SINGLE, ROLLOUT, LOWREG>(fk, td);
-    case 4: return pick_pr_stage<4, SINGLE, ROLLOUT, LOWREG>(fk, td);
-    case 5: return pick_pr_stage<5, SINGLE, ROLLOUT, LOWREG>(fk, td);
-    case 6: return pick_pr_stage<6, SINGLE, ROLLOUT, LOWREG>(fk, td);
-    case 7: return pick_pr_stage<7, SINGLE, ROLLOUT, LOWREG>(fk, td);
-    case 8: return pick_pr_stage<8, SINGLE, ROLLOUT, LOWREG>(fk, td);
-  }
-  return nullptr;
-}
-StepKernel pick_pr_split_kernel(uint32_t n) {
-  switch (n) {
-    case 6: return cdpr_split_kernel<6, true>;
-    case 7: return cdpr_split_kernel<7, true>;
-    case 8: return cdpr_split_kernel<8, true>;
-  }
-  return nullptr;
 }
 
 using SolveKernel = void (*)(const SolveArgs);
@@ -718,7 +493,7 @@ int upload_home(cdpr_engine* h) {
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_frc[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   }
-  if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, gen_record_rows(h->glay) * h->tstride * sizeof(float), h->stream));
+  if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, (size_t)h->glay.total_rows() * h->stride * sizeof(float), h->stream));
   if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157 (call count 0)
   if (h->d_target) HIP_TRY(h, hipMemsetAsync(h->d_target, 0, (size_t)h->stride * h->n * sizeof(float), h->stream));  // target 0 after Load
   HIP_TRY(h, wait_stream(h));
@@ -734,8 +509,8 @@ void free_all(cdpr_engine* h) {
   if (h->d_geom) (void)hipFree(h->d_geom);
   if (h->d_wtab) (void)hipFree(h->d_wtab);
   if (h->d_rec) (void)hipFree(h->d_rec);
-  if (h->d_force) (void)hipFree(h->d_force);
-  if (h->d_cable) (void)hipFree(h->d_cable);
+  if (h->d_gwtab) (void)hipFree(h->d_gwtab);
+  if (h->d_roll_rec) (void)hipFree(h->d_roll_rec);
   if (h->d_mode) (void)hipFree(h->d_mode);
   if (h->d_target) (void)hipFree(h->d_target);
   for (int i = 0; i < 3; ++i)
@@ -850,7 +625,30 @@ inline void set_weight_row(const cdpr_engine* h, StepArgs& a) {
   memcpy(a.wrow, &h->wtab_host[(h->per_robot || h->mode == kModeVelocity) ? 0 : 1][slot * (kWin + 2)], sizeof a.wrow);
 }
 
-int run_steps_general(cdpr_engine* h, int nsteps) {
+// The controller half of a general-path launch: records, latched commands, gains.
+GenCtl general_ctl(const cdpr_engine* h) {
+  GenCtl g{};
+  g.rec = h->d_rec;
+  g.rstride = h->stride;
+  g.rec_bytes = (uint32_t)((size_t)h->glay.total_rows() * h->stride * sizeof(float));
+  g.vel_cmd = h->have_vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : nullptr;
+  g.pos_cmd = h->have_pos ? (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]) : nullptr;
+  g.frc_cmd = h->have_frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0]) : nullptr;
+  g.mode_arr = h->per_robot ? h->d_mode : nullptr;
+  g.wtab = h->d_gwtab;
+  g.mode = h->mode;
+  g.any_noclamp = (!h->gpid[0].clamp || !h->gpid[1].clamp) ? 1 : 0;
+  g.eps = (float)h->cfg.velocity_epsilon;
+  g.dt = (float)h->cfg.dt;
+  g.lay = h->glay;
+  g.pid[0] = h->gpid[0];
+  g.pid[1] = h->gpid[1];
+  return g;
+}
+
+// General controller path: ONE launch per `per_launch` world steps (cdpr_general_step.hpp); with `record`, the observable
+// image of step j of the call goes to record + j * n_obs * stride.
+int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record) {
   if (h->step + (uint64_t)nsteps >= (1ull << 31)) {  // world-step stamps are int32 in the controller records
     h->err = "general controller path: world-step counter would pass 2^31";
     return CDPR_ERR_UNSUPPORTED;
@@ -859,70 +657,55 @@ int run_steps_general(cdpr_engine* h, int nsteps) {
   a.state = h->d_state;
   a.obs = h->d_obs;
   a.cmd = nullptr;
-  a.force = h->d_force;
   a.dbg = h->dbg ? h->d_dbg : nullptr;
   a.geom = h->d_geom;
   a.batch = h->batch;
   a.stride = h->stride;
-  a.nsteps = 1;
   a.pid_calls = 0;
-  copy_pid(h->pid_pos, a);  // unused by the EXT kernel
-  GenArgs g{};
-  g.state = h->d_state;
-  g.stride = h->stride;
-  g.batch = h->batch;
-  g.n = h->n;
-  g.cable = h->d_cable;
-  g.vel_cmd = h->have_vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : nullptr;
-  g.pos_cmd = h->have_pos ? (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]) : nullptr;
-  g.frc_cmd = h->have_frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0]) : nullptr;
-  g.mode_arr = h->per_robot ? h->d_mode : nullptr;
-  g.rec = h->d_rec;
-  g.tstride = h->tstride;
-  g.force = h->d_force;
-  g.dbg = a.dbg;
-  g.mode = h->mode;
-  g.eps = (float)h->cfg.velocity_epsilon;
-  g.dt = (float)h->cfg.dt;
-  g.lay = h->glay;
-  g.pid[0] = h->gpid[0];
-  g.pid[1] = h->gpid[1];
-  auto ctrl = (h->glay.nb <= 11) ? cdpr_general_ctrl_kernel<11> : cdpr_general_ctrl_kernel<kGenMaxBuf>;
-  StepKernel plat = h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysExt) : pick_ext_kernel(h->n, h->fk, h->td);
-  const uint32_t total = h->batch * h->n;
-  for (int k = 0; k < nsteps; ++k) {
-    const bool first_world = (h->step == 0);
-    g.first_world = first_world ? 1 : 0;
+  copy_pid(h->pid_pos, a);  // unused
+  const size_t image = (size_t)h->n_obs * h->stride;
+  a.obs_step_stride = record ? image : 0;
+  GenCtl g = general_ctl(h);
+  GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11);
+  int done = 0;
+  while (done < nsteps) {
+    const int k = std::min(per_launch, nsteps - done);
+    a.nsteps = k;
+    a.flags = (h->step == 0) ? kFlagFirstWorldStep : 0u;
     g.now_step = (int)h->step;
-    hipLaunchKernelGGL(ctrl, dim3((total + 255u) / 256u), dim3(256), 0, h->stream, g);
-    a.flags = first_world ? kFlagFirstWorldStep : 0u;
-    const double now = sim_time(h->step, h->cfg.dt);
+    if (record) a.obs = record + (size_t)done * image;
     a.publish_mask = 0;
-    if ((now - h->prev_publish) > h->cfg.publish_period) {  // PLG.cpp:236-242
-      h->prev_publish = now;
-      a.publish_mask = 1ull;
+    for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
+      const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
+      if ((now - h->prev_publish) > h->cfg.publish_period) {
+        h->prev_publish = now;
+        a.publish_mask |= (1ull << j);
+      }
     }
-    hipLaunchKernelGGL(plat, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a, g);
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
-    ++h->step;
+    h->step += (uint64_t)k;
+    done += k;
   }
+  if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
+    HIP_TRY(h, hipMemcpyAsync(h->d_obs, record + (size_t)(nsteps - 1) * image, image * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
   return CDPR_OK;
 }
 
 // The kernel a fast-path launch of k world steps uses on this handle, and its workgroup size.
 StepKernel select_step_kernel(const cdpr_engine* h, int k) {
   if (h->per_robot)
-    return (k == 1) ? (h->lowreg ? pick_pr_kernel<true, false, true>(h->n, h->fk, h->td)
-                                 : h->split ? pick_pr_split_kernel(h->n) : pick_pr_kernel<true, false>(h->n, h->fk, h->td))
-                    : pick_pr_kernel<false, false>(h->n, h->fk, h->td);
+    return (k == 1) ? (h->lowreg ? pick_pr_kernel(true, false, true, h->n, h->fk, h->td)
+                                 : h->split ? pick_pr_split_kernel(h->n) : pick_pr_kernel(true, false, false, h->n, h->fk, h->td))
+                    : pick_pr_kernel(false, false, false, h->n, h->fk, h->td);
   if (h->lane_cable) return pick_cable_kernel(h->n, h->fk, h->td);
   return h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
-         : h->lane_pair ? ((k == 1) ? pick_pair_kernel<true>(h->n, h->fk, h->td) : pick_pair_kernel<false>(h->n, h->fk, h->td))
+         : h->lane_pair ? pick_pair_kernel(k == 1, h->n, h->fk, h->td)
                         : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
                                                  : h->split ? pick_split_kernel(h->n)
-                                                 : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_kernel<true>(h->n, h->fk, h->td)))
-                                    : pick_kernel<false>(h->n, h->fk, h->td));
+                                                 : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_step_kernel(true, h->n, h->fk, h->td)))
+                                    : pick_step_kernel(false, h->n, h->fk, h->td));
 }
 uint32_t step_block_threads(const cdpr_engine* h, int k) {
   // the role-split kernel runs two waves (estimator, controller) per 64 robots
@@ -975,21 +758,6 @@ int warm_first_launch(cdpr_engine* h) {
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
-}
-
-using F64Kernel = void (*)(const F64Args);
-F64Kernel pick_f64_kernel(uint32_t n) {
-  switch (n) {
-    case 1: return cdpr_step_kernel_f64<1>;
-    case 2: return cdpr_step_kernel_f64<2>;
-    case 3: return cdpr_step_kernel_f64<3>;
-    case 4: return cdpr_step_kernel_f64<4>;
-    case 5: return cdpr_step_kernel_f64<5>;
-    case 6: return cdpr_step_kernel_f64<6>;
-    case 7: return cdpr_step_kernel_f64<7>;
-    case 8: return cdpr_step_kernel_f64<8>;
-  }
-  return nullptr;
 }
 
 void fill_pid64(const cdpr_pid_params_t& p, double dt, F64Args& k) {
@@ -1152,7 +920,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   };
   bool reset_pid = false;
   auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path)
-    return hipMemsetAsync(h->d_rec + h->tstride * (1 + (size_t)which * h->glay.rows()), 0, (size_t)h->glay.rows() * h->tstride * sizeof(float), h->stream);
+    return hipMemsetAsync(h->d_rec + (size_t)h->glay.block(which, 0) * h->stride, 0, (size_t)h->glay.pid_rows() * h->stride * sizeof(float), h->stream);
   };
   if (h->per_robot) {
     // every robot has its own mode: commands (masked or not) are latched on the device, robot by robot
@@ -1173,20 +941,19 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         HIP_TRY(h, hipGetLastError());
         return CDPR_OK;
       }
-      LatchArgs la{};
+      GenLatchArgs la{};
       la.mask = mask;
       la.mode = h->d_mode;
       la.pending = pending;
       la.latched = latched;
-      la.pid_block = which < 0 ? nullptr : h->d_rec + h->tstride * (1 + (size_t)which * h->glay.rows());
-      la.rows = h->glay.rows();
-      la.tstride = h->tstride;
+      la.rec = h->d_rec;
+      la.rstride = h->stride;
       la.batch = h->batch;
       la.n = h->n;
+      la.first_row = which < 0 ? 0 : h->glay.block(which, 0);
+      la.rows = which < 0 ? 0 : h->glay.pid_rows();  // setForce resets no Pid
       la.new_mode = new_mode;
-      const uint32_t total = h->batch * h->n;
-      hipLaunchKernelGGL(cdpr_latch_masked_kernel, dim3((total + 255u) / 256u), dim3(256), 0, h->stream, la);
-      hipLaunchKernelGGL(cdpr_set_mode_masked_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, mask, h->d_mode, h->batch, new_mode);
+      hipLaunchKernelGGL(cdpr_gen_latch_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, la);
       HIP_TRY(h, hipGetLastError());
       return CDPR_OK;
     };
@@ -1210,7 +977,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     }
     if (int rc = mark_free()) return rc;
     touched[0] = touched[1] = touched[2] = false;  // recorded; nothing below latches on a per-robot handle
-    if (h->general) return run_steps_general(h, nsteps);
+    if (h->general) return run_steps_general(h, nsteps, per_launch, record);
   }
   if (h->vel_pending) {
     if (h->ext_vel[1]) {  // bound caller buffer: latched by pointer, nothing copied
@@ -1256,7 +1023,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     h->mode = kModeForce;
   }
   if (int rc = mark_free()) return rc;
-  if (h->general) return run_steps_general(h, nsteps);
+  if (h->general) return run_steps_general(h, nsteps, per_launch, record);
   if (h->fp64) {
     if (record) {
       h->err = "trajectory records are fp32-only";
@@ -1673,25 +1440,33 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     if ((e = hipMemcpy(h->d_geom, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(geom)", e);
   }
   if (h->general) {
-    const size_t total = (size_t)h->batch * h->n;
-    h->tstride = (total + 63) & ~(size_t)63;
+    h->glay.n = (int)h->n;
     h->glay.nb = (int)std::max(cfg->velocity_pid.d_buffer_length, cfg->position_pid.d_buffer_length);
     h->glay.ncas = (int)std::max(std::max(cfg->velocity_pid.p_filter.cascade, cfg->velocity_pid.d_filter.cascade),
                                  std::max(cfg->position_pid.p_filter.cascade, cfg->position_pid.d_filter.cascade));
-    if ((e = hipMalloc(&h->d_rec, gen_record_rows(h->glay) * h->tstride * sizeof(float))) != hipSuccess) return fail("hipMalloc(rec)", e);
-    if ((e = hipMalloc(&h->d_force, total * sizeof(float))) != hipSuccess) return fail("hipMalloc(force)", e);
-    std::vector<float> cg((size_t)7 * h->n);
-    for (uint32_t i = 0; i < h->n; ++i) {
-      for (int k = 0; k < 3; ++k) {
-        cg[(size_t)k * h->n + i] = (float)cfg->frame_anchor[i][k];
-        cg[(size_t)(3 + k) * h->n + i] = (float)cfg->platform_anchor[i][k];
-      }
-      cg[(size_t)6 * h->n + i] = (float)cfg->cable_ref_length[i];
+    const size_t rec_bytes = (size_t)h->glay.total_rows() * h->stride * sizeof(float);
+    if (rec_bytes >= (1ull << 32)) {  // the record buffer is addressed with 32-bit offsets (one buffer resource)
+      g_create_error = "general controller path: the controller records of this batch pass 4 GiB; split the batch over several handles";
+      free_all(h);
+      return CDPR_ERR_UNSUPPORTED;
     }
-    if ((e = hipMalloc(&h->d_cable, cg.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(cable)", e);
-    if ((e = hipMemcpy(h->d_cable, cg.data(), cg.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(cable)", e);
+    if ((e = hipMalloc(&h->d_rec, rec_bytes)) != hipSuccess) return fail("hipMalloc(rec)", e);
     fill_gen_pid(cfg->position_pid, h->gpid[0]);
     fill_gen_pid(cfg->velocity_pid, h->gpid[1]);
+    // FIR weights by ring head: when the newest sample sits in slot `head`, slot j holds the sample of age (head - j) mod
+    // nbuf, whose end-point LS weight (oldest first) is w[nbuf - 1 - age]; slots >= nbuf weigh nothing
+    const int nbmax = h->glay.nb > 11 ? kGenMaxBuf : 11, nbp = gen_nbp(nbmax);
+    std::vector<float> wt((size_t)2 * nbmax * nbp, 0.f);
+    const cdpr_pid_params_t* pp[2] = {&cfg->position_pid, &cfg->velocity_pid};
+    for (int p = 0; p < 2; ++p) {
+      double w[CDPR_MAX_D_BUFFER];
+      const int nb = (int)pp[p]->d_buffer_length;
+      if (derivative_weights((uint32_t)nb, pp[p]->d_degree, w) != CDPR_OK) continue;
+      for (int head = 0; head < nb; ++head)
+        for (int j = 0; j < nb; ++j) wt[((size_t)p * nbmax + head) * nbp + j] = (float)w[nb - 1 - (((head - j) % nb + nb) % nb)];
+    }
+    if ((e = hipMalloc(&h->d_gwtab, wt.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(gwtab)", e);
+    if ((e = hipMemcpy(h->d_gwtab, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(gwtab)", e);
   }
   if (h->per_robot) {
     if (!h->general && (e = hipMalloc(&h->d_target, cmd_bytes)) != hipSuccess) return fail("hipMalloc(target)", e);
@@ -1950,8 +1725,8 @@ int cdpr_observable_image_bytes(cdpr_handle_t h, size_t* bytes) {
 
 int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void* d_record, size_t record_bytes) {
   if (!h) return CDPR_ERR_INVALID;
-  if (h->general || h->fp64) {
-    h->err = "cdpr_update_record: not available on the general controller path or with precision = 64";
+  if (h->fp64) {
+    h->err = "cdpr_update_record: not available with precision = 64";
     return CDPR_ERR_UNSUPPORTED;
   }
   if (h->cfg.publish_period != 0.0) {
@@ -2269,6 +2044,55 @@ int cdpr_get_limit_state(cdpr_handle_t h, uint32_t* cable_mask) {
 // Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in
 // DEVICE buffers.  Nothing is allocated, copied or synchronised here.
 static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float* d_commands, const float* d_ref, float* d_cost) {
+  if (h->general) {
+    // every trajectory steps a private copy of its robot's controller records (both Pids of every cable: the hold branch
+    // switches between them from step to step): one column per trajectory in a persistent, grow-only scratch
+    const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
+    const size_t cols = (size_t)((traj + 63u) & ~(uint64_t)63u);
+    const size_t bytes = (size_t)h->glay.total_rows() * cols * sizeof(float);
+    if (bytes >= (1ull << 32)) {
+      h->err = "rollout on the general controller path: the trajectories' controller records pass 4 GiB; use fewer samples per call";
+      return CDPR_ERR_UNSUPPORTED;
+    }
+    if (h->roll_rec_cols < cols) {
+      HIP_TRY(h, wait_stream(h));
+      if (h->d_roll_rec) (void)hipFree(h->d_roll_rec);
+      h->d_roll_rec = nullptr;
+      h->roll_rec_cols = 0;
+      HIP_TRY(h, hipMalloc(&h->d_roll_rec, bytes));
+      h->roll_rec_cols = cols;
+    }
+    if (h->step + (uint64_t)horizon >= (1ull << 31)) {
+      h->err = "general controller path: world-step counter would pass 2^31";
+      return CDPR_ERR_UNSUPPORTED;
+    }
+    StepArgs a = h->base;
+    a.state = h->d_state;
+    a.obs = h->d_obs;
+    a.geom = h->d_geom;
+    a.batch = h->batch;
+    a.stride = h->stride;
+    a.nsteps = horizon;
+    a.publish_mask = 0;
+    copy_pid(h->pid_vel, a);  // unused
+    a.flags = (h->step == 0) ? kFlagFirstWorldStep : 0u;
+    a.roll_cmd = d_commands;
+    a.roll_ref = d_ref;
+    a.roll_cost = d_cost;
+    a.roll_samples = (uint32_t)samples;
+    GenCtl g = general_ctl(h);
+    g.src_rec = h->d_rec;
+    g.src_rstride = h->stride;
+    g.rec = h->d_roll_rec;
+    g.rstride = (uint32_t)h->roll_rec_cols;
+    g.rec_bytes = (uint32_t)((size_t)h->glay.total_rows() * h->roll_rec_cols * sizeof(float));
+    g.now_step = (int)h->step;
+    GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, true, h->glay.nb > 11);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a, g);
+    HIP_TRY(h, hipGetLastError());
+    ++h->launches;
+    return CDPR_OK;
+  }
   StepArgs a = h->base;
   a.state = h->d_state;
   a.obs = h->d_obs;
@@ -2296,7 +2120,7 @@ static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float
   a.roll_cost = d_cost;
   a.roll_samples = (uint32_t)samples;
   const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  StepKernel kern = h->per_robot ? pick_pr_kernel<false, true>(h->n, h->fk, h->td)
+  StepKernel kern = h->per_robot ? pick_pr_kernel(false, true, false, h->n, h->fk, h->td)
                     : h->phys  ? pick_phys_kernel(h->n, h->fk, h->td, kPhysRollout) : pick_rollout_kernel(h->n, h->fk, h->td);
   hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
@@ -2309,8 +2133,8 @@ static int rollout_check(cdpr_engine* h, int samples, int horizon, const void* d
     h->err = "rollout: samples, horizon >= 1 and the command buffer are required";
     return CDPR_ERR_INVALID;
   }
-  if (h->general || h->fp64) {
-    h->err = "rollout: not available on the general controller path or with precision = 64";
+  if (h->fp64) {
+    h->err = "rollout: not available with precision = 64";
     return CDPR_ERR_UNSUPPORTED;
   }
   if ((uint64_t)h->batch * (uint64_t)samples > (1ull << 30)) {

@@ -464,7 +464,7 @@ struct Unpack64Args {
   uint32_t stride, batch, width, first_row;
   int as_float;
 };
-__global__ __launch_bounds__(256) void cdpr_unpack64_kernel(const Unpack64Args a) {
+static __global__ __launch_bounds__(256) void cdpr_unpack64_kernel(const Unpack64Args a) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   if (t >= a.batch * a.width) return;
   const uint32_t r = t / a.width, j = t - r * a.width;

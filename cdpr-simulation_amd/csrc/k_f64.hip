@@ -1,0 +1,8 @@
+// precision = 64: the step in the reference's own precision (cdpr_step_kernel_f64.hpp)
+#include "cdpr_kernels.hpp"
+namespace cdpr {
+namespace {
+template <int N> F64Kernel f64_n() { return cdpr_step_kernel_f64<N>; }
+}  // namespace
+F64Kernel pick_f64_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_n); }
+}  // namespace cdpr

@@ -1,0 +1,26 @@
+// second-generation one-step kernel (controller rows staged through LDS) and the role-split kernel, uniform and PR
+#include "cdpr_kernels.hpp"
+#include "cdpr_onestep_kernel.hpp"
+namespace cdpr {
+namespace {
+#define K_ONE(N, FK, TD) cdpr_onestep_kernel<N, FK, TD>
+template <int N> StepKernel one_n(bool fk, bool td) { CDPR_PICK_STAGES(N, K_ONE); }
+}  // namespace
+StepKernel pick_onestep_kernel(uint32_t n, bool fk, bool td) { CDPR_PICK_CABLES(one_n, fk, td); }
+StepKernel pick_split_kernel(uint32_t n) {
+  switch (n) {
+    case 6: return cdpr_split_kernel<6>;
+    case 7: return cdpr_split_kernel<7>;
+    case 8: return cdpr_split_kernel<8>;
+  }
+  return nullptr;
+}
+StepKernel pick_pr_split_kernel(uint32_t n) {
+  switch (n) {
+    case 6: return cdpr_split_kernel<6, true>;
+    case 7: return cdpr_split_kernel<7, true>;
+    case 8: return cdpr_split_kernel<8, true>;
+  }
+  return nullptr;
+}
+}  // namespace cdpr

@@ -1,0 +1,191 @@
+"""The general controller path (position-hold branch JFC.cpp:78-82, biquad cascades Pid.cpp:27-44, long windows, cmdLimit 0)
+as ONE plugin whose options compose: since round 4 it is one launch per step on a lane-per-robot kernel
+(cdpr_general_step.hpp) with the forms the fast path has — several steps per launch, the trajectory record, the MPC
+rollout, per-robot modes, the optional physics — each against the fp64 oracle.  Tolerances: tests/test_gpu_parity.py."""
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import TOL, compare, pair, perturbed_poses
+
+pytestmark = pytest.mark.gpu
+
+
+def hold_commands(rng, B, n, eps, share=0.35):
+    """Velocity Joys with a good share of the cables at or below epsilon (hold branch) and the rest clearly above."""
+    cmd = rng.uniform(-0.04, 0.04, (B, n)).astype(np.float32)
+    cmd[np.abs(cmd) <= 2 * eps] = np.float32(3 * eps)
+    low = rng.random((B, n)) < share
+    cmd[low] = (rng.uniform(-1.0, 1.0, int(low.sum())) * eps).astype(np.float32)
+    return cmd
+
+
+def cascade_config(pkg, model, B, stages, cascade=1, eps=-0.001):
+    """A gentle (stable) loop through low-pass biquads on the P and D inputs of both Pids."""
+    cfg = pkg.Config(model=model, batch=B, stages=stages, velocityEpsilon=eps)
+    for f in (cfg.velocityController.pFilter, cfg.velocityController.dFilter, cfg.positionController.pFilter, cfg.positionController.dFilter):
+        f.cascade, f.relCutoff, f.quality = cascade, 0.05, 0.5
+    cfg.velocityController.pGain, cfg.velocityController.iGain, cfg.velocityController.dGain = 4.0, 40.0, 0.01
+    cfg.positionController.pGain, cfg.positionController.iGain, cfg.positionController.dGain = 60.0, 20.0, 2.0
+    return cfg
+
+
+@pytest.mark.parametrize("cables,stages", [(8, 3), (4, 0), (7, 1), (6, 2)])
+def test_hold_branch_one_step_fused_and_recorded(pkg, oracle, cables, stages):
+    """velocityEpsilon > 0 with cables drifting in and out of the hold branch (both Pids of a cable sampled at non-uniform
+    times: the derivative is the uniform FIR where the window's samples are consecutive and a fit on the real stamps for
+    the ten steps after every switch): one step per launch, several steps per launch and the trajectory record give the
+    same bits, and every published step matches the oracle."""
+    B, eps = 150, 0.004
+    rng = np.random.default_rng(100 + cables)
+    full = pkg.eight_cable_model()
+    model = pkg.cube_model() if cables == 4 else replace(full, frame_anchors=full.frame_anchors[:cables], platform_anchors=full.platform_anchors[:cables])
+    cfg = pkg.Config(model=model, batch=B, stages=stages, velocityEpsilon=eps)
+    pose = perturbed_poses(model, B, rng, 0.02, 0.05)
+    one, ora = pair(pkg, oracle, cfg, pose)
+    fused, _ = pair(pkg, oracle, cfg, pose)
+    rec, _ = pair(pkg, oracle, cfg, pose)
+    for e in (one, fused, rec, ora):
+        e.update(14)
+    for j in range(9):
+        cmd = hold_commands(rng, B, cables, eps)
+        k = [3, 11, 17, 6, 25, 9, 12, 31, 10][j]
+        for e in (one, fused, rec, ora):
+            e.set_velocity_command(cmd)
+        ora_steps = []
+        for _ in range(k):  # one launch per step, the oracle beside it: every published step is compared
+            one.update(1), ora.update(1)
+            ora_steps.append((ora.platform_state(), ora.joint_states()))
+            compare(one, ora, where=f"n={cables} hold, round {j}")
+        fused.update(k, 7)
+        r = rec.update_record(k, 5)
+        for x, y in zip(one.platform_state() + one.joint_states(), fused.platform_state() + fused.joint_states()):
+            assert np.array_equal(x, y), f"fused launches differ from one-step launches in round {j}"
+        for x, y in zip(one.platform_state() + one.joint_states(), rec.platform_state() + rec.joint_states()):
+            assert np.array_equal(x, y)
+        for i, ((op, ot), (oq, oqd, oe)) in enumerate(ora_steps):
+            assert np.abs(r["pose"][i] - op).max() <= TOL["pose"] and np.abs(r["effort"][i] - oe).max() <= TOL["eff"], (j, i)
+            assert np.abs(r["velocity"][i] - oqd).max() <= TOL["qd"]
+    p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+    for e in (one, fused, ora):
+        e.set_position_command(p)
+    one.update(33), fused.update(33, 11), ora.update(33)
+    compare(one, ora, where="position mode after the hold rounds")
+    compare(fused, ora, where="position mode after the hold rounds (fused)")
+
+
+@pytest.mark.parametrize("kind", ["hold", "cascade", "long_window", "no_clamp"])
+def test_record_and_rollout_on_general_handles(pkg, oracle, kind):
+    """cdpr_update_record and cdpr_rollout_velocity on handles the fast path cannot serve: hold branch live (the sampled
+    sequences cross epsilon inside the horizon, so trajectories switch Pids on their own private records), biquad
+    cascades, a 21-sample degree-3 window, cmdLimit 0; rollouts entered from Position mode (velocity Pid reset,
+    JFC.cpp:113-115) and from Velocity mode; the handle's own state is untouched."""
+    B, S, H, n = 40, 6, 24, 8
+    rng = np.random.default_rng({"hold": 1, "cascade": 2, "long_window": 3, "no_clamp": 4}[kind])
+    model = pkg.eight_cable_model()
+    eps = 0.004 if kind == "hold" else -0.001
+    if kind == "cascade":
+        cfg = cascade_config(pkg, model, B, 3)
+    else:
+        cfg = pkg.Config(model=model, batch=B, stages=3, velocityEpsilon=eps)
+    if kind == "long_window":
+        for p in (cfg.velocityController, cfg.positionController):
+            p.dBufferLength, p.dDegree = 21, 3
+    if kind == "no_clamp":
+        cfg.velocityController.cmdLimit = 0.0
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05))
+    eng.update(25), ora.update(25)
+    tol = dict(TOL, eff=5e-2) if kind == "long_window" else TOL
+
+    def rollout(label):
+        nominal = rng.uniform(-0.03, 0.03, (B, H, 1, n))
+        cmds = (nominal + rng.normal(0.0, 0.01, (B, H, S, n))).astype(np.float32)
+        if kind == "hold":
+            low = rng.random((B, H, S, n)) < 0.3
+            cmds[low] = (rng.uniform(-1, 1, int(low.sum())) * eps).astype(np.float32)
+        ref = eng.raw_state()[0][:, :3].astype(np.float64) + [0.0, 0.0, 0.005]
+        before = eng.raw_state()
+        gc, oc = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref)
+        assert np.isfinite(gc).all() and np.abs(gc - oc).max() <= 1e-9 + 2e-4 * np.abs(oc).max(), f"{kind}: rollout {label}"
+        for x, y in zip(before, eng.raw_state()):
+            assert np.array_equal(x, y)
+
+    rollout("from Position mode")
+    v = hold_commands(rng, B, n, eps) if kind == "hold" else rng.uniform(0.005, 0.03, (B, n)).astype(np.float32)
+    eng.set_velocity_command(v), ora.set_velocity_command(v)
+    r = eng.update_record(23, 4)
+    ora_eff = []
+    for _ in range(23):
+        ora.update(1)
+        ora_eff.append(ora.joint_states()[2])
+    assert np.abs(r["effort"] - np.array(ora_eff)).max() <= tol["eff"]
+    compare(eng, ora, tol=tol, where=f"{kind}: after the record")
+    rollout("from Velocity mode")  # the handle's velocity Pids carry on inside the trajectories
+    eng.update(10), ora.update(10)
+    compare(eng, ora, tol=tol, where=f"{kind}: the handle after its rollouts")
+
+
+@pytest.mark.parametrize("physics", ["lumped", "stop"])
+def test_per_robot_modes_with_the_optional_physics_and_the_hold_branch(pkg, oracle, physics):
+    """per_robot_commands + lumped legs / joint stop + velocityEpsilon > 0 on one handle: masked Joys (velocity, position,
+    force) reach changing subsets of the robots, fused launches in between, a rollout at the end; against the oracle."""
+    B, n, eps = 130, 8, 0.004
+    rng = np.random.default_rng(50)
+    base = pkg.eight_cable_model()
+    if physics == "lumped":
+        model = replace(base, inertia=(0.9, 1.1, 1.0, 0.05, -0.03, 0.02), passive_damping=0.01, leg_inertia=0.004, cable_axial_mass=0.001,
+                        anchor_point_mass=0.002, anchor_inertia=0.001)
+    else:
+        model = replace(base, travel_lower=-0.012, travel_upper=0.012, travel_stop=4)
+    cfg = pkg.Config(model=model, batch=B, stages=3, velocityEpsilon=eps, perRobotCommands=True)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05))
+    eng.update(10), ora.update(10)
+    tol = TOL if physics == "lumped" else dict(TOL, eff=5e-2)
+    for rnd in range(6):
+        g = (np.arange(B) + rnd) % 4
+        v, p = hold_commands(rng, B, n, eps), rng.uniform(-0.004, 0.004, (B, n)).astype(np.float32)
+        f = (7.0 + rng.uniform(-0.5, 0.5, (B, n))).astype(np.float32)
+        for sim in (eng, ora):
+            sim.set_velocity_command(v, mask=g <= 1)
+            if rnd % 2:
+                sim.set_position_command(p, mask=g == 2)
+            if rnd >= 2:
+                sim.set_force_command(f, mask=g == 3)
+        k = [9, 14, 20, 6, 12, 17][rnd]
+        if rnd % 3 == 1:
+            eng.update(k, 6)
+        else:
+            eng.update(k)
+        ora.update(k)
+        if physics == "lumped":  # (a joint stop is a threshold: fp32 and fp64 may see a joint arrive a step apart)
+            compare(eng, ora, tol=tol, where=f"round {rnd}")
+    if physics == "stop":
+        gp, op = eng.platform_state()[0], ora.platform_state()[0]
+        assert np.isfinite(gp).all() and np.abs(gp - op).max() < 5e-4
+    else:
+        cmds = rng.uniform(-0.03, 0.03, (B, 12, 3, n)).astype(np.float32)
+        ref = eng.raw_state()[0][:, :3].astype(np.float64)
+        gc, oc = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref)
+        assert np.abs(gc - oc).max() <= 1e-9 + 2e-4 * np.abs(oc).max()
+
+
+def test_a_pid_that_sleeps_for_a_long_time_keeps_its_exact_stamps(pkg, oracle):
+    """The position Pid of a held cable keeps samples that may be arbitrarily old; the fit works on the real stamps (integer
+    world steps, differences taken before any rounding): a cable that holds for 12 steps, runs on its velocity Pid for
+    700 and holds again fits a window with one 700-step gap in it, as the reference would."""
+    B, n, eps = 20, 8, 0.004
+    rng = np.random.default_rng(8)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, velocityEpsilon=eps)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng, 0.02, 0.05))
+    fast = rng.uniform(0.01, 0.03, (B, n)).astype(np.float32)
+    slow = fast.copy()
+    slow[:, ::2] = 0.001
+    for cmd, k in ((slow, 12), (fast, 700), (slow, 5), (fast, 3), (slow, 30)):
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        if k > 100:
+            eng.update(k, 20)
+        else:
+            eng.update(k)
+        ora.update(k)
+        compare(eng, ora, where=f"after {k} steps")
