@@ -65,6 +65,7 @@ struct cdpr_engine {
   bool general = false;
   float* d_rec = nullptr;    // record rows: [mLastPosition per cable][position Pid rows][velocity Pid rows], one column per robot
   float* d_gwtab = nullptr;  // FIR weights by ring head, [pid][head][slot]
+  float* d_gptab = nullptr;  // the two Pids' parameters as the kernel stages them in LDS (gen_pid_table)
   GenPid gpid[2]{};
   GenLayout glay{};          // rows of a Pid block: sized by the configured window length and cascade count
   float* d_roll_rec = nullptr;   // MPC rollout on the general path: every trajectory's private copy of the records
@@ -493,7 +494,7 @@ int upload_home(cdpr_engine* h) {
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_frc[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   }
-  if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, (size_t)h->glay.total_rows() * h->stride * sizeof(float), h->stream));
+  if (h->d_rec) HIP_TRY(h, hipMemsetAsync(h->d_rec, 0, h->glay.bytes(h->stride), h->stream));
   if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157 (call count 0)
   if (h->d_target) HIP_TRY(h, hipMemsetAsync(h->d_target, 0, (size_t)h->stride * h->n * sizeof(float), h->stream));  // target 0 after Load
   HIP_TRY(h, wait_stream(h));
@@ -510,6 +511,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_wtab) (void)hipFree(h->d_wtab);
   if (h->d_rec) (void)hipFree(h->d_rec);
   if (h->d_gwtab) (void)hipFree(h->d_gwtab);
+  if (h->d_gptab) (void)hipFree(h->d_gptab);
   if (h->d_roll_rec) (void)hipFree(h->d_roll_rec);
   if (h->d_mode) (void)hipFree(h->d_mode);
   if (h->d_target) (void)hipFree(h->d_target);
@@ -630,19 +632,19 @@ GenCtl general_ctl(const cdpr_engine* h) {
   GenCtl g{};
   g.rec = h->d_rec;
   g.rstride = h->stride;
-  g.rec_bytes = (uint32_t)((size_t)h->glay.total_rows() * h->stride * sizeof(float));
+  g.rec_bytes = (uint32_t)h->glay.bytes(h->stride);
   g.vel_cmd = h->have_vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : nullptr;
   g.pos_cmd = h->have_pos ? (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]) : nullptr;
   g.frc_cmd = h->have_frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0]) : nullptr;
   g.mode_arr = h->per_robot ? h->d_mode : nullptr;
   g.wtab = h->d_gwtab;
   g.mode = h->mode;
-  g.any_noclamp = (!h->gpid[0].clamp || !h->gpid[1].clamp) ? 1 : 0;
   g.eps = (float)h->cfg.velocity_epsilon;
   g.dt = (float)h->cfg.dt;
   g.lay = h->glay;
-  g.pid[0] = h->gpid[0];
-  g.pid[1] = h->gpid[1];
+  g.ptab = h->d_gptab;
+  g.pcas_max = std::max(h->gpid[0].pcas, h->gpid[1].pcas);
+  g.dcas_max = std::max(h->gpid[0].dcas, h->gpid[1].dcas);
   return g;
 }
 
@@ -666,10 +668,10 @@ int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record
   const size_t image = (size_t)h->n_obs * h->stride;
   a.obs_step_stride = record ? image : 0;
   GenCtl g = general_ctl(h);
-  GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11);
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
+    GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11, k == 1);
     a.nsteps = k;
     a.flags = (h->step == 0) ? kFlagFirstWorldStep : 0u;
     g.now_step = (int)h->step;
@@ -919,8 +921,11 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     return CDPR_OK;
   };
   bool reset_pid = false;
-  auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path)
-    return hipMemsetAsync(h->d_rec + (size_t)h->glay.block(which, 0) * h->stride, 0, (size_t)h->glay.pid_rows() * h->stride * sizeof(float), h->stream);
+  auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path): its slots, its rows
+    const GenLayout& L = h->glay;
+    hipError_t e1 = hipMemsetAsync(h->d_rec + (size_t)L.block_a(which, 0) * h->stride * 4, 0, (size_t)L.pid_slots() * h->stride * 16, h->stream);
+    if (e1 != hipSuccess || L.pid_rows() == 0) return e1;
+    return hipMemsetAsync(h->d_rec + ((size_t)L.slots() * 4 + (size_t)L.block_b(which, 0)) * h->stride, 0, (size_t)L.pid_rows() * h->stride * 4, h->stream);
   };
   if (h->per_robot) {
     // every robot has its own mode: commands (masked or not) are latched on the device, robot by robot
@@ -950,8 +955,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       la.rstride = h->stride;
       la.batch = h->batch;
       la.n = h->n;
-      la.first_row = which < 0 ? 0 : h->glay.block(which, 0);
-      la.rows = which < 0 ? 0 : h->glay.pid_rows();  // setForce resets no Pid
+      la.reset_pid = which;  // (-1: setForce resets no Pid)
+      la.lay = h->glay;
       la.new_mode = new_mode;
       hipLaunchKernelGGL(cdpr_gen_latch_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, la);
       HIP_TRY(h, hipGetLastError());
@@ -1444,7 +1449,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     h->glay.nb = (int)std::max(cfg->velocity_pid.d_buffer_length, cfg->position_pid.d_buffer_length);
     h->glay.ncas = (int)std::max(std::max(cfg->velocity_pid.p_filter.cascade, cfg->velocity_pid.d_filter.cascade),
                                  std::max(cfg->position_pid.p_filter.cascade, cfg->position_pid.d_filter.cascade));
-    const size_t rec_bytes = (size_t)h->glay.total_rows() * h->stride * sizeof(float);
+    const size_t rec_bytes = h->glay.bytes(h->stride);
     if (rec_bytes >= (1ull << 32)) {  // the record buffer is addressed with 32-bit offsets (one buffer resource)
       g_create_error = "general controller path: the controller records of this batch pass 4 GiB; split the batch over several handles";
       free_all(h);
@@ -1465,6 +1470,11 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
       for (int head = 0; head < nb; ++head)
         for (int j = 0; j < nb; ++j) wt[((size_t)p * nbmax + head) * nbp + j] = (float)w[nb - 1 - (((head - j) % nb + nb) % nb)];
     }
+    float pt[2 * kGenPidFloats];
+    gen_pid_table(h->gpid[0], pt);
+    gen_pid_table(h->gpid[1], pt + kGenPidFloats);
+    if ((e = hipMalloc(&h->d_gptab, sizeof pt)) != hipSuccess) return fail("hipMalloc(gptab)", e);
+    if ((e = hipMemcpy(h->d_gptab, pt, sizeof pt, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(gptab)", e);
     if ((e = hipMalloc(&h->d_gwtab, wt.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(gwtab)", e);
     if ((e = hipMemcpy(h->d_gwtab, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(gwtab)", e);
   }
@@ -2049,7 +2059,7 @@ static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float
     // switches between them from step to step): one column per trajectory in a persistent, grow-only scratch
     const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
     const size_t cols = (size_t)((traj + 63u) & ~(uint64_t)63u);
-    const size_t bytes = (size_t)h->glay.total_rows() * cols * sizeof(float);
+    const size_t bytes = h->glay.bytes(cols);
     if (bytes >= (1ull << 32)) {
       h->err = "rollout on the general controller path: the trajectories' controller records pass 4 GiB; use fewer samples per call";
       return CDPR_ERR_UNSUPPORTED;
@@ -2085,9 +2095,9 @@ static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float
     g.src_rstride = h->stride;
     g.rec = h->d_roll_rec;
     g.rstride = (uint32_t)h->roll_rec_cols;
-    g.rec_bytes = (uint32_t)((size_t)h->glay.total_rows() * h->roll_rec_cols * sizeof(float));
+    g.rec_bytes = (uint32_t)h->glay.bytes(h->roll_rec_cols);
     g.now_step = (int)h->step;
-    GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, true, h->glay.nb > 11);
+    GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, true, h->glay.nb > 11, false);
     hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a, g);
     HIP_TRY(h, hipGetLastError());
     ++h->launches;

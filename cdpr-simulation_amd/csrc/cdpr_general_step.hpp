@@ -11,37 +11,39 @@
 // platform kernel).  Here one lane owns one robot for the whole step, as on the fast path: forces never leave the
 // registers, and the same kernel serves one step, several steps per launch, the trajectory record and the MPC rollout.
 //
-// Records (HBM, one dword ROW per field, one column per robot: a wave touches 256 contiguous bytes per row):
-//   row i (i < n)                           mLastPosition of cable i (JFC.h:45)
-//   block(pid, i) = n + (pid n + i) R       pid 0 = position Pid, 1 = velocity Pid; R = 2 nb + 4 + 8 ncas rows:
-//     + j          (j < nb)   mDbufferY ring slot j (the error samples)
-//     + nb + j                mDbufferX ring slot j as a world-step index (int32 bit pattern)
-//     + 2 nb                  mIerr
-//     + 2 nb + 1              meta: bit 0 mWasLastTime | samples in the window (6 bits) | ring head (6) | `run` (6) =
-//                             consecutive one-step gaps ending at the newest sample, saturating
-//     + 2 nb + 2              mLastTime as a world-step index
-//     + 2 nb + 3              mCmd (only read or written when some Pid has no command clamp)
-//     + 2 nb + 4 ...          P-input cascade x1 x2 y1 y2 per stage, then the D-input cascade
-//   A Pid::reset of the whole batch is one memset over the Pid's rows; all-zero rows ARE the reset state.
+// Records (HBM, one buffer, one column per robot), in two regions:
+//   A: float4 SLOT rows (16 B per robot and row: a wave moves 1 KiB per row, by LDS-DMA on the way in)
+//        slot g (g < ceil(n/4))                mLastPosition of cables 4g .. 4g+3 (JFC.h:45)
+//        blockA(pid, i) = lp + (pid n + i)(nv + 1), pid 0 = position Pid, 1 = velocity Pid, nv = ceil(nb / 4):
+//          + s (s < nv)     mDbufferY ring slots 4s .. 4s+3 (the error samples)
+//          + nv             "H": meta | mLastTime (world-step index) | mIerr | mCmd
+//                           meta: bit 0 mWasLastTime | samples in the window (6 bits) | ring head (6) | `run` (6) =
+//                           consecutive one-step gaps ending at the newest sample, saturating
+//   B: dword rows (4 B per robot and row), only touched where needed
+//        blockB(pid, i) = (pid n + i)(nb + 8 ncas): mDbufferX ring slot j as a world-step index (int32), then the P-input
+//        cascade's x1 x2 y1 y2 per stage, then the D-input cascade's
+//   A Pid::reset of the whole batch is two memsets (the Pid's slots, the Pid's rows); all-zero IS the reset state.
 //   (mDerr is not stored: Pid.cpp:154-157 reads the old value only when dt <= 0, and a Pid is updated at most once per
 //    world step with strictly increasing stamps.)
 //
-// Per step and cable only the ACTIVE Pid's rows are touched (position Pid in Position mode and in the hold branch,
-// velocity Pid otherwise): nb + 5 rows read (values, integral, meta, stamp of the last call, hold position), 5 written
-// (one value, one stamp, integral, meta, last call) = 84 B per cable at the shipped 11-sample window.  The stamps of the
-// window are only read when they are needed:
+// Per step and cable only the ACTIVE Pid is touched (position Pid in Position mode and in the hold branch, velocity Pid
+// otherwise): nv + 1 slots read (64 B at the shipped 11-sample window), the slot of the new sample and H written (32 B)
+// plus one stamp (4 B).  The stamps of the window are only READ when they are needed:
 //   * a window whose nb samples were taken at consecutive world steps (meta.run >= nb - 1) is the uniform grid of the
 //     fast path: the derivative is the closed-form FIR, weights looked up by ring head in LDS;
 //   * anything else (the nb - 1 steps after a switch between the two Pids in the hold branch) is a least-squares fit on
 //     the real stamps.  These are rare and scattered over lanes and cables, so they are COMPACTED: every lane queues its
 //     (cable, Pid) items in LDS, then the wave works the queue with one item per lane - orthogonal polynomials on the
 //     sample stamps (Forsythe recurrence, fp64): no normal equations, well conditioned for any gap pattern.
-// The record rows travel global -> LDS by LDS-DMA as soon as the commands (which select the Pid) are known, and stay in
-// flight under the IK and the Newton stage (stage order as in cdpr_onestep_kernel: IK -> early observables -> Newton ->
-// controller -> tension distribution -> world step).
+// The slots travel global -> LDS by LDS-DMA (16 B per lane and instruction; a first version with dword rows spent 6 us per
+// launch in 128 dword-wide DMA instructions per wave) as soon as the commands (which select the Pid) are known, and stay
+// in flight under the IK and the Newton stage (stage order as in cdpr_onestep_kernel: IK -> early observables -> Newton
+// -> controller -> tension distribution -> world step).
 //
 // Reference paths: Pid.cpp, JFC.cpp = JointForceCalculator.cpp, Filter.h (relative to src/cdpr_gazebo/).
 #pragma once
+#include <cstring>
+
 #include "cdpr_step_kernel.hpp"
 
 namespace cdpr {
@@ -52,17 +54,19 @@ constexpr int kGenMaxCas = 4;    // CDPR_MAX_CASCADE
 
 struct GenLayout {
   int n, nb, ncas;  // cables, longest window of the two Pids, deepest cascade
-  __host__ __device__ int rows_per_block() const { return 2 * nb + 4 + 8 * ncas; }
-  __host__ __device__ int block(int pid, int cable) const { return n + (pid * n + cable) * rows_per_block(); }
-  __host__ __device__ int pid_rows() const { return n * rows_per_block(); }      // one Pid of every cable: contiguous
-  __host__ __device__ int total_rows() const { return n + 2 * pid_rows(); }
-  __host__ __device__ int r_stamp() const { return nb; }
-  __host__ __device__ int r_ierr() const { return 2 * nb; }
-  __host__ __device__ int r_meta() const { return 2 * nb + 1; }
-  __host__ __device__ int r_last() const { return 2 * nb + 2; }
-  __host__ __device__ int r_cmd() const { return 2 * nb + 3; }
-  __host__ __device__ int r_pfilt() const { return 2 * nb + 4; }
-  __host__ __device__ int r_dfilt() const { return 2 * nb + 4 + 4 * ncas; }
+  __host__ __device__ int nv() const { return (nb + 3) / 4; }                    // value slots of one Pid of one cable
+  __host__ __device__ int lp() const { return (n + 3) / 4; }                     // hold-position slots
+  __host__ __device__ int spb() const { return nv() + 1; }                       // slots per (Pid, cable)
+  __host__ __device__ int block_a(int pid, int cable) const { return lp() + (pid * n + cable) * spb(); }
+  __host__ __device__ int pid_slots() const { return n * spb(); }                // one Pid of every cable: contiguous
+  __host__ __device__ int slots() const { return lp() + 2 * pid_slots(); }       // region A
+  __host__ __device__ int rpb() const { return nb + 8 * ncas; }                  // dword rows per (Pid, cable)
+  __host__ __device__ int block_b(int pid, int cable) const { return (pid * n + cable) * rpb(); }
+  __host__ __device__ int pid_rows() const { return n * rpb(); }
+  __host__ __device__ int rows() const { return 2 * pid_rows(); }                // region B
+  __host__ __device__ int r_pfilt() const { return nb; }
+  __host__ __device__ int r_dfilt() const { return nb + 4 * ncas; }
+  __host__ __device__ size_t bytes(size_t rstride) const { return ((size_t)slots() * 16 + (size_t)rows() * 4) * rstride; }
 };
 
 constexpr uint32_t kGmWasLast = 1u, kGmCountShift = 1u, kGmHeadShift = 7u, kGmRunShift = 13u, kGmField = 63u;
@@ -75,43 +79,82 @@ struct GenPid {
 };
 
 struct GenCtl {
-  float* rec;            // record rows: rec[row * rstride + column]
-  uint32_t rstride;      // columns per row (robots, or trajectories of a rollout, rounded up to 64)
-  uint32_t rec_bytes;    // rows x rstride x 4 (< 4 GiB: the buffer is addressed with 32-bit offsets)
+  float* rec;            // the record buffer: region A (slots), then region B (rows)
+  uint32_t rstride;      // columns (robots, or trajectories of a rollout, rounded up to 64)
+  uint32_t rec_bytes;    // GenLayout::bytes(rstride) (< 4 GiB: the buffer is addressed with 32-bit offsets)
   const float* vel_cmd;  // latched jointVelocities float[B][n], or nullptr (target 0)
   const float* pos_cmd;  // latched jointPositions, or nullptr
   const float* frc_cmd;  // latched force command (setForce), or nullptr
   const uint8_t* mode_arr;  // per-robot mode (0 Force, 1 Position, 2 Velocity), or nullptr: `mode` for every robot
-  const float* wtab;     // FIR weights by ring head: [pid][head][slot], rows of kNbp(NBMAX) floats
+  const float* wtab;     // FIR weights by ring head: [pid][head][slot], rows of gen_nbp(NBMAX) floats
   int mode;
   int now_step;          // world step of the launch's first step
-  int any_noclamp;       // some Pid has cmdMax <= cmdMin: the mCmd rows are live
   float eps, dt;
   GenLayout lay;
-  GenPid pid[2];         // [0] position Pid, [1] velocity Pid
+  const float* ptab;     // the two Pids' parameters, [pid][kGenPidFloats] (gen_pid_table): copied to LDS, read per lane by
+                         // the selected Pid - as kernel arguments the 2 x 23 scalars do not fit the scalar register file
+                         // next to the step's own constants (measured: 2 400 v_readlane / v_writelane per robot-step)
+  int pcas_max, dcas_max;  // deepest P-input / D-input cascade of the two Pids
   // ROLLOUT: every trajectory works on a private copy of its robot's records (column = trajectory index in `rec`)
   const float* src_rec;
   uint32_t src_rstride;
 };
 
-__host__ __device__ constexpr int gen_nbp(int nbmax) { return nbmax <= 11 ? 12 : 32; }  // padded weight-row length (float4 reads)
+// GenPid as the kernel reads it from LDS: six float4 per Pid
+//   [kf kp ki kd] [imax imin cmax cmin] [nbuf pcas dcas (int bit patterns) 1/ki] [pa0 pa1 pa2 pb1] [pb2 da0 da1 da2] [db1 db2 degree -]
+constexpr int kGenPidFloats = 24;
+inline void gen_pid_table(const GenPid& p, float* t) {
+  auto bits = [](int v) { float f; memcpy(&f, &v, sizeof f); return f; };
+  const float row[kGenPidFloats] = {p.kf, p.kp, p.ki, p.kd, p.imax, p.imin, p.cmax, p.cmin, bits(p.nbuf), bits(p.pcas), bits(p.dcas), p.ki != 0.f ? 1.f / p.ki : 0.f,
+                                    p.pa0, p.pa1, p.pa2, p.pb1, p.pb2, p.da0, p.da1, p.da2, p.db1, p.db2, bits(p.degree), 0.f};
+  for (int i = 0; i < kGenPidFloats; ++i) t[i] = row[i];
+}
 
-// The record buffer is addressed as ONE buffer resource (4 scalar registers): row = a 32-bit scalar offset, the lane's
-// column (and, where the row is the lane's own, its ring slot) = a 32-bit vector offset.  A cable's 16 rows then cost
-// one address register and one scalar per row; as 64-bit pointers the compiler hoists every row address of a launch
-// out of the step loop and spills them (measured: 1.4 KiB of scratch per lane).
+__host__ __device__ constexpr int gen_nbp(int nbmax) { return nbmax <= 11 ? 12 : 32; }  // padded weight-row length (float4 reads)
+__host__ __device__ constexpr int gen_nv(int nbmax) { return (nbmax + 3) / 4; }
+
+// The record buffer is addressed as ONE buffer resource (4 scalar registers): slot or row = a 32-bit scalar offset, the
+// lane's column (and, where the row is the lane's own, its ring slot) = a 32-bit vector offset.  A cable's rows then cost
+// one address register and one scalar per row; as 64-bit pointers the compiler hoists every row address of a launch out
+// of the step loop and spills them (measured: 1.4 KiB of scratch per lane).  Predicated stores need no branch: the
+// buffer's range check (vector offset >= num_records) drops the store of a lane whose offset is all ones.
 struct GenBuf {
   __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t rs4;  // bytes per row
-  CDPR_DEV float load(int row, uint32_t voff) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (uint32_t)row * rs4, 0)); }
-  CDPR_DEV int loadi(int row, uint32_t voff) const { return (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (uint32_t)row * rs4, 0); }
-  CDPR_DEV void store(int row, uint32_t voff, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, voff, (uint32_t)row * rs4, 0); }
-  CDPR_DEV void storei(int row, uint32_t voff, int v) const { __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, rsrc, voff, (uint32_t)row * rs4, 0); }
-  // global -> LDS without a register destination: lane l's dword lands at dst_row + 4 l
-  CDPR_DEV void to_lds(int row, uint32_t voff, float* dst_row) const {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst_row, 4, voff, (uint32_t)row * rs4, 0, 0);
+  uint32_t rs16;   // bytes per slot row (region A)
+  uint32_t rs4;    // bytes per dword row (region B)
+  uint32_t base_b; // byte offset of region B
+  // region A: float4 slots; voff = the lane's column * 16 (+ the selected Pid's offset)
+  CDPR_DEV float4 load4(int slot, uint32_t voff) const {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)slot * rs16, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  CDPR_DEV void store4_if(bool on, int slot, uint32_t voff, const float4& v) const {
+    const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, on ? voff : 0xFFFFFFFFu, (uint32_t)slot * rs16, 0);
+  }
+  // global -> LDS without a register destination: lane l's 16 bytes land at dst_row + 16 l
+  CDPR_DEV void slot_to_lds(int slot, uint32_t voff, float4* dst_row) const {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst_row, 16, voff, (uint32_t)slot * rs16, 0, 0);
+  }
+  // region B: dword rows; voff = the lane's column * 4 (+ the selected Pid's offset, + the lane's own ring slot)
+  CDPR_DEV float load(int row, uint32_t voff) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, base_b + (uint32_t)row * rs4, 0)); }
+  CDPR_DEV int loadi(int row, uint32_t voff) const { return (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, base_b + (uint32_t)row * rs4, 0); }
+  CDPR_DEV void store_if(bool on, int row, uint32_t voff, float v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, on ? voff : 0xFFFFFFFFu, base_b + (uint32_t)row * rs4, 0);
+  }
+  CDPR_DEV void storei_if(bool on, int row, uint32_t voff, int v) const {
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, rsrc, on ? voff : 0xFFFFFFFFu, base_b + (uint32_t)row * rs4, 0);
   }
 };
+CDPR_DEV GenBuf gen_buffer(float* rec, uint32_t rstride, uint32_t rec_bytes, const GenLayout& L) {
+  GenBuf b;
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc(rec, 0, (int)rec_bytes, 0x00020000);
+  b.rs16 = rstride * 16u;
+  b.rs4 = rstride * 4u;
+  b.base_b = (uint32_t)L.slots() * b.rs16;
+  return b;
+}
 
 // Derivative at the newest stamp of the least-squares polynomial of degree `degree` through the nb samples (t_j, y_j):
 // what Pid::derive + fitPolynomial compute (Pid.cpp:193-247), posed on orthogonal polynomials over the sample stamps
@@ -183,72 +226,302 @@ CDPR_DEV float gen_cascade(const GenBuf& B, int row0, uint32_t voff, int stages,
     const bool on = c < mine;
     const float x1 = B.load(rw, voff), x2 = B.load(rw + 1, voff), y1 = B.load(rw + 2, voff), y2 = B.load(rw + 3, voff);
     const float y0 = a0 * out + a1 * x1 + a2 * x2 - b1 * y1 - b2 * y2;
-    if (on && store) {
-      B.store(rw + 1, voff, x1);
-      B.store(rw, voff, out);
-      B.store(rw + 3, voff, y1);
-      B.store(rw + 2, voff, y0);
-    }
+    B.store_if(on && store, rw + 1, voff, x1);
+    B.store_if(on && store, rw, voff, out);
+    B.store_if(on && store, rw + 3, voff, y1);
+    B.store_if(on && store, rw + 2, voff, y0);
     out = on ? y0 : out;
   }
   return out;
 }
 
-// The Pid a lane runs for one cable this step: position or velocity Pid, field by field (v_cndmask); everything by value -
-// a reference into the kernel arguments makes the compiler keep a private copy of them in scratch memory.
+// The Pid a lane runs for one cable this step: position or velocity Pid, read from the LDS table by the lane's selection;
+// everything by value - a reference into the kernel arguments makes the compiler keep a private copy of them in scratch.
 struct GenSel {
-  float kf, kp, ki, kd, imax, imin, cmax, cmin;
+  float kf, kp, ki, kd, imax, imin, cmax, cmin, inv_ki;
   int nbuf, pcas, dcas;
   float pa0, pa1, pa2, pb1, pb2, da0, da1, da2, db1, db2;
 };
-CDPR_DEV GenSel gen_select(bool vel, const GenPid a, const GenPid b) {
+CDPR_DEV GenSel gen_select(bool vel, const float4 (*ptab)[kGenPidFloats / 4], bool filters) {
+  const float4* t = ptab[vel ? 1 : 0];
+  const float4 r0 = t[0], r1 = t[1], r2 = t[2];
   GenSel c;
-  c.kf = vel ? b.kf : a.kf, c.kp = vel ? b.kp : a.kp, c.ki = vel ? b.ki : a.ki, c.kd = vel ? b.kd : a.kd;
-  c.imax = vel ? b.imax : a.imax, c.imin = vel ? b.imin : a.imin, c.cmax = vel ? b.cmax : a.cmax, c.cmin = vel ? b.cmin : a.cmin;
-  c.nbuf = vel ? b.nbuf : a.nbuf, c.pcas = vel ? b.pcas : a.pcas, c.dcas = vel ? b.dcas : a.dcas;
-  c.pa0 = vel ? b.pa0 : a.pa0, c.pa1 = vel ? b.pa1 : a.pa1, c.pa2 = vel ? b.pa2 : a.pa2, c.pb1 = vel ? b.pb1 : a.pb1, c.pb2 = vel ? b.pb2 : a.pb2;
-  c.da0 = vel ? b.da0 : a.da0, c.da1 = vel ? b.da1 : a.da1, c.da2 = vel ? b.da2 : a.da2, c.db1 = vel ? b.db1 : a.db1, c.db2 = vel ? b.db2 : a.db2;
+  c.kf = r0.x, c.kp = r0.y, c.ki = r0.z, c.kd = r0.w;
+  c.imax = r1.x, c.imin = r1.y, c.cmax = r1.z, c.cmin = r1.w;
+  c.nbuf = __float_as_int(r2.x), c.pcas = __float_as_int(r2.y), c.dcas = __float_as_int(r2.z), c.inv_ki = r2.w;
+  c.pa0 = c.pa1 = c.pa2 = c.pb1 = c.pb2 = c.da0 = c.da1 = c.da2 = c.db1 = c.db2 = 0.f;
+  if (filters) {  // (wave-uniform: some Pid has a cascade)
+    const float4 r3 = t[3], r4 = t[4], r5 = t[5];
+    c.pa0 = r3.x, c.pa1 = r3.y, c.pa2 = r3.z, c.pb1 = r3.w;
+    c.pb2 = r4.x, c.da0 = r4.y, c.da1 = r4.z, c.da2 = r4.w;
+    c.db1 = r5.x, c.db2 = r5.y;
+  }
   return c;
 }
 
-// Pid.cpp:154-186 from the derivative on: D term (through the D-input cascade), command, clamp, anti-windup; returns mCmd.
-// `on`: this lane really finishes this cable's Pid::update now (the stores follow it).  row0 = first row of the cable's
-// position-Pid block, bo = the lane's byte offset (selects the Pid and the column).
-CDPR_DEV float gen_finish(const GenBuf& RB, const GenSel c, int row_ierr, int row_cmd, int row_dfilt, int dcas_max, bool noclamp, bool on, uint32_t bo,
-                          float derived, float err, float dt, float pre, float ie, float prev, float old, float& d_term) {
+// Pid.cpp:154-186 from the derivative on: D term (through the D-input cascade), command, clamp, anti-windup, and the H slot
+// (meta | mLastTime | mIerr | mCmd) back to the records; returns mCmd.  `on`: this lane really finishes this cable's
+// Pid::update now (the stores follow it).
+CDPR_DEV float gen_finish(const GenBuf& RB, const GenSel c, int slot_h, int row_dfilt, int dcas_max, bool on, bool filt_on, uint32_t voff_a, uint32_t voff_b, float derived,
+                          float err, float dt, float pre, float ie, float prev, float old, uint32_t nmeta, int now, float& d_term) {
   float derr = derived;
-  if (dcas_max) derr = gen_cascade(RB, row_dfilt, bo, dcas_max, c.dcas, on, c.da0, c.da1, c.da2, c.db1, c.db2, derr);
+  if (dcas_max) derr = gen_cascade(RB, row_dfilt, voff_b, dcas_max, filt_on ? c.dcas : 0, filt_on, c.da0, c.da1, c.da2, c.db1, c.db2, derr);
   d_term = c.kd * derr;
   const float cmd = pre + d_term;
   float out = (c.cmax > c.cmin) ? fmaxf(fminf(cmd, c.cmax), c.cmin) : old;  // Pid.cpp:175-177: without a clamp mCmd keeps its value
   const bool wind = out != cmd;                                              // Pid.cpp:181-184
   ie = wind ? prev : ie;
   out = wind ? fmaf(dt * err, c.ki, out) : out;
-  if (on) {
-    RB.store(row_ierr, bo, ie);
-    if (noclamp) RB.store(row_cmd, bo, out);
-  }
+  RB.store4_if(on, slot_h, voff_a, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
   return out;
 }
 
-// NBMAX bounds the window at compile time: 11 (the shipped length and everything below it: record rows staged through
-// LDS) or 32 (the maximum; rows read straight from HBM).
-template <int N, bool FK, bool TD, bool ROLLOUT, int NBMAX>
+// The controller of one wave's 64 robots for one world step (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191): per-cable
+// force into force[], the `pid` topic's terms of cable 0 into dbg.  Shared by the one-wave stepping kernel and the
+// controller wave of the role-split kernel.  LDS working set: `cab` = per cable NV + 1 DMA-staged slots of 64 float4 (the
+// values, then H); seen as rows of 64 floats, a cable's rows 0-6 double as the parking place of a cable that waits for the
+// fit and rows 7-9 as the fit queue (item, new sample, result) once the values are done with; `hold` = the staged
+// hold-position slots.
+// Only q, qd and the force live across the cables: a cable whose derivative is known at once (uniform window: the FIR;
+// window not full: 0) runs its whole Pid::update in the first loop; one that needs the fit parks seven numbers and
+// finishes after the pass.  Written WITHOUT divergent control flow around anything heavy (per-lane cases are selects and
+// predicated stores): the register allocator splits long live ranges around high-pressure regions, and a split made under
+// a partial exec mask does not carry the lanes that were masked off (seen: NaN in values that only crossed the fit pass).
+struct GenCtlConst {
+  int pcas_max, dcas_max;
+  float dt, inv_dt;
+};
+struct GenDbg {
+  float p, i, d, des;
+  bool pi, dw;
+};
+template <int N, int NBMAX>
+CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, uint32_t first_unit,
+                             uint32_t units, int mode, int now, const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)],
+                             const v2f (&qd)[cable_pairs(N)], float4* cab, const float4* hold_slots, const float* wrot,
+                             const float4 (*ptab)[kGenPidFloats / 4], uint32_t* q_count, float (&force)[N], GenDbg& dbg) {
+  constexpr int NV = gen_nv(NBMAX);
+  constexpr int NBP = gen_nbp(NBMAX);
+  constexpr int kCab = (NV + 1) * 64;    // float4 elements between the slot sets of consecutive cables
+  constexpr int kCabF = kCab * 4;        // the same in floats
+  constexpr int LP = (N + 3) / 4;
+  static_assert((NV + 1) * 4 >= 10, "parking and queue rows");
+  float* const cabf = reinterpret_cast<float*>(cab);
+  const int pcas_max = kc.pcas_max, dcas_max = kc.dcas_max;
+  const bool filters = (pcas_max | dcas_max) != 0;
+  const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16, pid_b = (uint32_t)L.pid_rows() * RB.rs4;
+  auto qitem = [&](uint32_t idx) -> uint32_t* { return reinterpret_cast<uint32_t*>(cabf + (idx >> 6) * kCabF + 7 * 64 + (idx & 63u)); };
+  auto qerr = [&](uint32_t idx) -> float* { return cabf + (idx >> 6) * kCabF + 8 * 64 + (idx & 63u); };
+  float4 held4[LP];
+#pragma unroll
+  for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
+  float newpos[N];
+  uint32_t need = 0u;  // cables whose derivative comes from the fit queue
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_barrier(0);  // one cable at a time: hoisting every cable's staged slots costs 128 registers (letting the
+                                        // scheduler interleave 2 or 4 cables changes nothing: 15.5 / 23.7 us at 16 384 / 65 536 x 8 either way)
+    const float qi = (i & 1) ? q[i / 2].y : q[i / 2].x;
+    const float qdi = (i & 1) ? qd[i / 2].y : qd[i / 2].x;
+    const bool is_force = (mode == 0);  // JFC.cpp:67-70
+    const bool sv = sel[i] != 0;
+    const bool hold = (mode == 2) && !sv;
+    const uint32_t va = col * 16u + (sv ? pid_a : 0u), vb = col * 4u + (sv ? pid_b : 0u);  // the lane's offsets into the selected Pid
+    const int sa = L.block_a(0, i), rb = L.block_b(0, i);
+    float4* const cs = cab + i * kCab + lane;  // this cable's staged slots of this lane, 64 float4 apart
+    float* const park = cabf + i * kCabF + lane;  // its float rows, 64 floats apart
+    const float held = comp4(held4[i / 4], i % 4);
+    const float desired = hold ? held : target[i];  // JFC.cpp:81: mLastPosition in the hold branch
+    newpos[i] = hold ? held : qi;                    // JFC.cpp:68,75,87: mLastPosition = joint position
+    const float actual = (mode == 2 && sv) ? qdi : qi;
+    const GenSel c = gen_select(sv, ptab, filters);
+    const int nbuf = c.nbuf;
+    const float4 h = cs[NV * 64];
+    const uint32_t meta = __float_as_uint(h.x);
+    const int last = __float_as_int(h.y);
+    const float prev_ierr = h.z, old_cmd = h.w;
+    const bool first = !is_force && !(meta & kGmWasLast);  // Pid.cpp:123-126: the first call since reset returns 0
+    const bool runs = !is_force && !first;
+    const float error = desired - actual;
+    const float dt = (float)(now - last) * kc.dt;
+    float perr = error;
+    if (pcas_max) perr = gen_cascade(RB, rb + L.r_pfilt(), vb, pcas_max, c.pcas, runs && live, c.pa0, c.pa1, c.pa2, c.pb1, c.pb2, error);
+    const float p_term = c.kp * perr;
+    float ie = fmaf(dt, error, prev_ierr);
+    float i_term = c.ki * ie;
+    if (i == 0) {  // `pid` topic (Pid.cpp:139-142,158-159): what the Pid call of cable 0 writes, when there is one
+      dbg.p = runs ? p_term : dbg.p;
+      dbg.i = runs ? i_term : dbg.i;
+      dbg.des = runs ? desired : dbg.des;
+      dbg.pi = runs;
+    }
+    const bool over = i_term > c.imax, under = i_term < c.imin;  // Pid.cpp:143-152
+    i_term = over ? c.imax : (under ? c.imin : i_term);
+    ie = (over || under) ? i_term * c.inv_ki : ie;  // (mIerr = iTerm / mIgain, as a multiplication like the fast path)
+    const float pre = (c.kf * desired + p_term) + i_term;  // Pid.cpp:170: fTerm + pTerm + iTerm (+ dTerm in gen_finish)
+    // Pid::derive (Pid.cpp:193-217): push the sample (dt > 0 always: a Pid is called at most once per world step)
+    const int count = (int)((meta >> kGmCountShift) & kGmField), head = (int)((meta >> kGmHeadShift) & kGmField);
+    const int run = (int)((meta >> kGmRunShift) & kGmField);
+    const int nhead = (count == 0) ? 0 : ((head + 1 == nbuf) ? 0 : head + 1);
+    const int ncount = min(count + 1, nbuf);
+    const int nrun = (count > 0 && now - last == 1) ? min(run + 1, (int)kGmField) : 0;
+    const uint32_t nmeta = first ? (meta | kGmWasLast)
+                                 : (kGmWasLast | ((uint32_t)ncount << kGmCountShift) | ((uint32_t)nhead << kGmHeadShift) | ((uint32_t)nrun << kGmRunShift));
+    // the new sample into its ring slot of the staged window, that slot back to the records with its stamp
+    park[(nhead >> 2) * 256 + lane * 3 + (nhead & 3)] = error;  // (park + lane * 3 = the lane's float4 inside a slot row)
+    const float4 vs = cs[(nhead >> 2) * 64];
+    RB.store4_if(live && runs, sa, va + (uint32_t)(nhead >> 2) * RB.rs16, vs);
+    RB.storei_if(live && runs, rb, vb + (uint32_t)nhead * RB.rs4, now);
+    // full window that is not a uniform grid (the nbuf - 1 steps after a switch between the two Pids): queued for the fit
+    const bool queued = runs && ncount >= nbuf && nrun < nbuf - 1;
+    // nbuf samples one world step apart: the closed-form end-point LS derivative, weights by ring head (zero for slots >= nbuf)
+    const float* wr = wrot + ((sv ? NBMAX : 0) + nhead) * NBP;
+    float acc = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < NV; ++s4) {
+      const float4 v = cs[s4 * 64];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * s4 + k < NBMAX) acc = fmaf(wr[4 * s4 + k], comp4(v, k), acc);
+    }
+    const float derived = (ncount >= nbuf) ? acc * kc.inv_dt : 0.f;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
+    float d_term;
+    const bool done = (runs && !queued) || first;  // first call: H = (meta | 1, now, mIerr as it was, mCmd = 0); out is not used
+    const float out = gen_finish(RB, c, sa + L.nv(), rb + L.r_dfilt(), dcas_max, done && live, runs && !queued && live, va, vb, derived, first ? 0.f : error, dt,
+                                 first ? 0.f : pre, first ? prev_ierr : ie, prev_ierr, first ? 0.f : old_cmd, nmeta, now, d_term);
+    if (i == 0) {
+      dbg.d = (runs && !queued) ? d_term : dbg.d;
+      dbg.dw = runs && !queued;
+    }
+    force[i] = is_force ? target[i] : ((runs && !queued) ? out : 0.f);
+    need |= queued ? (1u << i) : 0u;
+    if (queued) {  // park what the rest of Pid::update needs in the cable's own staged rows (the values there are done with)
+      park[0 * 64] = error, park[1 * 64] = dt, park[2 * 64] = pre, park[3 * 64] = ie, park[4 * 64] = prev_ierr, park[5 * 64] = old_cmd;
+      park[6 * 64] = __uint_as_float(nmeta);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // mLastPosition of every cable back (whole slots: a held cable keeps what it had)
+#pragma unroll
+  for (int g4 = 0; g4 < LP; ++g4)
+    RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
+                                                    (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
+
+  // the windows that are not a uniform grid, compacted over the wave: one (robot, cable) per lane and pass
+  if (__builtin_amdgcn_ballot_w64(need != 0u) != 0ull) {  // (wave-uniform)
+    const uint32_t cnt = (uint32_t)__builtin_popcount(need);
+    uint32_t slot = 0u;
+    if (cnt) slot = __hip_atomic_fetch_add(q_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (need & (1u << i)) {
+        const float* park = cabf + i * kCabF + lane;
+        const uint32_t hd = (__float_as_uint(park[6 * 64]) >> kGmHeadShift) & kGmField;
+        *qitem(slot) = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | (hd << 10);
+        *qerr(slot) = park[0];
+        ++slot;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t total = *q_count;
+    for (uint32_t first = 0; first < total; first += 64u) {  // (wave-uniform trip count)
+      // every lane runs the fit - lanes past the end of the queue on a copy of item 0 - and only the result is predicated
+      const uint32_t idx = first + lane;
+      const bool mine = idx < total;
+      const uint32_t it = *qitem(mine ? idx : 0u);
+      const float e_new = *qerr(mine ? idx : 0u);
+      const uint32_t ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u, hd = (it >> 10) & 63u;
+      const uint32_t ro = first_unit + ol;
+      const uint32_t ocol = (ro < units) ? ro : (units - 1u);
+      // the item's Pid of its cable, its owner's column: everything per lane goes into the vector offsets
+      const uint32_t oa = ocol * 16u + (uint32_t)(L.block_a(0, (int)ci) - L.block_a(0, 0)) * RB.rs16 + (sp ? pid_a : 0u);
+      const uint32_t ob = ocol * 4u + (uint32_t)L.block_b(0, (int)ci) * RB.rs4 + (sp ? pid_b : 0u);
+      const int nbuf = __float_as_int(ptab[sp][2].x), degree = __float_as_int(ptab[sp][5].z);
+      float y[NBMAX];
+      int t[NBMAX];
+#pragma unroll
+      for (int s4 = 0; s4 < NV; ++s4) {
+        const float4 v = RB.load4(L.block_a(0, 0) + s4, oa);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * s4 + k < NBMAX) y[4 * s4 + k] = comp4(v, k);
+      }
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
+      const uint32_t old = (hd + 1u == (uint32_t)nbuf) ? 0u : hd + 1u;  // the oldest sample sits right after the head
+      int t_old = now;
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j) {
+        y[j] = ((uint32_t)j == hd) ? e_new : ((j < nbuf) ? y[j] : 0.f);  // the sample just pushed (its store may still be in flight)
+        t[j] = ((uint32_t)j == hd || j >= nbuf) ? now : t[j];
+        t_old = ((uint32_t)j == old) ? t[j] : t_old;
+      }
+      const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
+      if (mine) cabf[ci * kCabF + 9 * 64 + ol] = res;
+    }
+    if (lane == 0) *q_count = 0u;  // for the next step
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const bool queued = (need & (1u << i)) != 0u;
+      const bool sv = sel[i] != 0;
+      const float* park = cabf + i * kCabF + lane;
+      const uint32_t va = col * 16u + (sv ? pid_a : 0u), vb = col * 4u + (sv ? pid_b : 0u);
+      float d_term;
+      const float out = gen_finish(RB, gen_select(sv, ptab, filters), L.block_a(0, i) + L.nv(), L.block_b(0, i) + L.r_dfilt(), dcas_max, queued && live, queued && live, va, vb,
+                                   cabf[i * kCabF + 9 * 64 + lane], park[0 * 64], park[1 * 64], park[2 * 64], park[3 * 64], park[4 * 64], park[5 * 64],
+                                   __float_as_uint(park[6 * 64]), now, d_term);
+      if (i == 0) {
+        dbg.d = queued ? d_term : dbg.d;
+        dbg.dw = dbg.dw || queued;
+      }
+      force[i] = queued ? out : force[i];
+    }
+  }
+}
+
+// Issue the LDS-DMA of one wave's record slots for this step: per cable the selected Pid's NV value slots and H, plus the
+// hold-position slots.  `keep`: a value every ordinary load issued so far feeds (hipcc drains every outstanding VMEM
+// operation at the first use of an ordinary load's result while an LDS-DMA is pending).
+template <int N, int NBMAX>
+CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t col, const int (&sel)[N], float4* cab, float4* hold_slots, float keep) {
+  constexpr int NV = gen_nv(NBMAX);
+  constexpr int kCab = (NV + 1) * 64;
+  constexpr int LP = (N + 3) / 4;
+  asm volatile("" ::"v"(keep));
+  const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16;
+#pragma unroll
+  for (int g4 = 0; g4 < LP; ++g4) RB.slot_to_lds(g4, col * 16u, hold_slots + g4 * 64);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const uint32_t va = col * 16u + (sel[i] ? pid_a : 0u);
+    const int sa = L.block_a(0, i);
+#pragma unroll
+    for (int s4 = 0; s4 < NV; ++s4) RB.slot_to_lds(sa + min(s4, L.nv() - 1), va, cab + i * kCab + s4 * 64);  // (slots past nv: a copy, weight 0)
+    RB.slot_to_lds(sa + L.nv(), va, cab + i * kCab + NV * 64);
+  }
+}
+
+// NBMAX bounds the window at compile time: 11 (the shipped length and everything below it: 32 KiB of staged slots per
+// wave) or 32 (the maximum: 72 KiB).  SINGLE: one world step per launch (no step loop: what is only needed late is not
+// live from the start).
+template <int N, bool FK, bool TD, bool ROLLOUT, int NBMAX, bool SINGLE = false>
 __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, const GenCtl g) {
   constexpr int NP = cable_pairs(N);
   constexpr int G = joint_groups(N);
-  constexpr bool STAGE = NBMAX <= 11;
+  constexpr int NV = gen_nv(NBMAX);
   constexpr int NBP = gen_nbp(NBMAX);
-  constexpr int kStageRows = NBMAX + 5;  // values | ierr | meta | last | cmd | hold position
-  constexpr int kSg = STAGE ? 64 : N * 64;  // floats between consecutive staged rows of one cable
+  constexpr int LP = (N + 3) / 4;
   __shared__ __attribute__((aligned(16))) float lds[NP * kGeomFloatsPerPair];
   __shared__ __attribute__((aligned(16))) float wrot[2][NBMAX][NBP];
-  __shared__ float stage[STAGE ? N : 1][STAGE ? kStageRows : 1][64];
-  __shared__ float park[STAGE ? 1 : 7][STAGE ? 1 : N][64];  // NBMAX = 32 (rows not staged): where a queued cable parks its Pid terms
-  __shared__ uint32_t q_item[64 * N];
-  __shared__ float q_err[64 * N];
-  __shared__ float q_res[N][64];
+  __shared__ float4 stage[N][NV + 1][64];  // gen_controller's working set: the DMA-staged value slots and H of every cable
+  __shared__ float4 hold_slots[LP][64];
   __shared__ uint32_t q_count;
+  __shared__ float4 ptab[2][kGenPidFloats / 4];
 
   const uint32_t lane = threadIdx.x;
   const uint32_t r = blockIdx.x * 64u + lane;  // robot, or trajectory index in a rollout
@@ -261,9 +534,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
   GenLayout L;
   L.n = g.lay.n, L.nb = g.lay.nb, L.ncas = g.lay.ncas;
   const uint32_t rs = g.rstride;
-  GenBuf RB;
-  RB.rsrc = __builtin_amdgcn_make_buffer_rsrc(g.rec, 0, (int)g.rec_bytes, 0x00020000);
-  RB.rs4 = rs * 4u;
+  GenBuf RB = gen_buffer(g.rec, rs, g.rec_bytes, L);
   const uint32_t col = ru;  // record column: the robot, or this trajectory's private copy
 
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
@@ -276,15 +547,25 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
   if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
   for (uint32_t k = lane; k < 2u * NBMAX * NBP; k += 64u) (&wrot[0][0][0])[k] = g.wtab[k];
   if (lane == 0) q_count = 0u;
+  if (lane < 2 * kGenPidFloats) (&ptab[0][0].x)[lane] = g.ptab[lane];
 
   if (ROLLOUT) {
     // private copy of the robot's records; a Joy on jointVelocities reaching a robot that is not in Velocity mode resets
-    // its velocity Pid (JFC.cpp:113-115): those rows start from zero
+    // its velocity Pid (JFC.cpp:113-115): those slots and rows start from zero
     const bool reset_vel = (mode != 2);
-    const int v0 = L.block(1, 0), v1 = v0 + L.pid_rows();
-    for (int row = 0; row < L.total_rows(); ++row) {
-      const float v = (reset_vel && row >= v0 && row < v1) ? 0.f : g.src_rec[(size_t)row * g.src_rstride + rr];
-      if (live) g.rec[(size_t)row * rs + col] = v;
+    const float4* srca = reinterpret_cast<const float4*>(g.src_rec);
+    float4* dsta = reinterpret_cast<float4*>(g.rec);
+    const int va0 = L.block_a(1, 0), va1 = va0 + L.pid_slots();
+    for (int sl = 0; sl < L.slots(); ++sl) {
+      const float4 v = (reset_vel && sl >= va0 && sl < va1) ? make_float4(0.f, 0.f, 0.f, 0.f) : srca[(size_t)sl * g.src_rstride + rr];
+      if (live) dsta[(size_t)sl * rs + col] = v;
+    }
+    const float* srcb = g.src_rec + (size_t)L.slots() * g.src_rstride * 4;
+    float* dstb = g.rec + (size_t)L.slots() * rs * 4;
+    const int vb0 = L.block_b(1, 0), vb1 = vb0 + L.pid_rows();
+    for (int row = 0; row < L.rows(); ++row) {
+      const float v = (reset_vel && row >= vb0 && row < vb1) ? 0.f : srcb[(size_t)row * g.src_rstride + rr];
+      if (live) dstb[(size_t)row * rs + col] = v;
     }
     mode = 2;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -330,7 +611,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     }
   }
 
-  for (int step = 0; step < a.nsteps; ++step) {
+  for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
     const int now = g.now_step + step;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
     if (ROLLOUT) {  // this step's Joy for this trajectory
@@ -344,36 +625,24 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    // ---- which Pid serves each cable this step (JFC.cpp:67-89), and its rows on their way to LDS
-    int sel[N];           // 0 position Pid, 1 velocity Pid (Force mode: 0, unused)
-    uint32_t boff[N];     // byte offset of this lane's column in the selected Pid's rows, relative to the position Pid's
-    const uint32_t cbytes = col * 4u;
+    // (opaque per step: in a launch of several steps every slot offset is loop-invariant, and hoisted out of the step loop
+    //  they overflow the scalar register file into v_writelane / v_readlane pairs)
+    if (!SINGLE) asm volatile("" : "+s"(RB.rs16), "+s"(RB.rs4));
+    // ---- which Pid serves each cable this step (JFC.cpp:67-89), and its slots on their way to LDS
+    int sel[N];  // 0 position Pid, 1 velocity Pid (Force mode: 0, unused)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       sel[i] = (mode == 2 && fabsf(target[i]) > g.eps) ? 1 : 0;
       // (opaque: in a launch of several steps the selection is the same in every step, and the compiler would hoist the
       //  selected gains of all cables - some hundred registers - out of the step loop)
-      asm volatile("" : "+v"(sel[i]));
-      boff[i] = ((uint32_t)(sel[i] * L.pid_rows()) * rs + col) * 4u;
+      if (!SINGLE) asm volatile("" : "+v"(sel[i]));
     }
     const bool run_ctl = !first_world;
-    if (STAGE && run_ctl) {
-      float keep = (s.px + s.qy) + (s.vy + s.wz) + fkqw;  // every ordinary load issued so far is consumed before the DMA is queued
+    if (run_ctl) {
+      float keep = (s.px + s.qy) + (s.vy + s.wz) + fkqw;
 #pragma unroll
       for (int i = 0; i < N; ++i) keep += target[i];
-      asm volatile("" ::"v"(keep));
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        const int b0 = L.block(0, i);
-#pragma unroll
-        for (int j = 0; j < NBMAX; ++j)
-          if (j < L.nb) RB.to_lds(b0 + j, boff[i], &stage[STAGE ? i : 0][STAGE ? j : 0][0]);
-        RB.to_lds(b0 + L.r_ierr(), boff[i], &stage[STAGE ? i : 0][STAGE ? NBMAX : 0][0]);
-        RB.to_lds(b0 + L.r_meta(), boff[i], &stage[STAGE ? i : 0][STAGE ? NBMAX + 1 : 0][0]);
-        RB.to_lds(b0 + L.r_last(), boff[i], &stage[STAGE ? i : 0][STAGE ? NBMAX + 2 : 0][0]);
-        if (g.any_noclamp) RB.to_lds(b0 + L.r_cmd(), boff[i], &stage[STAGE ? i : 0][STAGE ? NBMAX + 3 : 0][0]);
-        RB.to_lds(i, cbytes, &stage[STAGE ? i : 0][STAGE ? NBMAX + 4 : 0][0]);
-      }
+      gen_stage_records<N, NBMAX>(RB, L, col, sel, &stage[0][0][0], &hold_slots[0][0], keep);
     }
 
     // ---- IK on the state at t_k: only joint positions, rates and the measured lengths live on; the structure matrix is
@@ -438,177 +707,18 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       fk_res = fmaxf(rm.x, rm.y);
     }
 
-    // ---- per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191).  Only q, qd and the force live across the
-    //      cables: a cable whose derivative is known at once (uniform window: the FIR; window not full: 0) runs its whole
-    //      Pid::update here; one that needs the fit parks six numbers in its own staged rows and finishes after the pass.
-    //      Written WITHOUT divergent control flow around anything heavy (per-lane cases are selects and predicated
-    //      stores): the register allocator splits long live ranges around high-pressure regions, and a split made under a
-    //      partial exec mask does not carry the lanes that were masked off.
+    // ---- per-cable force: the general controller (gen_controller above)
     float force[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) force[i] = 0.f;
-    float dbg_p = 0.f, dbg_i = 0.f, dbg_d = 0.f, dbg_des = 0.f;
-    bool dbg_pi = false, dbg_dw = false;
+    GenDbg dbg{0.f, 0.f, 0.f, 0.f, false, false};
     if (run_ctl) {
-      if (STAGE) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA has landed
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-      const int pcas_max = max(g.pid[0].pcas, g.pid[1].pcas), dcas_max = max(g.pid[0].dcas, g.pid[1].dcas);
-      const bool noclamp = g.any_noclamp != 0;
-      uint32_t need = 0u;  // cables whose derivative comes from the fit queue
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        __builtin_amdgcn_sched_barrier(0);  // one cable at a time: hoisting every cable's staged rows costs 128 registers
-        const float qi = (i & 1) ? q[i / 2].y : q[i / 2].x;
-        const float qdi = (i & 1) ? qd[i / 2].y : qd[i / 2].x;
-        const int b0 = L.block(0, i);
-        const uint32_t bo = boff[i];
-        float* const sg = STAGE ? &stage[STAGE ? i : 0][0][lane] : &park[0][STAGE ? 0 : i][lane];  // this cable's staged rows, kSg floats apart
-        const bool is_force = (mode == 0);  // JFC.cpp:67-70
-        const bool sv = sel[i] != 0;
-        const bool hold = (mode == 2) && !sv;
-        const float held = STAGE ? sg[(NBMAX + 4) * kSg] : RB.load(i, cbytes);
-        const float desired = hold ? held : target[i];  // JFC.cpp:81: mLastPosition in the hold branch
-        if (live && !hold) RB.store(i, cbytes, qi);      // JFC.cpp:68,75,87: mLastPosition = joint position
-        const float actual = (mode == 2 && sv) ? qdi : qi;
-        const GenSel c = gen_select(sv, g.pid[0], g.pid[1]);
-        const float kf = c.kf, kp = c.kp, ki = c.ki, imax = c.imax, imin = c.imin;
-        const int nbuf = c.nbuf;
-        const uint32_t meta = __float_as_uint(STAGE ? sg[(NBMAX + 1) * kSg] : RB.load(b0 + L.r_meta(), bo));
-        const int last = __float_as_int(STAGE ? sg[(NBMAX + 2) * kSg] : RB.load(b0 + L.r_last(), bo));
-        const bool first = !is_force && !(meta & kGmWasLast);  // Pid.cpp:123-126: the first call since reset returns 0
-        const bool runs = !is_force && !first;
-        const float prev_ierr = STAGE ? sg[NBMAX * kSg] : RB.load(b0 + L.r_ierr(), bo);
-        const float old_cmd = g.any_noclamp ? (STAGE ? sg[(NBMAX + 3) * kSg] : RB.load(b0 + L.r_cmd(), bo)) : 0.f;
-        const float error = desired - actual;
-        const float dt = (float)(now - last) * g.dt;
-        float perr = error;
-        if (pcas_max) perr = gen_cascade(RB, b0 + L.r_pfilt(), bo, pcas_max, c.pcas, runs && live, c.pa0, c.pa1, c.pa2, c.pb1, c.pb2, error);
-        const float p_term = kp * perr;
-        float ie = fmaf(dt, error, prev_ierr);
-        float i_term = ki * ie;
-        if (i == 0) {  // `pid` topic (Pid.cpp:139-142,158-159): what the Pid call of cable 0 writes, when there is one
-          dbg_p = runs ? p_term : dbg_p;
-          dbg_i = runs ? i_term : dbg_i;
-          dbg_des = runs ? desired : dbg_des;
-          dbg_pi = runs;
-        }
-        const bool over = i_term > imax, under = i_term < imin;  // Pid.cpp:143-152
-        i_term = over ? imax : (under ? imin : i_term);
-        ie = (over || under) ? i_term / ki : ie;
-        const float pre = (kf * desired + p_term) + i_term;  // Pid.cpp:170: fTerm + pTerm + iTerm (+ dTerm in finish)
-        // Pid::derive (Pid.cpp:193-217): push the sample (dt > 0 always: a Pid is called at most once per world step)
-        const int count = (int)((meta >> kGmCountShift) & kGmField), head = (int)((meta >> kGmHeadShift) & kGmField);
-        const int run = (int)((meta >> kGmRunShift) & kGmField);
-        const int nhead = (count == 0) ? 0 : ((head + 1 == nbuf) ? 0 : head + 1);
-        const int ncount = min(count + 1, nbuf);
-        const int nrun = (count > 0 && now - last == 1) ? min(run + 1, (int)kGmField) : 0;
-        if (live && !is_force) {
-          const uint32_t nmeta = first ? (meta | kGmWasLast)
-                                       : (kGmWasLast | ((uint32_t)ncount << kGmCountShift) | ((uint32_t)nhead << kGmHeadShift) | ((uint32_t)nrun << kGmRunShift));
-          RB.storei(b0 + L.r_meta(), bo, (int)nmeta);
-          RB.storei(b0 + L.r_last(), bo, now);
-          if (g.any_noclamp && first) RB.store(b0 + L.r_cmd(), bo, 0.f);
-          if (runs) {
-            const uint32_t ho = bo + (uint32_t)nhead * rs * 4u;  // the ring slot is the lane's own
-            RB.store(b0, ho, error);
-            RB.storei(b0 + L.r_stamp(), ho, now);
-          }
-        }
-        // full window that is not a uniform grid (the nbuf - 1 steps after a switch between the two Pids): queued for the fit
-        const bool queued = runs && ncount >= nbuf && nrun < nbuf - 1;
-        // nbuf samples one world step apart: the closed-form end-point LS derivative, weights by ring head (zero for slots >= nbuf)
-        const float* wr = &wrot[sv ? 1 : 0][nhead][0];
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NBMAX; ++j) {
-          const float yj = (j == nhead) ? error : (STAGE ? sg[j * kSg] : ((j < L.nb) ? RB.load(b0 + j, bo) : 0.f));
-          acc = fmaf(wr[j], yj, acc);
-        }
-        const float derived = (ncount >= nbuf) ? acc / g.dt : 0.f;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
-        float d_term;
-        const float out = gen_finish(RB, c, b0 + L.r_ierr(), b0 + L.r_cmd(), b0 + L.r_dfilt(), dcas_max, noclamp, runs && !queued && live, bo, derived, error, dt,
-                                     pre, ie, prev_ierr, old_cmd, d_term);
-        if (i == 0) {
-          dbg_d = (runs && !queued) ? d_term : dbg_d;
-          dbg_dw = runs && !queued;
-        }
-        force[i] = is_force ? target[i] : ((runs && !queued) ? out : 0.f);
-        need |= queued ? (1u << i) : 0u;
-        if (queued) {  // park what the rest of Pid::update needs in the cable's own staged rows (the values there are done with)
-          sg[0 * kSg] = error, sg[1 * kSg] = dt, sg[2 * kSg] = pre, sg[3 * kSg] = ie, sg[4 * kSg] = prev_ierr, sg[5 * kSg] = old_cmd;
-          sg[6 * kSg] = __int_as_float(nhead);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-
-      // the windows that are not a uniform grid, compacted over the wave: one (robot, cable) per lane and pass
-      if (__builtin_amdgcn_ballot_w64(need != 0u) != 0ull) {  // (wave-uniform)
-        const uint32_t cnt = (uint32_t)__builtin_popcount(need);
-        uint32_t slot = 0u;
-        if (cnt) slot = __hip_atomic_fetch_add(&q_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-          if (need & (1u << i)) {
-            const float* sg = STAGE ? &stage[STAGE ? i : 0][0][lane] : &park[0][STAGE ? 0 : i][lane];
-            q_item[slot] = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | ((uint32_t)__float_as_int(sg[6 * kSg]) << 10);
-            q_err[slot] = sg[0];
-            ++slot;
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t total = q_count;
-        for (uint32_t first = 0; first < total; first += 64u) {  // (wave-uniform trip count)
-          // every lane runs the fit - lanes past the end of the queue on a copy of item 0 - and only the result is predicated
-          const uint32_t idx = first + lane;
-          const bool mine = idx < total;
-          const uint32_t it = q_item[mine ? idx : 0u];
-          const float e_new = q_err[mine ? idx : 0u];
-          const uint32_t ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u, hd = (it >> 10) & 63u;
-          const uint32_t ro = blockIdx.x * 64u + ol;
-          const uint32_t ocol = (ro < units) ? ro : (units - 1u);
-          const uint32_t oo = ((uint32_t)(L.block(0, (int)ci) + (int)sp * L.pid_rows()) * rs + ocol) * 4u;  // the item's block, its owner's column
-          const int nbuf = sp ? g.pid[1].nbuf : g.pid[0].nbuf, degree = sp ? g.pid[1].degree : g.pid[0].degree;
-          float y[NBMAX];
-          int t[NBMAX];
-#pragma unroll
-          for (int j = 0; j < NBMAX; ++j) {
-            y[j] = RB.load(j, oo);
-            t[j] = RB.loadi(L.r_stamp() + j, oo);
-          }
-          const uint32_t old = (hd + 1u == (uint32_t)nbuf) ? 0u : hd + 1u;  // the oldest sample sits right after the head
-          int t_old = now;
-#pragma unroll
-          for (int j = 0; j < NBMAX; ++j) {
-            y[j] = ((uint32_t)j == hd) ? e_new : ((j < nbuf) ? y[j] : 0.f);  // the sample just pushed (its store may still be in flight)
-            t[j] = ((uint32_t)j == hd || j >= nbuf) ? now : t[j];
-            t_old = ((uint32_t)j == old) ? t[j] : t_old;
-          }
-          const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)g.dt);
-          if (mine) q_res[ci][ol] = res;
-        }
-        if (lane == 0) q_count = 0u;  // for the next step
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-          const bool queued = (need & (1u << i)) != 0u;
-          const float* sg = STAGE ? &stage[STAGE ? i : 0][0][lane] : &park[0][STAGE ? 0 : i][lane];
-          const int b0 = L.block(0, i);
-          float d_term;
-          const float out = gen_finish(RB, gen_select(sel[i] != 0, g.pid[0], g.pid[1]), b0 + L.r_ierr(), b0 + L.r_cmd(), b0 + L.r_dfilt(), dcas_max, noclamp,
-                                       queued && live, boff[i], q_res[i][lane], sg[0 * kSg], sg[1 * kSg], sg[2 * kSg], sg[3 * kSg], sg[4 * kSg], sg[5 * kSg], d_term);
-          if (i == 0) {
-            dbg_d = queued ? d_term : dbg_d;
-            dbg_dw = dbg_dw || queued;
-          }
-          force[i] = queued ? out : force[i];
-        }
-      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA has landed
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      GenCtlConst cc;
+      cc.pcas_max = g.pcas_max, cc.dcas_max = g.dcas_max, cc.dt = g.dt, cc.inv_dt = a.inv_dt;
+      gen_controller<N, NBMAX>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &stage[0][0][0], &hold_slots[0][0],
+                               &wrot[0][0][0], ptab, &q_count, force, dbg);
     }
     v2f f[NP];
 #pragma unroll
@@ -660,12 +770,12 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
 
     if (!ROLLOUT && a.dbg && live) {  // `pid` topic, cable 0 only: stale entries stay (Pid.cpp:139-142,158-168)
       float* d = a.dbg + (size_t)r * 9;
-      if (dbg_pi) {
-        d[0] = dbg_p;
-        d[1] = dbg_i;
-        d[3] = dbg_des;
+      if (dbg.pi) {
+        d[0] = dbg.p;
+        d[1] = dbg.i;
+        d[3] = dbg.des;
       }
-      if (dbg_dw) d[2] = dbg_d;
+      if (dbg.dw) d[2] = dbg.d;
       d[4] = applied[0].x;
     }
     if (publish && live) {  // the rest of the observables
@@ -726,7 +836,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
 
 // Per-robot command arrival on the general path (cdpr_set_*_command_masked; PLG.cpp:206-219 per model): one thread per
 // robot copies the Joy's row into the latched buffer of its kind, and entering the mode from another one resets that
-// mode's Pid (JFC.cpp:101-103,113-115) = zero the robot's column of the Pid's rows.  setForce resets nothing.
+// mode's Pid (JFC.cpp:101-103,113-115) = zero the robot's column of the Pid's slots and rows.  setForce resets nothing.
 struct GenLatchArgs {
   const uint8_t* mask;   // uint8[B], or nullptr = every robot
   uint8_t* mode;         // per-robot mode
@@ -734,7 +844,8 @@ struct GenLatchArgs {
   float* latched;        // float[B][n]
   float* rec;
   uint32_t rstride, batch, n;
-  int first_row, rows;   // the Pid's rows (rows = 0: nothing to reset)
+  int reset_pid;         // 0 / 1: the Pid whose records this mode owns; -1: none (setForce)
+  GenLayout lay;
   int new_mode;
 };
 
@@ -744,7 +855,12 @@ static __global__ __launch_bounds__(256) void cdpr_gen_latch_kernel(const GenLat
   if (a.mask && !a.mask[r]) return;
   for (uint32_t i = 0; i < a.n; ++i) a.latched[(size_t)r * a.n + i] = a.pending[(size_t)r * a.n + i];
   if ((int)a.mode[r] != a.new_mode) {
-    for (int row = 0; row < a.rows; ++row) a.rec[(size_t)(a.first_row + row) * a.rstride + r] = 0.f;
+    if (a.reset_pid >= 0) {
+      float4* sa = reinterpret_cast<float4*>(a.rec) + (size_t)a.lay.block_a(a.reset_pid, 0) * a.rstride + r;
+      for (int sl = 0; sl < a.lay.pid_slots(); ++sl) sa[(size_t)sl * a.rstride] = make_float4(0.f, 0.f, 0.f, 0.f);
+      float* rb = a.rec + (size_t)a.lay.slots() * a.rstride * 4 + (size_t)a.lay.block_b(a.reset_pid, 0) * a.rstride + r;
+      for (int row = 0; row < a.lay.pid_rows(); ++row) rb[(size_t)row * a.rstride] = 0.f;
+    }
     a.mode[r] = (uint8_t)a.new_mode;
   }
 }

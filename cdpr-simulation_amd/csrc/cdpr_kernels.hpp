@@ -51,7 +51,7 @@ StepKernel pick_pr_split_kernel(uint32_t n);
 StepKernel pick_pair_kernel(bool single, uint32_t n, bool fk, bool td);
 StepKernel pick_cable_kernel(uint32_t n, bool fk, bool td);
 // k_gen.hip: the general controller path (cdpr_general_step.hpp); long_window: derivative windows of 12 .. 32 samples
-GenKernel pick_gen_kernel(uint32_t n, bool fk, bool td, bool rollout, bool long_window);
+GenKernel pick_gen_kernel(uint32_t n, bool fk, bool td, bool rollout, bool long_window, bool single);
 // k_f64.hip: precision = 64
 F64Kernel pick_f64_kernel(uint32_t n);
 

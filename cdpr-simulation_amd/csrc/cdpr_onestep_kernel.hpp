@@ -443,6 +443,115 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
 #define CDPR_CTL_STAMP(i) CDPR_SPLIT_STAMP(i)
 #endif
 
+// The estimator wave of a role-split workgroup (cdpr_split_kernel, and cdpr_gen_split_kernel on the general controller
+// path): platform rows -> measured lengths -> Newton-Raphson FK -> [forces from the controller wave] tension distribution
+// -> tensions and estimator results back.  x_force / x_tension: v2f rows XS elements apart, x_est: float rows ES apart.
+template <int N, int XS, int ES>
+CDPR_DEV void split_estimator_wave(const StepArgs& a, float* geo, float gval, uint32_t lane, bool live, size_t st, uint32_t off, uint32_t woff,
+                                   const float4& p0, const float4& p1, const float4& p3, const v2f* x_force, v2f* x_tension, float* x_est) {
+  constexpr int NP = cable_pairs(N);
+#if CDPR_SPLIT_PRIO == 1
+  __builtin_amdgcn_s_setprio(3);  // the estimator is the critical path: it wins the SIMD's issue arbitration
+#endif
+  const float4 p4 = load_slot(a.state, st, 4, off);
+  if (lane < NP * kGeomFloatsPerPair) geo[lane] = gval;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float fkx = p3.y, fky = p3.z, fkz = p3.w, fkqx = p4.x, fkqy = p4.y, fkqz = p4.z, fkqw = p4.w;
+  v2f len[NP];
+  {
+    v2f jac[NP][6], l0[NP];  // only the measured lengths L* are kept of the true-state evaluation
+    ik_pairs<N, false>(geo, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, len, jac, l0);
+  }
+  float fk_res = 0.f;
+  int fk_it = 0;
+  v2f jest[NP][6];
+  {
+    v2f elen[NP], unused[NP];
+    bool active = true;
+    for (int it = 0; it < a.fk_iters; ++it) {
+      ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+      v2f res[NP];
+      v2f rm = splat(0.f);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        res[k] = len[k] - elen[k];
+        rm = max2(rm, abs2(res[k]));
+      }
+      active = active && !(fmaxf(rm.x, rm.y) < a.fk_tol);
+      float g[6];
+      jt_times<NP>(jest, res, g);
+      normal_solve<NP>(jest, a.fk_lambda, g);
+      if (active) {
+        fkx += g[0];
+        fky += g[1];
+        fkz += g[2];
+        quat_apply_rotvec(fkqx, fkqy, fkqz, fkqw, g[3], g[4], g[5]);
+        ++fk_it;
+      }
+#ifdef CDPR_STAMPS_ITER
+      if (it < 3) {
+        asm volatile("" ::"v"(fkqw));
+        __builtin_amdgcn_sched_barrier(0);
+        if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 4 + it] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+    }
+    ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+    v2f rm = splat(0.f);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
+    fk_res = fmaxf(rm.x, rm.y);
+  }
+  if (live) store_slot_aux<CDPR_SPLIT_PLAT_AUX>(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
+  CDPR_SPLIT_STAMP(1);
+  // the tension distribution's matrix and its factor need no forces: done while the controller wave may still be busy
+  v2f td_l[6][3];
+  float td_invd[6];
+  normal_matrix_pk<NP, false>(jest, 0.f, td_l);
+  chol_factor_pk(td_l, td_invd);
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): nothing of this wave's LDS traffic is pending
+  __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in x_force
+  CDPR_SPLIT_STAMP(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  v2f f[NP], df[NP], t_out[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    f[k] = x_force[k * XS + lane];
+    df[k] = f[k] - splat(a.td_mid);
+  }
+  int td_flag = 0;
+  {
+    float g[6];
+    jt_times<NP>(jest, df, g);
+    chol_apply_pk(td_l, td_invd, g);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      v2f t = splat(a.td_mid);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) t = fma2(g[c], jest[k][c], t);
+      const v2f tc = max2(min2(t, splat(a.td_max)), splat(a.td_min));
+      td_flag |= (tc.x != t.x) ? 1 : 0;
+      if (2 * k + 1 < N) td_flag |= (tc.y != t.y) ? 1 : 0;
+      t_out[k] = tc;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) x_tension[k * XS + lane] = t_out[k];
+  x_est[0 * ES + lane] = fkx;
+  x_est[1 * ES + lane] = fky;
+  x_est[2 * ES + lane] = fkz;
+  x_est[3 * ES + lane] = fk_res;
+  x_est[4 * ES + lane] = (float)fk_it;
+  x_est[5 * ES + lane] = (float)td_flag;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  CDPR_SPLIT_STAMP(3);
+  __builtin_amdgcn_s_barrier();  // #2: tensions and estimator results are out
+}
+
 // PR = true: per-robot handles (StepArgs::meta, see cdpr_step_kernel.hpp): the controller wave takes mode and Pid call
 // count per lane; the estimator wave is the same.
 template <int N, bool PR = false>
@@ -477,107 +586,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
                p3 = load_slot(a.state, st, 3, off);
   if (wave == 0) {
-    // ------------------------------------------------------------------------------------------------ estimator wave
-#if CDPR_SPLIT_PRIO == 1
-    __builtin_amdgcn_s_setprio(3);  // the estimator is the critical path: it wins the SIMD's issue arbitration
-#endif
-    const float4 p4 = load_slot(a.state, st, 4, off);
-    if (lane < NP * kGeomFloatsPerPair) geo[lane] = gval;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float fkx = p3.y, fky = p3.z, fkz = p3.w, fkqx = p4.x, fkqy = p4.y, fkqz = p4.z, fkqw = p4.w;
-    v2f len[NP];
-    {
-      v2f jac[NP][6], l0[NP];  // only the measured lengths L* are kept of the true-state evaluation
-      ik_pairs<N, false>(geo, p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, len, jac, l0);
-    }
-    float fk_res = 0.f;
-    int fk_it = 0;
-    v2f jest[NP][6];
-    {
-      v2f elen[NP], unused[NP];
-      bool active = true;
-      for (int it = 0; it < a.fk_iters; ++it) {
-        ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
-        v2f res[NP];
-        v2f rm = splat(0.f);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          res[k] = len[k] - elen[k];
-          rm = max2(rm, abs2(res[k]));
-        }
-        active = active && !(fmaxf(rm.x, rm.y) < a.fk_tol);
-        float g[6];
-        jt_times<NP>(jest, res, g);
-        normal_solve<NP>(jest, a.fk_lambda, g);
-        if (active) {
-          fkx += g[0];
-          fky += g[1];
-          fkz += g[2];
-          quat_apply_rotvec(fkqx, fkqy, fkqz, fkqw, g[3], g[4], g[5]);
-          ++fk_it;
-        }
-#ifdef CDPR_STAMPS_ITER
-        if (it < 3) {
-          asm volatile("" ::"v"(fkqw));
-          __builtin_amdgcn_sched_barrier(0);
-          if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 4 + it] = __builtin_amdgcn_s_memrealtime();
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-      }
-      ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
-      v2f rm = splat(0.f);
-#pragma unroll
-      for (int k = 0; k < NP; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
-      fk_res = fmaxf(rm.x, rm.y);
-    }
-    if (live) store_slot_aux<CDPR_SPLIT_PLAT_AUX>(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
-    CDPR_SPLIT_STAMP(1);
-    // the tension distribution's matrix and its factor need no forces: done while the controller wave may still be busy
-    v2f td_l[6][3];
-    float td_invd[6];
-    normal_matrix_pk<NP, false>(jest, 0.f, td_l);
-    chol_factor_pk(td_l, td_invd);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): nothing of this wave's LDS traffic is pending
-    __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in x_force
-    CDPR_SPLIT_STAMP(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    v2f f[NP], df[NP], t_out[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      f[k] = x_force[k][lane];
-      df[k] = f[k] - splat(a.td_mid);
-    }
-    int td_flag = 0;
-    {
-      float g[6];
-      jt_times<NP>(jest, df, g);
-      chol_apply_pk(td_l, td_invd, g);
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        v2f t = splat(a.td_mid);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) t = fma2(g[c], jest[k][c], t);
-        const v2f tc = max2(min2(t, splat(a.td_max)), splat(a.td_min));
-        td_flag |= (tc.x != t.x) ? 1 : 0;
-        if (2 * k + 1 < N) td_flag |= (tc.y != t.y) ? 1 : 0;
-        t_out[k] = tc;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NP; ++k) x_tension[k][lane] = t_out[k];
-    x_est[0][lane] = fkx;
-    x_est[1][lane] = fky;
-    x_est[2][lane] = fkz;
-    x_est[3][lane] = fk_res;
-    x_est[4][lane] = (float)fk_it;
-    x_est[5][lane] = (float)td_flag;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    CDPR_SPLIT_STAMP(3);
-    __builtin_amdgcn_s_barrier();  // #2: tensions and estimator results are out
+    split_estimator_wave<N, 64, 64>(a, geo, gval, lane, live, st, off, woff, p0, p1, p3, &x_force[0][0], &x_tension[0][0], &x_est[0][0]);
     return;
   }
   // ---------------------------------------------------------------------------------------------------- controller wave

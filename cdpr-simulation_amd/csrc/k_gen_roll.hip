@@ -3,7 +3,7 @@
 #include "cdpr_general_step.hpp"
 namespace cdpr {
 namespace {
-#define K_GEN(N, FK, TD) cdpr_gen_step_kernel<N, FK, TD, true, 11>
+#define K_GEN(N, FK, TD) cdpr_gen_step_kernel<N, FK, TD, true, 11, false>
 template <int N> GenKernel gen_n(bool fk, bool td) { CDPR_PICK_STAGES(N, K_GEN); }
 }  // namespace
 GenKernel pick_gen_roll11(uint32_t n, bool fk, bool td) { CDPR_PICK_CABLES(gen_n, fk, td); }

@@ -3,7 +3,7 @@
 #include "cdpr_general_step.hpp"
 namespace cdpr {
 namespace {
-#define K_GEN(N, FK, TD) cdpr_gen_step_kernel<N, FK, TD, true, kGenMaxBuf>
+#define K_GEN(N, FK, TD) cdpr_gen_step_kernel<N, FK, TD, true, kGenMaxBuf, false>
 template <int N> GenKernel gen_n(bool fk, bool td) { CDPR_PICK_STAGES(N, K_GEN); }
 }  // namespace
 GenKernel pick_gen_roll32(uint32_t n, bool fk, bool td) { CDPR_PICK_CABLES(gen_n, fk, td); }

@@ -3,7 +3,8 @@
   rollout    512 x 128 x 64 MPC rollout, device-resident reference and costs (kernel only)
   config2m1  4 096 x 4, lane-per-robot          config2m2  4 096 x 4, lane-pair
   lowreg     524 288 x 8, all stages, one launch per step (auto-selected low-register kernel)
-  general    16 384 x 8 on the general controller path (velocityEpsilon = 0.001: hold branch live)
+  general / general65k        16 384 / 65 536 x 8 on the general controller path (velocityEpsilon = 0.001: hold branch live), one held Joy
+  general_sw / general65k_sw  the same with epsilon = 0.004 and the bench's sines refreshed every 10 steps: cables keep switching Pids
   onestep    65 536 x 8, all stages, one launch per step (the headline kernel)
   perrobot   65 536 x 8, all stages, one launch per step on a per_robot_commands handle: a third of the robots in
              Position mode, the rest in Velocity mode with Pids reset at two different times (PR split kernel)
@@ -70,12 +71,22 @@ elif case in ("perrobot", "perrobot_general"):
     eng.set_velocity_command(np.where(np.abs(command(1)) < 1e-3, 1e-3, command(1)).astype(np.float32), mask=grp == 2)
     eng.set_position_command(np.zeros((B, 8), np.float32), mask=grp == 0); eng.update(20); eng.synchronize()
     eng.update(reps * 3); eng.synchronize()
-elif case == "general":
-    B = 16384
-    model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 10)
-    eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3, velocityEpsilon=0.001), 0)
+elif case in ("general", "general65k", "general_sw", "general65k_sw"):
+    # general controller path (hold branch live).  plain: one Joy, held (round 3's case: every window stays a uniform grid);
+    # _sw: the bench's per-robot sines refreshed every 10 steps with epsilon = 0.004, so cables keep crossing into and out
+    # of the hold branch and their windows go through the fit
+    B = 65536 if "65k" in case else 16384
+    sw = case.endswith("_sw")
+    model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 4000)
+    eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3, velocityEpsilon=0.004 if sw else 0.001), 0)
     eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
-    eng.update(reps * 2); eng.synchronize()
+    if sw:
+        sched = [eng.device_upload(command(j)) for j in range(1, 1 + reps // 5 + 1)]
+        for d in sched:
+            eng.bind_velocity_command_device(d, B * 8); eng.update(10)
+    else:
+        eng.update(reps * 2)
+    eng.synchronize()
 else:
     raise SystemExit(f"unknown case {case}")
 print("done", case, flush=True)
