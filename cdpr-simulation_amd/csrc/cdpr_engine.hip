@@ -338,10 +338,6 @@ void fill_consts(const cdpr_config_t& c, StepArgs& k) {
   k.split_swap = 0x9;  // measured on MI355X (65 536 x 8): masks 0 .. 0xf8 give 10.8-11.3 us/step, 0x9 the best; bits 8-9 (the
                        // workgroups that share a CU) make it 12.8: the dispatcher already alternates the SIMD pairs there
   if (const char* sw = std::getenv("CDPR_SPLIT_SWAP")) k.split_swap = (uint32_t)strtoul(sw, nullptr, 0);
-  k.stagger_sleeps = 0;
-  k.stagger_period = 1024;  // one wave slot on each of the chip's 1 024 SIMDs
-  if (const char* sg = std::getenv("CDPR_STAGGER")) k.stagger_sleeps = (uint32_t)strtoul(sg, nullptr, 0);
-  if (const char* sp = std::getenv("CDPR_STAGGER_PERIOD")) k.stagger_period = std::max(1u, (uint32_t)strtoul(sp, nullptr, 0));
   k.fk_lambda = (float)c.fk_lambda;
   k.fk_tol = (float)c.fk_tolerance;
   k.fk_iters = (int)c.fk_max_iterations;
@@ -1331,17 +1327,19 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     if (const char* lr = std::getenv("CDPR_LOWREG"))
       h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
     // Between one and a few robots per hardware lane a single launch is a bulk-synchronous load -> compute -> store in which
-    // the co-resident waves of a SIMD start together: their memory phases coincide and their compute phases coincide, so
-    // two waves per SIMD cost 2.1-2.7x one (rocprofv3 PMC at 65 536 / 98 304 / 131 072 / 196 608: the vector pipes are busy
-    // 45 % of the launch at one AND at two waves per SIMD, profiles/r04a_cliff_pmc.txt).  The same step issued as back-to-back
-    // launches over blocks of <= 65 536 robots, each at the role-split kernel's operating point, is never slower there.
-    const uint32_t kChunkRobots = 65536u, kChunkMaxBatch = 393216u;
-    if (split_case && !h->lane_pair && !h->lane_cable && cfg->batch > kChunkRobots && cfg->batch <= kChunkMaxBatch) h->chunk = kChunkRobots;
+    // the co-resident waves of a SIMD start together: their memory phases coincide and their compute phases coincide, so two
+    // waves per SIMD cost 2.1-2.7x one (rocprofv3 PMC at 65 536 / 98 304 / 131 072 / 196 608: the vector pipes are busy 45 % of
+    // the launch at one AND at two waves per SIMD, profiles/r04_cliff_analysis.txt).  Round 4 measured the two obvious
+    // mitigations and keeps neither as a default: the same step as back-to-back launches over blocks of <= 65 536 robots
+    // (CDPR_CHUNK=N; bit-identical, tested) is within +-4 % of the single launch at every size and 20-30 % slower from 262 144
+    // robots on, where a large launch de-phases by itself (waves start as slots free up) and streams at the copy rate; delaying
+    // the second wave slot's workgroups by 2-6 us (s_sleep) changes nothing.  What would: a persistent kernel that prefetches
+    // the next block's rows while it computes.
     if (const char* ck = std::getenv("CDPR_CHUNK")) {  // A/B: 0 = never, N = blocks of at most N robots whatever the batch
       const long v = std::atol(ck);
       h->chunk = (v > 0 && !general && !h->fp64 && !h->lane_pair && !h->lane_cable) ? (uint32_t)((v + 63) & ~63L) : 0u;
     }
-    if (h->chunk && !std::getenv("CDPR_LOWREG")) h->lowreg = false;  // every block runs at <= 65 536 robots: the role-split kernel's range
+    if (h->chunk && h->chunk <= 90112u && !std::getenv("CDPR_LOWREG")) h->lowreg = false;  // every block runs in the role-split kernel's range
   }
   // second-generation one-step kernel: wins wherever there is a Newton stage to hide the controller rows under, and
   // without one from ~32 768 robots on (65 536 x 8, no FK: 6.3 vs 7.0 us/step); small batches without FK are pure

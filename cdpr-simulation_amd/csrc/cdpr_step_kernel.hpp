@@ -128,10 +128,6 @@ struct StepArgs {
   float wrow[kWin + 2];
   int nbuf, clamp_cmd;
   uint32_t split_swap;  // cdpr_split_kernel: workgroups whose index has odd parity under this mask swap the roles of their waves
-  // LOWREG launches over more robots than hardware lanes: the workgroups that fill the SECOND wave slot of every SIMD
-  // (workgroup index / stagger_period odd) sleep stagger_sleeps x 2 048 cycles (~1 us) before their first load, so that
-  // the two co-resident waves of a SIMD are out of phase: one loads or stores while the other computes.  0: off.
-  uint32_t stagger_sleeps, stagger_period;
 };
 
 __host__ __device__ constexpr int plat_slots(bool fk) { return fk ? 5 : 4; }
@@ -806,9 +802,6 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   const bool live = r < units;
   const size_t st = a.stride;
 
-  if (LOWREG && a.stagger_sleeps != 0u && ((blockIdx.x / a.stagger_period) & 1u)) {
-    for (uint32_t k = 0; k < a.stagger_sleeps; ++k) __builtin_amdgcn_s_sleep(32);
-  }
   // geometry load first (oldest outstanding load), then the robot's whole record: the LDS fill
   // below waits for the geometry only, the record stays in flight behind it
   CDPR_STAMP(0);
