@@ -52,6 +52,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide
 FLOP_PER_STATE_STEP = {8: 6325, 4: 648}
 METRIC = "CDPR sim-steps/sec (whole node), 65 536 parallel 8-cable robots, 1 ms dt"
 CONFIGS = {2: dict(batch=4096, cables=4), 3: dict(batch=65536, cables=8)}
+SCHED_CHUNK = 1000  # world steps per launch on the scheduled path (small batches)
 FUSED_WARM, FUSED_LAUNCHES = 3, 30  # the fused leg's own schedule: untimed / minimum timed launches of 10 steps each
 ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
 
@@ -322,6 +323,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default: the config's)")
     ap.add_argument("--cables", type=int, default=None, choices=(4, 8))
     ap.add_argument("--steps-per-launch", type=int, default=1)
+    ap.add_argument("--launch-per-step", action="store_true", help="small batches: one launch per world step (hipGraph replays) instead of the scheduled update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fused / rollout secondary figures")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -451,16 +453,24 @@ def main():
     sched = [eng.device_upload(command(j)) for j in range(n_cmd)]
     count = args.batch * n
 
-    # Small batches (a launch shorter than the host's ~3.5 us launch cost: config 2) are host-bound unless the launches
-    # replay from a captured hipGraph, and a graph is tied to the buffer its kernels read: there the Joy batch is copied
-    # (device to device, 64 KiB) into the handle's own latched buffer instead of being read in place.
-    copy_commands = args.batch * n <= 131072
+    # Small batches (config 2: a 4 096 x 4 step is 1.4 us of work behind 3-4 us of launch) take the whole schedule in one
+    # launch per SCHED_CHUNK steps (cdpr_update_scheduled: the Joy batch of every 10th step is read from the schedule in
+    # HBM inside the kernel, every step's observables are written, bit-identical to the launch-per-step path: tested)
+    scheduled = args.batch * n <= 131072 and args.steps_per_launch == 1 and not args.launch_per_step
+    d_sched_all = eng.device_upload(np.stack([command(j) for j in range(n_cmd)])) if scheduled else 0
 
     def advance(first_step, nsteps):
         done = 0
         while done < nsteps:
             s = first_step + done
-            if s % refresh == 0 and copy_commands:
+            if scheduled and s % refresh == 0:
+                k = min(SCHED_CHUNK, nsteps - done)
+                eng.update_scheduled(k, refresh, d_sched_all + (s // refresh) * count * 4)
+                done += k
+                continue
+            if s % refresh == 0 and args.batch * n <= 131072:
+                # launch per step on a small batch: the launches replay from captured hipGraphs, and a graph is tied to the buffer
+                # its kernels read, so the Joy batch is copied (device to device, 64 KiB) into the handle's own latched buffer
                 eng.set_velocity_command_device(sched[s // refresh], count)
             elif s % refresh == 0:  # the schedule lives in HBM: the engine reads the Joy batch in place (zero copy)
                 eng.bind_velocity_command_device(sched[s // refresh], count)
@@ -657,6 +667,8 @@ def main():
                 "robots_per_gpu": args.batch,
                 "cables": n,
                 "steps_per_launch": args.steps_per_launch,
+                "launch_form": (f"cdpr_update_scheduled: one launch per {SCHED_CHUNK} steps, Joy batches read from the schedule inside the kernel" if scheduled
+                                else "one launch per world step" if args.steps_per_launch == 1 else f"{args.steps_per_launch} steps per launch"),
                 "mapping": eng.mapping,
                 "state_finite": finite,
                 "rendezvous": ctx.backend_name(),  # "none" (one rank), "nccl" (= RCCL) or "gloo": barrier + max only, no data-path collective

@@ -58,6 +58,8 @@ struct cdpr_engine {
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
   bool split = false;       // FK + TD one-step launches use cdpr_split_kernel (estimator wave + controller wave per 64 robots)
+  int sched_refresh = 0;            // cdpr_update_scheduled in progress: Joy batches per launch (StepArgs::sched_*)
+  const uint32_t* sched_ready = nullptr;
   uint32_t chunk = 0;       // > 0: a step over the batch is issued as back-to-back launches over contiguous blocks of at most
                             // this many robots (batches between one and ~5 robots per hardware lane: see cdpr_create)
   bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
@@ -780,7 +782,9 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
   a.cmd = frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0])
               : vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
   a.wtab = h->d_wtab64 + (vel ? 0 : kWin * (kWin + 2));
-  F64Kernel kern = pick_f64_kernel(n);
+  // the rings in LDS (64 KiB per wave at n = 8: two waves per CU) while the batch leaves CUs to spare
+  static const int ring_env = [] { const char* v = std::getenv("CDPR_F64_RING_LDS"); return v ? atoi(v) : -1; }();
+  F64Kernel kern = pick_f64_kernel(n, ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u);
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
@@ -885,7 +889,7 @@ void launch_step(cdpr_engine* h, StepKernel kern, uint32_t robots_per_block, dim
 
 int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullptr) {
   if (!h) return CDPR_ERR_INVALID;
-  if (nsteps < 0 || per_launch < 1 || per_launch > 64) {
+  if (nsteps < 0 || per_launch < 1 || (per_launch > 64 && !h->sched_refresh)) {
     h->err = "nsteps must be >= 0 and steps_per_launch in 1..64";
     return CDPR_ERR_INVALID;
   }
@@ -1091,7 +1095,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // (the ring position advances with every step, so a captured chain is only valid from the position it was captured at:
     //  part of the cache key; the call count must be saturated (per-robot handles keep theirs on the device))
     if (record) a.obs = record + (size_t)done * image;
-    const bool steady = !record && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && (h->per_robot || a.pid_calls == kCallSat || h->mode == kModeForce) &&
+    const bool steady = !record && !h->sched_refresh && h->use_graphs && (size_t)h->batch * h->n <= 131072u && !first_world && (h->per_robot || a.pid_calls == kCallSat || h->mode == kModeForce) &&
                         h->cfg.publish_period == 0.0 && (nsteps - done) >= kGraphChunk * k;
     if (steady) {
       a.publish_mask = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
@@ -1140,11 +1144,19 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     }
 
     a.publish_mask = 0;
-    for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
-      const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
-      if ((now - h->prev_publish) > h->cfg.publish_period) {
-        h->prev_publish = now;
-        a.publish_mask |= (1ull << j);
+    if (h->sched_refresh) {  // a whole schedule in one launch (publish_period == 0: every step but world step 0 is published)
+      a.flags |= kFlagPublishAll;
+      a.sched_refresh = h->sched_refresh;
+      a.sched_stride = (size_t)h->batch * h->n;
+      a.sched_ready = h->sched_ready;
+      h->prev_publish = sim_time(h->step + (uint64_t)k - 1, h->cfg.dt);
+    } else {
+      for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
+        const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
+        if ((now - h->prev_publish) > h->cfg.publish_period) {
+          h->prev_publish = now;
+          a.publish_mask |= (1ull << j);
+        }
       }
     }
     launch_step(h, kern, robots_per_block, block, a);
@@ -1747,6 +1759,45 @@ int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void* 
     return CDPR_ERR_INVALID;
   }
   return run_steps(h, nsteps, steps_per_launch, static_cast<float4*>(d_record));
+}
+
+int cdpr_update_scheduled(cdpr_handle_t h, int nsteps, int refresh_steps, const float* d_commands, const uint32_t* d_ready, void* d_record,
+                          size_t record_bytes) {
+  if (!h) return CDPR_ERR_INVALID;
+  if (h->general || h->fp64 || h->per_robot || h->lane_cable) {
+    h->err = "cdpr_update_scheduled: uniform-mode handles on the register-resident path, one or two lanes per robot, only";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (h->cfg.publish_period != 0.0) {
+    h->err = "cdpr_update_scheduled needs publish_period == 0 (every step published)";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (nsteps < 0 || refresh_steps < 1 || !d_commands) {
+    h->err = "cdpr_update_scheduled: nsteps >= 0, refresh_steps >= 1 and the command schedule are required";
+    return CDPR_ERR_INVALID;
+  }
+  const size_t image = (size_t)h->n_obs * h->stride;
+  if (d_record && record_bytes < image * sizeof(float4) * (size_t)nsteps) {
+    h->err = "cdpr_update_scheduled: record buffer smaller than nsteps observable images";
+    return CDPR_ERR_INVALID;
+  }
+  if (nsteps == 0) return CDPR_OK;
+  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
+  // the first Joy of the schedule arrives as any jointVelocities Joy does: pending commands of the other kinds are latched
+  // first (run_steps' order), then this one; entering Velocity mode resets the Pid (JFC.cpp:113-115)
+  h->ext_vel[1] = d_commands;
+  h->vel_pending = true;
+  h->vel_masked = false;
+  // one launch: latch + nsteps steps with the schedule's refresh inside the kernel
+  h->sched_refresh = refresh_steps;
+  h->sched_ready = d_ready;
+  const int rc = run_steps(h, nsteps, nsteps, static_cast<float4*>(d_record));
+  h->sched_refresh = 0;
+  h->sched_ready = nullptr;
+  if (rc != CDPR_OK) return rc;
+  const int last = (nsteps - 1) / refresh_steps;
+  if (h->mode == kModeVelocity) h->ext_vel[0] = d_commands + (size_t)last * h->batch * h->n;  // the batch that stays latched
+  return CDPR_OK;
 }
 
 int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position, float* velocity, float* effort,

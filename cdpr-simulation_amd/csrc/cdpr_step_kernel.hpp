@@ -52,6 +52,8 @@ enum StepFlags : uint32_t {
   kFlagFirstWorldStep = 1u << 0,    // JFC.cpp:61-66: stepTime <= 0 at t = 0 -> force 0, no Pid call
   kFlagRolloutResetPid = 1u << 1,   // rollout entered from Position mode: setVelocityTarget resets the Pid (JFC.cpp:113-115)
   kFlagActualIsVelocity = 1u << 2,  // velocity mode: Pid sees joint velocity (JFC.cpp:76), else position (JFC.cpp:88)
+  kFlagPublishAll = 1u << 4,        // every step of the launch is published (publishPeriod 0; world step 0 never is, PLG.cpp:237): launches
+                                    // of more than 64 steps (cdpr_update_scheduled), where publish_mask has no bits left
   kFlagForceMode = 1u << 3,         // UpdateMode::Force (JFC.cpp:67-70): force = the commanded force, no Pid runs (uniform handles;
                                     // per-robot handles carry the mode per lane: meta mode bits 0)
 };
@@ -128,6 +130,12 @@ struct StepArgs {
   float wrow[kWin + 2];
   int nbuf, clamp_cmd;
   uint32_t split_swap;  // cdpr_split_kernel: workgroups whose index has odd parity under this mask swap the roles of their waves
+  // Command schedule inside a launch of several steps (cdpr_update_scheduled): every sched_refresh steps the lanes take the
+  // next Joy batch (batch j at cmd + j * sched_stride floats), after sched_ready[j] has become non-zero if a mailbox is
+  // given (a host that fills the schedule while the launch runs).  sched_refresh = 0: one Joy for the whole launch.
+  int sched_refresh;
+  size_t sched_stride;
+  const uint32_t* sched_ready;
 };
 
 __host__ __device__ constexpr int plat_slots(bool fk) { return fk ? 5 : 4; }
@@ -138,6 +146,23 @@ __host__ __device__ constexpr int state_slots(int n, bool fk) { return plat_slot
 __host__ __device__ constexpr int obs_slots(int n) { return 4 + 3 * joint_groups(n); }
 
 #define CDPR_DEV __device__ __forceinline__
+
+// Is step `step` of this launch published (PLG.cpp:236-242)?
+CDPR_DEV bool step_published(const StepArgs& a, int step) {
+  if (a.flags & kFlagPublishAll) return !(step == 0 && (a.flags & kFlagFirstWorldStep));
+  return ((a.publish_mask >> step) & 1ull) != 0ull;
+}
+// The mailbox of a scheduled launch: wait until Joy batch j is there (the host, or a producer kernel on another stream, sets
+// the word after it has written the batch)
+CDPR_DEV void sched_wait(const StepArgs& a, int j) {
+  if (a.sched_ready) {
+    // (bounded: ~2^23 polls of ~0.5 us; a producer that never delivers must not hang the GPU - the launch then goes on with
+    //  whatever the schedule holds)
+    for (uint32_t spins = 0; spins < (1u << 23) && __hip_atomic_load(a.sched_ready + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u; ++spins)
+      __builtin_amdgcn_s_sleep(16);
+  }
+}
+
 
 // Diagnostic build only (-DCDPR_STAMPS, scripts/stamp_probe.py): per-wave s_memrealtime stamps (100 MHz) at the
 // phase boundaries of the step kernel, written to a buffer of their own (StepArgs.stamps); never compiled into
@@ -828,8 +853,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 #pragma unroll
   for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
   const float* vec_in = EXT ? a.force : a.cmd;  // never null: before the first Joy the latched buffer holds zeros
-  if (!ROLLOUT) {
-    const float* cp = vec_in + (size_t)rr * N;
+  auto load_joy = [&](const float* cp) {  // one robot's Joy.axes (float[N]) as cable pairs
     if (N % 4 == 0) {
 #pragma unroll
       for (int g = 0; g < N / 4; ++g) {
@@ -846,7 +870,9 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
           desired[i / 2].x = cp[i];
       }
     }
-  }
+  };
+  if (!SINGLE && !ROLLOUT && !EXT && a.sched_refresh > 0) sched_wait(a, 0);
+  if (!ROLLOUT) load_joy(vec_in + (size_t)rr * N);
 
   if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
   // single-wave workgroup: LDS operations of one wave execute in order, so the broadcast reads
@@ -916,6 +942,12 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   }
 
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
+    if (!SINGLE && !ROLLOUT && !EXT && a.sched_refresh > 0 && step > 0 && step % a.sched_refresh == 0) {
+      // a launch over a command schedule (cdpr_update_scheduled): the next Joy batch at every refresh boundary
+      const int j = step / a.sched_refresh;
+      sched_wait(a, j);
+      load_joy(a.cmd + (size_t)j * a.sched_stride + (size_t)rr * N);
+    }
     if (ROLLOUT) {  // this step's Joy for this trajectory
       const float* cp = a.roll_cmd + (((size_t)rr * a.nsteps + step) * a.roll_samples + sample) * N;
       if (N % 4 == 0) {
@@ -950,7 +982,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
     // the observables that are final already go out here (7 of 10 rows at n = 8): every wave of a launch reaches its
     // stores at the same moment, and ten rows per robot in one burst back the store path up when each step writes a NEW
     // image (trajectory record); spread over the step they drain under the Newton stage
-    if (!ROLLOUT && ((a.publish_mask >> step) & 1ull) && live) {
+    if (!ROLLOUT && step_published(a, step) && live) {
       float4* const obs = a.obs + (size_t)step * a.obs_step_stride;
       store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
       store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
@@ -1159,7 +1191,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 
     CDPR_STAMP(5);
     // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
-    if (!ROLLOUT && ((a.publish_mask >> step) & 1ull) && live) {
+    if (!ROLLOUT && step_published(a, step) && live) {
       float4* const obs = a.obs + (size_t)step * a.obs_step_stride;
 #if !CDPR_EARLY_OBS
       store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));

@@ -53,6 +53,24 @@ struct F64Args {
 __host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
 __host__ __device__ constexpr int f64_obs_rows(int n) { return 16 + 3 * n; }
 
+// 1 / sqrt(x) to double precision: v_rsq_f64 (about 26 good bits) + two Newton steps, y <- y + y e / 2 with e = 1 - x y^2
+// (quadratic: 2^-26 -> 2^-51 -> rounding).  The library's sqrt() followed by a division is ~55 double instructions, this is
+// 9 - and the step evaluates 9 structure matrices and 5 Cholesky factorizations per robot.  Agreement with the fp64 CPU restatement
+// stays at the 1e-15 level (tests/test_gpu_fp64.py).
+__device__ __forceinline__ double rsqrt64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  e = fma(-x * y, y, 1.0);
+  y = fma(0.5 * y, e, y);
+  return y;
+}
+// sqrt(x) = x * rsqrt(x), with one correction step on the product (s <- s + (x - s^2) y / 2)
+__device__ __forceinline__ double sqrt_from_rsqrt64(double x, double y) {
+  const double s0 = x * y;
+  return fma(fma(-s0, s0, x), 0.5 * y, s0);
+}
+
 struct Rot64 {
   double r00, r01, r02, r10, r11, r12, r20, r21, r22;
 };
@@ -118,7 +136,7 @@ __device__ __forceinline__ void sinc_cos64(double x, double& sinc, double& c) {
 // q <- exp(theta / 2) (x) q, renormalised (world-frame rotation increment)
 __device__ __forceinline__ void quat_apply_rotvec64(double (&q)[4], double tx, double ty, double tz) {
   const double a2 = tx * tx + ty * ty + tz * tz;
-  const double a = sqrt(a2);
+  const double a = (a2 > 0.0) ? sqrt_from_rsqrt64(a2, rsqrt64(a2)) : 0.0;
   double sinc, c;
   sinc_cos64(0.5 * a, sinc, c);
   const double k = 0.5 * sinc;  // sin(a/2) / a
@@ -128,7 +146,7 @@ __device__ __forceinline__ void quat_apply_rotvec64(double (&q)[4], double tx, d
   const double nx = c * x + w * dx + dy * z - dz * y;
   const double ny = c * y + w * dy + dz * x - dx * z;
   const double nz = c * z + w * dz + dx * y - dy * x;
-  const double inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+  const double inv = rsqrt64(nx * nx + ny * ny + nz * nz + nw * nw);
   q[0] = nx * inv;
   q[1] = ny * inv;
   q[2] = nz * inv;
@@ -141,8 +159,9 @@ __device__ __forceinline__ void ik_row64(const double* g, const Rot64& r, const 
   const double rby = r.r10 * g[3] + r.r11 * g[4] + r.r12 * g[5];
   const double rbz = r.r20 * g[3] + r.r21 * g[4] + r.r22 * g[5];
   const double lx = p[0] + rbx - g[0], ly = p[1] + rby - g[1], lz = p[2] + rbz - g[2];
-  L = sqrt(lx * lx + ly * ly + lz * lz);
-  const double inv = 1.0 / L;
+  const double l2 = lx * lx + ly * ly + lz * lz;
+  const double inv = rsqrt64(l2);
+  L = sqrt_from_rsqrt64(l2, inv);
   const double ux = lx * inv, uy = ly * inv, uz = lz * inv;
   j[0] = ux;
   j[1] = uy;
@@ -160,7 +179,7 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
     double d = m[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) d -= m[j][k] * m[j][k];
-    invd[j] = 1.0 / sqrt(d);
+    invd[j] = rsqrt64(d);
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double s = m[i][j];
@@ -189,9 +208,13 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 // with a run-time index: the structure matrix is never held as a whole, every stage rebuilds the rows it needs and
 // accumulates J^T J / J^T v on the fly.  (Fully unrolled, with both structure matrices in registers, the double
 // version of this kernel needed 512 registers and 2 KiB of scratch per lane.)
-template <int N>
+// RING_LDS: the derivative rings of a lane's cables are loaded once, in one batch, into LDS columns (40 KiB per wave at
+// n = 8) and written back at the end: the FIR then costs no memory round trip per cable and step (small batches: the step
+// is one latency chain).  Otherwise they stay in HBM / L2 (large batches: four waves per CU need the LDS).
+template <int N, bool RING_LDS = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
+  __shared__ double c_win[RING_LDS ? N : 1][RING_LDS ? kWin : 1][64];
   const uint32_t lane = threadIdx.x;
   const uint32_t r = blockIdx.x * 64u + lane;
   if (r >= a.batch) return;  // no barrier below: lanes are independent, LDS columns are private
@@ -202,11 +225,15 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   double v[3] = {S[7 * st], S[8 * st], S[9 * st]}, om[3] = {S[10 * st], S[11 * st], S[12 * st]};
   double fkp[3] = {S[13 * st], S[14 * st], S[15 * st]};
   double fkq[4] = {S[16 * st], S[17 * st], S[18 * st], S[19 * st]};
-  // the derivative ring stays in HBM / L2 (read by the FIR of every step, one slot written back)
-#pragma unroll 1
+  // the integrals and the commands (and, RING_LDS, the derivative rings) in one batch of loads
+#pragma unroll
   for (int i = 0; i < N; ++i) {
     c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
     c_des[i][lane] = (double)a.cmd[(size_t)r * N + i];
+    if (RING_LDS) {
+#pragma unroll
+      for (int k = 0; k < kWin; ++k) c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] = S[(size_t)(20 + 11 * i + k) * st];
+    }
   }
   const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
   int calls = a.pid_calls;
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           const double error = desired - (actual_is_vel ? qd : q);
           double acc = wt[kWin] * error;
 #pragma unroll
-          for (int k = 0; k < kWin; ++k) acc += wt[k] * S[(size_t)(20 + 11 * i + k) * st];
+          for (int k = 0; k < kWin; ++k) acc += wt[k] * (RING_LDS ? c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] : S[(size_t)(20 + 11 * i + k) * st]);
           const double p_term = a.kp * error;
           const double prev_ierr = c_ierr[i][lane];
           double ie = prev_ierr + a.dt * error;
@@ -260,7 +287,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           }
           c_ierr[i][lane] = ie;
           force = out;
-          S[(size_t)(20 + 11 * i + ring_slot) * st] = error;  // after the FIR has read the slot's old content
+          if (RING_LDS)
+            c_win[RING_LDS ? i : 0][RING_LDS ? ring_slot : 0][lane] = error;
+          else
+            S[(size_t)(20 + 11 * i + ring_slot) * st] = error;  // after the FIR has read the slot's old content
           if (i == 0) {
             dbg_p = p_term;
             dbg_i = i_raw;
@@ -433,7 +463,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       const double ny = y + h * (ww * om[1] + om[2] * x - om[0] * z);
       const double nz = z + h * (ww * om[2] + om[0] * y - om[1] * x);
       const double nw = ww - h * (om[0] * x + om[1] * y + om[2] * z);
-      const double inv = 1.0 / sqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+      const double inv = rsqrt64(nx * nx + ny * ny + nz * nz + nw * nw);
       q4[0] = nx * inv;
       q4[1] = ny * inv;
       q4[2] = nz * inv;
@@ -454,7 +484,13 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     S[(size_t)(16 + c) * st] = fkq[c];
   }
 #pragma unroll 1
-  for (int i = 0; i < N; ++i) S[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
+  for (int i = 0; i < N; ++i) {
+    S[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
+    if (RING_LDS) {
+#pragma unroll
+      for (int k = 0; k < kWin; ++k) S[(size_t)(20 + 11 * i + k) * st] = c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane];
+    }
+  }
 }
 
 // Read-out of double rows into robot-major arrays (double or float), one thread per (robot, column)

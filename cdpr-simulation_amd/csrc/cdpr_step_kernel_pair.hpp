@@ -86,8 +86,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
   v2f desired[NPL];
 #pragma unroll
   for (int k = 0; k < NPL; ++k) desired[k] = splat(0.f);
-  {
-    const float* cp = a.cmd + (size_t)rr * N + c0;
+  auto load_joy = [&](const float* cp) {  // this lane's half of one robot's Joy.axes
     if (NL == 4) {
       const float4 v = *reinterpret_cast<const float4*>(cp);
       desired[0] = (v2f){v.x, v.y};
@@ -96,7 +95,9 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       const float2 v = *reinterpret_cast<const float2*>(cp);
       desired[0] = (v2f){v.x, v.y};
     }
-  }
+  };
+  if (!SINGLE && a.sched_refresh > 0) sched_wait(a, 0);
+  load_joy(a.cmd + (size_t)rr * N + c0);
 
   if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -130,6 +131,12 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
   int calls = a.pid_calls;
 
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
+    if (!SINGLE && a.sched_refresh > 0 && step > 0 && step % a.sched_refresh == 0) {
+      // a launch over a command schedule (cdpr_update_scheduled): the next Joy batch at every refresh boundary
+      const int j = step / a.sched_refresh;
+      sched_wait(a, j);
+      load_joy(a.cmd + (size_t)j * a.sched_stride + (size_t)rr * N + c0);
+    }
     CDPR_STAMP(1);
     // ---- IK rows of this lane's cables on the state at t_k
     v2f len[NPL], jac[NPL][6], l0[NPL], q[NPL], qd[NPL];
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
       mine <<= par * NL;
       limit_mask = mine | __float_as_uint(partner(__uint_as_float(mine)));
     }
-    if (((a.publish_mask >> step) & 1ull) && live) {
+    if (step_published(a, step) && live) {
       if (par == 0u) {
         store_slot(obs, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
         store_slot(obs, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(64, 2) void cdpr_step_kernel_pair(const StepArgs a)
     if (NL == 2) {  // n = 4: one group of four = both lanes' pairs; lane 0 collects the partner's pair
       const float oq0 = partner(q[0].x), oq1 = partner(q[0].y), ov0 = partner(qd[0].x), ov1 = partner(qd[0].y);
       const float oa0 = partner(applied[0].x), oa1 = partner(applied[0].y);
-      if (((a.publish_mask >> step) & 1ull) && live && par == 0u) {
+      if (step_published(a, step) && live && par == 0u) {
         store_slot(obs, st, 4, woff, make_float4(q[0].x, q[0].y, oq0, oq1));
         store_slot(obs, st, 4 + G, woff, make_float4(qd[0].x, qd[0].y, ov0, ov1));
         store_slot(obs, st, 4 + 2 * G, woff, make_float4(applied[0].x, applied[0].y, oa0, oa1));

@@ -2,7 +2,7 @@
 #include "cdpr_kernels.hpp"
 namespace cdpr {
 namespace {
-template <int N> F64Kernel f64_n() { return cdpr_step_kernel_f64<N>; }
+template <int N> F64Kernel f64_n(bool ring_lds) { return ring_lds ? cdpr_step_kernel_f64<N, true> : cdpr_step_kernel_f64<N, false>; }
 }  // namespace
-F64Kernel pick_f64_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_n); }
+F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds) { CDPR_PICK_CABLES(f64_n, ring_lds); }
 }  // namespace cdpr

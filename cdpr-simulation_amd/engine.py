@@ -136,6 +136,13 @@ class Engine:
         """As update_record, into a caller-owned device buffer (nothing is copied back)."""
         self._check(lib().cdpr_update_record(self._h, int(nsteps), int(steps_per_launch), C.c_void_p(d_record), record_bytes))
 
+    def update_scheduled(self, nsteps: int, refresh_steps: int, d_commands: int, d_record: int = 0, record_bytes: int = 0, d_ready: int = 0) -> None:
+        """A whole jointVelocities schedule in one launch: Joy batch j (device buffer float[batches][B][n] at d_commands) is
+        latched at step j * refresh_steps; every step's observables go to the record (device buffer) if one is given.
+        d_ready: optional device-visible uint32[batches] mailbox (batch j is taken once d_ready[j] != 0)."""
+        self._check(lib().cdpr_update_scheduled(self._h, int(nsteps), int(refresh_steps), C.c_void_p(d_commands), C.c_void_p(d_ready) if d_ready else None,
+                                                C.c_void_p(d_record) if d_record else None, int(record_bytes)))
+
     def update_record(self, nsteps: int, steps_per_launch: int = 10):
         """Advance nsteps world steps (fused launches) and return the observables of EVERY step:
         dict of arrays position/velocity/effort [nsteps, B, n], pose [nsteps, B, 7], twist [nsteps, B, 6]."""
@@ -156,6 +163,13 @@ class Engine:
             self._check(lib().cdpr_decode_observables(self._h, img.ctypes.data_as(C.c_void_p), _fp(out["position"][j]), _fp(out["velocity"][j]),
                                                       _fp(out["effort"][j]), _fp(out["pose"][j]), _fp(out["twist"][j])))
         return out
+
+    def decode_observables(self, image: np.ndarray):
+        """One downloaded observable image (uint8[observable_image_bytes]) -> (position, velocity, effort, pose7, twist6)."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        out = [np.empty((self.B, w), dtype=np.float32) for w in (self.n, self.n, self.n, 7, 6)]
+        self._check(lib().cdpr_decode_observables(self._h, img.ctypes.data_as(C.c_void_p), *[_fp(o) for o in out]))
+        return tuple(out)
 
     def synchronize(self) -> None:
         self._check(lib().cdpr_synchronize(self._h))
@@ -333,6 +347,11 @@ class Engine:
         self._check(lib().cdpr_device_malloc(self._h, a.nbytes, C.byref(ptr)))
         self._check(lib().cdpr_device_upload(self._h, ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
         return int(ptr.value)
+
+    def device_upload_into(self, dptr: int, array: np.ndarray) -> None:
+        """Host array into an existing device buffer, on THIS handle's stream (e.g. to fill another handle's mailbox)."""
+        a = np.ascontiguousarray(array)
+        self._check(lib().cdpr_device_upload(self._h, C.c_void_p(dptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
 
     def device_alloc(self, nbytes: int) -> int:
         ptr = C.c_void_p()

@@ -253,6 +253,19 @@ int cdpr_observable_image_bytes(cdpr_handle_t h, size_t *bytes);
 int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void *d_record, size_t record_bytes);
 int cdpr_decode_observables(cdpr_handle_t h, const void *image, float *position, float *velocity, float *effort,
                             float *pose7, float *twist6);
+/* A whole command schedule in ONE launch: what `for j: cableVelocityCommandCallback(batch j); refresh_steps x update()`
+ * does (the reference's 100 Hz publishers against the 1 kHz world: a Joy every 10 world steps, PLG.cpp:206-211 +
+ * sinevelocitytest.cpp:34-48), for callers whose batch is too small for a launch per step to pay (a 4 096 x 4-cable step
+ * is 1.4 us of work behind 3-4 us of launch).  d_commands: DEVICE buffer float[ceil(nsteps / refresh_steps)][B][n], Joy
+ * batch j is latched at world step first + j * refresh_steps.  d_ready: optional DEVICE-visible mailbox uint32[batches]:
+ * the launch takes batch j only once d_ready[j] != 0 (a host or a producer kernel that fills the schedule while the
+ * launch runs; pinned host memory mapped to the device works); NULL = the whole schedule is there.  d_record: as
+ * cdpr_update_record (every step's observable image kept), or NULL (each published step overwrites the last, as the topic
+ * does).  Bit-identical to the call sequence above (tested).  Afterwards the last batch stays latched (it must stay valid
+ * like a bound buffer).  Needs publish_period == 0, a uniform-mode handle on the register-resident path with one lane or two
+ * lanes per robot; CDPR_ERR_UNSUPPORTED otherwise.  Asynchronous. */
+int cdpr_update_scheduled(cdpr_handle_t h, int nsteps, int refresh_steps, const float *d_commands, const uint32_t *d_ready,
+                          void *d_record, size_t record_bytes);
 /* Waits until everything queued on the handle has completed.  Every wait of the library polls the stream for up to 2 ms
  * before it blocks (a blocked host thread wakes up 15-25 us late, two step kernels; environment CDPR_SYNC_SPIN_US
  * overrides, 0 = always block). */

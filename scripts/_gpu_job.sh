@@ -1,21 +1,8 @@
 cd $GRAFT_REPO_ROOT
-cat > /tmp/t.py <<'PY'
-import sys, os, numpy as np
-sys.path.insert(0, '.')
-import cdpr_simulation_amd as pkg, bench
-for B in (16384, 65536):
-    model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 10)
-    eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3, velocityEpsilon=0.001), 0)
-    eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(50); eng.synchronize()
-    ts = []
-    for _ in range(7):
-        eng.profile_begin(); eng.update(100); ms, nl = eng.profile_end(); ts.append(ms / 100 * 1e3)
-    print(os.environ.get("LABEL"), B, "us/step %.2f (min %.2f)" % (np.median(ts), min(ts)), flush=True)
-    eng.close()
-PY
-for rep in 1 2; do
-LABEL="group 1" python /tmp/t.py
-LABEL="group 2" CDPR_LIB=libcdpr_hip_g2.so python /tmp/t.py
-LABEL="group 4" CDPR_LIB=libcdpr_hip_g4.so python /tmp/t.py
-done
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+timeout 600 python -m pytest tests/test_gpu_force_mode.py -x -q -k "scheduled" 2>&1 | tail -8
+python bench.py --config 2 --no-cpu-baseline > gpurun_out/r04_bench_config2.json 2> gpurun_out/r04_bench_config2.err; tail -c 600 gpurun_out/r04_bench_config2.err; python -c "
+import json; d=json.load(open('gpurun_out/r04_bench_config2.json')); print({k: d[k] for k in ('value','ms_per_step')}, d['config']['launch_form'], d['roofline']['frac'], d['parity_check']['ok'], d.get('fused',{}).get('value'))"
+python bench.py --config 2 --no-cpu-baseline --launch-per-step --no-secondary | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('launch per step', {k: d[k] for k in ('value','ms_per_step')}, d['parity_check']['ok'])"
+python bench.py --no-cpu-baseline --steps 2000 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('config3', {k: d[k] for k in ('value','ms_per_step')}, d['roofline']['frac'], d['parity_check']['ok'], 'fused', d['fused']['value'], 'rollout', d['rollout']['f32_vector_frac'], d['rollout']['parity_check']['ok'])"

@@ -231,3 +231,76 @@ def test_chunked_launches_are_bit_identical_to_one_launch(pkg, monkeypatch, per_
         assert np.array_equal(x, y)
     for key in a[2]:
         assert np.array_equal(a[2][key], b[2][key]), key
+
+
+@pytest.mark.parametrize("cables,stages,mapping_env", [(4, 0, "2"), (4, 0, "1"), (8, 3, "1"), (8, 0, "2")])
+def test_scheduled_update_equals_the_call_sequence(pkg, oracle, monkeypatch, cables, stages, mapping_env):
+    """cdpr_update_scheduled (a whole jointVelocities schedule in ONE launch, Joy batch j latched at step 10 j, every step's
+    observables recorded) against what it replaces - set_velocity_command_device + update_record per batch - bit for bit,
+    from Load (world step 0, Position mode: the first Joy resets the velocity Pid) and again in steady state; 137 steps
+    (ragged last hold); the last batch stays latched; and against the oracle."""
+    monkeypatch.setenv("CDPR_MAPPING", mapping_env)
+    B, T, refresh = 300, 137, 10
+    rng = np.random.default_rng(90 + cables)
+    model = pkg.cube_model() if cables == 4 else pkg.eight_cable_model()
+    cfg = pkg.Config(model=model, batch=B, stages=stages)
+    pose = perturbed_poses(model, B, rng, 0.02, 0.05).astype(np.float32)
+    nb = (T + refresh - 1) // refresh
+    a, b = pkg.Engine(cfg, 0), pkg.Engine(cfg, 0)
+    ora = oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+    ora.set_platform_state(pose7=pose.astype(np.float64))
+    for e in (a, b):
+        e.set_platform_state(pose7=pose)
+    image = a.observable_image_bytes()
+    for rnd in range(2):
+        sched = rng.uniform(-0.03, 0.03, (nb, B, cables)).astype(np.float32)
+        d_sched = a.device_upload(sched)
+        d_rec = a.device_alloc(image * T)
+        a.update_scheduled(T, refresh, d_sched, d_rec, image * T)
+        raw = a.device_download(d_rec, (T, image), dtype=np.uint8)
+        eff_a = np.array([a.decode_observables(raw[j])[2] for j in range(T)])
+        eff_b = []
+        for j in range(nb):
+            b.set_velocity_command(sched[j]), ora.set_velocity_command(sched[j])
+            k = min(refresh, T - j * refresh)
+            rec = b.update_record(k, k)
+            eff_b.append(rec["effort"])
+            ora.update(k)
+        eff_b = np.concatenate(eff_b)
+        first = 1 if rnd == 0 else 0  # world step 0 is never published: its image is left as it was
+        assert np.array_equal(eff_a[first:], eff_b[first:]), f"round {rnd}"
+        for x, y in zip(a.platform_state() + a.joint_states(), b.platform_state() + b.joint_states()):
+            assert np.array_equal(x, y)
+        compare(a, ora, where=f"scheduled update, round {rnd}")
+        # the last batch stays latched: plain updates carry on with it
+        a.update(7), b.update(7), ora.update(7)
+        for x, y in zip(a.platform_state() + a.joint_states(), b.platform_state() + b.joint_states()):
+            assert np.array_equal(x, y)
+        a.device_free(d_rec)  # (the schedule stays: its last batch is the latched command)
+
+
+def test_scheduled_update_waits_for_its_mailbox(pkg):
+    """With a mailbox, batch j is only taken once ready[j] != 0: a second handle (its own stream) releases the batches one
+    by one while the launch spins; the result equals the launch without a mailbox."""
+    B, T, refresh = 64, 60, 10
+    rng = np.random.default_rng(4)
+    cfg = pkg.Config(batch=B)
+    sched = rng.uniform(-0.03, 0.03, (T // refresh, B, 4)).astype(np.float32)
+    out = []
+    for use_mailbox in (False, True):
+        eng, other = pkg.Engine(cfg, 0), pkg.Engine(pkg.Config(batch=1), 0)
+        eng.update(20)
+        d_sched = eng.device_upload(sched)
+        ready = np.zeros(T // refresh, np.uint32)
+        ready[0] = 1
+        d_ready = eng.device_upload(ready)
+        eng.update_scheduled(T, refresh, d_sched, d_ready=d_ready if use_mailbox else 0)
+        if use_mailbox:
+            for j in range(1, T // refresh):  # release batch by batch from another stream while the launch polls
+                ready[j] = 1
+                other.device_upload_into(d_ready, ready)
+        eng.synchronize()
+        out.append(eng.platform_state() + eng.joint_states())
+        eng.close(), other.close()
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
