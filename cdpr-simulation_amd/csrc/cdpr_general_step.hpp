@@ -290,7 +290,25 @@ CDPR_DEV float gen_finish(const GenBuf& RB, const GenSel c, int slot_h, int row_
 struct GenCtlConst {
   int pcas_max, dcas_max;
   float dt, inv_dt;
+#ifdef CDPR_STAMPS
+  unsigned long long* stamps;  // this wave's eight stamps (diagnostic build)
+#endif
 };
+#if defined(CDPR_STAMPS) && defined(CDPR_STAMPS_CTL)  // stamps 1..3 inside the controller instead of the phases before it
+#define GEN_CTL_STAMP(i)                                                                      \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if (kc.stamps && lane == 0) kc.stamps[i] = __builtin_amdgcn_s_memrealtime();              \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  } while (0)
+#define GEN_PHASE_STAMP(i) do { } while (0)
+#elif defined(CDPR_STAMPS) && defined(CDPR_STAMPS_PRO)  // stamps 2, 3 inside the prologue (loads back | Pid selection done)
+#define GEN_CTL_STAMP(i) do { } while (0)
+#define GEN_PHASE_STAMP(i) do { if ((i) == 1) CDPR_STAMP(1); } while (0)
+#else
+#define GEN_CTL_STAMP(i) do { } while (0)
+#define GEN_PHASE_STAMP(i) CDPR_STAMP(i)
+#endif
 struct GenDbg {
   float p, i, d, des;
   bool pi, dw;
@@ -316,6 +334,131 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
 #pragma unroll
   for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
   float newpos[N];
+
+  // ---- the steady state, decided for the whole wave: every cable of every robot calls a Pid that was called one world step
+  //      ago and whose window is a full uniform grid, no cascades, a command clamp - what a handle does on all steps but the
+  //      dozen after a mode change or a switch between the two Pids of a hold-branch cable.  Then Pid::update is the fast
+  //      path's arithmetic (Pid.cpp:128-186 with derive() as the closed-form FIR) plus the ring bookkeeping, without any of
+  //      the per-lane case selection below: ~70 vector instructions per cable instead of ~240.
+  // (a single wave per SIMD hides nothing: every dependent LDS round trip costs ~50 ns, so the reads of a phase are issued
+  //  for a group of cables together and the group then pays the latency once)
+  bool simple = (mode != 0) && !filters;
+  float4 hs[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) hs[i] = cab[i * kCab + NV * 64 + lane];
+  {
+    const float4 lim0 = ptab[0][1], lim1 = ptab[1][1];
+    const int nb0 = __float_as_int(ptab[0][2].x), nb1 = __float_as_int(ptab[1][2].x);
+    const bool clamp0 = lim0.z > lim0.w, clamp1 = lim1.z > lim1.w;  // cmdMax > cmdMin
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t meta = __float_as_uint(hs[i].x);
+      const int nbuf = sel[i] ? nb1 : nb0;
+      const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
+      simple = simple & ((meta & kGmWasLast) != 0u) & (count >= nbuf) & (run + 1 >= nbuf - 1) & (now - __float_as_int(hs[i].y) == 1) & (sel[i] ? clamp1 : clamp0);
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(!simple) == 0ull) {  // (wave-uniform)
+    GEN_CTL_STAMP(1);
+    constexpr int GW = (NV > 3) ? 2 : 4;               // cables per group (registers: 8 NV + 20 per cable)
+    constexpr int G = (N < GW) ? N : GW;
+#pragma unroll
+    for (int b = 0; b < N; b += G) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (b == G) GEN_CTL_STAMP(2);
+      float4 g0[G], g1[G], g2[G];  // kf kp ki kd | imax imin cmax cmin | nbuf . . 1/ki
+      float error[G], desired[G];
+      int nhead[G];
+      uint32_t nmeta[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int i = b + j;
+        if (i < N) {
+          const float4* pt = ptab[sel[i] ? 1 : 0];
+          g0[j] = pt[0], g1[j] = pt[1], g2[j] = pt[2];
+        }
+      }
+      // the new sample into its ring slot of the staged window
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int i = b + j;
+        if (i < N) {
+          const float qi = (i & 1) ? q[i / 2].y : q[i / 2].x;
+          const float qdi = (i & 1) ? qd[i / 2].y : qd[i / 2].x;
+          const bool sv = sel[i] != 0;
+          const bool hold = (mode == 2) && !sv;
+          const float held = comp4(held4[i / 4], i % 4);
+          desired[j] = hold ? held : target[i];  // JFC.cpp:81
+          newpos[i] = hold ? held : qi;          // JFC.cpp:75,87
+          error[j] = desired[j] - ((mode == 2 && sv) ? qdi : qi);
+          const uint32_t meta = __float_as_uint(hs[i].x);
+          const int nbuf = __float_as_int(g2[j].x);
+          const int head = (int)((meta >> kGmHeadShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
+          nhead[j] = (head + 1 == nbuf) ? 0 : head + 1;
+          nmeta[j] = kGmWasLast | ((uint32_t)nbuf << kGmCountShift) | ((uint32_t)nhead[j] << kGmHeadShift) | ((uint32_t)min(run + 1, (int)kGmField) << kGmRunShift);
+          (cabf + i * kCabF + lane)[(nhead[j] >> 2) * 256 + lane * 3 + (nhead[j] & 3)] = error[j];
+        }
+      }
+      // the window, its weights by ring head, and the slot that took the sample (as it goes back to the records)
+      float4 v[G][NV], vs[G], w[G][NV];
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int i = b + j;
+        if (i < N) {
+          const float4* cs = cab + i * kCab + lane;
+          const float4* wr = reinterpret_cast<const float4*>(wrot + ((sel[i] ? NBMAX : 0) + nhead[j]) * NBP);
+#pragma unroll
+          for (int s4 = 0; s4 < NV; ++s4) v[j][s4] = cs[s4 * 64], w[j][s4] = wr[s4];
+          vs[j] = cs[(nhead[j] >> 2) * 64];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int i = b + j;
+        if (i < N) {
+          const bool sv = sel[i] != 0;
+          const uint32_t va = col * 16u + (sv ? pid_a : 0u), vb = col * 4u + (sv ? pid_b : 0u);
+          const int sa = L.block_a(0, i), rb = L.block_b(0, i);
+          const float prev_ierr = hs[i].z;
+          const float p_term = g0[j].y * error[j];
+          float ie = fmaf(kc.dt, error[j], prev_ierr);  // dt = one world step
+          const float i_term = g0[j].z * ie;
+          if (i == 0) dbg.p = p_term, dbg.i = i_term, dbg.des = desired[j], dbg.pi = true;
+          const float i_cl = fmaxf(fminf(i_term, g1[j].x), g1[j].y);  // Pid.cpp:143-152
+          ie = (i_cl != i_term) ? i_cl * g2[j].w : ie;
+          float acc = 0.f;
+#pragma unroll
+          for (int s4 = 0; s4 < NV; ++s4)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (4 * s4 + k < NBMAX) acc = fmaf(comp4(w[j][s4], k), comp4(v[j][s4], k), acc);
+          const float d_term = g0[j].w * (acc * kc.inv_dt);
+          if (i == 0) dbg.d = d_term, dbg.dw = true;
+          const float cmd = ((g0[j].x * desired[j] + p_term) + i_cl) + d_term;  // Pid.cpp:170
+          float out = fmaxf(fminf(cmd, g1[j].z), g1[j].w);                       // Pid.cpp:175-177
+          const bool wind = out != cmd;                                           // Pid.cpp:181-184
+          ie = wind ? prev_ierr : ie;
+          out = wind ? fmaf(kc.dt * error[j], g0[j].z, out) : out;
+          force[i] = out;
+          if (live) {
+            RB.store4_if(true, sa, va + (uint32_t)(nhead[j] >> 2) * RB.rs16, vs[j]);
+            RB.storei_if(true, rb, vb + (uint32_t)nhead[j] * RB.rs4, now);
+            RB.store4_if(true, sa + L.nv(), va, make_float4(__uint_as_float(nmeta[j]), __int_as_float(now), ie, out));
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    GEN_CTL_STAMP(3);
+    if (live) {
+#pragma unroll
+      for (int g4 = 0; g4 < LP; ++g4)
+        RB.store4_if(true, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
+                                                      (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
+    }
+    return;
+  }
+
   uint32_t need = 0u;  // cables whose derivative comes from the fit queue
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -537,17 +680,54 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
   GenBuf RB = gen_buffer(g.rec, rs, g.rec_bytes, L);
   const uint32_t col = ru;  // record column: the robot, or this trajectory's private copy
 
+  CDPR_STAMP(0);
+  // every load of the prologue is issued before anything waits: one round trip to memory (a table loaded and stored to
+  // LDS in a loop costs a round trip per pass)
+  constexpr uint32_t kW4 = 2u * NBMAX * NBP / 4u;  // the weight table in float4
+  constexpr int kWPass = (int)((kW4 + 63u) / 64u);
+  static_assert((2 * NBMAX * NBP) % 4 == 0, "weight rows are float4 multiples");
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
+  float4 wv[kWPass];
+#pragma unroll
+  for (int j = 0; j < kWPass; ++j) wv[j] = reinterpret_cast<const float4*>(g.wtab)[min(lane + 64u * j, kW4 - 1u)];
+  const float pv = g.ptab[min(lane, 2u * kGenPidFloats - 1u)];
   const uint32_t off = rr * 16u, woff = r * 16u;
   const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
                p3 = load_slot(a.state, st, 3, off);
   float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
   if (FK) p4 = load_slot(a.state, st, 4, off);
   int mode = g.mode_arr ? (int)g.mode_arr[rr] : g.mode;
+  // the latched command of the lane's mode (constant over the launch unless this is a rollout); issued with the state
+  // loads: one round trip to memory, not two
+  const float* cmd_src = (mode == 2) ? g.vel_cmd : (mode == 1) ? g.pos_cmd : g.frc_cmd;
+  float target[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) target[i] = 0.f;
+  if (!ROLLOUT) {
+    if (g.mode_arr) {  // per-robot modes: the buffer differs from lane to lane
+#pragma unroll
+      for (int i = 0; i < N; ++i) target[i] = cmd_src ? cmd_src[(size_t)rr * N + i] : 0.f;
+    } else if (cmd_src) {
+      const float* cp = cmd_src + (size_t)rr * N;
+      if (N % 4 == 0) {
+#pragma unroll
+        for (int q4 = 0; q4 < N / 4; ++q4) {
+          const float4 v = reinterpret_cast<const float4*>(cp)[q4];
+          target[4 * q4] = v.x, target[4 * q4 + 1] = v.y, target[4 * q4 + 2] = v.z, target[4 * q4 + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) target[i] = cp[i];
+      }
+    }
+  }
+
   if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
-  for (uint32_t k = lane; k < 2u * NBMAX * NBP; k += 64u) (&wrot[0][0][0])[k] = g.wtab[k];
+#pragma unroll
+  for (int j = 0; j < kWPass; ++j)
+    if (lane + 64u * j < kW4) reinterpret_cast<float4*>(&wrot[0][0][0])[lane + 64u * j] = wv[j];
   if (lane == 0) q_count = 0u;
-  if (lane < 2 * kGenPidFloats) (&ptab[0][0].x)[lane] = g.ptab[lane];
+  if (lane < 2 * kGenPidFloats) (&ptab[0][0].x)[lane] = pv;
 
   if (ROLLOUT) {
     // private copy of the robot's records; a Joy on jointVelocities reaching a robot that is not in Velocity mode resets
@@ -575,6 +755,9 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+#ifdef CDPR_STAMPS_PRO
+  CDPR_STAMP(2);
+#endif
   Platform s;
   s.px = p0.x; s.py = p0.y; s.pz = p0.z; s.qx = p0.w;
   s.qy = p1.x; s.qz = p1.y; s.qw = p1.z; s.vx = p1.w;
@@ -587,30 +770,6 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     refy = a.roll_ref[(size_t)rr * 3 + 1];
     refz = a.roll_ref[(size_t)rr * 3 + 2];
   }
-  // the latched command of the lane's mode (constant over the launch unless this is a rollout)
-  const float* cmd_src = (mode == 2) ? g.vel_cmd : (mode == 1) ? g.pos_cmd : g.frc_cmd;
-  float target[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) target[i] = 0.f;
-  if (!ROLLOUT) {
-    if (g.mode_arr) {  // per-robot modes: the buffer differs from lane to lane
-#pragma unroll
-      for (int i = 0; i < N; ++i) target[i] = cmd_src ? cmd_src[(size_t)rr * N + i] : 0.f;
-    } else if (cmd_src) {
-      const float* cp = cmd_src + (size_t)rr * N;
-      if (N % 4 == 0) {
-#pragma unroll
-        for (int q4 = 0; q4 < N / 4; ++q4) {
-          const float4 v = reinterpret_cast<const float4*>(cp)[q4];
-          target[4 * q4] = v.x, target[4 * q4 + 1] = v.y, target[4 * q4 + 2] = v.z, target[4 * q4 + 3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) target[i] = cp[i];
-      }
-    }
-  }
-
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
     const int now = g.now_step + step;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
@@ -638,12 +797,20 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       if (!SINGLE) asm volatile("" : "+v"(sel[i]));
     }
     const bool run_ctl = !first_world;
+#ifdef CDPR_STAMPS_PRO
+    { float k2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) k2 += target[i] + (float)sel[i];
+      asm volatile("" ::"v"(k2)); }
+    CDPR_STAMP(3);
+#endif
     if (run_ctl) {
       float keep = (s.px + s.qy) + (s.vy + s.wz) + fkqw;
 #pragma unroll
       for (int i = 0; i < N; ++i) keep += target[i];
       gen_stage_records<N, NBMAX>(RB, L, col, sel, &stage[0][0][0], &hold_slots[0][0], keep);
     }
+    GEN_PHASE_STAMP(1);
 
     // ---- IK on the state at t_k: only joint positions, rates and the measured lengths live on; the structure matrix is
     //      rebuilt where it is needed again (after the controller: 56 registers that would otherwise ride through it)
@@ -673,6 +840,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       }
     }
 
+    GEN_PHASE_STAMP(2);
     // ---- Newton-Raphson forward kinematics ([NEW] SURVEY 8(a) row 14)
     float fk_res = 0.f;
     int fk_it = 0, td_flag = 0;
@@ -707,6 +875,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       fk_res = fmaxf(rm.x, rm.y);
     }
 
+    GEN_PHASE_STAMP(3);
     // ---- per-cable force: the general controller (gen_controller above)
     float force[N];
 #pragma unroll
@@ -715,11 +884,16 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     if (run_ctl) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA has landed
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      CDPR_STAMP(4);
       GenCtlConst cc;
       cc.pcas_max = g.pcas_max, cc.dcas_max = g.dcas_max, cc.dt = g.dt, cc.inv_dt = a.inv_dt;
+#ifdef CDPR_STAMPS
+      cc.stamps = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+#endif
       gen_controller<N, NBMAX>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &stage[0][0][0], &hold_slots[0][0],
                                &wrot[0][0][0], ptab, &q_count, force, dbg);
     }
+    CDPR_STAMP(5);
     v2f f[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) f[k] = (v2f){force[2 * k], (2 * k + 1 < N) ? force[2 * k + 1] : 0.f};
@@ -789,6 +963,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       }
     }
 
+    CDPR_STAMP(6);
     // ---- world step to t_{k+1}: wrench = -J^T (applied - d qdot) + m g; the optional physics terms by run-time flags
     {
       v2f tens[NP];
@@ -832,6 +1007,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
     if (FK) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
   }
+  CDPR_STAMP(7);
 }
 
 // Per-robot command arrival on the general path (cdpr_set_*_command_masked; PLG.cpp:206-219 per model): one thread per
