@@ -643,6 +643,13 @@ GenCtl general_ctl(const cdpr_engine* h) {
   g.ptab = h->d_gptab;
   g.pcas_max = std::max(h->gpid[0].pcas, h->gpid[1].pcas);
   g.dcas_max = std::max(h->gpid[0].dcas, h->gpid[1].dcas);
+  g.nbuf0 = h->gpid[0].nbuf, g.nbuf1 = h->gpid[1].nbuf;
+  {
+    const GenPid &p0 = h->gpid[0], &p1 = h->gpid[1];
+    const bool same_window = p0.nbuf == p1.nbuf && p0.degree == p1.degree;
+    const bool clamps = p0.cmax > p0.cmin && p1.cmax > p1.cmin && p0.imax >= p0.imin && p1.imax >= p1.imin;
+    g.simple_ok = (same_window && clamps && g.pcas_max == 0 && g.dcas_max == 0) ? 1 : 0;
+  }
   return g;
 }
 
@@ -1469,20 +1476,25 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     fill_gen_pid(cfg->position_pid, h->gpid[0]);
     fill_gen_pid(cfg->velocity_pid, h->gpid[1]);
     // FIR weights by ring head: when the newest sample sits in slot `head`, slot j holds the sample of age (head - j) mod
-    // nbuf, whose end-point LS weight (oldest first) is w[nbuf - 1 - age]; slots >= nbuf weigh nothing
+    // nbuf, whose end-point LS weight (oldest first) is w[nbuf - 1 - age]; slots >= nbuf weigh nothing.  The head slot itself
+    // weighs nothing in the table: the newest sample is still in a register when the FIR runs, its weight rides in the Pid
+    // table (last float)
     const int nbmax = h->glay.nb > 11 ? kGenMaxBuf : 11, nbp = gen_nbp(nbmax);
     std::vector<float> wt((size_t)2 * nbmax * nbp, 0.f);
     const cdpr_pid_params_t* pp[2] = {&cfg->position_pid, &cfg->velocity_pid};
+    float w_new[2] = {0.f, 0.f};
     for (int p = 0; p < 2; ++p) {
       double w[CDPR_MAX_D_BUFFER];
       const int nb = (int)pp[p]->d_buffer_length;
       if (derivative_weights((uint32_t)nb, pp[p]->d_degree, w) != CDPR_OK) continue;
       for (int head = 0; head < nb; ++head)
-        for (int j = 0; j < nb; ++j) wt[((size_t)p * nbmax + head) * nbp + j] = (float)w[nb - 1 - (((head - j) % nb + nb) % nb)];
+        for (int j = 0; j < nb; ++j) wt[((size_t)p * nbmax + head) * nbp + j] = (j == head) ? 0.f : (float)w[nb - 1 - (((head - j) % nb + nb) % nb)];
+      w_new[p] = (float)w[nb - 1];
     }
     float pt[2 * kGenPidFloats];
     gen_pid_table(h->gpid[0], pt);
     gen_pid_table(h->gpid[1], pt + kGenPidFloats);
+    pt[kGenPidFloats - 1] = w_new[0], pt[2 * kGenPidFloats - 1] = w_new[1];
     if ((e = hipMalloc(&h->d_gptab, sizeof pt)) != hipSuccess) return fail("hipMalloc(gptab)", e);
     if ((e = hipMemcpy(h->d_gptab, pt, sizeof pt, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(gptab)", e);
     if ((e = hipMalloc(&h->d_gwtab, wt.size() * sizeof(float))) != hipSuccess) return fail("hipMalloc(gwtab)", e);

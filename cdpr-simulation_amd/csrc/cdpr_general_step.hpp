@@ -95,13 +95,17 @@ struct GenCtl {
                          // the selected Pid - as kernel arguments the 2 x 23 scalars do not fit the scalar register file
                          // next to the step's own constants (measured: 2 400 v_readlane / v_writelane per robot-step)
   int pcas_max, dcas_max;  // deepest P-input / D-input cascade of the two Pids
+  int nbuf0, nbuf1;        // window lengths of the position / velocity Pid (the ring slot of a sample is its stamp mod nbuf)
+  int simple_ok;           // the steady-state branch may be taken: both Pids have the same window length and degree (one ring
+                           // head and one weight row serve every cable), no cascades, a command clamp and iMin <= iMax
   // ROLLOUT: every trajectory works on a private copy of its robot's records (column = trajectory index in `rec`)
   const float* src_rec;
   uint32_t src_rstride;
 };
 
 // GenPid as the kernel reads it from LDS: six float4 per Pid
-//   [kf kp ki kd] [imax imin cmax cmin] [nbuf pcas dcas (int bit patterns) 1/ki] [pa0 pa1 pa2 pb1] [pb2 da0 da1 da2] [db1 db2 degree -]
+//   [kf kp ki kd] [imax imin cmax cmin] [nbuf pcas dcas (int bit patterns) 1/ki] [pa0 pa1 pa2 pb1] [pb2 da0 da1 da2] [db1 db2 degree w_new]
+//   (w_new: the FIR weight of the newest sample, set by the engine next to the weight table)
 constexpr int kGenPidFloats = 24;
 inline void gen_pid_table(const GenPid& p, float* t) {
   auto bits = [](int v) { float f; memcpy(&f, &v, sizeof f); return f; };
@@ -238,7 +242,7 @@ CDPR_DEV float gen_cascade(const GenBuf& B, int row0, uint32_t voff, int stages,
 // The Pid a lane runs for one cable this step: position or velocity Pid, read from the LDS table by the lane's selection;
 // everything by value - a reference into the kernel arguments makes the compiler keep a private copy of them in scratch.
 struct GenSel {
-  float kf, kp, ki, kd, imax, imin, cmax, cmin, inv_ki;
+  float kf, kp, ki, kd, imax, imin, cmax, cmin, inv_ki, w_new;
   int nbuf, pcas, dcas;
   float pa0, pa1, pa2, pb1, pb2, da0, da1, da2, db1, db2;
 };
@@ -249,6 +253,7 @@ CDPR_DEV GenSel gen_select(bool vel, const float4 (*ptab)[kGenPidFloats / 4], bo
   c.kf = r0.x, c.kp = r0.y, c.ki = r0.z, c.kd = r0.w;
   c.imax = r1.x, c.imin = r1.y, c.cmax = r1.z, c.cmin = r1.w;
   c.nbuf = __float_as_int(r2.x), c.pcas = __float_as_int(r2.y), c.dcas = __float_as_int(r2.z), c.inv_ki = r2.w;
+  c.w_new = t[5].w;
   c.pa0 = c.pa1 = c.pa2 = c.pb1 = c.pb2 = c.da0 = c.da1 = c.da2 = c.db1 = c.db2 = 0.f;
   if (filters) {  // (wave-uniform: some Pid has a cascade)
     const float4 r3 = t[3], r4 = t[4], r5 = t[5];
@@ -290,6 +295,9 @@ CDPR_DEV float gen_finish(const GenBuf& RB, const GenSel c, int slot_h, int row_
 struct GenCtlConst {
   int pcas_max, dcas_max;
   float dt, inv_dt;
+  int nm0, nm1;  // this step's ring slot in the position / velocity Pid's window: now mod nbuf
+  int nbuf0;     // the position Pid's window length
+  bool simple_ok;  // the handle's configuration admits the steady-state branch (GenCtl::simple_ok)
 #ifdef CDPR_STAMPS
   unsigned long long* stamps;  // this wave's eight stamps (diagnostic build)
 #endif
@@ -342,43 +350,65 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   //      the per-lane case selection below: ~70 vector instructions per cable instead of ~240.
   // (a single wave per SIMD hides nothing: every dependent LDS round trip costs ~50 ns, so the reads of a phase are issued
   //  for a group of cables together and the group then pays the latency once)
-  bool simple = (mode != 0) && !filters;
-  float4 hs[N];
-#pragma unroll
-  for (int i = 0; i < N; ++i) hs[i] = cab[i * kCab + NV * 64 + lane];
-  {
-    const float4 lim0 = ptab[0][1], lim1 = ptab[1][1];
-    const int nb0 = __float_as_int(ptab[0][2].x), nb1 = __float_as_int(ptab[1][2].x);
-    const bool clamp0 = lim0.z > lim0.w, clamp1 = lim1.z > lim1.w;  // cmdMax > cmdMin
+  bool simple = false;
+  if (kc.simple_ok) {  // (scalar: no cascades, one window for both Pids, both with a command clamp and iMin <= iMax)
+    // all-integer, no per-cable lane masks: sign bits collect "count < nbuf" and "run + 1 < nbuf - 1", any bit collects
+    // "not called one step ago", an AND collects mWasLastTime
+    const int nbuf = kc.nbuf0;
+    int neg = 0;
+    uint32_t nz = (mode == 0) ? 1u : 0u, was = 1u;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      const uint32_t meta = __float_as_uint(hs[i].x);
-      const int nbuf = sel[i] ? nb1 : nb0;
+      const float2 ml = *reinterpret_cast<const float2*>(&cab[i * kCab + NV * 64 + lane]);
+      const uint32_t meta = __float_as_uint(ml.x);
       const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
-      simple = simple & ((meta & kGmWasLast) != 0u) & (count >= nbuf) & (run + 1 >= nbuf - 1) & (now - __float_as_int(hs[i].y) == 1) & (sel[i] ? clamp1 : clamp0);
+      neg |= (count - nbuf) | (run + 2 - nbuf);
+      nz |= (uint32_t)(now - 1 - __float_as_int(ml.y));
+      was &= meta;
     }
+    simple = (neg >= 0) && (nz == 0u) && (was & 1u) != 0u;
   }
-  if (__builtin_amdgcn_ballot_w64(!simple) == 0ull) {  // (wave-uniform)
+  if (__builtin_amdgcn_ballot_w64(!simple) == 0ull) {  // (wave-uniform; a __builtin_expect layout hint here changed results: left alone)
     GEN_CTL_STAMP(1);
-    constexpr int GW = (NV > 3) ? 2 : 4;               // cables per group (registers: 8 NV + 20 per cable)
+    // same window for both Pids and consecutive steps everywhere: ONE ring head for the whole wave (now mod nbuf, a
+    // scalar), one row of weights, static LDS addresses; the table weighs the head slot with 0 and the new sample enters
+    // the FIR from its register, so nothing is written to the staged window before it is read
+    const int nhead = kc.nm0, nbuf = kc.nbuf0;
+    const int q4 = nhead >> 2, qc = nhead & 3;
+    const uint32_t meta_lo = kGmWasLast | ((uint32_t)nbuf << kGmCountShift) | ((uint32_t)nhead << kGmHeadShift);
+    float4 w[NV];
+    {
+      const float4* wr = reinterpret_cast<const float4*>(wrot + nhead * NBP);
+#pragma unroll
+      for (int s4 = 0; s4 < NV; ++s4) w[s4] = wr[s4];
+    }
+#ifndef GEN_G
+#define GEN_G 4
+#endif
+    constexpr int GW = (NV > 3) ? 2 : GEN_G;  // cables per group (registers: 4 NV + 20 per cable)
     constexpr int G = (N < GW) ? N : GW;
 #pragma unroll
     for (int b = 0; b < N; b += G) {
+#ifndef GEN_NOBAR
       __builtin_amdgcn_sched_barrier(0);
+#endif
       if (b == G) GEN_CTL_STAMP(2);
       float4 g0[G], g1[G], g2[G];  // kf kp ki kd | imax imin cmax cmin | nbuf . . 1/ki
-      float error[G], desired[G];
-      int nhead[G];
-      uint32_t nmeta[G];
+      float wn[G];
+      float4 v[G][NV], vs[G], hh[G];
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int i = b + j;
         if (i < N) {
+          hh[j] = cab[i * kCab + NV * 64 + lane];
           const float4* pt = ptab[sel[i] ? 1 : 0];
-          g0[j] = pt[0], g1[j] = pt[1], g2[j] = pt[2];
+          g0[j] = pt[0], g1[j] = pt[1], g2[j] = pt[2], wn[j] = pt[5].w;
+          const float4* cs = cab + i * kCab + lane;
+#pragma unroll
+          for (int s4 = 0; s4 < NV; ++s4) v[j][s4] = cs[s4 * 64];
+          vs[j] = cs[q4 * 64];  // the slot that takes the new sample
         }
       }
-      // the new sample into its ring slot of the staged window
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int i = b + j;
@@ -388,62 +418,42 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           const bool sv = sel[i] != 0;
           const bool hold = (mode == 2) && !sv;
           const float held = comp4(held4[i / 4], i % 4);
-          desired[j] = hold ? held : target[i];  // JFC.cpp:81
-          newpos[i] = hold ? held : qi;          // JFC.cpp:75,87
-          error[j] = desired[j] - ((mode == 2 && sv) ? qdi : qi);
-          const uint32_t meta = __float_as_uint(hs[i].x);
-          const int nbuf = __float_as_int(g2[j].x);
-          const int head = (int)((meta >> kGmHeadShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
-          nhead[j] = (head + 1 == nbuf) ? 0 : head + 1;
-          nmeta[j] = kGmWasLast | ((uint32_t)nbuf << kGmCountShift) | ((uint32_t)nhead[j] << kGmHeadShift) | ((uint32_t)min(run + 1, (int)kGmField) << kGmRunShift);
-          (cabf + i * kCabF + lane)[(nhead[j] >> 2) * 256 + lane * 3 + (nhead[j] & 3)] = error[j];
-        }
-      }
-      // the window, its weights by ring head, and the slot that took the sample (as it goes back to the records)
-      float4 v[G][NV], vs[G], w[G][NV];
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int i = b + j;
-        if (i < N) {
-          const float4* cs = cab + i * kCab + lane;
-          const float4* wr = reinterpret_cast<const float4*>(wrot + ((sel[i] ? NBMAX : 0) + nhead[j]) * NBP);
-#pragma unroll
-          for (int s4 = 0; s4 < NV; ++s4) v[j][s4] = cs[s4 * 64], w[j][s4] = wr[s4];
-          vs[j] = cs[(nhead[j] >> 2) * 64];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int i = b + j;
-        if (i < N) {
-          const bool sv = sel[i] != 0;
+          const float desired = hold ? held : target[i];  // JFC.cpp:81
+          newpos[i] = hold ? held : qi;                    // JFC.cpp:75,87
+          const float error = desired - ((mode == 2 && sv) ? qdi : qi);
           const uint32_t va = col * 16u + (sv ? pid_a : 0u), vb = col * 4u + (sv ? pid_b : 0u);
           const int sa = L.block_a(0, i), rb = L.block_b(0, i);
-          const float prev_ierr = hs[i].z;
-          const float p_term = g0[j].y * error[j];
-          float ie = fmaf(kc.dt, error[j], prev_ierr);  // dt = one world step
+          const uint32_t meta = __float_as_uint(hh[j].x);
+          const int run = (int)((meta >> kGmRunShift) & kGmField);
+          const uint32_t nmeta = meta_lo | ((uint32_t)min(run + 1, (int)kGmField) << kGmRunShift);
+          const float prev_ierr = hh[j].z;
+          const float p_term = g0[j].y * error;
+          float ie = fmaf(kc.dt, error, prev_ierr);  // dt = one world step
           const float i_term = g0[j].z * ie;
-          if (i == 0) dbg.p = p_term, dbg.i = i_term, dbg.des = desired[j], dbg.pi = true;
-          const float i_cl = fmaxf(fminf(i_term, g1[j].x), g1[j].y);  // Pid.cpp:143-152
+          if (i == 0) dbg.p = p_term, dbg.i = i_term, dbg.des = desired, dbg.pi = true;
+          const float i_cl = __builtin_amdgcn_fmed3f(i_term, g1[j].y, g1[j].x);  // Pid.cpp:143-152 (iMin <= iMax here)
           ie = (i_cl != i_term) ? i_cl * g2[j].w : ie;
           float acc = 0.f;
 #pragma unroll
           for (int s4 = 0; s4 < NV; ++s4)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-              if (4 * s4 + k < NBMAX) acc = fmaf(comp4(w[j][s4], k), comp4(v[j][s4], k), acc);
+              if (4 * s4 + k < NBMAX) acc = fmaf(comp4(w[s4], k), comp4(v[j][s4], k), acc);
+          acc = fmaf(wn[j], error, acc);
           const float d_term = g0[j].w * (acc * kc.inv_dt);
           if (i == 0) dbg.d = d_term, dbg.dw = true;
-          const float cmd = ((g0[j].x * desired[j] + p_term) + i_cl) + d_term;  // Pid.cpp:170
-          float out = fmaxf(fminf(cmd, g1[j].z), g1[j].w);                       // Pid.cpp:175-177
-          const bool wind = out != cmd;                                           // Pid.cpp:181-184
+          const float cmd = ((g0[j].x * desired + p_term) + i_cl) + d_term;  // Pid.cpp:170
+          float out = __builtin_amdgcn_fmed3f(cmd, g1[j].w, g1[j].z);          // Pid.cpp:175-177 (cmdMin < cmdMax here)
+          const bool wind = out != cmd;                                         // Pid.cpp:181-184
           ie = wind ? prev_ierr : ie;
-          out = wind ? fmaf(kc.dt * error[j], g0[j].z, out) : out;
+          out = wind ? fmaf(kc.dt * error, g0[j].z, out) : out;
           force[i] = out;
+          float4 o = vs[j];
+          o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
           if (live) {
-            RB.store4_if(true, sa, va + (uint32_t)(nhead[j] >> 2) * RB.rs16, vs[j]);
-            RB.storei_if(true, rb, vb + (uint32_t)nhead[j] * RB.rs4, now);
-            RB.store4_if(true, sa + L.nv(), va, make_float4(__uint_as_float(nmeta[j]), __int_as_float(now), ie, out));
+            RB.store4_if(true, sa + q4, va, o);
+            RB.storei_if(true, rb + nhead, vb, now);
+            RB.store4_if(true, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
           }
         }
       }
@@ -460,6 +470,7 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   }
 
   uint32_t need = 0u;  // cables whose derivative comes from the fit queue
+  bool any_rot = false;  // some ring of this wave turned this step (wave-uniform)
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     __builtin_amdgcn_sched_barrier(0);  // one cable at a time: hoisting every cable's staged slots costs 128 registers (letting the
@@ -505,7 +516,33 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     // Pid::derive (Pid.cpp:193-217): push the sample (dt > 0 always: a Pid is called at most once per world step)
     const int count = (int)((meta >> kGmCountShift) & kGmField), head = (int)((meta >> kGmHeadShift) & kGmField);
     const int run = (int)((meta >> kGmRunShift) & kGmField);
-    const int nhead = (count == 0) ? 0 : ((head + 1 == nbuf) ? 0 : head + 1);
+    // the ring slot of a sample is its stamp mod nbuf: a Pid called on consecutive steps moves its head by one, and windows
+    // of consecutive steps have the same head in every lane (what the steady-state branch above lives on).  The first call
+    // after a gap turns the ring, values and stamps, so that the previous sample sits right before the new one.
+    const int nhead = sv ? kc.nm1 : kc.nm0;
+    int shift = nhead - 1 - head;
+    shift += (shift < 0) ? nbuf : 0;
+    const bool rot = runs && count > 0 && shift != 0;
+    shift = rot ? shift : 0;
+    if (__builtin_amdgcn_ballot_w64(rot) != 0ull) {  // (wave-uniform; lanes that do not turn move every sample onto itself)
+      any_rot = true;
+      float tv[NBMAX];
+      int ts[NBMAX];
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j) {
+        int src = j - shift;
+        src += (src < 0) ? nbuf : 0;
+        src = (j < nbuf) ? src : j;
+        tv[j] = park[(src >> 2) * 256 + lane * 3 + (src & 3)];
+        ts[j] = RB.loadi(rb, vb + (uint32_t)min(src, L.nb - 1) * RB.rs4);
+      }
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j) park[(j >> 2) * 256 + lane * 3 + (j & 3)] = tv[j];
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j) RB.storei_if(live && rot && j < nbuf && j != nhead, rb + min(j, L.nb - 1), vb, ts[j]);
+#pragma unroll
+      for (int s4 = 0; s4 < NV; ++s4) RB.store4_if(live && rot && s4 != (nhead >> 2) && s4 < L.nv(), sa + min(s4, L.nv() - 1), va, cs[s4 * 64]);
+    }
     const int ncount = min(count + 1, nbuf);
     const int nrun = (count > 0 && now - last == 1) ? min(run + 1, (int)kGmField) : 0;
     const uint32_t nmeta = first ? (meta | kGmWasLast)
@@ -527,6 +564,7 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       for (int k = 0; k < 4; ++k)
         if (4 * s4 + k < NBMAX) acc = fmaf(wr[4 * s4 + k], comp4(v, k), acc);
     }
+    acc = fmaf(c.w_new, error, acc);  // (the table weighs the head slot with 0: the newest sample enters here)
     const float derived = (ncount >= nbuf) ? acc * kc.inv_dt : 0.f;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
     float d_term;
     const bool done = (runs && !queued) || first;  // first call: H = (meta | 1, now, mIerr as it was, mCmd = 0); out is not used
@@ -552,6 +590,10 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
 
   // the windows that are not a uniform grid, compacted over the wave: one (robot, cable) per lane and pass
   if (__builtin_amdgcn_ballot_w64(need != 0u) != 0ull) {  // (wave-uniform)
+    if (any_rot) {  // the fit reads other lanes' rings from the records: the turned ones have to be there
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     const uint32_t cnt = (uint32_t)__builtin_popcount(need);
     uint32_t slot = 0u;
     if (cnt) slot = __hip_atomic_fetch_add(q_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -770,6 +812,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     refy = a.roll_ref[(size_t)rr * 3 + 1];
     refz = a.roll_ref[(size_t)rr * 3 + 2];
   }
+  int nm0 = g.now_step % max(g.nbuf0, 1), nm1 = g.now_step % max(g.nbuf1, 1);  // this step's ring slot per Pid (scalar)
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
     const int now = g.now_step + step;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
@@ -794,7 +837,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       sel[i] = (mode == 2 && fabsf(target[i]) > g.eps) ? 1 : 0;
       // (opaque: in a launch of several steps the selection is the same in every step, and the compiler would hoist the
       //  selected gains of all cables - some hundred registers - out of the step loop)
-      if (!SINGLE) asm volatile("" : "+v"(sel[i]));
+      asm volatile("" : "+v"(sel[i]));  // (also keeps the selection a 0 / 1 register: as eight lane masks it crowds the scalar file)
     }
     const bool run_ctl = !first_world;
 #ifdef CDPR_STAMPS_PRO
@@ -887,6 +930,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       CDPR_STAMP(4);
       GenCtlConst cc;
       cc.pcas_max = g.pcas_max, cc.dcas_max = g.dcas_max, cc.dt = g.dt, cc.inv_dt = a.inv_dt;
+      cc.nm0 = nm0, cc.nm1 = nm1, cc.nbuf0 = g.nbuf0, cc.simple_ok = g.simple_ok != 0;
 #ifdef CDPR_STAMPS
       cc.stamps = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
 #endif
@@ -995,6 +1039,8 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       const float ex = s.px - refx, ey = s.py - refy, ez = s.pz - refz;
       cost = fmaf(ez, ez, fmaf(ey, ey, fmaf(ex, ex, cost)));
     }
+    nm0 = (nm0 + 1 == g.nbuf0) ? 0 : nm0 + 1;
+    nm1 = (nm1 + 1 == g.nbuf1) ? 0 : nm1 + 1;
   }
   if (ROLLOUT) {
     if (live) a.roll_cost[r] = cost;
