@@ -1276,6 +1276,15 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   // two Pids that fit different derivative windows, take the general controller path
   const bool pr_windows_differ = cfg->velocity_pid.d_buffer_length != cfg->position_pid.d_buffer_length || cfg->velocity_pid.d_degree != cfg->position_pid.d_degree;
   const bool general = !fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && (phys_cfg || pr_windows_differ));
+  // The per-robot kernels of the register-resident path do not clear a reset Pid's derivative ring (the latch zeroes only
+  // the integral rows) and a velocity rollout keeps stale position-Pid errors in it: that is correct only while
+  // full = calls >= nbuf hides every stale slot, i.e. nbuf <= kWin + 1 and one window shared by both Pids.  Both follow
+  // from the routing above; checked here so that a change to the routing cannot silently break the kernels' invariant.
+  if (!general && cfg->per_robot_commands != 0 &&
+      (pr_windows_differ || cfg->velocity_pid.d_buffer_length > (uint32_t)kWin + 1 || cfg->position_pid.d_buffer_length > (uint32_t)kWin + 1)) {
+    g_create_error = "internal: per-robot handle routed to the register-resident path with windows it cannot hold";
+    return CDPR_ERR_UNSUPPORTED;
+  }
   if (cfg->precision == 64 && (general || cfg->per_robot_commands != 0 || phys_cfg)) {
     g_create_error = "precision = 64 covers uniform-mode handles on the register-resident path only (no per_robot_commands, lumped legs, "
                      "travel_stop, hold branch, cascades, long windows or cmd_limit 0): " +

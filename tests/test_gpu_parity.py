@@ -1460,6 +1460,53 @@ def test_per_robot_handle_is_bit_identical_to_the_uniform_one_when_every_robot_h
         uni.close(), per.close()
 
 
+@pytest.mark.parametrize("nbuf,deg", [(3, 1), (4, 1), (5, 1)])
+def test_per_robot_short_windows_with_staggered_resets(pkg, oracle, mapping, nbuf, deg):
+    """Per-robot handle on the register-resident path with a SHORT derivative window (the ring still has kWin slots):
+    groups of robots have their Pids reset at staggered steps (a Joy on the other topic), fewer than nbuf steps apart, so
+    every reset Pid starts with stale samples of the other Pid in the ring slots it has not refilled yet.  The kernels
+    never clear the ring on reset and rely on full = calls >= nbuf to hide those slots: any stale slot leaking into a
+    derivative shows up against the oracle (B independent JointForceCalculator sets), which starts every reset window
+    empty.  (Degree 1: with 4 - 5 samples and degree 2 the D term's noise gain makes the loop amplify fp32 rounding
+    threefold per step for a few steps - the register-resident and the general path then both leave the oracle by ~2 N at
+    the same steps, which says nothing about stale slots.)"""
+    once(mapping)
+    rng = np.random.default_rng(300 + nbuf)
+    B, n = 192, 8
+    model = pkg.eight_cable_model()
+    cfg = pkg.Config(model=model, batch=B, stages=3, perRobotCommands=True)
+    for c in (cfg.velocityController, cfg.positionController):
+        c.dBufferLength, c.dDegree = nbuf, deg
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.03, 0.05))
+    # (shipped velocityEpsilon < 0, one window for both Pids, <= 11 samples: the register-resident per-robot kernels)
+    grp = rng.integers(0, 4, B)
+    v = rng.uniform(0.004, 0.03, (B, n)).astype(np.float32) * rng.choice([-1.0, 1.0], (B, n)).astype(np.float32)
+    p = rng.uniform(-0.003, 0.003, (B, n)).astype(np.float32)
+    # a short end-point derivative amplifies the fp32 rounding of the errors more than the shipped 11-sample, degree-2 one,
+    # and the loop feeds it back: tolerances scale with the RMS gain of the weights (x 0.9 - 2 here, doubled for the
+    # feedback).  A stale ring slot (an error of the OTHER Pid, ~3e-3, in a derivative over 1 ms) moves the effort by newtons.
+    def rms_gain(nb, dg):
+        x = np.arange(nb) - (nb - 1.0)
+        return float(np.sqrt((np.linalg.pinv(np.vander(x, dg + 1, increasing=True))[1] ** 2).sum()))
+    scale = max(1.0, 2.0 * rms_gain(nbuf, deg) / rms_gain(11, 2))
+    tol = {k: scale * t for k, t in TOL.items()}
+    for e in (eng, ora):
+        e.update(7)
+    for rnd in range(6):
+        for g in range(4):  # group g switches topic (= resets the Pid it switches to) 1, 2 or nbuf - 1 steps after group g - 1
+            to_velocity = (rnd + g) % 2 == 0
+            for e in (eng, ora):
+                if to_velocity:
+                    e.set_velocity_command(v if rnd % 3 else -v, mask=grp == g)
+                else:
+                    e.set_position_command(p * np.float32(1 + rnd), mask=grp == g)
+            k = [1, 2, nbuf - 1, 1][g]
+            eng.update(k, k if rnd % 2 else 1), ora.update(k)  # fused and one-step launches alternate
+            compare(eng, ora, tol, where=f"nbuf={nbuf} round {rnd} group {g}")
+        eng.update(nbuf + 2), ora.update(nbuf + 2)
+        compare(eng, ora, tol, where=f"nbuf={nbuf} round {rnd} settled")
+
+
 @pytest.mark.parametrize("kind", ["fast", "general"])
 def test_per_robot_rollout_record_and_fused_updates_against_the_oracle(pkg, oracle, mapping, kind):
     """What per-robot handles gained with the register-resident path: fused launches, the trajectory record and the MPC
