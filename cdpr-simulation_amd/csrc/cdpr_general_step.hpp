@@ -19,6 +19,8 @@
 //          + nv             "H": meta | mLastTime (world-step index) | mIerr | mCmd
 //                           meta: bit 0 mWasLastTime | samples in the window (6 bits) | ring head (6) | `run` (6) =
 //                           consecutive one-step gaps ending at the newest sample, saturating
+//                         The ring slot of a sample is its stamp mod nbuf (head = mLastTime mod nbuf): the first call of a
+//                         Pid after a gap turns its ring, values and stamps, so that this holds again.
 //   B: dword rows (4 B per robot and row), only touched where needed
 //        blockB(pid, i) = (pid n + i)(nb + 8 ncas): mDbufferX ring slot j as a world-step index (int32), then the P-input
 //        cascade's x1 x2 y1 y2 per stage, then the D-input cascade's
@@ -30,7 +32,10 @@
 // otherwise): nv + 1 slots read (64 B at the shipped 11-sample window), the slot of the new sample and H written (32 B)
 // plus one stamp (4 B).  The stamps of the window are only READ when they are needed:
 //   * a window whose nb samples were taken at consecutive world steps (meta.run >= nb - 1) is the uniform grid of the
-//     fast path: the derivative is the closed-form FIR, weights looked up by ring head in LDS;
+//     fast path: the derivative is the closed-form FIR, weights looked up by ring head in LDS (0 at the head slot: the
+//     newest sample enters from its register, weight in the Pid table).  When that holds for every cable of every robot
+//     of a wave - all steps but the dozen after a mode change or a Pid switch - the wave takes a branch with ONE scalar
+//     ring head, one weight row and static LDS addresses (gen_controller, "steady state");
 //   * anything else (the nb - 1 steps after a switch between the two Pids in the hold branch) is a least-squares fit on
 //     the real stamps.  These are rare and scattered over lanes and cables, so they are COMPACTED: every lane queues its
 //     (cable, Pid) items in LDS, then the wave works the queue with one item per lane - orthogonal polynomials on the
@@ -347,7 +352,8 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   //      ago and whose window is a full uniform grid, no cascades, a command clamp - what a handle does on all steps but the
   //      dozen after a mode change or a switch between the two Pids of a hold-branch cable.  Then Pid::update is the fast
   //      path's arithmetic (Pid.cpp:128-186 with derive() as the closed-form FIR) plus the ring bookkeeping, without any of
-  //      the per-lane case selection below: ~70 vector instructions per cable instead of ~240.
+  //      the per-lane case selection below: ~95 instructions of all kinds per cable (46 of them the Pid's own vector
+  //      arithmetic) instead of ~300.
   // (a single wave per SIMD hides nothing: every dependent LDS round trip costs ~50 ns, so the reads of a phase are issued
   //  for a group of cables together and the group then pays the latency once)
   bool simple = false;
@@ -382,16 +388,13 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
 #pragma unroll
       for (int s4 = 0; s4 < NV; ++s4) w[s4] = wr[s4];
     }
-#ifndef GEN_G
-#define GEN_G 4
-#endif
-    constexpr int GW = (NV > 3) ? 2 : GEN_G;  // cables per group (registers: 4 NV + 20 per cable)
+    // cables per group: 4 NV + 20 registers per cable; groups of 2 or 8 and no scheduling barrier between the groups were
+    // measured too (+-0.05 us: the phase is bound by the instruction count, ~2.5 ns per instruction of any kind)
+    constexpr int GW = (NV > 3) ? 2 : 4;
     constexpr int G = (N < GW) ? N : GW;
 #pragma unroll
     for (int b = 0; b < N; b += G) {
-#ifndef GEN_NOBAR
       __builtin_amdgcn_sched_barrier(0);
-#endif
       if (b == G) GEN_CTL_STAMP(2);
       float4 g0[G], g1[G], g2[G];  // kf kp ki kd | imax imin cmax cmin | nbuf . . 1/ki
       float wn[G];
