@@ -57,6 +57,9 @@ struct cdpr_engine {
   bool lane_cable = false;  // one lane per cable, 8 (or 4) lanes per robot (cdpr_step_kernel_cable.hpp)
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
+  bool persist = false;     // one-step launches use the persistent one-wave kernel: one wave per SIMD walks over blocks of 64
+                            // robots, the next block's rows in flight under the current block's arithmetic (large batches)
+  uint32_t persist_grid = 0;  // waves of such a launch: SIMDs of the device
   bool split = false;       // FK + TD one-step launches use cdpr_split_kernel (estimator wave + controller wave per 64 robots)
   int sched_refresh = 0;            // cdpr_update_scheduled in progress: Joy batches per launch (StepArgs::sched_*)
   const uint32_t* sched_ready = nullptr;
@@ -709,14 +712,15 @@ StepKernel select_step_kernel(const cdpr_engine* h, int k) {
   if (h->lane_cable) return pick_cable_kernel(h->n, h->fk, h->td);
   return h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
          : h->lane_pair ? pick_pair_kernel(k == 1, h->n, h->fk, h->td)
-                        : ((k == 1) ? (h->lowreg ? pick_lowreg_kernel(h->n, h->td)
+                        : ((k == 1) ? (h->persist ? pick_onestep_persist_kernel(h->n, h->fk, h->td)
+                                                 : h->lowreg ? pick_lowreg_kernel(h->n, h->td)
                                                  : h->split ? pick_split_kernel(h->n)
                                                  : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_step_kernel(true, h->n, h->fk, h->td)))
                                     : pick_step_kernel(false, h->n, h->fk, h->td));
 }
 uint32_t step_block_threads(const cdpr_engine* h, int k) {
   // the role-split kernel runs two waves (estimator, controller) per 64 robots
-  return (k == 1 && h->split && !h->phys && !h->lane_pair && !h->lowreg) ? 128u : 64u;
+  return (k == 1 && h->split && !h->phys && !h->lane_pair && !h->lowreg && !h->persist) ? 128u : 64u;
 }
 
 // cdpr_create pays the cold costs of the handle's one-step kernel (the runtime loads a kernel's code object and sets up
@@ -876,7 +880,7 @@ int set_platform_state64(cdpr_engine* h, const double* pose7, const double* twis
 // One step-kernel launch over the whole batch, or (h->chunk) the same launch cut into contiguous blocks of robots issued
 // back to back on the handle's stream: every pointer that is indexed by robot moves to the block's first robot, the row
 // stride stays.  Robots are independent, so the results are bit-identical to the single launch (tested).
-void launch_step(cdpr_engine* h, StepKernel kern, uint32_t robots_per_block, dim3 block, const StepArgs& a) {
+void launch_step(cdpr_engine* h, StepKernel kern, uint32_t robots_per_block, dim3 block, const StepArgs& a, uint32_t max_grid = 0) {
   const uint32_t B = a.batch;
   const uint32_t chunk = (h->chunk && B > h->chunk) ? h->chunk : B;
   const uint32_t pieces = (B + chunk - 1u) / chunk;
@@ -889,7 +893,9 @@ void launch_step(cdpr_engine* h, StepKernel kern, uint32_t robots_per_block, dim
     if (a.cmd) c.cmd = a.cmd + (size_t)first * h->n;
     if (a.dbg) c.dbg = a.dbg + (size_t)first * CDPR_PID_DEBUG_AXES;
     if (a.meta) c.meta = a.meta + first;
-    hipLaunchKernelGGL(kern, dim3((c.batch + robots_per_block - 1u) / robots_per_block), block, 0, h->stream, c);
+    uint32_t grid = (c.batch + robots_per_block - 1u) / robots_per_block;
+    if (max_grid && grid > max_grid) grid = max_grid;  // persistent kernel: the waves walk over the blocks
+    hipLaunchKernelGGL(kern, dim3(grid), block, 0, h->stream, c);
     ++h->launches;
   }
 }
@@ -1166,7 +1172,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         }
       }
     }
-    launch_step(h, kern, robots_per_block, block, a);
+    launch_step(h, kern, robots_per_block, block, a, (h->persist && k == 1 && !h->per_robot) ? h->persist_grid : 0u);
     HIP_TRY(h, hipGetLastError());
     h->step += (uint64_t)k;
     if (h->mode != kModeForce) h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
@@ -1368,13 +1374,24 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
       h->chunk = (v > 0 && !general && !h->fp64 && !h->lane_pair && !h->lane_cable) ? (uint32_t)((v + 63) & ~63L) : 0u;
     }
     if (h->chunk && h->chunk <= 90112u && !std::getenv("CDPR_LOWREG")) h->lowreg = false;  // every block runs in the role-split kernel's range
+    // the persistent one-wave kernel (cdpr_onestep_kernel<..., PERSIST>): uniform-mode handles on the lane-per-robot mapping
+    const bool can_persist = !general && !h->phys && !h->lane_pair && !h->lane_cable && cfg->per_robot_commands == 0 && cfg->precision != 64 && !h->chunk;
+    h->persist = false;
+    if (const char* ps = std::getenv("CDPR_PERSIST")) h->persist = (ps[0] == '1') && can_persist;
+    if (h->persist) {
+      h->lowreg = false;
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+      h->persist_grid = (uint32_t)cus * 4u;
+      if (const char* pg = std::getenv("CDPR_PERSIST_GRID")) h->persist_grid = (uint32_t)std::max(1L, std::atol(pg));
+    }
   }
   // second-generation one-step kernel: wins wherever there is a Newton stage to hide the controller rows under, and
   // without one from ~32 768 robots on (65 536 x 8, no FK: 6.3 vs 7.0 us/step); small batches without FK are pure
   // latency and the extra LDS round trip loses (4 096 x 4: 4.18 vs 3.99 us by rocprofv3)
   h->onestep_v2 = h->fk || cfg->batch > 32768u;
   if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
-  h->split = (h->onestep_v2 || h->per_robot) && !general && !h->phys && !h->lane_pair && !h->lane_cable && !h->lowreg && h->fk && h->td && cfg->n_cables >= 6;
+  h->split = (h->onestep_v2 || h->per_robot) && !general && !h->phys && !h->lane_pair && !h->lane_cable && !h->lowreg && !h->persist && h->fk && h->td && cfg->n_cables >= 6;
   if (const char* sp = std::getenv("CDPR_SPLIT")) h->split = h->split && sp[0] != '0';
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);

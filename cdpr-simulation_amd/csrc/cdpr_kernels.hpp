@@ -45,6 +45,7 @@ StepKernel pick_phys_kernel(uint32_t n, bool fk, bool td, int kind);
 StepKernel pick_pr_kernel(bool single, bool rollout, bool lowreg, uint32_t n, bool fk, bool td);
 // k_onestep.hip: second-generation one-step kernel and the role-split kernel (cdpr_onestep_kernel.hpp)
 StepKernel pick_onestep_kernel(uint32_t n, bool fk, bool td);
+StepKernel pick_onestep_persist_kernel(uint32_t n, bool fk, bool td);  // one wave per SIMD walking over blocks of 64 robots
 StepKernel pick_split_kernel(uint32_t n);
 StepKernel pick_pr_split_kernel(uint32_t n);
 // k_pair.hip / k_cable.hip: the other two wavefront mappings

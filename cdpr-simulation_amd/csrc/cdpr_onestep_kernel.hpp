@@ -90,8 +90,52 @@ CDPR_DEV void pid_pairs(const StepArgs& a, int calls, bool is_vel, const v2f (&d
   }
 }
 
-template <int N, bool FK, bool TD>
-__global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
+// PERSIST (batches beyond one robot per hardware lane): the grid is one wave per SIMD and every wave walks over blocks of
+// 64 robots, blockIdx.x, blockIdx.x + gridDim.x, ...  A launch whose waves each take ONE block is bulk-synchronous (load,
+// ~8 us of arithmetic, store), and a second wave on the same SIMD runs in phase with the first and adds its whole issue
+// time (profiles/r04_cliff_analysis.txt); here the NEXT block's rows are requested while the current block computes -
+// its controller rows and Joy by LDS-DMA as soon as the PID stage has read the staged ones, its platform rows into
+// registers right after - so from the second block on a wave never waits for memory.
+// A row load the compiler does not track (inline asm): the persistent kernel requests the next block's platform rows a
+// whole block ahead and waits for them with an explicit vmcnt(N) that leaves the N later operations (the next block's
+// LDS-DMA, this block's last observable stores) in flight.  Through ordinary loads the compiler would drain EVERY
+// outstanding memory operation at their first use (it does so whenever an LDS-DMA is pending), and the DMA - 24 KiB per
+// wave that the next block needs 9 us later - would have to land within 2 us of its issue, all waves at once.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+CDPR_DEV f32x4 load_slot_untracked(const float4* base, size_t stride, int slot, uint32_t off) {
+  const char* p = reinterpret_cast<const char*>(base + (size_t)slot * stride) + off;
+  f32x4 v;
+  // (into ACCUMULATION registers: the compiler takes an asm's result for valid at once and may copy it anywhere - a
+  //  vector-register result it moved into a spare AGPR straight away, before the data was there; an AGPR result has no
+  //  reason to move before its use.  Checked in the ISA: nothing reads these registers between the load and the wait.)
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(v) : "v"(p) : "memory");
+  return v;
+}
+// s_waitcnt immediate (gfx9): vmcnt = n (6 bits, split 3:0 | 15:14), expcnt and lgkmcnt untouched
+constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
+
+// The kernel's arguments as one block of a persistent kernel sees them: re-read from the kernarg segment (the StepArgs
+// struct is the kernel's only argument: offset 0) through a pointer the compiler cannot see through.
+template <bool PERSIST>
+CDPR_DEV StepArgs block_args(const StepArgs& a_in) {
+  if constexpr (PERSIST) {
+    static_assert(sizeof(StepArgs) % 4 == 0, "StepArgs is read word by word");
+    struct Words { uint32_t w[sizeof(StepArgs) / 4]; };
+    typedef __attribute__((address_space(4))) const uint32_t* KArg;
+    KArg kp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    Words u;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(StepArgs) / 4; ++i) u.w[i] = kp[i];
+    return __builtin_bit_cast(StepArgs, u);
+  } else {
+    return a_in;
+  }
+}
+
+template <int N, bool FK, bool TD, bool PERSIST = false>
+__global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a_in) {
+  const StepArgs& a = a_in;  // (shadowed inside the block loop, see there)
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
   constexpr int G = joint_groups(N);
@@ -103,24 +147,42 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
   __shared__ float4 stage[kCtrl + (kCmdRows ? kCmdRows : 1)][64];
 
   const uint32_t lane = threadIdx.x;
-  const uint32_t r = blockIdx.x * 64u + lane;
-  const uint32_t rr = (r < a.batch) ? r : (a.batch - 1u);  // tail lanes shadow the last robot, stores are masked
-  const bool live = r < a.batch;
-  const size_t st = a.stride;
-  const uint32_t off = rr * 16u, woff = r * 16u;
+  const size_t st0 = a.stride;
+  const uint32_t nblocks = (a.batch + 63u) / 64u;
+  uint32_t blk = blockIdx.x;
+  uint32_t r = blk * 64u + lane;
+  uint32_t rr = (r < a.batch) ? r : (a.batch - 1u);  // tail lanes shadow the last robot, stores are masked
+  bool live = r < a.batch;
+  uint32_t off = rr * 16u, woff = r * 16u;
 
   // ---- loads that the first stages need: geometry (oldest), platform rows, and the Joy when it is not LDS-staged
   CDPR_STAMP(0);
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
-  const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
-               p3 = load_slot(a.state, st, 3, off);
+  float4 p0 = load_slot(a.state, st0, 0, off), p1 = load_slot(a.state, st0, 1, off), p2 = load_slot(a.state, st0, 2, off),
+         p3 = load_slot(a.state, st0, 3, off);
   float4 p4 = make_float4(0.f, 0.f, 0.f, 1.f);
-  if (FK) p4 = load_slot(a.state, st, 4, off);
+  if (FK) p4 = load_slot(a.state, st0, 4, off);
+  if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
+  const bool force_mode = (a.flags & kFlagForceMode) != 0u;  // UpdateMode::Force (JFC.cpp:67-70): no Pid, no controller rows
+  const bool first_world = (a.flags & kFlagFirstWorldStep) != 0u;
+  const bool run_pid = !first_world && !force_mode && a.pid_calls != 0;  // wave-uniform (Pid.cpp:123-126: the first call returns 0)
+  bool staged = false;  // PERSIST: this block's controller rows were requested during the previous block
+
+  for (;;) {  // (one pass unless PERSIST)
+  // (opaque per block: every row address of the loop is loop-invariant, and hoisted out of it they overflow the scalar
+  //  register file into v_writelane / v_readlane pairs - measured: 762 of them)
+  size_t st = st0;
+  uint32_t goff = 0;  // (likewise the geometry in LDS: hoisted, its 7n values would ride through the whole loop in registers)
+  if (PERSIST) asm volatile("" : "+s"(st), "+v"(goff));
+  const float* const geo = lds + goff;
+  // ... and the kernel arguments themselves: every scalar the loop body reads would stay in a register across the whole
+  // loop, and everything computed from them once (packed broadcasts, negated constants) with it; read through an opaque
+  // pointer to the kernarg segment they are scalar loads of THIS block, as in the one-block kernel
+  const StepArgs a = block_args<PERSIST>(a_in);
   v2f desired[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
   const float* cp = a.cmd + (size_t)rr * N;  // never null: before the first Joy the latched buffer holds zeros
-  const bool force_mode = (a.flags & kFlagForceMode) != 0u;  // UpdateMode::Force (JFC.cpp:67-70): no Pid, no controller rows
   if (!kCmdLds || force_mode) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -130,7 +192,6 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
         desired[i / 2].x = cp[i];
     }
   }
-  if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
   // single-wave workgroup: LDS operations of one wave execute in order (see cdpr_step_kernel)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -146,15 +207,13 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
   // ---- controller rows and the Joy: global -> LDS, in flight until the PID stage.  Issued AFTER the platform rows
   //      are in registers: hipcc drains every outstanding VMEM operation (vmcnt(0)) at the first use of an ordinary
   //      load's result while an LDS-DMA is pending, so the DMA must not be pending yet when the platform rows are used.
-  const bool first_world = (a.flags & kFlagFirstWorldStep) != 0u;
-  const bool run_pid = !first_world && !force_mode && a.pid_calls != 0;  // wave-uniform (Pid.cpp:123-126: the first call returns 0)
   {
     // every ordinary load issued so far is consumed here (data dependence: no use of one can sink below the DMA issue)
     float keep = (s.px + s.qy) + (s.vy + s.wz) + fkqw;
 #pragma unroll
     for (int k = 0; k < NP; ++k) keep += desired[k].x + desired[k].y;
     asm volatile("" ::"v"(keep));
-    if (run_pid) {
+    if (run_pid && !staged) {
 #pragma unroll
       for (int j = 0; j < kCtrl; ++j)
         row_to_lds(reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.state + (size_t)(P + j) * st) + off), &stage[j][0]);
@@ -165,12 +224,26 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     }
   }
 
+  // ---- PERSIST: the next block's platform rows, requested a whole block ahead (untracked: see load_slot_untracked)
+  const uint32_t nblk = blk + gridDim.x;
+  const bool more = PERSIST && nblk < nblocks;
+  uint32_t nr = 0, nrr = 0;
+  f32x4 n0 = {0.f, 0.f, 0.f, 0.f}, n1 = n0, n2 = n0, n3 = n0, n4 = {0.f, 0.f, 0.f, 1.f};
+  if (PERSIST && more) {
+    nr = nblk * 64u + lane;
+    nrr = (nr < a.batch) ? nr : (a.batch - 1u);
+    const uint32_t noff = nrr * 16u;
+    n0 = load_slot_untracked(a.state, st, 0, noff), n1 = load_slot_untracked(a.state, st, 1, noff);
+    n2 = load_slot_untracked(a.state, st, 2, noff), n3 = load_slot_untracked(a.state, st, 3, noff);
+    if (FK) n4 = load_slot_untracked(a.state, st, 4, noff);
+  }
+
   CDPR_STAMP(1);
   // ---- IK on the state at t_k: joint positions and rates (observables), measured lengths L* for the estimator
   v2f len[NP], q[NP], qd[NP], jac[NP][6];
   {
     v2f l0[NP];
-    ik_pairs<N, true>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
+    ik_pairs<N, true>(geo, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len, jac, l0);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       q[k] = l0[k] - len[k];
@@ -201,7 +274,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     v2f elen[NP], unused[NP];
     bool active = true;
     for (int it = 0; it < a.fk_iters; ++it) {
-      ik_pairs<N, false>(lds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+      ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
       v2f res[NP];
       v2f rm = splat(0.f);
 #pragma unroll
@@ -221,7 +294,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
         ++fk_it;
       }
     }
-    ik_pairs<N, false>(lds, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
+    ik_pairs<N, false>(geo, fkx, fky, fkz, fkqx, fkqy, fkqz, fkqw, elen, jest, unused);
     v2f rm = splat(0.f);
 #pragma unroll
     for (int k = 0; k < NP; ++k) rm = max2(rm, abs2(len[k] - elen[k]));
@@ -296,6 +369,22 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
   if (force_mode && !first_world) {
 #pragma unroll
     for (int k = 0; k < NP; ++k) f[k] = desired[k];
+  }
+
+  // ---- PERSIST: the staged rows have been read: request the next block's (controller rows and Joy by LDS-DMA into the
+  //      same staging buffer, platform rows into registers); they arrive under this block's remaining stages
+  if (PERSIST && more) {
+    const uint32_t noff = nrr * 16u;
+    if (run_pid) {
+#pragma unroll
+      for (int j = 0; j < kCtrl; ++j)
+        row_to_lds(reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.state + (size_t)(P + j) * st) + noff), &stage[j][0]);
+      if (kCmdLds) {
+        const float* ncp = a.cmd + (size_t)nrr * N;
+#pragma unroll
+        for (int g = 0; g < kCmdRows; ++g) row_to_lds(reinterpret_cast<const float4*>(ncp) + g, &stage[kCtrl + g][0]);
+      }
+    }
   }
 
   CDPR_STAMP(5);
@@ -388,6 +477,19 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     w[5] = -w[5];
     integrate(a, s, w);
   }
+  if (PERSIST && more) {
+    // the next block's rows are waited for HERE, before this block's last stores are issued: the compiler drains every
+    // outstanding memory operation at the first use of a load's result while an LDS-DMA is pending, and at the top of
+    // the next block that would include these stores
+    // (everything issued before the last kDmaOps operations is complete: the platform rows went out before the DMA)
+    constexpr int kDmaOps = kCtrl + kCmdRows;
+    static_assert(kDmaOps < 64, "vmcnt is a 6-bit counter");
+    if (run_pid)
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(kDmaOps));
+    else
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    asm volatile("" : "+a"(n0), "+a"(n1), "+a"(n2), "+a"(n3), "+a"(n4));
+  }
   if (live) {
     CDPR_STORE_STATE(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
     CDPR_STORE_STATE(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
@@ -396,6 +498,16 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a) {
     if (FK) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
   }
   CDPR_STAMP(7);
+  if (!(PERSIST && more)) break;
+  blk = nblk;
+  r = nr;
+  rr = nrr;
+  live = r < a.batch;
+  off = rr * 16u, woff = r * 16u;
+  p0 = make_float4(n0.x, n0.y, n0.z, n0.w), p1 = make_float4(n1.x, n1.y, n1.z, n1.w), p2 = make_float4(n2.x, n2.y, n2.z, n2.w);
+  p3 = make_float4(n3.x, n3.y, n3.z, n3.w), p4 = make_float4(n4.x, n4.y, n4.z, n4.w);
+  staged = run_pid;
+  }  // blocks
 }
 
 // =====================================================================================================================

@@ -2,6 +2,8 @@
 against the fp64 oracle.  Force mode is the mode a JointForceCalculator is constructed in; `force = mForce`, no Pid runs,
 setForce resets nothing, leaving Force through a Joy resets the Pid of the mode entered (JFC.cpp:99-119).
 Tolerances: tests/test_gpu_parity.py."""
+from dataclasses import replace
+
 import numpy as np
 import pytest
 
@@ -231,6 +233,50 @@ def test_chunked_launches_are_bit_identical_to_one_launch(pkg, monkeypatch, per_
         assert np.array_equal(x, y)
     for key in a[2]:
         assert np.array_equal(a[2][key], b[2][key]), key
+
+
+@pytest.mark.parametrize("cables,stages", [(8, 3), (8, 1), (4, 0), (7, 3)])
+def test_persistent_one_wave_kernel_is_bit_identical(pkg, monkeypatch, cables, stages):
+    """CDPR_PERSIST=1: one-step launches on the persistent one-wave kernel (a fixed grid of waves walks over the blocks of 64
+    robots, the next block's rows requested while the current block computes - platform rows by untracked loads into
+    accumulation registers behind an explicit vmcnt, controller rows by LDS-DMA into the staging buffer the PID stage has
+    just read).  Forced onto 3 waves here so that every wave takes several blocks, ragged last block, Velocity, Position
+    and Force mode, the first world step: same bits as the default kernels."""
+    B = 64 * 13 + 5
+    rng = np.random.default_rng(77)
+    full = pkg.eight_cable_model()
+    model = pkg.cube_model() if cables == 4 else replace(full, frame_anchors=full.frame_anchors[:cables], platform_anchors=full.platform_anchors[:cables])
+    cfg = pkg.Config(model=model, batch=B, stages=stages)
+    pose = perturbed_poses(model, B, rng).astype(np.float32)
+    v = rng.uniform(-0.03, 0.03, (B, cables)).astype(np.float32)
+    p = rng.uniform(-0.003, 0.003, (B, cables)).astype(np.float32)
+    f = rng.uniform(5.0, 25.0, (B, cables)).astype(np.float32)
+    monkeypatch.setenv("CDPR_MAPPING", "1")
+    monkeypatch.setenv("CDPR_NO_GRAPH", "1")
+    out = []
+    for persist in ("0", "1"):
+        monkeypatch.setenv("CDPR_PERSIST", persist)
+        monkeypatch.setenv("CDPR_PERSIST_GRID", "3")
+        eng = pkg.Engine(cfg, 0)
+        eng.set_platform_state(pose7=pose)
+        eng.update(1)  # the first world step: no Pid call
+        eng.set_velocity_command(v)
+        for _ in range(17):
+            eng.update(1)
+        eng.set_position_command(p)
+        for _ in range(13):
+            eng.update(1)
+        eng.set_force_command(f)
+        for _ in range(5):
+            eng.update(1)
+        eng.set_velocity_command(-v)
+        for _ in range(12):
+            eng.update(1)
+        out.append(eng.platform_state() + eng.joint_states() + (eng.fk_state() if stages & 1 else ()) + (eng.td_state() if stages & 2 else ()))
+        eng.close()
+    a, b = out
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
 
 
 @pytest.mark.parametrize("cables,stages,mapping_env", [(4, 0, "2"), (4, 0, "1"), (8, 3, "1"), (8, 0, "2")])
