@@ -555,8 +555,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a_in
 #define CDPR_CTL_STAMP(i) CDPR_SPLIT_STAMP(i)
 #endif
 
-// The estimator wave of a role-split workgroup (cdpr_split_kernel, and cdpr_gen_split_kernel on the general controller
-// path): platform rows -> measured lengths -> Newton-Raphson FK -> [forces from the controller wave] tension distribution
+// The estimator wave of a role-split workgroup (cdpr_split_kernel): platform rows -> measured lengths -> Newton-Raphson FK -> [forces from the controller wave] tension distribution
 // -> tensions and estimator results back.  x_force / x_tension: v2f rows XS elements apart, x_est: float rows ES apart.
 template <int N, int XS, int ES>
 CDPR_DEV void split_estimator_wave(const StepArgs& a, float* geo, float gval, uint32_t lane, bool live, size_t st, uint32_t off, uint32_t woff,

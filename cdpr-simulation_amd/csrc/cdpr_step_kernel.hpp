@@ -70,7 +70,6 @@ struct StepArgs {
   const float* cmd;   // latched Joy.axes of the active mode, float[B][n] (all zeros until the first message: target 0 after Load)
   float* dbg;         // float[B][9] `pid` debug topic, or nullptr
   const float* geom;  // cable_pairs(n) * 16 floats, pair-interleaved cable geometry
-  const float* force; // EXT only: raw per-cable forces from the general controller kernel, float[B][n]
   // ROLLOUT only: S sampled command sequences per robot over `nsteps` steps, nothing written but one cost per trajectory
   const float* roll_cmd;  // float[B][H][S][n]: per robot and step, a batch of S Joy.axes
   const float* roll_ref;  // float[B][3] reference position
@@ -795,8 +794,6 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
 #define CDPR_LPR_WAVES 1  // minimum waves per SIMD the lane-per-robot kernel is compiled for (register budget 512 / this)
 #endif
 
-// EXT = true: the controller ran in cdpr_general_ctrl_kernel; forces come from a.force and the state has
-// no controller records (platform slots only).
 // ROLLOUT = true: MPC fan-out (BASELINE config 5): one lane = one (robot, sampled command sequence); the robot's
 // current state is the common start, commands change every step, state never leaves the chip.
 #if CDPR_STATE_STORE_PLAIN
@@ -811,7 +808,7 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
 // PHYS = true: the world step carries the lumped legs (integrate_lumped): handles created with any of
 // cdpr_config_t.passive_damping / leg_inertia / cable_axial_mass / anchor_point_mass / anchor_inertia.
 // PR = true: per-robot handles (StepArgs::meta): mode, Pid call count and therefore the Pid in use are per lane.
-template <int N, bool FK, bool TD, bool SINGLE, bool EXT = false, bool ROLLOUT = false, bool LOWREG = false, bool PHYS = false, bool PR = false>
+template <int N, bool FK, bool TD, bool SINGLE, bool ROLLOUT = false, bool LOWREG = false, bool PHYS = false, bool PR = false>
 __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a) {
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
@@ -840,7 +837,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   if (FK) p4 = load_slot(a.state, st, 4, off);
   constexpr int NH = (NP + 1) / 2;  // hot rows
   float4 wraw[NP][5], hraw[NH];
-  if (!EXT) {
+  {
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
 #pragma unroll
@@ -849,10 +846,10 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 #pragma unroll
     for (int g = 0; g < NH; ++g) hraw[g] = load_slot(a.state, st, P + 5 * NP + g, off);
   }
-  v2f desired[NP];  // EXT: the raw forces instead of the Joy targets
+  v2f desired[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) desired[k] = splat(0.f);
-  const float* vec_in = EXT ? a.force : a.cmd;  // never null: before the first Joy the latched buffer holds zeros
+  const float* vec_in = a.cmd;  // never null: before the first Joy the latched buffer holds zeros
   auto load_joy = [&](const float* cp) {  // one robot's Joy.axes (float[N]) as cable pairs
     if (N % 4 == 0) {
 #pragma unroll
@@ -871,7 +868,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       }
     }
   };
-  if (!SINGLE && !ROLLOUT && !EXT && a.sched_refresh > 0) sched_wait(a, 0);
+  if (!SINGLE && !ROLLOUT && a.sched_refresh > 0) sched_wait(a, 0);
   if (!ROLLOUT) load_joy(vec_in + (size_t)rr * N);
 
   if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
@@ -891,7 +888,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   // controller records as cable pairs: ring of the last 10 errors, integral
   v2f win[NP][kWin], ierr[NP];
 #pragma unroll
-  for (int k = 0; k < (EXT ? 0 : NP); ++k) {
+  for (int k = 0; k < NP; ++k) {
 #pragma unroll
     for (int m = 0; m < 5; ++m) {
       win[k][2 * m] = (v2f){wraw[k][m].x, wraw[k][m].y};      // register pairs as loaded: no moves
@@ -901,7 +898,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   }
   // uniform handles: mode and call count are launch arguments; PR: this robot's own (per lane)
   uint32_t meta = 0u;
-  if (PR && !EXT) meta = a.meta[rr];
+  if (PR) meta = a.meta[rr];
   bool actual_is_vel = PR ? ((meta & kMetaModeMask) == kMetaVelocity) : ((a.flags & kFlagActualIsVelocity) != 0u);
   int calls = PR ? (int)(meta >> kMetaCallShift) : a.pid_calls;
   float cost = 0.f, refx = 0.f, refy = 0.f, refz = 0.f;
@@ -931,7 +928,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   // window is 80 VGPRs that push the kernel past 256 (hundreds of v_accvgpr moves per step) and a ring push is 80
   // v_cndmask (the slot is a run-time value): every one of those is a vector instruction of the one wave that is
   // issue-bound, the LDS operations are not.  Same values either way.
-  constexpr bool kLdsWin = CDPR_LDS_WINDOW && !SINGLE && !EXT;
+  constexpr bool kLdsWin = CDPR_LDS_WINDOW && !SINGLE;
   __shared__ v2f lwin[kLdsWin ? kWin : 1][kLdsWin ? NP : 1][64];
   if (kLdsWin) {
 #pragma unroll
@@ -942,7 +939,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   }
 
   for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
-    if (!SINGLE && !ROLLOUT && !EXT && a.sched_refresh > 0 && step > 0 && step % a.sched_refresh == 0) {
+    if (!SINGLE && !ROLLOUT && a.sched_refresh > 0 && step > 0 && step % a.sched_refresh == 0) {
       // a launch over a command schedule (cdpr_update_scheduled): the next Joy batch at every refresh boundary
       const int j = step / a.sched_refresh;
       sched_wait(a, j);
@@ -1008,10 +1005,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
     bool dbg_wrote = false;
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
     int ring_slot = -1;  // ring slot this step's error goes to (-1: no sample taken)
-    if (EXT) {
-#pragma unroll
-      for (int k = 0; k < NP; ++k) f[k] = first_world ? splat(0.f) : desired[k];
-    } else if (!first_world && !PR && (a.flags & kFlagForceMode)) {
+    if (!first_world && !PR && (a.flags & kFlagForceMode)) {
       // UpdateMode::Force (JFC.cpp:67-70): the commanded force goes out as it is, no Pid is called
 #pragma unroll
       for (int k = 0; k < NP; ++k) f[k] = desired[k];
@@ -1071,7 +1065,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
       calls = PR ? min(calls + 1, (int)kMetaCallMax) : calls + 1;
     }
 
-    if (!EXT && !SINGLE && ring_slot >= 0) {
+    if (!SINGLE && ring_slot >= 0) {
       if (kLdsWin) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) lwin[ring_slot][k][lane] = e_new[k];
@@ -1079,7 +1073,7 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
         ring_push<NP>(win, e_new, ring_slot);
       }
     }
-    if (!EXT && SINGLE && live) {
+    if (SINGLE && live) {
       // controller records are final: one ring row per cable pair (the one that takes the new error) + the hot rows
       if (ring_slot >= 0) {
 #pragma unroll
@@ -1257,14 +1251,14 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 
   CDPR_STAMP(6);
   // ---- store
-  if (PR && !EXT && live) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)calls << kMetaCallShift));
+  if (PR && live) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)calls << kMetaCallShift));
   if (live) {
     CDPR_STORE_STATE(a.state, st, 0, woff, make_float4(s.px, s.py, s.pz, s.qx));
     CDPR_STORE_STATE(a.state, st, 1, woff, make_float4(s.qy, s.qz, s.qw, s.vx));
     CDPR_STORE_STATE(a.state, st, 2, woff, make_float4(s.vy, s.vz, s.wx, s.wy));
     CDPR_STORE_STATE(a.state, st, 3, woff, make_float4(s.wz, fkx, fky, fkz));
     if (FK) CDPR_STORE_STATE(a.state, st, 4, woff, make_float4(fkqx, fkqy, fkqz, fkqw));
-    if (!SINGLE && !EXT) {
+    if (!SINGLE) {
       if (kLdsWin) {
 #pragma unroll
         for (int j = 0; j < kWin; ++j) {

@@ -6,12 +6,12 @@ namespace {
 template <int N, bool SINGLE, bool ROLLOUT, bool LOWREG>
 StepKernel stage(bool fk, bool td) {
   if constexpr (N >= 6) {
-    if (fk && td) return cdpr_step_kernel<N, true, true, SINGLE, false, ROLLOUT, LOWREG, false, true>;
-    if (fk) return cdpr_step_kernel<N, true, false, SINGLE, false, ROLLOUT, LOWREG, false, true>;
+    if (fk && td) return cdpr_step_kernel<N, true, true, SINGLE, ROLLOUT, LOWREG, false, true>;
+    if (fk) return cdpr_step_kernel<N, true, false, SINGLE, ROLLOUT, LOWREG, false, true>;
     if constexpr (!LOWREG)
-      if (td) return cdpr_step_kernel<N, false, true, SINGLE, false, ROLLOUT, false, false, true>;
+      if (td) return cdpr_step_kernel<N, false, true, SINGLE, ROLLOUT, false, false, true>;
   }
-  if constexpr (!LOWREG) return cdpr_step_kernel<N, false, false, SINGLE, false, ROLLOUT, false, false, true>;
+  if constexpr (!LOWREG) return cdpr_step_kernel<N, false, false, SINGLE, ROLLOUT, false, false, true>;
   return nullptr;
 }
 template <int N>

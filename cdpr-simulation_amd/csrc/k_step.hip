@@ -5,11 +5,11 @@ namespace {
 #define K_STEP(N, FK, TD) cdpr_step_kernel<N, FK, TD, SINGLE>
 template <int N, bool SINGLE> StepKernel stage(bool fk, bool td) { CDPR_PICK_STAGES(N, K_STEP); }
 template <int N> StepKernel step_n(bool single, bool fk, bool td) { return single ? stage<N, true>(fk, td) : stage<N, false>(fk, td); }
-#define K_ROLL(N, FK, TD) cdpr_step_kernel<N, FK, TD, false, false, true>
+#define K_ROLL(N, FK, TD) cdpr_step_kernel<N, FK, TD, false, true>
 template <int N> StepKernel roll_n(bool fk, bool td) { CDPR_PICK_STAGES(N, K_ROLL); }
 // lumped-leg physics / joint stop (PHYS = true): one generic stepping kernel (any steps per launch) and the MPC rollout
-#define K_PHYS_STEP(N, FK, TD) cdpr_step_kernel<N, FK, TD, false, false, false, false, true>
-#define K_PHYS_ROLL(N, FK, TD) cdpr_step_kernel<N, FK, TD, false, false, true, false, true>
+#define K_PHYS_STEP(N, FK, TD) cdpr_step_kernel<N, FK, TD, false, false, false, true>
+#define K_PHYS_ROLL(N, FK, TD) cdpr_step_kernel<N, FK, TD, false, true, false, true>
 template <int N> StepKernel phys_step_n(bool fk, bool td) { CDPR_PICK_STAGES(N, K_PHYS_STEP); }
 template <int N> StepKernel phys_roll_n(bool fk, bool td) { CDPR_PICK_STAGES(N, K_PHYS_ROLL); }
 template <int N> StepKernel phys_n(bool fk, bool td, int kind) { return kind == kPhysRollout ? phys_roll_n<N>(fk, td) : phys_step_n<N>(fk, td); }
@@ -21,9 +21,9 @@ StepKernel pick_phys_kernel(uint32_t n, bool fk, bool td, int kind) { CDPR_PICK_
 // one-step kernels compiled for two waves per SIMD (FK on, n >= 6): see LOWREG in cdpr_step_kernel.hpp
 StepKernel pick_lowreg_kernel(uint32_t n, bool td) {
   switch (n) {
-    case 6: return td ? cdpr_step_kernel<6, true, true, true, false, false, true> : cdpr_step_kernel<6, true, false, true, false, false, true>;
-    case 7: return td ? cdpr_step_kernel<7, true, true, true, false, false, true> : cdpr_step_kernel<7, true, false, true, false, false, true>;
-    case 8: return td ? cdpr_step_kernel<8, true, true, true, false, false, true> : cdpr_step_kernel<8, true, false, true, false, false, true>;
+    case 6: return td ? cdpr_step_kernel<6, true, true, true, false, true> : cdpr_step_kernel<6, true, false, true, false, true>;
+    case 7: return td ? cdpr_step_kernel<7, true, true, true, false, true> : cdpr_step_kernel<7, true, false, true, false, true>;
+    case 8: return td ? cdpr_step_kernel<8, true, true, true, false, true> : cdpr_step_kernel<8, true, false, true, false, true>;
   }
   return nullptr;
 }

@@ -380,7 +380,7 @@ def test_full_size_position_mode_config3(pkg, oracle):
 
 
 # ---------------------------------------------------------------------------------------------
-# general controller path (cdpr_general_ctrl.hpp): hold branch, biquad cascades, long windows, cmdLimit 0
+# general controller path (cdpr_general_step.hpp): hold branch, biquad cascades, long windows, cmdLimit 0
 # ---------------------------------------------------------------------------------------------
 def run_script(eng, ora, script, tol=TOL, label=""):
     for kind, val in script:
