@@ -57,6 +57,7 @@ struct cdpr_engine {
   bool lane_cable = false;  // one lane per cable, 8 (or 4) lanes per robot (cdpr_step_kernel_cable.hpp)
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
+  bool gen_split = false;   // general path: one-step launches use the role-split kernel (FK + TD, n >= 6, windows <= 11, <= 2 workgroups per CU)
   bool persist = false;     // one-step launches use the persistent one-wave kernel: one wave per SIMD walks over blocks of 64
                             // robots, the next block's rows in flight under the current block's arithmetic (large batches)
   uint32_t persist_grid = 0;  // waves of such a launch: SIMDs of the device
@@ -679,7 +680,9 @@ int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
-    GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11, k == 1);
+    // one step per launch on FK + TD handles up to two workgroups per CU: the role-split form (cdpr_general_split.hpp)
+    const bool gsplit = h->gen_split && k == 1;
+    GenKernel kern = gsplit ? pick_gen_split11(h->n) : pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11, k == 1);
     a.nsteps = k;
     a.flags = (h->step == 0) ? kFlagFirstWorldStep : 0u;
     g.now_step = (int)h->step;
@@ -692,7 +695,7 @@ int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record
         a.publish_mask |= (1ull << j);
       }
     }
-    hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a, g);
+    hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(gsplit ? 128 : 64), 0, h->stream, a, g);
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;
@@ -1492,6 +1495,15 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     h->glay.nb = (int)std::max(cfg->velocity_pid.d_buffer_length, cfg->position_pid.d_buffer_length);
     h->glay.ncas = (int)std::max(std::max(cfg->velocity_pid.p_filter.cascade, cfg->velocity_pid.d_filter.cascade),
                                  std::max(cfg->position_pid.p_filter.cascade, cfg->position_pid.d_filter.cascade));
+    {
+      // role-split one-step kernel: compiled for one workgroup per pair of SIMDs (each wave may use the whole register
+      // file), so it serves batches up to two workgroups of 64 robots per CU; CDPR_GEN_SPLIT=0|1 overrides (A/B)
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+      const bool can = h->fk && h->td && h->n >= 6 && h->glay.nb <= 11;
+      h->gen_split = can && cfg->batch <= (uint32_t)cus * 128u;
+      if (const char* gs = std::getenv("CDPR_GEN_SPLIT")) h->gen_split = can && gs[0] == '1';
+    }
     const size_t rec_bytes = h->glay.bytes(h->stride);
     if (rec_bytes >= (1ull << 32)) {  // the record buffer is addressed with 32-bit offsets (one buffer resource)
       g_create_error = "general controller path: the controller records of this batch pass 4 GiB; split the batch over several handles";
