@@ -13,8 +13,9 @@
 // (__launch_bounds__(128, 1): each wave may use the whole register file, as the one-wave kernel does), so it serves
 // batches up to 2 workgroups per CU; the engine uses the one-wave kernel beyond.  Measured and not kept: the same kernel
 // compiled for two waves per SIMD (__launch_bounds__(128, 2): 256 registers, 300 B of scratch per lane in the controller
-// wave) runs 65 536 x 8 in 30 - 47 us against the one-wave kernel's 21.4; this build at 65 536 (two rounds of 512
-// workgroups) in 22.5.
+// wave) runs 65 536 x 8 in 30 - 47 us against the one-wave kernel's 21.4, and 28.7 us with the scratch cut to 48 B (cables
+// in groups of two, structure matrix rebuilt for the world step); this build at 65 536 (two rounds of 512 workgroups) in
+// 22.5.  At 65 536 the launch moves 87 MB - 13.6 us at the 6.4 TB/s a copy reaches - so there is little to win there.
 // Same device functions, same arithmetic order as the one-wave kernel: bit-identical (tested).
 #pragma once
 #include "cdpr_general_step.hpp"

@@ -189,3 +189,53 @@ def test_a_pid_that_sleeps_for_a_long_time_keeps_its_exact_stamps(pkg, oracle):
             eng.update(k)
         ora.update(k)
         compare(eng, ora, where=f"after {k} steps")
+
+
+@pytest.mark.parametrize("cables,variant", [(8, "hold"), (6, "hold"), (7, "per_robot_lumped"), (8, "per_robot_stop"), (8, "pid_debug")])
+def test_role_split_general_kernel_is_bit_identical_to_the_one_wave_kernel(pkg, monkeypatch, cables, variant):
+    """One-step launches of FK + TD handles on the general path run on the role-split kernel up to two workgroups per CU
+    (cdpr_general_split.hpp: estimator wave + controller wave per 64 robots; CDPR_GEN_SPLIT=0 keeps the one-wave kernel):
+    same bits for the whole state, every observable, the estimator's results and the `pid` topic, with cables switching Pids
+    (fit queue, ring turns), per-robot modes incl. Force, the lumped legs, the joint stop, a ragged last block and the first
+    world step.  Fused launches and the record run on the one-wave kernel on both handles and continue from either."""
+    B, eps = 64 * 5 + 23, 0.004
+    rng = np.random.default_rng(400 + cables)
+    full = pkg.eight_cable_model()
+    model = replace(full, frame_anchors=full.frame_anchors[:cables], platform_anchors=full.platform_anchors[:cables])
+    if variant == "per_robot_lumped":
+        model = replace(model, inertia=(0.9, 1.1, 1.0, 0.05, -0.03, 0.02), passive_damping=0.01, leg_inertia=0.004, cable_axial_mass=0.001,
+                        anchor_point_mass=0.002, anchor_inertia=0.001)
+    if variant == "per_robot_stop":
+        model = replace(model, travel_lower=-0.012, travel_upper=0.012, travel_stop=4)
+    stages = 3 | (pkg._abi.STAGE_PID_DEBUG if variant == "pid_debug" else 0)
+    cfg = pkg.Config(model=model, batch=B, stages=stages, velocityEpsilon=eps, perRobotCommands=variant.startswith("per_robot"))
+    pose = perturbed_poses(model, B, rng, 0.02, 0.05)
+    joys = [(hold_commands(rng, B, cables, eps), rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32),
+             (7.0 + rng.uniform(-0.5, 0.5, (B, cables))).astype(np.float32)) for _ in range(6)]
+    out = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("CDPR_GEN_SPLIT", split)
+        eng = pkg.Engine(cfg, 0)
+        eng.set_platform_state(pose7=pose)
+        eng.update(1)  # the first world step
+        snaps = []
+        for rnd, (v, p, f) in enumerate(joys):
+            if cfg.perRobotCommands:
+                g = (np.arange(B) + rnd) % 4
+                eng.set_velocity_command(v, mask=g <= 1)
+                if rnd % 2:
+                    eng.set_position_command(p, mask=g == 2)
+                if rnd >= 2:
+                    eng.set_force_command(f, mask=g == 3)
+            else:
+                eng.set_velocity_command(v)
+            for _ in range([9, 14, 3, 12, 17, 5][rnd]):
+                eng.update(1)
+            if rnd == 3:
+                eng.update(8, 4)  # a fused launch in between: the one-wave multi-step kernel on both handles
+            snaps.append(eng.platform_state() + eng.joint_states() + eng.fk_state() + eng.td_state() + ((eng.pid_debug(),) if variant == "pid_debug" else ()))
+        out.append(snaps)
+        eng.close()
+    for rnd, (a, b) in enumerate(zip(*out)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), f"round {rnd}"
