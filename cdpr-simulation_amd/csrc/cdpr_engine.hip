@@ -1316,6 +1316,12 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->n = cfg->n_cables;
   h->batch = (uint32_t)cfg->batch;
   h->stride = (h->batch + 63u) & ~63u;
+  // A robot's rows lie `stride` x 16 B apart.  When that is a multiple of 2 MiB (131 072 robots) every row of a wavefront
+  // maps to the same HBM channels and the launch loses 17 % (131 072 x 8: 29.8 -> 24.7 us per step, 262 144: 46-54 -> 43.3;
+  // profiles/r04_stride_padding.txt: this was most of "the 131 072 anomaly").  Any pad of 64 .. 1 088 columns cures it
+  // alike; smaller batches are not padded (16 384: a pad costs 3-4 %).  CDPR_STRIDE_PAD=<columns> forces a pad (A/B).
+  if (h->stride % 131072u == 0u) h->stride += 128u;
+  if (const char* sp = std::getenv("CDPR_STRIDE_PAD")) h->stride = ((h->batch + 63u) & ~63u) + ((uint32_t)(std::max(0L, std::atol(sp)) + 63L) & ~63u);
   h->fk = (cfg->stages & CDPR_STAGE_FK) != 0;
   h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
