@@ -10,6 +10,8 @@
 // Rounds 1-3 ran this as two launches (one thread per (robot, cable) for the controller, forces through HBM, then the
 // platform kernel).  Here one lane owns one robot for the whole step, as on the fast path: forces never leave the
 // registers, and the same kernel serves one step, several steps per launch, the trajectory record and the MPC rollout.
+// (One-step launches of FK + TD handles up to two workgroups per CU run gen_controller in the controller wave of a
+//  role-split workgroup instead: cdpr_general_split.hpp.)
 //
 // Records (HBM, one buffer, one column per robot), in two regions:
 //   A: float4 SLOT rows (16 B per robot and row: a wave moves 1 KiB per row, by LDS-DMA on the way in)
