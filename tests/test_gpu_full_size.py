@@ -134,6 +134,38 @@ def test_auto_selected_low_register_kernel_at_131072_robots(pkg, oracle, monkeyp
     check_slice(pkg, oracle, cfg_kwargs, slice(70000, 70128), pose, [(15, None), (45, cmd)], got)
 
 
+def test_row_stride_is_padded_at_131072_robots(pkg, monkeypatch):
+    """cdpr_create pads the row stride by 128 columns where it would be a multiple of 2 MiB of row distance (HBM channel
+    aliasing, profiles/r04_stride_padding.txt): the observable image grows accordingly, records and read-outs follow the
+    stride, and nothing a caller sees changes - same bits as a handle forced to the unpadded stride."""
+    monkeypatch.setenv("CDPR_MAPPING", "1")
+    B, n = 131072, 4
+    rng = np.random.default_rng(9)
+    cfg = pkg.Config(batch=B, stages=0)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    cmd = rng.uniform(-0.04, 0.04, (B, n)).astype(np.float32)
+    out, image = [], []
+    for pad in (None, "0"):
+        if pad is None:
+            monkeypatch.delenv("CDPR_STRIDE_PAD", raising=False)
+        else:
+            monkeypatch.setenv("CDPR_STRIDE_PAD", pad)
+        e = pkg.Engine(cfg, 0)
+        image.append(e.observable_image_bytes())
+        e.set_platform_state(pose7=pose)
+        e.update(3)
+        e.set_velocity_command(cmd)
+        e.update(12)
+        rec = e.update_record(4, 2)
+        assert np.array_equal(rec["pose"][-1], e.platform_state()[0]) and np.array_equal(rec["effort"][-1], e.joint_states()[2])
+        out.append(e.raw_state() + e.joint_states() + (rec["pose"], rec["velocity"]))
+        e.close()
+    n_obs = image[1] // (B * 16)
+    assert image[1] == n_obs * B * 16 and image[0] == n_obs * (B + 128) * 16
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+
+
 def test_sharded_engine_against_the_oracle(pkg, oracle, monkeypatch):
     """Config-4 placement against the ORACLE: contiguous robot blocks on every device the box has (on a 1-GPU lease:
     two handles on device 0), nothing exchanged; stepping, both command kinds, the concurrent rollout."""
