@@ -239,3 +239,64 @@ def test_role_split_general_kernel_is_bit_identical_to_the_one_wave_kernel(pkg, 
     for rnd, (a, b) in enumerate(zip(*out)):
         for x, y in zip(a, b):
             assert np.array_equal(x, y), f"round {rnd}"
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_call_sequences_on_the_general_path(pkg, oracle, seed):
+    """The general path's host-side state machine under random call sequences, hold branch live: velocity Joys with cables at
+    or below epsilon, position and force Joys (to random subsets of the robots on the per-robot seeds), updates issued one
+    launch per step (role-split kernel on FK + TD handles), fused, as a trajectory record, MPC rollouts in between (they
+    must leave the handle alone), world resets and state writes - compared with the oracle after every update.  Rings
+    turn, windows refill, fit queues form and drain at moments no scripted test picks."""
+    rng = np.random.default_rng(900 + seed)
+    n = [8, 4, 8, 7][seed]
+    per_robot = seed >= 2
+    eps = 0.004
+    full = pkg.eight_cable_model()
+    model = pkg.cube_model() if n == 4 else replace(full, frame_anchors=full.frame_anchors[:n], platform_anchors=full.platform_anchors[:n])
+    B = [130, 200, 97, 64][seed]
+    stages = {4: 0, 7: 3, 8: 3}[n]
+    cfg = pkg.Config(model=model, batch=B, stages=stages, velocityEpsilon=eps, perRobotCommands=per_robot)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05))
+    total = 0
+    for op in range(55):
+        kind = rng.choice(["vel", "pos", "frc", "run", "fused", "record", "rollout", "reset", "state"], p=[0.22, 0.08, 0.05, 0.3, 0.12, 0.08, 0.06, 0.04, 0.05])
+        where = f"seed {seed} op {op} ({kind}) after {total} steps"
+        mask = (rng.random(B) < rng.choice([0.3, 0.7, 1.0])) if per_robot else None
+        kw = {"mask": mask} if per_robot else {}
+        if kind == "vel":
+            c = hold_commands(rng, B, n, eps)
+            eng.set_velocity_command(c, **kw), ora.set_velocity_command(c, **kw)
+        elif kind == "pos":
+            c = rng.uniform(-0.004, 0.004, (B, n)).astype(np.float32)
+            eng.set_position_command(c, **kw), ora.set_position_command(c, **kw)
+        elif kind == "frc":
+            c = (7.0 + rng.uniform(-0.5, 0.5, (B, n))).astype(np.float32)
+            eng.set_force_command(c, **kw), ora.set_force_command(c, **kw)
+        elif kind == "reset":
+            eng.reset(), ora.reset()
+            total = 0
+        elif kind == "state":
+            p = perturbed_poses(model, B, rng, 0.02, 0.05).astype(np.float32)
+            eng.set_platform_state(pose7=p), ora.set_platform_state(pose7=p.astype(np.float64))
+        elif kind == "rollout":
+            cmds = rng.uniform(-0.03, 0.03, (B, 6, 3, n)).astype(np.float32)
+            ref = eng.raw_state()[0][:, :3].astype(np.float64) + np.array([0.0, 0.0, 0.01])  # (a cost well above fp32 rounding of the positions)
+            gc, oc = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref)
+            assert np.abs(gc - oc).max() <= 1e-9 + 2e-4 * np.abs(oc).max(), where
+        else:
+            k = int(rng.integers(1, 30))
+            if kind == "run":
+                for _ in range(k):
+                    eng.update(1)
+            elif kind == "fused":
+                eng.update(k, int(rng.choice([2, 5, 10])))
+            else:
+                rec = eng.update_record(k, int(rng.choice([1, 4, 10])))
+                assert rec["pose"].shape == (k, B, 7)
+            ora.update(k)
+            total += k
+            compare(eng, ora, where=where)
+            if kind == "record" and total > k:
+                assert np.array_equal(rec["pose"][-1], eng.platform_state()[0]), where
+    eng.close()
