@@ -798,7 +798,10 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
   a.wtab = h->d_wtab64 + (vel ? 0 : kWin * (kWin + 2));
   // the rings in LDS (64 KiB per wave at n = 8: two waves per CU) while the batch leaves CUs to spare
   static const int ring_env = [] { const char* v = std::getenv("CDPR_F64_RING_LDS"); return v ? atoi(v) : -1; }();
-  F64Kernel kern = pick_f64_kernel(n, ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u);
+  // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
+  static const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();
+  const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
+  F64Kernel kern = pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);

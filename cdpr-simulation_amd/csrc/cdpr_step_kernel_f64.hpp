@@ -211,10 +211,16 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 // RING_LDS: the derivative rings of a lane's cables are loaded once, in one batch, into LDS columns (40 KiB per wave at
 // n = 8) and written back at the end: the FIR then costs no memory round trip per cable and step (small batches: the step
 // is one latency chain).  Otherwise they stay in HBM / L2 (large batches: four waves per CU need the LDS).
-template <int N, bool RING_LDS = false>
+// JCACHE (small batches: one workgroup per CU): the structure-matrix rows are kept in private LDS columns where they are
+// needed again - the rows at the true pose (IK stage) for the world step, the rows at the estimate (the Newton stage's
+// closing evaluation) for both passes of the tension distribution - instead of being recomputed: 48 row evaluations per
+// step instead of 72 at n = 8 (a row is ~60 fp64 instructions, a reload 6 LDS reads).  Same values, same bits.
+template <int N, bool RING_LDS = false, bool JCACHE = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
   __shared__ double c_win[RING_LDS ? N : 1][RING_LDS ? kWin : 1][64];
+  __shared__ double c_jt[JCACHE ? N : 1][JCACHE ? 6 : 1][64];  // rows at the true pose
+  __shared__ double c_je[JCACHE ? N : 1][JCACHE ? 6 : 1][64];  // rows at the FK estimate
   const uint32_t lane = threadIdx.x;
   const uint32_t r = blockIdx.x * 64u + lane;
   if (r >= a.batch) return;  // no barrier below: lanes are independent, LDS columns are private
@@ -258,6 +264,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         c_len[i][lane] = L;
         c_q[i][lane] = q;
         c_qd[i][lane] = qd;
+        if (JCACHE) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane] = j[c];
+        }
         double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
         if (run_pid) {
           const double desired = c_des[i][lane];
@@ -344,6 +354,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, fkp, L, j);
         fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
+        if (JCACHE) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) c_je[JCACHE ? i : 0][JCACHE ? c : 0][lane] = j[c];
+        }
       }
     }
     // ---- tension distribution ([NEW] SURVEY 8(a) row 15): T = Tm 1 + J (J^T J)^-1 J^T (f - Tm 1) with J at the FK
@@ -363,7 +377,12 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll 1
         for (int i = 0; i < N; ++i) {
           double L, j[6];
-          ik_row64(a.geom + i * 7, Rt, pt, L, j);
+          if (JCACHE) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) j[c] = a.fk ? c_je[JCACHE ? i : 0][JCACHE ? c : 0][lane] : c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane];
+          } else {
+            ik_row64(a.geom + i * 7, Rt, pt, L, j);
+          }
           const double df = c_f[i][lane] - a.td_mid;
 #pragma unroll
           for (int x = 0; x < 6; ++x) {
@@ -379,7 +398,12 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         double applied = c_f[i][lane];
         if (a.td) {
           double L, j[6];
-          ik_row64(a.geom + i * 7, Rt, pt, L, j);
+          if (JCACHE) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) j[c] = a.fk ? c_je[JCACHE ? i : 0][JCACHE ? c : 0][lane] : c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane];
+          } else {
+            ik_row64(a.geom + i * 7, Rt, pt, L, j);
+          }
           double t = a.td_mid;
 #pragma unroll
           for (int c = 0; c < 6; ++c) t += g[c] * j[c];
@@ -433,7 +457,12 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll 1
       for (int i = 0; i < N; ++i) {
         double L, j[6];
-        ik_row64(a.geom + i * 7, R, p, L, j);
+        if (JCACHE) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) j[c] = c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane];
+        } else {
+          ik_row64(a.geom + i * 7, R, p, L, j);
+        }
         double t = c_f[i][lane] - a.damping * c_qd[i][lane];
         if (a.unilateral) t = fmax(t, 0.0);
 #pragma unroll

@@ -2,7 +2,10 @@
 #include "cdpr_kernels.hpp"
 namespace cdpr {
 namespace {
-template <int N> F64Kernel f64_n(bool ring_lds) { return ring_lds ? cdpr_step_kernel_f64<N, true> : cdpr_step_kernel_f64<N, false>; }
+template <int N> F64Kernel f64_n(bool ring_lds, bool jcache) {
+  if (jcache) return cdpr_step_kernel_f64<N, true, true>;  // (112 KiB of LDS per wave at n = 8: one workgroup per CU)
+  return ring_lds ? cdpr_step_kernel_f64<N, true> : cdpr_step_kernel_f64<N, false>;
+}
 }  // namespace
-F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds) { CDPR_PICK_CABLES(f64_n, ring_lds); }
+F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }
 }  // namespace cdpr
