@@ -55,6 +55,7 @@ CONFIGS = {2: dict(batch=4096, cables=4), 3: dict(batch=65536, cables=8)}
 SCHED_CHUNK = 1000  # world steps per launch on the scheduled path (small batches)
 FUSED_WARM, FUSED_LAUNCHES = 3, 30  # the fused leg's own schedule: untimed / minimum timed launches of 10 steps each
 ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
+GENERAL_SHAPE = (16384, 0.001, 60, 300)  # general-path leg: robots, velocityEpsilon, untimed steps (past the window fill), timed steps
 
 
 def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
@@ -633,6 +634,51 @@ def main():
                 "parity_check": roll_parity,
             }
 
+        # (c) the general controller path (position-hold branch live: velocityEpsilon > 0 keeps both Pids of every cable
+        #     alive), one launch per step, 16 384 x 8 with every stage: the case VERDICT r03 item 1 is quoted on
+        if n == 8 and args.config == 3:
+            Bg, eps_g, warm_g, steps_g = GENERAL_SHAPE
+            model_g, pose_g, command_g, _ = make_workload(pkg, Bg, n, 1235 + rank, refresh)
+            cfg_g = pkg.Config(batch=Bg, **dict(cfg_kwargs, velocityEpsilon=eps_g))
+            eg = pkg.Engine(cfg_g, device=device)
+            eg.set_platform_state(pose7=pose_g)
+            d_cmd_g = eg.device_upload(command_g(0))
+            eg.bind_velocity_command_device(d_cmd_g, Bg * n)
+            eg.update(warm_g)  # past the window fill: every Pid on a full uniform window
+            eg.synchronize()
+            eg.profile_begin()
+            eg.update(steps_g)
+            msg, nlg = eg.profile_end()
+            gen_parity = None
+            if not args.no_parity_check:  # 64 robots of this run on the fp64 oracle (hold branch, both Pids, fit on real stamps)
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle
+
+                gs = slice(Bg - 64, Bg)
+                osim = oracle.OracleSim(pkg.Config(batch=64, **dict(cfg_kwargs, velocityEpsilon=eps_g)).to_struct(), oracle.DERIV_EXACT)
+                osim.set_platform_state(pose7=pose_g[gs].astype(np.float64))
+                osim.set_velocity_command(command_g(0)[gs])
+                osim.update(warm_g + steps_g)
+                gp, ge = eg.platform_state()[0][gs], eg.joint_states()[2][gs]
+                op, oe = osim.platform_state()[0], osim.joint_states()[2]
+                osim.close()
+                dp, de = float(np.abs(gp - op).max()), float(np.abs(ge - oe).max())
+                gen_parity = {"robots": [Bg - 64, Bg], "steps": warm_g + steps_g, "max_abs_pose": dp, "max_abs_effort": de,
+                              "tolerance": {"pose": PARITY_TOL["pose"], "eff": PARITY_TOL["eff"]},
+                              "ok": bool(np.isfinite(gp).all() and dp <= PARITY_TOL["pose"] and de <= PARITY_TOL["eff"])}
+            eg.device_free(d_cmd_g)
+            eg.close()
+            kus = msg * 1e3 / max(nlg, 1)
+            secondary["general_path"] = {
+                "workload": f"{Bg} x {n}-cable robots, every stage, velocityEpsilon = {eps_g} (position-hold branch live: general controller path), "
+                            "one launch per step, one held Joy",
+                "kernel_us": kus,
+                "value_per_gpu": Bg / (kus * 1e-6),
+                "unit": "state-steps/s",
+                "steps_timed": steps_g,
+                "parity_check": gen_parity,
+            }
+
     if rank == 0:
         bytes_step = eng.bytes_per_state_step()
         launch_s = ev_ms * 1e-3 / max(launches, 1)
@@ -722,7 +768,8 @@ def main():
     eng.close()
     ctx.close()
     # a number that is not tied to a verified computation is not reported as a success
-    failed = [name for name, chk in (("step", parity), ("rollout", (secondary.get("rollout") or {}).get("parity_check"))) if chk and not chk.get("ok_all_ranks", chk["ok"])]
+    failed = [name for name, chk in (("step", parity), ("rollout", (secondary.get("rollout") or {}).get("parity_check")),
+                                     ("general_path", (secondary.get("general_path") or {}).get("parity_check"))) if chk and not chk.get("ok_all_ranks", chk["ok"])]
     if failed:
         print(f"bench.py: parity check against the oracle FAILED for: {', '.join(failed)}", file=sys.stderr)
         sys.exit(3)
