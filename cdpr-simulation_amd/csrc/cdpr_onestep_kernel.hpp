@@ -114,25 +114,6 @@ CDPR_DEV f32x4 load_slot_untracked(const float4* base, size_t stride, int slot, 
 // s_waitcnt immediate (gfx9): vmcnt = n (6 bits, split 3:0 | 15:14), expcnt and lgkmcnt untouched
 constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | (7 << 4) | (15 << 8); }
 
-// The kernel's arguments as one block of a persistent kernel sees them: re-read from the kernarg segment (the StepArgs
-// struct is the kernel's only argument: offset 0) through a pointer the compiler cannot see through.
-template <bool PERSIST>
-CDPR_DEV StepArgs block_args(const StepArgs& a_in) {
-  if constexpr (PERSIST) {
-    static_assert(sizeof(StepArgs) % 4 == 0, "StepArgs is read word by word");
-    struct Words { uint32_t w[sizeof(StepArgs) / 4]; };
-    typedef __attribute__((address_space(4))) const uint32_t* KArg;
-    KArg kp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    Words u;
-#pragma unroll
-    for (size_t i = 0; i < sizeof(StepArgs) / 4; ++i) u.w[i] = kp[i];
-    return __builtin_bit_cast(StepArgs, u);
-  } else {
-    return a_in;
-  }
-}
-
 template <int N, bool FK, bool TD, bool PERSIST = false>
 __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a_in) {
   const StepArgs& a = a_in;  // (shadowed inside the block loop, see there)

@@ -802,6 +802,26 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
 #define CDPR_STORE_STATE store_slot
 #endif
 
+// The kernel's arguments as ONE iteration of a loop over blocks or steps sees them: re-read from the kernarg segment (the
+// StepArgs struct is the kernel's first argument: offset 0) through a pointer the compiler cannot see through, so that
+// neither the scalars nor what is computed from them once rides through the whole loop in registers.
+template <bool PERSIST>
+CDPR_DEV StepArgs block_args(const StepArgs& a_in) {
+  if constexpr (PERSIST) {
+    static_assert(sizeof(StepArgs) % 4 == 0, "StepArgs is read word by word");
+    struct Words { uint32_t w[sizeof(StepArgs) / 4]; };
+    typedef __attribute__((address_space(4))) const uint32_t* KArg;
+    KArg kp = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    Words u;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(StepArgs) / 4; ++i) u.w[i] = kp[i];
+    return __builtin_bit_cast(StepArgs, u);
+  } else {
+    return a_in;
+  }
+}
+
 // LOWREG = true (one-step kernel, large batches): fit two waves per SIMD (<= 256 registers) by NOT keeping what can be
 // recomputed: the cable constants are re-read from LDS in every Newton iteration instead of being hoisted into 48
 // registers, and the true structure matrix is rebuilt after the Newton stage instead of living through it.
@@ -809,7 +829,11 @@ CDPR_DEV float4 ring_row(const v2f (&w)[kWin], int m, v2f e, int slot) {
 // cdpr_config_t.passive_damping / leg_inertia / cable_axial_mass / anchor_point_mass / anchor_inertia.
 // PR = true: per-robot handles (StepArgs::meta): mode, Pid call count and therefore the Pid in use are per lane.
 template <int N, bool FK, bool TD, bool SINGLE, bool ROLLOUT = false, bool LOWREG = false, bool PHYS = false, bool PR = false>
-__global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a) {
+#ifndef CDPR_STEP_RELOAD_ARGS
+#define CDPR_STEP_RELOAD_ARGS 0  // multi-step launches: re-read the kernel arguments per step (A/B)
+#endif
+__global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_kernel(const StepArgs a_in) {
+  const StepArgs& a = a_in;  // (shadowed inside the step loop where CDPR_STEP_RELOAD_ARGS is set)
   constexpr int NP = cable_pairs(N);
   constexpr int P = plat_slots(FK);
   constexpr int G = joint_groups(N);
@@ -938,7 +962,8 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
     }
   }
 
-  for (int step = 0; step < (SINGLE ? 1 : a.nsteps); ++step) {
+  for (int step = 0; step < (SINGLE ? 1 : a_in.nsteps); ++step) {
+    const StepArgs a = block_args<(CDPR_STEP_RELOAD_ARGS != 0) && !SINGLE>(a_in);
     if (!SINGLE && !ROLLOUT && a.sched_refresh > 0 && step > 0 && step % a.sched_refresh == 0) {
       // a launch over a command schedule (cdpr_update_scheduled): the next Joy batch at every refresh boundary
       const int j = step / a.sched_refresh;
