@@ -23,6 +23,12 @@
 
 #include "cdpr_step_kernel.hpp"
 
+// Multiply-adds of THIS file may contract into v_fma_f64 (the build's -ffp-contract=off exists for the fp32 kernels, whose
+// instantiations must give the same bits as each other; here it only doubled the instruction count of every accumulation:
+// 165 v_mul_f64 + 100 v_add_f64 per cable in the Newton loop).  The results move by a few ulp against the CPU restatement,
+// which is compiled without contraction: tolerances in tests/test_gpu_fp64.py.  Switched off again at the end of the file.
+#pragma clang fp contract(fast)
+
 namespace cdpr {
 
 struct F64Args {
@@ -541,3 +547,5 @@ static __global__ __launch_bounds__(256) void cdpr_unpack64_kernel(const Unpack6
 }
 
 }  // namespace cdpr
+
+#pragma clang fp contract(off)
