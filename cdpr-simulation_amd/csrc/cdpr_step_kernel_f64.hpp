@@ -64,12 +64,11 @@ __host__ __device__ constexpr int f64_obs_rows(int n) { return 16 + 3 * n; }
 // 9 - and the step evaluates 9 structure matrices and 5 Cholesky factorizations per robot.  Agreement with the fp64 CPU restatement
 // stays at the 1e-15 level (tests/test_gpu_fp64.py).
 __device__ __forceinline__ double rsqrt64(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double e = fma(-x * y, y, 1.0);
-  y = fma(0.5 * y, e, y);
-  e = fma(-x * y, y, 1.0);
-  y = fma(0.5 * y, e, y);
-  return y;
+  // v_rsq_f64 is good to ~26 bits; ONE third-order step (y <- y + y e (1/2 + 3/8 e), e = 1 - x y^2: the error goes with e^3)
+  // leaves it at rounding level in 5 operations, where two Newton steps take 8
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
 }
 // sqrt(x) = x * rsqrt(x), with one correction step on the product (s <- s + (x - s^2) y / 2)
 __device__ __forceinline__ double sqrt_from_rsqrt64(double x, double y) {
