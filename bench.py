@@ -669,6 +669,11 @@ def main():
             eg.device_free(d_cmd_g)
             eg.close()
             kus = msg * 1e3 / max(nlg, 1)
+            gen_traffic = None  # HBM bytes per launch of this leg's kernel (rocprofv3 PMC, profiles/traffic.json)
+            try:
+                gen_traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"general_n{n}_b{Bg}_spl1")
+            except (OSError, ValueError):
+                pass
             secondary["general_path"] = {
                 "workload": f"{Bg} x {n}-cable robots, every stage, velocityEpsilon = {eps_g} (position-hold branch live: general controller path), "
                             "one launch per step, one held Joy",
@@ -676,6 +681,8 @@ def main():
                 "value_per_gpu": Bg / (kus * 1e-6),
                 "unit": "state-steps/s",
                 "steps_timed": steps_g,
+                "traffic": gen_traffic,
+                "traffic_frac": (gen_traffic / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if gen_traffic else None,
                 "parity_check": gen_parity,
             }
 
