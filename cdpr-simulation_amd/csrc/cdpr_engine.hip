@@ -797,11 +797,14 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
               : vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
   a.wtab = h->d_wtab64 + (vel ? 0 : kWin * (kWin + 2));
   // the rings in LDS (64 KiB per wave at n = 8: two waves per CU) while the batch leaves CUs to spare
-  static const int ring_env = [] { const char* v = std::getenv("CDPR_F64_RING_LDS"); return v ? atoi(v) : -1; }();
+  const int ring_env = [] { const char* v = std::getenv("CDPR_F64_RING_LDS"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
-  static const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();
+  const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
   F64Kernel kern = pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
+  // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
+  const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
+  F64Kernel split_kern = (a.fk && a.td && (sp_env >= 0 ? sp_env != 0 : h->batch <= 16384u)) ? pick_f64_split_kernel(n) : nullptr;
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
@@ -819,7 +822,10 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
         a.publish_mask |= (1ull << j);
       }
     }
-    hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
+    if (k == 1 && split_kern)
+      hipLaunchKernelGGL(split_kern, dim3((h->batch + 63u) / 64u), dim3(128), 0, h->stream, a);
+    else
+      hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;

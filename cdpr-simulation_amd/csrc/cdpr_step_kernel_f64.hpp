@@ -23,11 +23,11 @@
 
 #include "cdpr_step_kernel.hpp"
 
-// Multiply-adds of THIS file may contract into v_fma_f64 (the build's -ffp-contract=off exists for the fp32 kernels, whose
-// instantiations must give the same bits as each other; here it only doubled the instruction count of every accumulation:
-// 165 v_mul_f64 + 100 v_add_f64 per cable in the Newton loop).  The results move by a few ulp against the CPU restatement,
-// which is compiled without contraction: tolerances in tests/test_gpu_fp64.py.  Switched off again at the end of the file.
-#pragma clang fp contract(fast)
+// Every multiply-add of this file is an explicit fma(), as in the fp32 kernels (the build runs with -ffp-contract=off so
+// that all instantiations - here: the one-wave kernel in its LDS variants, its multi-step launches and the role-split
+// kernel - give the same bits).  Written as a * b + c the accumulations cost twice the instructions: 165 v_mul_f64 +
+// 100 v_add_f64 per cable in the Newton loop.  The CPU restatement is compiled without contraction: a few ulp apart,
+// tolerances in tests/test_gpu_fp64.py.
 
 namespace cdpr {
 
@@ -81,15 +81,15 @@ struct Rot64 {
 };
 __device__ __forceinline__ Rot64 quat_to_rot64(double x, double y, double z, double w) {
   Rot64 r;
-  r.r00 = 1.0 - 2.0 * (y * y + z * z);
-  r.r01 = 2.0 * (x * y - z * w);
-  r.r02 = 2.0 * (x * z + y * w);
-  r.r10 = 2.0 * (x * y + z * w);
-  r.r11 = 1.0 - 2.0 * (x * x + z * z);
-  r.r12 = 2.0 * (y * z - x * w);
-  r.r20 = 2.0 * (x * z - y * w);
-  r.r21 = 2.0 * (y * z + x * w);
-  r.r22 = 1.0 - 2.0 * (x * x + y * y);
+  r.r00 = fma(-2.0, fma(y, y, z * z), 1.0);
+  r.r01 = 2.0 * fma(x, y, -(z * w));
+  r.r02 = 2.0 * fma(x, z, y * w);
+  r.r10 = 2.0 * fma(x, y, z * w);
+  r.r11 = fma(-2.0, fma(x, x, z * z), 1.0);
+  r.r12 = 2.0 * fma(y, z, -(x * w));
+  r.r20 = 2.0 * fma(x, z, -(y * w));
+  r.r21 = 2.0 * fma(y, z, x * w);
+  r.r22 = fma(-2.0, fma(x, x, y * y), 1.0);
   return r;
 }
 
@@ -106,30 +106,30 @@ __device__ __forceinline__ void sinc_cos64(double x, double& sinc, double& c) {
   const double z = x * x;
   // sin(x)/x = sum (-z)^k / (2k+1)!,  cos(x) = sum (-z)^k / (2k)!
   double sc = 1.0 / 51090942171709440000.0;  // 1/21!
-  sc = sc * -z + 1.0 / 121645100408832000.0;  // 1/19!
-  sc = sc * -z + 1.0 / 355687428096000.0;     // 1/17!
-  sc = sc * -z + 1.0 / 1307674368000.0;       // 1/15!
-  sc = sc * -z + 1.0 / 6227020800.0;          // 1/13!
-  sc = sc * -z + 1.0 / 39916800.0;            // 1/11!
-  sc = sc * -z + 1.0 / 362880.0;              // 1/9!
-  sc = sc * -z + 1.0 / 5040.0;                // 1/7!
-  sc = sc * -z + 1.0 / 120.0;                 // 1/5!
-  sc = sc * -z + 1.0 / 6.0;                   // 1/3!
-  sc = sc * -z + 1.0;
+  sc = fma(sc, -z, 1.0 / 121645100408832000.0);  // 1/19!
+  sc = fma(sc, -z, 1.0 / 355687428096000.0);     // 1/17!
+  sc = fma(sc, -z, 1.0 / 1307674368000.0);       // 1/15!
+  sc = fma(sc, -z, 1.0 / 6227020800.0);          // 1/13!
+  sc = fma(sc, -z, 1.0 / 39916800.0);            // 1/11!
+  sc = fma(sc, -z, 1.0 / 362880.0);              // 1/9!
+  sc = fma(sc, -z, 1.0 / 5040.0);                // 1/7!
+  sc = fma(sc, -z, 1.0 / 120.0);                 // 1/5!
+  sc = fma(sc, -z, 1.0 / 6.0);                   // 1/3!
+  sc = fma(sc, -z, 1.0);
   double cc = 1.0 / 2432902008176640000.0;    // 1/20!
-  cc = cc * -z + 1.0 / 6402373705728000.0;    // 1/18!
-  cc = cc * -z + 1.0 / 20922789888000.0;      // 1/16!
-  cc = cc * -z + 1.0 / 87178291200.0;         // 1/14!
-  cc = cc * -z + 1.0 / 479001600.0;           // 1/12!
-  cc = cc * -z + 1.0 / 3628800.0;             // 1/10!
-  cc = cc * -z + 1.0 / 40320.0;               // 1/8!
-  cc = cc * -z + 1.0 / 720.0;                 // 1/6!
-  cc = cc * -z + 1.0 / 24.0;                  // 1/4!
-  cc = cc * -z + 0.5;                         // 1/2!
-  cc = cc * -z + 1.0;
+  cc = fma(cc, -z, 1.0 / 6402373705728000.0);    // 1/18!
+  cc = fma(cc, -z, 1.0 / 20922789888000.0);      // 1/16!
+  cc = fma(cc, -z, 1.0 / 87178291200.0);         // 1/14!
+  cc = fma(cc, -z, 1.0 / 479001600.0);           // 1/12!
+  cc = fma(cc, -z, 1.0 / 3628800.0);             // 1/10!
+  cc = fma(cc, -z, 1.0 / 40320.0);               // 1/8!
+  cc = fma(cc, -z, 1.0 / 720.0);                 // 1/6!
+  cc = fma(cc, -z, 1.0 / 24.0);                  // 1/4!
+  cc = fma(cc, -z, 0.5);                         // 1/2!
+  cc = fma(cc, -z, 1.0);
   double sn = sc * x;
   for (int k = 0; k < halvings; ++k) {  // sin 2x = 2 s c, cos 2x = c^2 - s^2
-    const double s2 = 2.0 * sn * cc, c2 = cc * cc - sn * sn;
+    const double s2 = 2.0 * sn * cc, c2 = fma(cc, cc, -(sn * sn));
     sn = s2;
     cc = c2;
     x *= 2.0;
@@ -140,18 +140,18 @@ __device__ __forceinline__ void sinc_cos64(double x, double& sinc, double& c) {
 
 // q <- exp(theta / 2) (x) q, renormalised (world-frame rotation increment)
 __device__ __forceinline__ void quat_apply_rotvec64(double (&q)[4], double tx, double ty, double tz) {
-  const double a2 = tx * tx + ty * ty + tz * tz;
+  const double a2 = fma(tz, tz, fma(ty, ty, tx * tx));
   const double a = (a2 > 0.0) ? sqrt_from_rsqrt64(a2, rsqrt64(a2)) : 0.0;
   double sinc, c;
   sinc_cos64(0.5 * a, sinc, c);
   const double k = 0.5 * sinc;  // sin(a/2) / a
   const double dx = k * tx, dy = k * ty, dz = k * tz;
   const double x = q[0], y = q[1], z = q[2], w = q[3];
-  const double nw = c * w - dx * x - dy * y - dz * z;
-  const double nx = c * x + w * dx + dy * z - dz * y;
-  const double ny = c * y + w * dy + dz * x - dx * z;
-  const double nz = c * z + w * dz + dx * y - dy * x;
-  const double inv = rsqrt64(nx * nx + ny * ny + nz * nz + nw * nw);
+  const double nw = fma(-dz, z, fma(-dy, y, fma(-dx, x, c * w)));
+  const double nx = fma(-dz, y, fma(dy, z, fma(w, dx, c * x)));
+  const double ny = fma(-dx, z, fma(dz, x, fma(w, dy, c * y)));
+  const double nz = fma(-dy, x, fma(dx, y, fma(w, dz, c * z)));
+  const double inv = rsqrt64(fma(nw, nw, fma(nz, nz, fma(ny, ny, nx * nx))));
   q[0] = nx * inv;
   q[1] = ny * inv;
   q[2] = nz * inv;
@@ -160,53 +160,61 @@ __device__ __forceinline__ void quat_apply_rotvec64(double (&q)[4], double tx, d
 
 // One IK row (gen:113-118): l = p + R b - a, L = |l|, u = l / L, J row = [u, (R b) x u]
 __device__ __forceinline__ void ik_row64(const double* g, const Rot64& r, const double (&p)[3], double& L, double (&j)[6]) {
-  const double rbx = r.r00 * g[3] + r.r01 * g[4] + r.r02 * g[5];
-  const double rby = r.r10 * g[3] + r.r11 * g[4] + r.r12 * g[5];
-  const double rbz = r.r20 * g[3] + r.r21 * g[4] + r.r22 * g[5];
+  const double rbx = fma(r.r02, g[5], fma(r.r01, g[4], r.r00 * g[3]));
+  const double rby = fma(r.r12, g[5], fma(r.r11, g[4], r.r10 * g[3]));
+  const double rbz = fma(r.r22, g[5], fma(r.r21, g[4], r.r20 * g[3]));
   const double lx = p[0] + rbx - g[0], ly = p[1] + rby - g[1], lz = p[2] + rbz - g[2];
-  const double l2 = lx * lx + ly * ly + lz * lz;
+  const double l2 = fma(lz, lz, fma(ly, ly, lx * lx));
   const double inv = rsqrt64(l2);
   L = sqrt_from_rsqrt64(l2, inv);
   const double ux = lx * inv, uy = ly * inv, uz = lz * inv;
   j[0] = ux;
   j[1] = uy;
   j[2] = uz;
-  j[3] = rby * uz - rbz * uy;
-  j[4] = rbz * ux - rbx * uz;
-  j[5] = rbx * uy - rby * ux;
+  j[3] = fma(rby, uz, -(rbz * uy));
+  j[4] = fma(rbz, ux, -(rbx * uz));
+  j[5] = fma(rbx, uy, -(rby * ux));
 }
 
-// m x = g for the SPD 6x6 system whose lower triangle is given (g -> x), Cholesky
-__device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) {
-  double invd[6];
+// m x = g for the SPD 6x6 system whose lower triangle is given (g -> x), Cholesky; factorization and the two substitutions
+// apart (the role-split kernel factors the tension distribution's matrix before the forces arrive), same operations in the
+// same order as one piece
+__device__ __forceinline__ void chol_factor64(double (&m)[6][6], double (&invd)[6]) {
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     double d = m[j][j];
 #pragma unroll
-    for (int k = 0; k < j; ++k) d -= m[j][k] * m[j][k];
+    for (int k = 0; k < j; ++k) d = fma(-m[j][k], m[j][k], d);
     invd[j] = rsqrt64(d);
 #pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double s = m[i][j];
 #pragma unroll
-      for (int k = 0; k < j; ++k) s -= m[i][k] * m[j][k];
+      for (int k = 0; k < j; ++k) s = fma(-m[i][k], m[j][k], s);
       m[i][j] = s * invd[j];
     }
   }
+}
+__device__ __forceinline__ void chol_apply64(const double (&m)[6][6], const double (&invd)[6], double (&g)[6]) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     double s = g[i];
 #pragma unroll
-    for (int k = 0; k < i; ++k) s -= m[i][k] * g[k];
+    for (int k = 0; k < i; ++k) s = fma(-m[i][k], g[k], s);
     g[i] = s * invd[i];
   }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
     double s = g[i];
 #pragma unroll
-    for (int k = i + 1; k < 6; ++k) s -= m[k][i] * g[k];
+    for (int k = i + 1; k < 6; ++k) s = fma(-m[k][i], g[k], s);
     g[i] = s * invd[i];
   }
+}
+__device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) {
+  double invd[6];
+  chol_factor64(m, invd);
+  chol_apply64(m, invd, g);
 }
 
 // Per-cable scalars of a lane live in LDS columns (one column per lane), so the loops over the cables are real loops
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, p, L, j);
         const double q = a.geom[i * 7 + 6] - L;
-        const double qd = -(j[0] * v[0] + j[1] * v[1] + j[2] * v[2] + j[3] * om[0] + j[4] * om[1] + j[5] * om[2]);
+        const double qd = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
         c_len[i][lane] = L;
         c_q[i][lane] = q;
         c_qd[i][lane] = qd;
@@ -279,10 +287,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           const double error = desired - (actual_is_vel ? qd : q);
           double acc = wt[kWin] * error;
 #pragma unroll
-          for (int k = 0; k < kWin; ++k) acc += wt[k] * (RING_LDS ? c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] : S[(size_t)(20 + 11 * i + k) * st]);
+          for (int k = 0; k < kWin; ++k) acc = fma(wt[k], RING_LDS ? c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] : S[(size_t)(20 + 11 * i + k) * st], acc);
           const double p_term = a.kp * error;
           const double prev_ierr = c_ierr[i][lane];
-          double ie = prev_ierr + a.dt * error;
+          double ie = fma(a.dt, error, prev_ierr);
           double i_term = a.ki * ie;
           const double i_raw = i_term;
           if (i_term > a.imax) {  // Pid.cpp:143-152
@@ -294,11 +302,11 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           }
           const double derived = full ? acc * a.inv_dt : 0.0;
           const double d_term = a.kd * derived;
-          const double cmd = a.kf * desired + p_term + i_term + d_term;
+          const double cmd = fma(a.kf, desired, p_term) + i_term + d_term;
           double out = a.clamp_cmd ? fmax(fmin(cmd, a.cmax), a.cmin) : cmd;  // Pid.cpp:175-177
           if (out != cmd) {                                                    // Pid.cpp:181-184
             ie = prev_ierr;
-            out += a.dt * error * a.ki;
+            out = fma(a.dt * error, a.ki, out);
           }
           c_ierr[i][lane] = ie;
           force = out;
@@ -338,9 +346,9 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           rmax = fmax(rmax, fabs(res));
 #pragma unroll
           for (int x = 0; x < 6; ++x) {
-            g[x] += j[x] * res;
+            g[x] = fma(j[x], res, g[x]);
 #pragma unroll
-            for (int y = 0; y <= x; ++y) m[x][y] += j[x] * j[y];
+            for (int y = 0; y <= x; ++y) m[x][y] = fma(j[x], j[y], m[x][y]);
           }
         }
         active = active && !(rmax < a.fk_tol);
@@ -391,9 +399,9 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           const double df = c_f[i][lane] - a.td_mid;
 #pragma unroll
           for (int x = 0; x < 6; ++x) {
-            g[x] += j[x] * df;
+            g[x] = fma(j[x], df, g[x]);
 #pragma unroll
-            for (int y = 0; y <= x; ++y) m[x][y] += j[x] * j[y];
+            for (int y = 0; y <= x; ++y) m[x][y] = fma(j[x], j[y], m[x][y]);
           }
         }
         chol_solve64(m, g);
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           }
           double t = a.td_mid;
 #pragma unroll
-          for (int c = 0; c < 6; ++c) t += g[c] * j[c];
+          for (int c = 0; c < 6; ++c) t = fma(g[c], j[c], t);
           const double tc = fmax(fmin(t, a.td_max), a.td_min);
           td_flag |= (tc != t) ? 1 : 0;
           applied = tc;
@@ -468,36 +476,36 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         } else {
           ik_row64(a.geom + i * 7, R, p, L, j);
         }
-        double t = c_f[i][lane] - a.damping * c_qd[i][lane];
+        double t = fma(-a.damping, c_qd[i][lane], c_f[i][lane]);
         if (a.unilateral) t = fmax(t, 0.0);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) w[c] -= j[c] * t;
+        for (int c = 0; c < 6; ++c) w[c] = fma(-j[c], t, w[c]);
       }
-      v[0] += a.dt * w[0] * a.inv_mass;
-      v[1] += a.dt * w[1] * a.inv_mass;
-      v[2] += a.dt * w[2] * a.inv_mass;
-      double tb[3] = {R.r00 * w[3] + R.r10 * w[4] + R.r20 * w[5], R.r01 * w[3] + R.r11 * w[4] + R.r21 * w[5], R.r02 * w[3] + R.r12 * w[4] + R.r22 * w[5]};
-      const double ob[3] = {R.r00 * om[0] + R.r10 * om[1] + R.r20 * om[2], R.r01 * om[0] + R.r11 * om[1] + R.r21 * om[2],
-                            R.r02 * om[0] + R.r12 * om[1] + R.r22 * om[2]};
-      const double io[3] = {a.ib[0] * ob[0] + a.ib[3] * ob[1] + a.ib[4] * ob[2], a.ib[3] * ob[0] + a.ib[1] * ob[1] + a.ib[5] * ob[2],
-                            a.ib[4] * ob[0] + a.ib[5] * ob[1] + a.ib[2] * ob[2]};
-      tb[0] -= ob[1] * io[2] - ob[2] * io[1];
-      tb[1] -= ob[2] * io[0] - ob[0] * io[2];
-      tb[2] -= ob[0] * io[1] - ob[1] * io[0];
-      const double ab[3] = {a.ibinv[0] * tb[0] + a.ibinv[3] * tb[1] + a.ibinv[4] * tb[2], a.ibinv[3] * tb[0] + a.ibinv[1] * tb[1] + a.ibinv[5] * tb[2],
-                            a.ibinv[4] * tb[0] + a.ibinv[5] * tb[1] + a.ibinv[2] * tb[2]};
-      om[0] += a.dt * (R.r00 * ab[0] + R.r01 * ab[1] + R.r02 * ab[2]);
-      om[1] += a.dt * (R.r10 * ab[0] + R.r11 * ab[1] + R.r12 * ab[2]);
-      om[2] += a.dt * (R.r20 * ab[0] + R.r21 * ab[1] + R.r22 * ab[2]);
-      p[0] += a.dt * v[0];
-      p[1] += a.dt * v[1];
-      p[2] += a.dt * v[2];
+      v[0] = fma(a.dt * w[0], a.inv_mass, v[0]);
+      v[1] = fma(a.dt * w[1], a.inv_mass, v[1]);
+      v[2] = fma(a.dt * w[2], a.inv_mass, v[2]);
+      double tb[3] = {fma(R.r20, w[5], fma(R.r10, w[4], R.r00 * w[3])), fma(R.r21, w[5], fma(R.r11, w[4], R.r01 * w[3])), fma(R.r22, w[5], fma(R.r12, w[4], R.r02 * w[3]))};
+      const double ob[3] = {fma(R.r20, om[2], fma(R.r10, om[1], R.r00 * om[0])), fma(R.r21, om[2], fma(R.r11, om[1], R.r01 * om[0])),
+                            fma(R.r22, om[2], fma(R.r12, om[1], R.r02 * om[0]))};
+      const double io[3] = {fma(a.ib[4], ob[2], fma(a.ib[3], ob[1], a.ib[0] * ob[0])), fma(a.ib[5], ob[2], fma(a.ib[1], ob[1], a.ib[3] * ob[0])),
+                            fma(a.ib[2], ob[2], fma(a.ib[5], ob[1], a.ib[4] * ob[0]))};
+      tb[0] -= fma(ob[1], io[2], -(ob[2] * io[1]));
+      tb[1] -= fma(ob[2], io[0], -(ob[0] * io[2]));
+      tb[2] -= fma(ob[0], io[1], -(ob[1] * io[0]));
+      const double ab[3] = {fma(a.ibinv[4], tb[2], fma(a.ibinv[3], tb[1], a.ibinv[0] * tb[0])), fma(a.ibinv[5], tb[2], fma(a.ibinv[1], tb[1], a.ibinv[3] * tb[0])),
+                            fma(a.ibinv[2], tb[2], fma(a.ibinv[5], tb[1], a.ibinv[4] * tb[0]))};
+      om[0] = fma(a.dt, fma(R.r02, ab[2], fma(R.r01, ab[1], R.r00 * ab[0])), om[0]);
+      om[1] = fma(a.dt, fma(R.r12, ab[2], fma(R.r11, ab[1], R.r10 * ab[0])), om[1]);
+      om[2] = fma(a.dt, fma(R.r22, ab[2], fma(R.r21, ab[1], R.r20 * ab[0])), om[2]);
+      p[0] = fma(a.dt, v[0], p[0]);
+      p[1] = fma(a.dt, v[1], p[1]);
+      p[2] = fma(a.dt, v[2], p[2]);
       const double h = a.half_dt, x = q4[0], y = q4[1], z = q4[2], ww = q4[3];
-      const double nx = x + h * (ww * om[0] + om[1] * z - om[2] * y);
-      const double ny = y + h * (ww * om[1] + om[2] * x - om[0] * z);
-      const double nz = z + h * (ww * om[2] + om[0] * y - om[1] * x);
-      const double nw = ww - h * (om[0] * x + om[1] * y + om[2] * z);
-      const double inv = rsqrt64(nx * nx + ny * ny + nz * nz + nw * nw);
+      const double nx = fma(h, fma(-om[2], y, fma(om[1], z, ww * om[0])), x);
+      const double ny = fma(h, fma(-om[0], z, fma(om[2], x, ww * om[1])), y);
+      const double nz = fma(h, fma(-om[1], x, fma(om[0], y, ww * om[2])), z);
+      const double nw = fma(-h, fma(om[2], z, fma(om[1], y, om[0] * x)), ww);
+      const double inv = rsqrt64(fma(nw, nw, fma(nz, nz, fma(ny, ny, nx * nx))));
       q4[0] = nx * inv;
       q4[1] = ny * inv;
       q4[2] = nz * inv;
@@ -527,6 +535,319 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   }
 }
 
+// cdpr_split_kernel_f64 - one step per launch with TWO waves per 64 robots, split by role like cdpr_split_kernel: FK + TD
+// handles, up to one workgroup per CU (117 KiB of LDS).  The step in double is one dependent chain of ~6 500 vector
+// instructions, 60 % of them the Newton stage: here the estimator wave (measured lengths, Newton-Raphson FK, the
+// tension distribution's matrix and factor, then - forces in - the tensions) and the controller wave (IK, PID, forces out,
+// - tensions in - SetForce limits, observables, world step) each have a SIMD to themselves.  The same statements in the
+// same order as cdpr_step_kernel_f64<N, true, true> over the same LDS columns: same bits (tested).
+template <int N>
+__global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a) {
+  __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
+  __shared__ double c_win[N][kWin][64];
+  __shared__ double c_jt[N][6][64];  // rows at the true pose (controller wave: IK stage -> world step)
+  __shared__ double c_je[N][6][64];  // rows at the FK estimate (estimator wave: closing evaluation -> tension distribution)
+  __shared__ double x_est[3][64];    // estimator -> controller: residual, iterations, infeasible flag
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t r = blockIdx.x * 64u + lane;
+  const bool live = r < a.batch;  // (no early return: both waves meet at two barriers; tail lanes shadow the last robot)
+  const size_t st = a.stride;
+  double* const S = a.state + (live ? r : a.batch - 1u);
+  const bool first_world = (a.flags & kFlagFirstWorldStep) != 0u;
+  const bool force_mode = (a.flags & kFlagForceMode) != 0u;
+
+  if (wave == 0) {
+    // ------------------------------------------------------------------------------------------------ estimator wave
+    const double p[3] = {S[0 * st], S[1 * st], S[2 * st]};
+    const double q4[4] = {S[3 * st], S[4 * st], S[5 * st], S[6 * st]};
+    double fkp[3] = {S[13 * st], S[14 * st], S[15 * st]};
+    double fkq[4] = {S[16 * st], S[17 * st], S[18 * st], S[19 * st]};
+    {
+      const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
+#pragma unroll 1
+      for (int i = 0; i < N; ++i) {
+        double L, j[6];
+        ik_row64(a.geom + i * 7, R, p, L, j);
+        c_len[i][lane] = L;
+      }
+    }
+    double fk_res = 0.0;
+    int fk_it = 0, td_flag = 0;
+    {
+      bool active = true;
+      for (int it = 0; it < a.fk_iters; ++it) {
+        const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
+        double m[6][6], g[6], rmax = 0.0;
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+          g[x] = 0.0;
+#pragma unroll
+          for (int y = 0; y <= x; ++y) m[x][y] = (x == y) ? a.fk_lambda : 0.0;
+        }
+#pragma unroll 1
+        for (int i = 0; i < N; ++i) {
+          double L, j[6];
+          ik_row64(a.geom + i * 7, R, fkp, L, j);
+          const double res = c_len[i][lane] - L;
+          rmax = fmax(rmax, fabs(res));
+#pragma unroll
+          for (int x = 0; x < 6; ++x) {
+            g[x] = fma(j[x], res, g[x]);
+#pragma unroll
+            for (int y = 0; y <= x; ++y) m[x][y] = fma(j[x], j[y], m[x][y]);
+          }
+        }
+        active = active && !(rmax < a.fk_tol);
+        chol_solve64(m, g);
+        if (active) {
+          fkp[0] += g[0];
+          fkp[1] += g[1];
+          fkp[2] += g[2];
+          quat_apply_rotvec64(fkq, g[3], g[4], g[5]);
+          ++fk_it;
+        }
+      }
+      const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
+#pragma unroll 1
+      for (int i = 0; i < N; ++i) {
+        double L, j[6];
+        ik_row64(a.geom + i * 7, R, fkp, L, j);
+        fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
+#pragma unroll
+        for (int c = 0; c < 6; ++c) c_je[i][c][lane] = j[c];
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) S[(size_t)(13 + c) * st] = fkp[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) S[(size_t)(16 + c) * st] = fkq[c];
+    }
+    // the tension distribution's matrix and its factor need no forces
+    double m[6][6], invd[6];
+#pragma unroll
+    for (int x = 0; x < 6; ++x) {
+#pragma unroll
+      for (int y = 0; y <= x; ++y) m[x][y] = 0.0;
+    }
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+      for (int x = 0; x < 6; ++x) {
+#pragma unroll
+        for (int y = 0; y <= x; ++y) m[x][y] = fma(c_je[i][x][lane], c_je[i][y][lane], m[x][y]);
+      }
+    }
+    chol_factor64(m, invd);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in c_f
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      const double df = c_f[i][lane] - a.td_mid;
+#pragma unroll
+      for (int x = 0; x < 6; ++x) g[x] = fma(c_je[i][x][lane], df, g[x]);
+    }
+    chol_apply64(m, invd, g);
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      double t = a.td_mid;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) t = fma(g[c], c_je[i][c][lane], t);
+      const double tc = fmax(fmin(t, a.td_max), a.td_min);
+      td_flag |= (tc != t) ? 1 : 0;
+      c_f[i][lane] = tc;
+    }
+    x_est[0][lane] = fk_res;
+    x_est[1][lane] = (double)fk_it;
+    x_est[2][lane] = (double)td_flag;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();  // #2: tensions and estimator results are out
+    return;
+  }
+  // -------------------------------------------------------------------------------------------------- controller wave
+  double p[3] = {S[0 * st], S[1 * st], S[2 * st]};
+  double q4[4] = {S[3 * st], S[4 * st], S[5 * st], S[6 * st]};
+  double v[3] = {S[7 * st], S[8 * st], S[9 * st]}, om[3] = {S[10 * st], S[11 * st], S[12 * st]};
+  const uint32_t rc = live ? r : a.batch - 1u;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
+    c_des[i][lane] = (double)a.cmd[(size_t)rc * N + i];
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) c_win[i][k][lane] = S[(size_t)(20 + 11 * i + k) * st];
+  }
+  const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
+  const int calls = a.pid_calls;
+  const bool run_pid = !first_world && !force_mode && calls != 0;  // Pid.cpp:123-126: the first call since reset returns 0
+  const bool full = calls >= a.nbuf;
+  const int ring_slot = a.ring_slot % kWin;
+  const double* wt = a.wtab + ring_slot * (kWin + 2);
+  double dbg_p = 0.0, dbg_i = 0.0, dbg_d = 0.0;
+  // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
+  {
+    const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      double L, j[6];
+      ik_row64(a.geom + i * 7, R, p, L, j);
+      const double q = a.geom[i * 7 + 6] - L;
+      const double qd = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
+      c_q[i][lane] = q;
+      c_qd[i][lane] = qd;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) c_jt[i][c][lane] = j[c];
+      double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
+      if (run_pid) {
+        const double desired = c_des[i][lane];
+        const double error = desired - (actual_is_vel ? qd : q);
+        double acc = wt[kWin] * error;
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) acc = fma(wt[k], c_win[i][k][lane], acc);
+        const double p_term = a.kp * error;
+        const double prev_ierr = c_ierr[i][lane];
+        double ie = fma(a.dt, error, prev_ierr);
+        double i_term = a.ki * ie;
+        const double i_raw = i_term;
+        if (i_term > a.imax) {  // Pid.cpp:143-152
+          i_term = a.imax;
+          ie = i_term / a.ki;
+        } else if (i_term < a.imin) {
+          i_term = a.imin;
+          ie = i_term / a.ki;
+        }
+        const double derived = full ? acc * a.inv_dt : 0.0;
+        const double d_term = a.kd * derived;
+        const double cmd = fma(a.kf, desired, p_term) + i_term + d_term;
+        double out = a.clamp_cmd ? fmax(fmin(cmd, a.cmax), a.cmin) : cmd;  // Pid.cpp:175-177
+        if (out != cmd) {                                                    // Pid.cpp:181-184
+          ie = prev_ierr;
+          out = fma(a.dt * error, a.ki, out);
+        }
+        c_ierr[i][lane] = ie;
+        force = out;
+        c_win[i][ring_slot][lane] = error;
+        if (i == 0) {
+          dbg_p = p_term;
+          dbg_i = i_raw;
+          dbg_d = d_term;
+        }
+      }
+      c_f[i][lane] = force;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the forces are in LDS
+  __builtin_amdgcn_s_barrier();        // #1
+  __builtin_amdgcn_s_barrier();        // #2: the estimator wave has finished the tension distribution
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const double fk_res = x_est[0][lane], fk_it = x_est[1][lane];
+  const uint32_t td_flag = (uint32_t)x_est[2][lane];
+  uint32_t lim = 0u;
+#pragma unroll 1
+  for (int i = 0; i < N; ++i) {
+    double applied = c_f[i][lane];
+    const double qd = c_qd[i][lane], q = c_q[i][lane];
+    if (a.vel_limit > 0.0)  // Joint::SetForce velocity truncation [EXT]
+      applied = ((qd > a.vel_limit && applied > 0.0) || (qd < -a.vel_limit && applied < 0.0)) ? 0.0 : applied;
+    if (a.effort >= 0.0) applied = fmax(fmin(applied, a.effort), -a.effort);  // Joint::SetForce clamp (cube.sdf:438)
+    if (a.travel_on && (q < a.travel_lo || q > a.travel_hi)) lim |= 1u << i;
+    c_f[i][lane] = applied;
+  }
+  if (a.dbg && live) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
+    double* d = a.dbg + (size_t)r * 9;
+    if (run_pid) {
+      d[0] = dbg_p;
+      d[1] = dbg_i;
+      d[2] = dbg_d;
+      d[3] = c_des[0][lane];
+    }
+    d[4] = c_f[0][lane];
+  }
+  // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
+  if ((a.publish_mask & 1ull) && live) {
+    double* const O = a.obs + r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      O[(size_t)c * st] = p[c];
+      O[(size_t)(7 + c) * st] = v[c];
+      O[(size_t)(10 + c) * st] = om[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) O[(size_t)(3 + c) * st] = q4[c];
+    O[13 * st] = fk_res;
+    O[14 * st] = fk_it;
+    O[15 * st] = (double)(td_flag | (lim << 1));
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      O[(size_t)(16 + i) * st] = c_q[i][lane];
+      O[(size_t)(16 + N + i) * st] = c_qd[i][lane];
+      O[(size_t)(16 + 2 * N + i) * st] = c_f[i][lane];
+    }
+  }
+  // ---- world step to t_{k+1}: wrench = -J^T (applied - d qdot) + m g, semi-implicit Euler
+  {
+    double w[6] = {a.fgx, a.fgy, a.fgz, 0.0, 0.0, 0.0};
+    const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      double t = fma(-a.damping, c_qd[i][lane], c_f[i][lane]);
+      if (a.unilateral) t = fmax(t, 0.0);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) w[c] = fma(-c_jt[i][c][lane], t, w[c]);
+    }
+    v[0] = fma(a.dt * w[0], a.inv_mass, v[0]);
+    v[1] = fma(a.dt * w[1], a.inv_mass, v[1]);
+    v[2] = fma(a.dt * w[2], a.inv_mass, v[2]);
+    double tb[3] = {fma(R.r20, w[5], fma(R.r10, w[4], R.r00 * w[3])), fma(R.r21, w[5], fma(R.r11, w[4], R.r01 * w[3])), fma(R.r22, w[5], fma(R.r12, w[4], R.r02 * w[3]))};
+    const double ob[3] = {fma(R.r20, om[2], fma(R.r10, om[1], R.r00 * om[0])), fma(R.r21, om[2], fma(R.r11, om[1], R.r01 * om[0])),
+                            fma(R.r22, om[2], fma(R.r12, om[1], R.r02 * om[0]))};
+    const double io[3] = {fma(a.ib[4], ob[2], fma(a.ib[3], ob[1], a.ib[0] * ob[0])), fma(a.ib[5], ob[2], fma(a.ib[1], ob[1], a.ib[3] * ob[0])),
+                            fma(a.ib[2], ob[2], fma(a.ib[5], ob[1], a.ib[4] * ob[0]))};
+    tb[0] -= fma(ob[1], io[2], -(ob[2] * io[1]));
+    tb[1] -= fma(ob[2], io[0], -(ob[0] * io[2]));
+    tb[2] -= fma(ob[0], io[1], -(ob[1] * io[0]));
+    const double ab[3] = {fma(a.ibinv[4], tb[2], fma(a.ibinv[3], tb[1], a.ibinv[0] * tb[0])), fma(a.ibinv[5], tb[2], fma(a.ibinv[1], tb[1], a.ibinv[3] * tb[0])),
+                            fma(a.ibinv[2], tb[2], fma(a.ibinv[5], tb[1], a.ibinv[4] * tb[0]))};
+    om[0] = fma(a.dt, fma(R.r02, ab[2], fma(R.r01, ab[1], R.r00 * ab[0])), om[0]);
+    om[1] = fma(a.dt, fma(R.r12, ab[2], fma(R.r11, ab[1], R.r10 * ab[0])), om[1]);
+    om[2] = fma(a.dt, fma(R.r22, ab[2], fma(R.r21, ab[1], R.r20 * ab[0])), om[2]);
+    p[0] = fma(a.dt, v[0], p[0]);
+    p[1] = fma(a.dt, v[1], p[1]);
+    p[2] = fma(a.dt, v[2], p[2]);
+    const double h = a.half_dt, x = q4[0], y = q4[1], z = q4[2], ww = q4[3];
+    const double nx = fma(h, fma(-om[2], y, fma(om[1], z, ww * om[0])), x);
+    const double ny = fma(h, fma(-om[0], z, fma(om[2], x, ww * om[1])), y);
+    const double nz = fma(h, fma(-om[1], x, fma(om[0], y, ww * om[2])), z);
+    const double nw = fma(-h, fma(om[2], z, fma(om[1], y, om[0] * x)), ww);
+    const double inv = rsqrt64(fma(nw, nw, fma(nz, nz, fma(ny, ny, nx * nx))));
+    q4[0] = nx * inv;
+    q4[1] = ny * inv;
+    q4[2] = nz * inv;
+    q4[3] = nw * inv;
+  }
+  // ---- store
+  if (live) {
+    double* const W = a.state + r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      W[(size_t)c * st] = p[c];
+      W[(size_t)(7 + c) * st] = v[c];
+      W[(size_t)(10 + c) * st] = om[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) W[(size_t)(3 + c) * st] = q4[c];
+#pragma unroll 1
+    for (int i = 0; i < N; ++i) {
+      W[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
+#pragma unroll
+      for (int k = 0; k < kWin; ++k) W[(size_t)(20 + 11 * i + k) * st] = c_win[i][k][lane];
+    }
+  }
+}
+
 // Read-out of double rows into robot-major arrays (double or float), one thread per (robot, column)
 struct Unpack64Args {
   const double* rows;
@@ -546,5 +867,3 @@ static __global__ __launch_bounds__(256) void cdpr_unpack64_kernel(const Unpack6
 }
 
 }  // namespace cdpr
-
-#pragma clang fp contract(off)

@@ -177,3 +177,48 @@ def test_fp64_refuses_what_it_does_not_cover(pkg):
 
 def test_zz_report_measured_agreement():
     print("fp64 kernel vs fp64 oracle, worst over this module:", {k: f"{v:.2e}" for k, v in WORST.items()})
+
+
+@pytest.mark.parametrize("cables", [8, 6])
+def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, cables):
+    """One-step launches of FK + TD fp64 handles up to one workgroup per CU run on cdpr_split_kernel_f64 (estimator wave +
+    controller wave per 64 robots; CDPR_F64_SPLIT=0 keeps the one-wave kernel): same statements in the same order over the
+    same LDS columns.  Velocity, Position and Force mode, the first world step, a ragged last block, the `pid` topic, the
+    travel-limit flags; fused launches (one-wave kernel on both handles) in between.  Same bits: every multiply-add of the
+    fp64 kernels is an explicit fma (the variable is read per call, so both builds run in this process)."""
+    from dataclasses import replace
+
+    B = 64 * 3 + 11
+    rng = np.random.default_rng(640 + cables)
+    full = pkg.eight_cable_model()
+    model = replace(full, frame_anchors=full.frame_anchors[:cables], platform_anchors=full.platform_anchors[:cables], travel_lower=-0.004, travel_upper=0.004)
+    cfg = pkg.Config(model=model, batch=B, stages=3 | pkg._abi.STAGE_PID_DEBUG, precision=64)
+    pose = perturbed_poses(model, B, rng, 0.02, 0.05)
+    v = rng.uniform(-0.03, 0.03, (B, cables)).astype(np.float32)
+    p = rng.uniform(-0.003, 0.003, (B, cables)).astype(np.float32)
+    f = rng.uniform(5.0, 25.0, (B, cables)).astype(np.float32)
+    out = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("CDPR_F64_SPLIT", split)
+        eng = pkg.Engine(cfg, 0)
+        eng.set_platform_state(pose7=pose)
+        eng.update(1)
+        snaps = []
+        for kind, cmd, k in (("vel", v, 17), ("pos", p, 13), ("frc", f, 5), ("vel", -v, 12)):
+            getattr(eng, {"vel": "set_velocity_command", "pos": "set_position_command", "frc": "set_force_command"}[kind])(cmd)
+            for _ in range(k):
+                eng.update(1)
+            if kind == "pos":
+                eng.update(6, 3)
+            snaps.append(eng.observables_f64() + eng.raw_state_f64() + (eng.pid_debug(), eng.limit_state()))
+        out.append(snaps)
+        eng.close()
+    worst = 0.0
+    for a, b in zip(*out):
+        for x, y in zip(a, b):
+            if x.dtype.kind == "f":
+                worst = max(worst, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
+            else:
+                assert np.array_equal(x, y)
+    print(f"fp64 role-split vs one-wave kernel, n = {cables}: worst difference {worst:.3e}")
+    assert worst == 0.0
