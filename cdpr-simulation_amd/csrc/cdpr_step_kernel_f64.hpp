@@ -230,6 +230,13 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 // step instead of 72 at n = 8 (a row is ~60 fp64 instructions, a reload 6 LDS reads).  Same values, same bits.
 template <int N, bool RING_LDS = false, bool JCACHE = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
+  // cables per pass of the loops over the cables.  One lane's step is a dependent chain (rotate the anchor, length,
+  // reciprocal square root, row, accumulate): with a single wave per SIMD a dependent fp64 instruction waits ~8 cycles for
+  // its predecessor, and only several cables in flight fill those slots.  The role-split kernel
+  // unrolls fully (14.3 us at one robot x 8 against 18.9 rolled); this kernel's LDS variants take four cables per pass
+  // (fully unrolled: 512 registers and 668 B of scratch per lane); the large-batch variant, whose registers also carry the global ring addresses, gains
+  // nothing beyond two (65 536 x 8: 35.3 us at 2, 36.5 at 4, 54.8 at 8 - `profiles/r04final_fp64_timing.txt`)
+  constexpr int kCableUnroll = RING_LDS ? (N < 4 ? N : 4) : (N < 2 ? N : 2);
   __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
   __shared__ double c_win[RING_LDS ? N : 1][RING_LDS ? kWin : 1][64];
   __shared__ double c_jt[JCACHE ? N : 1][JCACHE ? 6 : 1][64];  // rows at the true pose
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
     {
       const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, p, L, j);
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll
           for (int y = 0; y <= x; ++y) m[x][y] = (x == y) ? a.fk_lambda : 0.0;
         }
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
         for (int i = 0; i < N; ++i) {
           double L, j[6];
           ik_row64(a.geom + i * 7, R, fkp, L, j);
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         }
       }
       const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, fkp, L, j);
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll
           for (int y = 0; y <= x; ++y) m[x][y] = 0.0;
         }
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
         for (int i = 0; i < N; ++i) {
           double L, j[6];
           if (JCACHE) {
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         }
         chol_solve64(m, g);
       }
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         double applied = c_f[i][lane];
         if (a.td) {
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       O[13 * st] = fk_res;
       O[14 * st] = (double)fk_it;
       O[15 * st] = (double)((uint32_t)td_flag | (lim << 1));
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         O[(size_t)(16 + i) * st] = c_q[i][lane];
         O[(size_t)(16 + N + i) * st] = c_qd[i][lane];
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     {
       double w[6] = {a.fgx, a.fgy, a.fgz, 0.0, 0.0, 0.0};
       const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
         if (JCACHE) {
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     S[(size_t)(3 + c) * st] = q4[c];
     S[(size_t)(16 + c) * st] = fkq[c];
   }
-#pragma unroll 1
+#pragma clang loop unroll_count(kCableUnroll)
   for (int i = 0; i < N; ++i) {
     S[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
     if (RING_LDS) {
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     double fkq[4] = {S[16 * st], S[17 * st], S[18 * st], S[19 * st]};
     {
       const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll 1
+#pragma unroll
       for (int i = 0; i < N; ++i) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, p, L, j);
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
 #pragma unroll
           for (int y = 0; y <= x; ++y) m[x][y] = (x == y) ? a.fk_lambda : 0.0;
         }
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < N; ++i) {
           double L, j[6];
           ik_row64(a.geom + i * 7, R, fkp, L, j);
@@ -608,7 +615,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
         }
       }
       const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
-#pragma unroll 1
+#pragma unroll
       for (int i = 0; i < N; ++i) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, fkp, L, j);
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
 #pragma unroll
       for (int y = 0; y <= x; ++y) m[x][y] = 0.0;
     }
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
       for (int x = 0; x < 6; ++x) {
@@ -643,14 +650,14 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in c_f
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       const double df = c_f[i][lane] - a.td_mid;
 #pragma unroll
       for (int x = 0; x < 6; ++x) g[x] = fma(c_je[i][x][lane], df, g[x]);
     }
     chol_apply64(m, invd, g);
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       double t = a.td_mid;
 #pragma unroll
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
   // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
   {
     const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       double L, j[6];
       ik_row64(a.geom + i * 7, R, p, L, j);
@@ -746,7 +753,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
   const double fk_res = x_est[0][lane], fk_it = x_est[1][lane];
   const uint32_t td_flag = (uint32_t)x_est[2][lane];
   uint32_t lim = 0u;
-#pragma unroll 1
+#pragma unroll
   for (int i = 0; i < N; ++i) {
     double applied = c_f[i][lane];
     const double qd = c_qd[i][lane], q = c_q[i][lane];
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     O[13 * st] = fk_res;
     O[14 * st] = fk_it;
     O[15 * st] = (double)(td_flag | (lim << 1));
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       O[(size_t)(16 + i) * st] = c_q[i][lane];
       O[(size_t)(16 + N + i) * st] = c_qd[i][lane];
@@ -791,7 +798,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
   {
     double w[6] = {a.fgx, a.fgy, a.fgz, 0.0, 0.0, 0.0};
     const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       double t = fma(-a.damping, c_qd[i][lane], c_f[i][lane]);
       if (a.unilateral) t = fmax(t, 0.0);
@@ -839,7 +846,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) W[(size_t)(3 + c) * st] = q4[c];
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       W[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
 #pragma unroll
