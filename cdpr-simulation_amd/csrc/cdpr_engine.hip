@@ -804,7 +804,9 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
   F64Kernel kern = pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
-  F64Kernel split_kern = (a.fk && a.td && (sp_env >= 0 ? sp_env != 0 : h->batch <= 16384u)) ? pick_f64_split_kernel(n) : nullptr;
+  // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
+  const bool sp_lean = sp_env >= 0 ? sp_env == 2 : h->batch > 16384u;
+  F64Kernel split_kern = (a.fk && a.td && sp_env != 0) ? pick_f64_split_kernel(n, sp_lean) : nullptr;
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);

@@ -548,13 +548,19 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 // tension distribution's matrix and factor, then - forces in - the tensions) and the controller wave (IK, PID, forces out,
 // - tensions in - SetForce limits, observables, world step) each have a SIMD to themselves.  The same statements in the
 // same order as cdpr_step_kernel_f64<N, true, true> over the same LDS columns: same bits (tested).
-template <int N>
-__global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a) {
+// LEAN (batches beyond one workgroup per CU): nothing cached in LDS (26 KiB: four workgroups per CU, both waves of a
+// workgroup on one SIMD) - the rings are read from HBM / L2 inside the PID loop and the structure-matrix rows are rebuilt
+// where they are needed again, as in the one-wave kernel's large-batch variant; what the split buys there is the other
+// wave's arithmetic under this wave's memory round trips.
+template <int N, bool LEAN = false>
+__global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const F64Args a) {
   __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
-  __shared__ double c_win[N][kWin][64];
-  __shared__ double c_jt[N][6][64];  // rows at the true pose (controller wave: IK stage -> world step)
-  __shared__ double c_je[N][6][64];  // rows at the FK estimate (estimator wave: closing evaluation -> tension distribution)
+  __shared__ double c_win[LEAN ? 1 : N][LEAN ? 1 : kWin][64];
+  __shared__ double c_jt[LEAN ? 1 : N][LEAN ? 1 : 6][64];  // rows at the true pose (controller wave: IK stage -> world step)
+  __shared__ double c_je[LEAN ? 1 : N][LEAN ? 1 : 6][64];  // rows at the FK estimate (estimator wave: closing evaluation -> tension distribution)
   __shared__ double x_est[3][64];    // estimator -> controller: residual, iterations, infeasible flag
+  constexpr int kU = LEAN ? (N < 4 ? N : 4) : N;  // cables per pass of the loops over the cables (see cdpr_step_kernel_f64); LEAN at
+                                                  // 65 536 x 8: 31.8 us with 2, 29.4 with 4, 44.9 with 8 (356 B of scratch)
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t r = blockIdx.x * 64u + lane;
   const bool live = r < a.batch;  // (no early return: both waves meet at two barriers; tail lanes shadow the last robot)
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     double fkq[4] = {S[16 * st], S[17 * st], S[18 * st], S[19 * st]};
     {
       const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll
+#pragma clang loop unroll_count(kU)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, p, L, j);
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
 #pragma unroll
           for (int y = 0; y <= x; ++y) m[x][y] = (x == y) ? a.fk_lambda : 0.0;
         }
-#pragma unroll
+#pragma clang loop unroll_count(kU)
         for (int i = 0; i < N; ++i) {
           double L, j[6];
           ik_row64(a.geom + i * 7, R, fkp, L, j);
@@ -615,13 +621,15 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
         }
       }
       const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
-#pragma unroll
+#pragma clang loop unroll_count(kU)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
         ik_row64(a.geom + i * 7, R, fkp, L, j);
         fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
+        if (!LEAN) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) c_je[i][c][lane] = j[c];
+          for (int c = 0; c < 6; ++c) c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane] = j[c];
+        }
       }
     }
     if (live) {
@@ -637,12 +645,20 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
 #pragma unroll
       for (int y = 0; y <= x; ++y) m[x][y] = 0.0;
     }
-#pragma unroll
+    const Rot64 Rt = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
+#pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
+      double L, j[6];
+      if (LEAN) {
+        ik_row64(a.geom + i * 7, Rt, fkp, L, j);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) j[c] = c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
+      }
 #pragma unroll
       for (int x = 0; x < 6; ++x) {
 #pragma unroll
-        for (int y = 0; y <= x; ++y) m[x][y] = fma(c_je[i][x][lane], c_je[i][y][lane], m[x][y]);
+        for (int y = 0; y <= x; ++y) m[x][y] = fma(j[x], j[y], m[x][y]);
       }
     }
     chol_factor64(m, invd);
@@ -650,18 +666,32 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in c_f
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
+#pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
+      double L, j[6];
+      if (LEAN) {
+        ik_row64(a.geom + i * 7, Rt, fkp, L, j);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) j[c] = c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
+      }
       const double df = c_f[i][lane] - a.td_mid;
 #pragma unroll
-      for (int x = 0; x < 6; ++x) g[x] = fma(c_je[i][x][lane], df, g[x]);
+      for (int x = 0; x < 6; ++x) g[x] = fma(j[x], df, g[x]);
     }
     chol_apply64(m, invd, g);
-#pragma unroll
+#pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
+      double L, j[6];
+      if (LEAN) {
+        ik_row64(a.geom + i * 7, Rt, fkp, L, j);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) j[c] = c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
+      }
       double t = a.td_mid;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) t = fma(g[c], c_je[i][c][lane], t);
+      for (int c = 0; c < 6; ++c) t = fma(g[c], j[c], t);
       const double tc = fmax(fmin(t, a.td_max), a.td_min);
       td_flag |= (tc != t) ? 1 : 0;
       c_f[i][lane] = tc;
@@ -679,12 +709,14 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
   double q4[4] = {S[3 * st], S[4 * st], S[5 * st], S[6 * st]};
   double v[3] = {S[7 * st], S[8 * st], S[9 * st]}, om[3] = {S[10 * st], S[11 * st], S[12 * st]};
   const uint32_t rc = live ? r : a.batch - 1u;
-#pragma unroll
+#pragma clang loop unroll_count(kU)
   for (int i = 0; i < N; ++i) {
     c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
     c_des[i][lane] = (double)a.cmd[(size_t)rc * N + i];
+    if (!LEAN) {
 #pragma unroll
-    for (int k = 0; k < kWin; ++k) c_win[i][k][lane] = S[(size_t)(20 + 11 * i + k) * st];
+      for (int k = 0; k < kWin; ++k) c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane] = S[(size_t)(20 + 11 * i + k) * st];
+    }
   }
   const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
   const int calls = a.pid_calls;
@@ -696,7 +728,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
   // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
   {
     const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll
+#pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
       double L, j[6];
       ik_row64(a.geom + i * 7, R, p, L, j);
@@ -704,15 +736,17 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
       const double qd = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
       c_q[i][lane] = q;
       c_qd[i][lane] = qd;
+      if (!LEAN) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) c_jt[i][c][lane] = j[c];
+        for (int c = 0; c < 6; ++c) c_jt[LEAN ? 0 : i][LEAN ? 0 : c][lane] = j[c];
+      }
       double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
       if (run_pid) {
         const double desired = c_des[i][lane];
         const double error = desired - (actual_is_vel ? qd : q);
         double acc = wt[kWin] * error;
 #pragma unroll
-        for (int k = 0; k < kWin; ++k) acc = fma(wt[k], c_win[i][k][lane], acc);
+        for (int k = 0; k < kWin; ++k) acc = fma(wt[k], LEAN ? S[(size_t)(20 + 11 * i + k) * st] : c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane], acc);
         const double p_term = a.kp * error;
         const double prev_ierr = c_ierr[i][lane];
         double ie = fma(a.dt, error, prev_ierr);
@@ -735,7 +769,11 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
         }
         c_ierr[i][lane] = ie;
         force = out;
-        c_win[i][ring_slot][lane] = error;
+        if (LEAN) {
+          if (live) a.state[(size_t)(20 + 11 * i + ring_slot) * st + r] = error;  // after the FIR has read the slot's old content
+        } else {
+          c_win[LEAN ? 0 : i][LEAN ? 0 : ring_slot][lane] = error;
+        }
         if (i == 0) {
           dbg_p = p_term;
           dbg_i = i_raw;
@@ -753,7 +791,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
   const double fk_res = x_est[0][lane], fk_it = x_est[1][lane];
   const uint32_t td_flag = (uint32_t)x_est[2][lane];
   uint32_t lim = 0u;
-#pragma unroll
+#pragma clang loop unroll_count(kU)
   for (int i = 0; i < N; ++i) {
     double applied = c_f[i][lane];
     const double qd = c_qd[i][lane], q = c_q[i][lane];
@@ -787,7 +825,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     O[13 * st] = fk_res;
     O[14 * st] = fk_it;
     O[15 * st] = (double)(td_flag | (lim << 1));
-#pragma unroll
+#pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
       O[(size_t)(16 + i) * st] = c_q[i][lane];
       O[(size_t)(16 + N + i) * st] = c_qd[i][lane];
@@ -798,12 +836,19 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
   {
     double w[6] = {a.fgx, a.fgy, a.fgz, 0.0, 0.0, 0.0};
     const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma unroll
+#pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
+      double L, j[6];
+      if (LEAN) {
+        ik_row64(a.geom + i * 7, R, p, L, j);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) j[c] = c_jt[LEAN ? 0 : i][LEAN ? 0 : c][lane];
+      }
       double t = fma(-a.damping, c_qd[i][lane], c_f[i][lane]);
       if (a.unilateral) t = fmax(t, 0.0);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) w[c] = fma(-c_jt[i][c][lane], t, w[c]);
+      for (int c = 0; c < 6; ++c) w[c] = fma(-j[c], t, w[c]);
     }
     v[0] = fma(a.dt * w[0], a.inv_mass, v[0]);
     v[1] = fma(a.dt * w[1], a.inv_mass, v[1]);
@@ -846,11 +891,13 @@ __global__ __launch_bounds__(128, 1) void cdpr_split_kernel_f64(const F64Args a)
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) W[(size_t)(3 + c) * st] = q4[c];
-#pragma unroll
+#pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
       W[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
+      if (!LEAN) {
 #pragma unroll
-      for (int k = 0; k < kWin; ++k) W[(size_t)(20 + 11 * i + k) * st] = c_win[i][k][lane];
+        for (int k = 0; k < kWin; ++k) W[(size_t)(20 + 11 * i + k) * st] = c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane];
+      }
     }
   }
 }

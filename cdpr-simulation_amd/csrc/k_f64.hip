@@ -8,7 +8,15 @@ template <int N> F64Kernel f64_n(bool ring_lds, bool jcache) {
 }
 }  // namespace
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }
-F64Kernel pick_f64_split_kernel(uint32_t n) {
+F64Kernel pick_f64_split_kernel(uint32_t n, bool lean) {
+  if (lean) {
+    switch (n) {
+      case 6: return cdpr_split_kernel_f64<6, true>;
+      case 7: return cdpr_split_kernel_f64<7, true>;
+      case 8: return cdpr_split_kernel_f64<8, true>;
+    }
+    return nullptr;
+  }
   switch (n) {
     case 6: return cdpr_split_kernel_f64<6>;
     case 7: return cdpr_split_kernel_f64<7>;

@@ -179,11 +179,11 @@ def test_zz_report_measured_agreement():
     print("fp64 kernel vs fp64 oracle, worst over this module:", {k: f"{v:.2e}" for k, v in WORST.items()})
 
 
-@pytest.mark.parametrize("cables", [8, 6])
-def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, cables):
+@pytest.mark.parametrize("cables,build", [(8, "1"), (6, "1"), (8, "2"), (7, "2")])
+def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, cables, build):
     """One-step launches of FK + TD fp64 handles up to one workgroup per CU run on cdpr_split_kernel_f64 (estimator wave +
-    controller wave per 64 robots; CDPR_F64_SPLIT=0 keeps the one-wave kernel): same statements in the same order over the
-    same LDS columns.  Velocity, Position and Force mode, the first world step, a ragged last block, the `pid` topic, the
+    controller wave per 64 robots; CDPR_F64_SPLIT=0 keeps the one-wave kernel, 1 forces the LDS-cached build, 2 the lean
+    build that serves batches beyond one workgroup per CU): same statements in the same order over the same LDS columns.  Velocity, Position and Force mode, the first world step, a ragged last block, the `pid` topic, the
     travel-limit flags; fused launches (one-wave kernel on both handles) in between.  Same bits: every multiply-add of the
     fp64 kernels is an explicit fma (the variable is read per call, so both builds run in this process)."""
     from dataclasses import replace
@@ -198,7 +198,7 @@ def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, ca
     p = rng.uniform(-0.003, 0.003, (B, cables)).astype(np.float32)
     f = rng.uniform(5.0, 25.0, (B, cables)).astype(np.float32)
     out = []
-    for split in ("0", "1"):
+    for split in ("0", build):
         monkeypatch.setenv("CDPR_F64_SPLIT", split)
         eng = pkg.Engine(cfg, 0)
         eng.set_platform_state(pose7=pose)
@@ -220,5 +220,5 @@ def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, ca
                 worst = max(worst, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
             else:
                 assert np.array_equal(x, y)
-    print(f"fp64 role-split vs one-wave kernel, n = {cables}: worst difference {worst:.3e}")
+    print(f"fp64 role-split (build {build}) vs one-wave kernel, n = {cables}: worst difference {worst:.3e}")
     assert worst == 0.0
