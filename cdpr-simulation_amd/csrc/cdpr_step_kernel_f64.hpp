@@ -646,11 +646,14 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
       for (int y = 0; y <= x; ++y) m[x][y] = 0.0;
     }
     const Rot64 Rt = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
-#pragma clang loop unroll_count(kU)
+    double jr[LEAN ? N : 1][6];  // LEAN: the rows at the estimate, built once in registers for the three passes below (fully unrolled)
+#pragma unroll
     for (int i = 0; i < N; ++i) {
       double L, j[6];
       if (LEAN) {
         ik_row64(a.geom + i * 7, Rt, fkp, L, j);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) jr[LEAN ? i : 0][c] = j[c];
       } else {
 #pragma unroll
         for (int c = 0; c < 6; ++c) j[c] = c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
@@ -666,29 +669,21 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in c_f
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma clang loop unroll_count(kU)
-    for (int i = 0; i < N; ++i) {
-      double L, j[6];
-      if (LEAN) {
-        ik_row64(a.geom + i * 7, Rt, fkp, L, j);
-      } else {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) j[c] = c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
-      }
+    for (int i = 0; i < N; ++i) {
+      double j[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) j[c] = LEAN ? jr[LEAN ? i : 0][c] : c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
       const double df = c_f[i][lane] - a.td_mid;
 #pragma unroll
       for (int x = 0; x < 6; ++x) g[x] = fma(j[x], df, g[x]);
     }
     chol_apply64(m, invd, g);
-#pragma clang loop unroll_count(kU)
-    for (int i = 0; i < N; ++i) {
-      double L, j[6];
-      if (LEAN) {
-        ik_row64(a.geom + i * 7, Rt, fkp, L, j);
-      } else {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) j[c] = c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
-      }
+    for (int i = 0; i < N; ++i) {
+      double j[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) j[c] = LEAN ? jr[LEAN ? i : 0][c] : c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane];
       double t = a.td_mid;
 #pragma unroll
       for (int c = 0; c < 6; ++c) t = fma(g[c], j[c], t);
