@@ -56,6 +56,9 @@ SCHED_CHUNK = 1000  # world steps per launch on the scheduled path (small batche
 FUSED_WARM, FUSED_LAUNCHES = 3, 30  # the fused leg's own schedule: untimed / minimum timed launches of 10 steps each
 ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
 GENERAL_SHAPE = (16384, 0.001, 60, 300)  # general-path leg: robots, velocityEpsilon, untimed steps (past the window fill), timed steps
+FP64_SHAPES = ((65536, 30, 100), (1, 30, 300))  # precision = 64 leg: (robots, untimed steps, timed steps) at the contract's size and for one robot
+FP64_TOL = {"pose": 1e-10, "eff": 1e-7}         # fp64 kernels against the fp64 oracle (two double implementations; tests/test_gpu_fp64.py: 1e-13 / 1e-9 over short runs)
+LARGE_BATCH_SHAPE = (524288, 30, 60)            # HBM-streaming regime on ONE GPU: robots, untimed steps, timed steps
 
 
 def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
@@ -78,6 +81,33 @@ def make_workload(pkg, batch, n_cables, seed, steps_total, refresh=10, dt=1e-3):
         return np.repeat((amp * np.sin(2 * np.pi * freq * t + phase)).astype(np.float32), n_cables, axis=1)
 
     return model, pose.astype(np.float32), command, n_cmd
+
+
+def make_square_workload(pkg, batch, n_cables, seed, steps_total, which, dt=1e-3):
+    """Config 2 under the reference's square publishers: squarepositiontest
+    (squarepositiontest.cpp:6-10,21-35: bias + copysign(amp, sin), 10 Hz) or squarevelocitytest (squarevelocitytest.cpp:6-9,20-34),
+    one amplitude per robot, the same value on every axis as the publisher sends it; a sample every 100 world steps."""
+    import itertools
+
+    from scipy.spatial.transform import Rotation
+
+    model = pkg.eight_cable_model() if n_cables == 8 else pkg.cube_model()
+    rng = np.random.default_rng(seed)
+    pose = np.tile(model.home_pose(), (batch, 1))
+    pose[:, :3] += rng.uniform(-0.01, 0.01, (batch, 3))
+    pose[:, 3:7] = Rotation.from_rotvec(rng.uniform(-0.03, 0.03, (batch, 3))).as_quat()
+    refresh = 100
+    n_cmd = (steps_total + refresh - 1) // refresh
+    if which == "squareposition":
+        gen, amp = pkg.stimulus.square_position(n_cables, amp=1.0, freq=0.7), rng.uniform(0.002, 0.004, (batch, 1))
+    else:
+        gen, amp = pkg.stimulus.square_velocity(n_cables, amp=1.0, freq=0.9), rng.uniform(0.01, 0.04, (batch, 1))
+    base = np.array(list(itertools.islice(gen, n_cmd)), dtype=np.float64)[:, 0]  # the publisher's value per tick
+
+    def command(j):
+        return np.repeat((amp * base[j]).astype(np.float32), n_cables, axis=1)
+
+    return model, pose.astype(np.float32), command, n_cmd, refresh
 
 
 def make_rollout_commands(n_robots, horizon, samples, n_cables, seed=1236):
@@ -106,7 +136,7 @@ def effective_cpu_count():
     return n
 
 
-def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
+def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0, kind="velocity"):
     """Time the fp64 oracle ("port" of the reference step) on the host cores, bounded sample.  Two derivative modes
     (BASELINE.md section 3): `fir`-equivalent EXACT (same least-squares problem in centred time; the headline `value`)
     and FAITHFUL (per-step normal equations in absolute time + pow() + column-pivoted QR, as Pid.cpp:219-247)."""
@@ -124,7 +154,7 @@ def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0):
         t0 = time.perf_counter()
         done = 0
         while done < nsteps:
-            sim.set_velocity_command(command(done // refresh)[:nb])
+            getattr(sim, f"set_{kind}_command")(command(done // refresh)[:nb])
             k = min(refresh, nsteps - done)
             sim.update(k, cores if threads is None else threads)
             done += k
@@ -172,7 +202,7 @@ def parity_slices(batch, width=64):
     return out
 
 
-def parity_check(pkg, cfg_kwargs, pose, command, refresh, total_steps, got, slices, threads=1):
+def parity_check(pkg, cfg_kwargs, pose, command, refresh, total_steps, got, slices, threads=1, kind="velocity"):
     """The checker for the number this run reports: replay the SAME schedule (initial poses, one Joy batch per `refresh`
     steps, `total_steps` world steps) for the robots of `slices` on the fp64 oracle and compare every published observable
     of the last step with what the engine held right after the timed region.  got = (pose7, twist6, q, qd, effort)."""
@@ -187,7 +217,7 @@ def parity_check(pkg, cfg_kwargs, pose, command, refresh, total_steps, got, slic
         sim.set_platform_state(pose7=pose[sl].astype(np.float64))
         done = 0
         while done < total_steps:
-            sim.set_velocity_command(command(done // refresh)[sl])
+            getattr(sim, f"set_{kind}_command")(command(done // refresh)[sl])
             k = min(refresh, total_steps - done)
             sim.update(k, threads)
             done += k
@@ -315,6 +345,41 @@ def host_placement(local_rank, local_world, sysfs="/sys"):
     return info
 
 
+def device_identity(local_rank, rendezvous_backend):
+    """Pre-flight of a rank's GPU: the HIP ordinal this rank will time (local_rank modulo the visible
+    devices) with its PCI address as libcdpr_hip sees it, and - when the rendezvous runs on RCCL, i.e. torch drives a GPU
+    too - the check that torch's device of the same ordinal is the same PCI device and that both runtimes see the same number
+    of GPUs (rank r must not time GPU r while RCCL sits on GPU r').  Returns a dict; `problem` is None when all is well."""
+    import ctypes as C
+
+    from cdpr_simulation_amd._native import lib
+
+    ndev = lib().cdpr_device_count()
+    info = {"hip_devices": int(ndev), "device": None, "pci": None, "torch_devices": None, "torch_pci": None, "problem": None}
+    if ndev <= 0:
+        return info
+    dev = local_rank % ndev
+    buf = C.create_string_buffer(32)
+    if lib().cdpr_device_pci_bus_id(dev, buf, 32) == 0:
+        info["pci"] = buf.value.decode().lower()
+    info["device"] = int(dev)
+    if rendezvous_backend == "nccl":
+        import torch
+
+        info["torch_devices"] = int(torch.cuda.device_count())
+        if info["torch_devices"] != ndev:
+            info["problem"] = f"torch sees {info['torch_devices']} GPUs, libcdpr_hip {ndev}"
+        else:
+            try:
+                p = torch.cuda.get_device_properties(dev)
+                info["torch_pci"] = f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}"
+                if info["pci"] and not info["pci"].startswith(info["torch_pci"]):
+                    info["problem"] = f"ordinal {dev} is PCI {info['pci']} for libcdpr_hip but {info['torch_pci']} for torch"
+            except AttributeError:  # an older torch without the PCI properties: nothing to compare
+                pass
+    return info
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +389,9 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="robots per GPU (default: the config's)")
     ap.add_argument("--cables", type=int, default=None, choices=(4, 8))
     ap.add_argument("--steps-per-launch", type=int, default=1)
+    ap.add_argument("--stimulus", default="sine", choices=("sine", "squareposition", "squarevelocity"),
+                    help="command generator: the contract's per-robot sines every 10 steps (default), or the reference's square publishers "
+                         "(squarepositiontest / squarevelocitytest: 10 Hz, a Joy every 100 steps)")
     ap.add_argument("--launch-per-step", action="store_true", help="small batches: one launch per world step (hipGraph replays) instead of the scheduled update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the fused / rollout secondary figures")
@@ -427,9 +495,12 @@ def main():
         mine = time.perf_counter() - t0
         elapsed = ctx.max_over_ranks(mine)
         per_rank = ctx.gather_over_ranks([mine, float(len(os.sched_getaffinity(0))), float(-1 if placement.get("numa_node") is None else placement["numa_node"])])
+        ident = device_identity(local_rank, ctx.backend_name())
+        idents = [json.loads(x) for x in ctx.gather_strings(json.dumps(ident))]
         if rank == 0:
-            emit(json.dumps({"metric": METRIC, "value": 0.0, "placement": placement,
-                             "per_rank": [{"rank": i, "elapsed_s": v[0], "cpus": int(v[1]), "placement": {"numa_node": None if v[2] < 0 else int(v[2])}} for i, v in enumerate(per_rank)], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
+            emit(json.dumps({"metric": METRIC, "value": 0.0, "placement": placement, "rendezvous": ctx.backend_name(), "rendezvous_fallback": ctx.fallback,
+                             "per_rank": [{"rank": i, "elapsed_s": v[0], "cpus": int(v[1]), "placement": {"numa_node": None if v[2] < 0 else int(v[2])},
+                                           "device": idents[i]["device"], "pci": idents[i]["pci"], "torch_pci": idents[i]["torch_pci"]} for i, v in enumerate(per_rank)], "unit": "state-steps/s", "n_gpus": world, "steps": args.steps,
                              "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
                              "config": {"workload": "dry run: rank plumbing only, no GPU work"}}))
@@ -443,11 +514,23 @@ def main():
     stages = (_abi.STAGE_FK | _abi.STAGE_TD) if n == 8 else 0
     total = args.warmup + args.steps
     seed = (1235 if n == 8 else 1234) + rank
-    model, pose, command, n_cmd = make_workload(pkg, args.batch, n, seed, total, refresh)
+    kind = "position" if args.stimulus == "squareposition" else "velocity"
+    if args.stimulus == "sine":
+        model, pose, command, n_cmd = make_workload(pkg, args.batch, n, seed, total, refresh)
+    else:
+        model, pose, command, n_cmd, refresh = make_square_workload(pkg, args.batch, n, seed, total, args.stimulus)
     cfg_kwargs = dict(model=model, stages=stages)
     cfg = pkg.Config(batch=args.batch, **cfg_kwargs)
     ndev = lib().cdpr_device_count()
     device = local_rank % max(ndev, 1)  # one rank per GPU; ranks only share a GPU on a box with fewer GPUs than ranks
+    ident = device_identity(local_rank, ctx.backend_name())
+    idents = [json.loads(x) for x in ctx.gather_strings(json.dumps(ident))]
+    problems = [f"rank {i}: {d['problem']}" for i, d in enumerate(idents) if d.get("problem")]
+    if problems:  # every rank sees the same list: all stop together, before any GPU work
+        if rank == 0:
+            print("bench.py: device pre-flight FAILED: " + "; ".join(problems), file=sys.stderr)
+        ctx.close()
+        sys.exit(4)
     eng = pkg.Engine(cfg, device=device)
     eng.set_platform_state(pose7=pose)
     # command schedule resident in HBM before timing starts
@@ -466,15 +549,15 @@ def main():
             s = first_step + done
             if scheduled and s % refresh == 0:
                 k = min(SCHED_CHUNK, nsteps - done)
-                eng.update_scheduled(k, refresh, d_sched_all + (s // refresh) * count * 4)
+                eng.update_scheduled(k, refresh, d_sched_all + (s // refresh) * count * 4, kind=kind)
                 done += k
                 continue
             if s % refresh == 0 and args.batch * n <= 131072:
                 # launch per step on a small batch: the launches replay from captured hipGraphs, and a graph is tied to the buffer
                 # its kernels read, so the Joy batch is copied (device to device, 64 KiB) into the handle's own latched buffer
-                eng.set_velocity_command_device(sched[s // refresh], count)
+                getattr(eng, f"set_{kind}_command_device")(sched[s // refresh], count)
             elif s % refresh == 0:  # the schedule lives in HBM: the engine reads the Joy batch in place (zero copy)
-                eng.bind_velocity_command_device(sched[s // refresh], count)
+                getattr(eng, f"bind_{kind}_command_device")(sched[s // refresh], count)
             k = min(refresh - s % refresh, nsteps - done)
             eng.update(k, args.steps_per_launch)
             done += k
@@ -512,13 +595,13 @@ def main():
     parity = None
     if not args.no_parity_check:
         parity = parity_check(pkg, cfg_kwargs, pose, command, refresh, total, (pose_end, twist_end) + tuple(joint_end),
-                              parity_slices(args.batch), threads=max(1, min(4, int(placement["cpus_effective"] // max(world, 1)))))
+                              parity_slices(args.batch), threads=max(1, min(4, int(placement["cpus_effective"] // max(world, 1)))), kind=kind)
         worst_ok = ctx.min_over_ranks(1.0 if parity["ok"] else 0.0)
         parity["ok_all_ranks"] = bool(worst_ok > 0.5)
 
     # ---- secondary figures (every rank runs them, outside the timed region above; never substituted for `value`)
     secondary = {}
-    if args.steps_per_launch == 1 and not args.no_secondary:
+    if args.steps_per_launch == 1 and not args.no_secondary and args.stimulus == "sine":
         # (a) same workload with the 10 steps of each command hold fused into one launch: state stays on chip
         #     between the steps, observables are still written every step
         # A schedule of its own, whatever --steps says (the driver's --steps 20 used to leave this leg two cold launches):
@@ -686,6 +769,96 @@ def main():
                 "parity_check": gen_parity,
             }
 
+        # (d) the step in the reference's own precision (cdpr_config_t.precision = 64: Pid.h and Gazebo/ODE compute in double):
+        #     the contract's size and one robot, kernel time by HIP events, 64 robots replayed on the fp64 oracle
+        if n == 8 and args.config == 3:
+            fp64_legs = []
+            for Bf, warm_f, steps_f in FP64_SHAPES:
+                Bf = min(Bf, args.batch)  # (--batch below the contract's size: the leg follows)
+                ef = pkg.Engine(pkg.Config(batch=Bf, precision=64, **cfg_kwargs), device=device)
+                ef.set_platform_state(pose7=pose[:Bf])
+                d_cmd_f = ef.device_upload(command(0)[:Bf])
+                ef.bind_velocity_command_device(d_cmd_f, Bf * n)
+                ef.update(warm_f)
+                ef.synchronize()
+                ef.profile_begin()
+                ef.update(steps_f)
+                msf, nlf = ef.profile_end()
+                fpar = None
+                if not args.no_parity_check:
+                    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                    import oracle
+
+                    fs = slice(max(0, Bf - 64), Bf)
+                    osim = oracle.OracleSim(pkg.Config(batch=fs.stop - fs.start, **cfg_kwargs).to_struct(), oracle.DERIV_EXACT)
+                    osim.set_platform_state(pose7=pose[fs].astype(np.float64))
+                    osim.set_velocity_command(command(0)[fs])
+                    osim.update(warm_f + steps_f)
+                    g64 = ef.observables_f64()
+                    dp = float(np.abs(g64[3][fs] - osim.platform_state()[0]).max())
+                    de = float(np.abs(g64[2][fs] - osim.joint_states()[2]).max())
+                    osim.close()
+                    fpar = {"robots": [fs.start, fs.stop], "steps": warm_f + steps_f, "max_abs_pose": dp, "max_abs_effort": de, "tolerance": FP64_TOL,
+                            "ok": bool(np.isfinite(g64[3]).all() and dp <= FP64_TOL["pose"] and de <= FP64_TOL["eff"])}
+                ef.device_free(d_cmd_f)
+                ef.close()
+                kus_f = msf * 1e3 / max(nlf, 1)
+                fp64_legs.append({"robots": Bf, "kernel_us": kus_f, "value_per_gpu": Bf / (kus_f * 1e-6), "steps_timed": steps_f, "parity_check": fpar})
+            secondary["fp64"] = {
+                "workload": f"precision = 64 (the reference's own arithmetic): {n}-cable robots, every stage, one launch per step, one held Joy",
+                "dtype": "f64",
+                "unit": "state-steps/s",
+                "legs": fp64_legs,
+                "value_per_gpu": fp64_legs[0]["value_per_gpu"],
+                "kernel_us": fp64_legs[0]["kernel_us"],
+                "kernel_us_one_robot": fp64_legs[-1]["kernel_us"],
+                "parity_check": {"ok": all((l["parity_check"] or {"ok": True})["ok"] for l in fp64_legs)} if not args.no_parity_check else None,
+            }
+
+        # (e) the HBM-streaming regime: 524 288 x 8 on ONE GPU (a 65 536-robot handle's ~40 MB of state and observables stay in
+        #     L2 + Infinity Cache between launches; eight times that does not), one launch per step
+        if n == 8 and args.config == 3 and world == 1:
+            Bl, warm_l, steps_l = LARGE_BATCH_SHAPE
+            model_l, pose_l, command_l, _ = make_workload(pkg, Bl, n, 1235, refresh)
+            el = pkg.Engine(pkg.Config(batch=Bl, **cfg_kwargs), device=device)
+            el.set_platform_state(pose7=pose_l)
+            d_cmd_l = el.device_upload(command_l(0))
+            el.bind_velocity_command_device(d_cmd_l, Bl * n)
+            el.update(warm_l)
+            el.synchronize()
+            el.profile_begin()
+            tl0 = time.perf_counter()
+            el.update(steps_l)
+            msl, nll = el.profile_end()
+            wall_l = time.perf_counter() - tl0
+            lpar = None
+            if not args.no_parity_check:
+                lp_, lt_ = el.platform_state()
+                lpar = parity_check(pkg, cfg_kwargs, pose_l, lambda j: command_l(0), refresh, warm_l + steps_l, (lp_, lt_) + tuple(el.joint_states()),
+                                    parity_slices(Bl), threads=max(1, min(4, int(placement["cpus_effective"]))))
+            el.device_free(d_cmd_l)
+            el.close()
+            kus_l = msl * 1e3 / max(nll, 1)
+            t_l = None
+            try:
+                t_l = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"n{n}_b{Bl}_spl1")
+            except (OSError, ValueError):
+                pass
+            bytes_l = 4 * (39 + 28 * n) * Bl
+            secondary["large_batch"] = {
+                "workload": f"{Bl} x {n}-cable robots on one GPU (config 4's whole batch: the HBM-streaming regime), every stage, one launch per step, one held Joy",
+                "kernel_us": kus_l,
+                "value_per_gpu": Bl / (kus_l * 1e-6),
+                "value_wall": Bl * steps_l / wall_l,
+                "unit": "state-steps/s",
+                "steps_timed": steps_l,
+                "frac": bytes_l / (kus_l * 1e-6) / 1e9 / HBM_PEAK_GBS,  # algorithmic bytes per launch / kernel time / 8 TB/s
+                "traffic": t_l,                                           # HBM bytes per launch (rocprofv3 PMC of this round's layout)
+                "traffic_frac": (t_l / (kus_l * 1e-6) / 1e9 / HBM_PEAK_GBS) if t_l else None,
+                "traffic_frac_of_copy_rate": (t_l / (kus_l * 1e-6) / 1e9 / HBM_COPY_GBS) if t_l else None,
+                "parity_check": lpar,
+            }
+
     if rank == 0:
         bytes_step = eng.bytes_per_state_step()
         launch_s = ev_ms * 1e-3 / max(launches, 1)
@@ -697,9 +870,22 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"n{n}_b{args.batch}_spl{args.steps_per_launch}")
+                # (key by what ONE launch really is: the scheduled path's launches are SCHED_CHUNK steps long)
+                tkey = f"n{n}_b{args.batch}_sched{SCHED_CHUNK}" if scheduled else f"n{n}_b{args.batch}_spl{args.steps_per_launch}"
+                traffic = json.load(open(tpath)).get(tkey)
             except Exception:
                 traffic = None
+        residency = None
+        try:
+            res_tab = json.load(open(tpath)).get("_residency", {})
+            r_ = res_tab.get(f"n{n}_b{args.batch}")
+            if r_:
+                state_mb = (eng.observable_image_bytes() + args.batch * 16 * (30 if n == 8 else 16)) / 1e6
+                residency = {"tcc_hit_rate": r_["tcc_hit_rate"], "source": r_["file"], "working_set_MB": state_mb,
+                             "note": "state and observables of the handle stay in L2 + Infinity Cache (256 MiB) between launches: `traffic` counts "
+                                     "L2 <-> fabric bytes, not HBM row activations; see `large_batch` for the HBM-streaming regime"}
+        except Exception:
+            residency = None
         out = {
             "metric": METRIC,
             "value": value,
@@ -716,7 +902,8 @@ def main():
             "config": {
                 "workload": f"{'config3' if n == 8 else 'config2'}: {args.batch} x {n}-cable robots per GPU, "
                             + ("IK + NR-FK(4 it) + tension distribution + PID + dynamics" if n == 8 else "IK + PID + dynamics")
-                            + ", observables every step, commands refreshed every 10 steps from HBM",
+                            + f", observables every step, commands ({'per-robot sines' if args.stimulus == 'sine' else args.stimulus + 'test, one amplitude per robot'}: "
+                            f"{'jointPositions' if kind == 'position' else 'jointVelocities'}) refreshed every {refresh} steps from HBM",
                 "robots_per_gpu": args.batch,
                 "cables": n,
                 "steps_per_launch": args.steps_per_launch,
@@ -725,6 +912,7 @@ def main():
                 "mapping": eng.mapping,
                 "state_finite": finite,
                 "rendezvous": ctx.backend_name(),  # "none" (one rank), "nccl" (= RCCL) or "gloo": barrier + max only, no data-path collective
+                "rendezvous_fallback": ctx.fallback,  # why the rendezvous is not on RCCL, if it is not (cdpr_simulation_amd/sharding.py)
             },
             "roofline": {
                 # what limits the launch, and the tighter of the two roofs it is priced against (frozen in round 4: these
@@ -743,9 +931,11 @@ def main():
                 "frac": achieved_kernel / HBM_PEAK_GBS,
                 "basis": "algorithmic bytes (SURVEY 8(d), shifted-window accounting) per launch / average launch duration by HIP events",
                 "traffic": traffic,
-                "traffic_model": modelled_traffic_bytes(n, n >= 6, args.batch, args.steps_per_launch),  # from the data layout
+                "traffic_model": modelled_traffic_bytes(n, n >= 6, args.batch, max(1, int(round(args.steps / max(launches, 1))))),  # from the data layout, for the steps one launch really runs
                 "bytes_per_state_step": bytes_step,
-                "kernel_us": launch_s * 1e6,
+                "kernel_us": launch_s * 1e6,  # one LAUNCH (the scheduled path: SCHED_CHUNK steps)
+                "steps_per_launch": args.steps / max(launches, 1),
+                "kernel_us_per_step": launch_s * 1e6 / (args.steps / max(launches, 1)),
                 "achieved_kernel": achieved_kernel,  # (same as `achieved`; kept for readers of earlier rounds' lines)
                 "frac_kernel": achieved_kernel / HBM_PEAK_GBS,
                 # BASELINE.md section 3's formula: per-GPU state-steps/s by the WALL clock x the same algorithmic bytes
@@ -759,16 +949,20 @@ def main():
                 # ... and against what a plain copy kernel reaches on this part: how much of the practical ceiling the launch uses
                 "traffic_frac_of_copy_rate": (traffic / launch_s / 1e9 / HBM_COPY_GBS) if traffic else None,
                 "limiter": "instruction issue of the one wave that carries a robot's serial chain (5 cycles per vector instruction, DESIGN.md section 4), not HBM bandwidth",
+                # where the bytes of this launch come from: a 65 536-robot handle's state + observables (~40 MB) fit the 256 MiB
+                # Infinity Cache and partly L2, so consecutive launches are NOT streaming from HBM; the HBM-streaming figure is
+                # the `large_batch` leg (524 288 robots on one GPU).  tcc_hit_rate: L2 hits / requests of the step kernel (PMC)
+                "residency": residency,
             },
         }
         out["parity_check"] = parity
         out["placement"] = placement
         out["per_rank"] = [{"rank": i, "value": args.batch * args.steps / v[0], "ms_per_step": v[0] / args.steps * 1e3, "kernel_us": v[1],
-                            "device": int(v[2]), "placement": {"numa_node": None if v[3] < 0 else int(v[3]), "first_cpu": None if v[4] < 0 else int(v[4]),
+                            "device": int(v[2]), "pci": idents[i]["pci"], "torch_pci": idents[i]["torch_pci"], "placement": {"numa_node": None if v[3] < 0 else int(v[3]), "first_cpu": None if v[4] < 0 else int(v[4]),
                                                                 "cpus": int(v[5])}} for i, v in enumerate(per_rank)]
         out.update(secondary)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, args.cpu_seconds, kind=kind)
         emit(json.dumps(out))
     for p in sched:
         eng.device_free(p)
@@ -776,7 +970,9 @@ def main():
     ctx.close()
     # a number that is not tied to a verified computation is not reported as a success
     failed = [name for name, chk in (("step", parity), ("rollout", (secondary.get("rollout") or {}).get("parity_check")),
-                                     ("general_path", (secondary.get("general_path") or {}).get("parity_check"))) if chk and not chk.get("ok_all_ranks", chk["ok"])]
+                                     ("general_path", (secondary.get("general_path") or {}).get("parity_check")),
+                                     ("fp64", (secondary.get("fp64") or {}).get("parity_check")),
+                                     ("large_batch", (secondary.get("large_batch") or {}).get("parity_check"))) if chk and not chk.get("ok_all_ranks", chk["ok"])]
     if failed:
         print(f"bench.py: parity check against the oracle FAILED for: {', '.join(failed)}", file=sys.stderr)
         sys.exit(3)

@@ -14,12 +14,12 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("CDPR_LIB", "libcdpr_hip.so"))  # 
 
 # every symbol include/cdpr.h declares
 EXPORTS = [
-    "cdpr_abi_version", "cdpr_config_size", "cdpr_device_count", "cdpr_bytes_per_state_step", "cdpr_derivative_weights",
+    "cdpr_abi_version", "cdpr_config_size", "cdpr_device_count", "cdpr_device_pci_bus_id", "cdpr_bytes_per_state_step", "cdpr_derivative_weights",
     "cdpr_create", "cdpr_destroy", "cdpr_reset", "cdpr_last_error", "cdpr_set_platform_state",
     "cdpr_set_velocity_command", "cdpr_set_position_command", "cdpr_set_velocity_command_device",
     "cdpr_set_position_command_device", "cdpr_bind_velocity_command_device", "cdpr_bind_position_command_device",
     "cdpr_set_velocity_command_masked", "cdpr_set_position_command_masked", "cdpr_set_force_command", "cdpr_set_force_command_device",
-    "cdpr_bind_force_command_device", "cdpr_set_force_command_masked", "cdpr_update", "cdpr_update_fused", "cdpr_observable_image_bytes", "cdpr_update_record", "cdpr_update_scheduled", "cdpr_decode_observables", "cdpr_synchronize", "cdpr_mapping", "cdpr_step_count",
+    "cdpr_bind_force_command_device", "cdpr_set_force_command_masked", "cdpr_update", "cdpr_update_fused", "cdpr_observable_image_bytes", "cdpr_update_record", "cdpr_update_scheduled", "cdpr_update_scheduled_kind", "cdpr_decode_observables", "cdpr_synchronize", "cdpr_mapping", "cdpr_step_count",
     "cdpr_get_joint_states", "cdpr_get_platform_state", "cdpr_get_observables", "cdpr_get_pid_debug", "cdpr_get_fk_state", "cdpr_get_td_state", "cdpr_get_limit_state", "cdpr_get_observables_f64", "cdpr_get_raw_state_f64", "cdpr_set_platform_state_f64",
     "cdpr_get_raw_state", "cdpr_rollout_velocity", "cdpr_rollout_velocity_launch", "cdpr_rollout_velocity_fetch",
     "cdpr_rollout_velocity_device", "cdpr_device_malloc", "cdpr_device_free", "cdpr_device_upload", "cdpr_device_download",
@@ -50,6 +50,7 @@ def lib():
     L.cdpr_abi_version.restype = C.c_uint32
     L.cdpr_config_size.restype = C.c_size_t
     L.cdpr_device_count.restype = C.c_int
+    L.cdpr_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.cdpr_bytes_per_state_step.restype = C.c_size_t
     L.cdpr_bytes_per_state_step.argtypes = [cfgp]
     L.cdpr_derivative_weights.argtypes = [C.c_uint32, C.c_uint32, dp]
@@ -72,6 +73,7 @@ def lib():
     L.cdpr_observable_image_bytes.argtypes = [H, C.POINTER(C.c_size_t)]
     L.cdpr_update_record.argtypes = [H, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.cdpr_update_scheduled.argtypes = [H, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.cdpr_update_scheduled_kind.argtypes = [H, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.cdpr_decode_observables.argtypes = [H, C.c_void_p, fp, fp, fp, fp, fp]
     L.cdpr_synchronize.argtypes = [H]
     L.cdpr_mapping.argtypes = [H]

@@ -64,6 +64,12 @@ struct cdpr_engine {
   bool split = false;       // FK + TD one-step launches use cdpr_split_kernel (estimator wave + controller wave per 64 robots)
   int sched_refresh = 0;            // cdpr_update_scheduled in progress: Joy batches per launch (StepArgs::sched_*)
   const uint32_t* sched_ready = nullptr;
+  // cdpr_update_scheduled_kind on a per-robot handle: batch j of the schedule is latched straight from the caller's device
+  // buffers (rows d_commands + j * B * n, mask d_robot_masks + j * B or nullptr = every robot), nothing staged
+  const float* sched_rows[3] = {nullptr, nullptr, nullptr};
+  const uint8_t* sched_mask[3] = {nullptr, nullptr, nullptr};
+  uint32_t* h_fault = nullptr;      // pinned, device-mapped status word: a schedule mailbox that never delivered (kernels OR bits into it)
+  uint32_t* d_fault = nullptr;      // its device address
   uint32_t chunk = 0;       // > 0: a step over the batch is issued as back-to-back launches over contiguous blocks of at most
                             // this many robots (batches between one and ~5 robots per hardware lane: see cdpr_create)
   bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
@@ -522,6 +528,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_unpack) (void)hipFree(h->d_unpack);
   for (void* p64 : {(void*)h->d_state64, (void*)h->d_obs64, (void*)h->d_geom64, (void*)h->d_wtab64, (void*)h->d_dbg64, h->d_unpack64})
     if (p64) (void)hipFree(p64);
+  if (h->h_fault) (void)hipHostFree(h->h_fault);
   if (h->h_pub) (void)hipHostFree(h->h_pub);
   if (h->h_pub_done) (void)hipHostFree(h->h_pub_done);
   if (h->d_pub_arrivals) (void)hipFree(h->d_pub_arrivals);
@@ -554,6 +561,8 @@ void free_all(cdpr_engine* h) {
 void engine_reset_host(cdpr_engine* h) {
   h->vel_pending = h->pos_pending = h->frc_pending = false;
   h->vel_masked = h->pos_masked = h->frc_masked = false;
+  for (int k = 0; k < 3; ++k) h->sched_rows[k] = nullptr, h->sched_mask[k] = nullptr;
+  if (h->h_fault) *h->h_fault = 0u;
   h->ext_vel[0] = h->ext_vel[1] = h->ext_pos[0] = h->ext_pos[1] = h->ext_frc[0] = h->ext_frc[1] = nullptr;
   h->have_vel = h->have_pos = h->have_frc = false;
   h->mode = kModePosition;  // PLG.cpp:153-157: Position mode, target 0 after operator= -> reset()
@@ -996,24 +1005,28 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       HIP_TRY(h, hipGetLastError());
       return CDPR_OK;
     };
+    // (a batch of a device-resident schedule, cdpr_update_scheduled_kind, is latched from the caller's buffers in place)
+    auto rows_of = [&](int kind, float* pending) -> float* { return h->sched_rows[kind] ? const_cast<float*>(h->sched_rows[kind]) : pending; };
+    auto mask_of = [&](int kind, bool masked) -> const uint8_t* { return h->sched_rows[kind] ? h->sched_mask[kind] : (masked ? h->d_mask[kind] : nullptr); };
     if (h->vel_pending) {
-      if (int rc = latch(h->d_vel[1], h->d_vel[0], h->vel_masked ? h->d_mask[0] : nullptr, 1, kModeVelocity)) return rc;
+      if (int rc = latch(rows_of(0, h->d_vel[1]), h->d_vel[0], mask_of(0, h->vel_masked), 1, kModeVelocity)) return rc;
       h->vel_pending = h->vel_masked = false;
       h->have_vel = true;
-      touched[0] = true;  // the latch kernel reads the pending buffer
+      touched[0] = !h->sched_rows[0];  // the latch kernel reads the pending buffer
     }
     if (h->pos_pending) {
-      if (int rc = latch(h->d_pos[1], h->d_pos[0], h->pos_masked ? h->d_mask[1] : nullptr, 0, kModePosition)) return rc;
+      if (int rc = latch(rows_of(1, h->d_pos[1]), h->d_pos[0], mask_of(1, h->pos_masked), 0, kModePosition)) return rc;
       h->pos_pending = h->pos_masked = false;
       h->have_pos = true;
-      touched[1] = true;
+      touched[1] = !h->sched_rows[1];
     }
     if (h->frc_pending) {  // [NEW] ordering: after the two Joy topics (the reference has no force callback)
-      if (int rc = latch(h->d_frc[1], h->d_frc[0], h->frc_masked ? h->d_mask[2] : nullptr, -1, kModeForce)) return rc;
+      if (int rc = latch(rows_of(2, h->d_frc[1]), h->d_frc[0], mask_of(2, h->frc_masked), -1, kModeForce)) return rc;
       h->frc_pending = h->frc_masked = false;
       h->have_frc = true;
-      touched[2] = true;
+      touched[2] = !h->sched_rows[2];
     }
+    h->sched_rows[0] = h->sched_rows[1] = h->sched_rows[2] = nullptr;
     if (int rc = mark_free()) return rc;
     touched[0] = touched[1] = touched[2] = false;  // recorded; nothing below latches on a per-robot handle
     if (h->general) return run_steps_general(h, nsteps, per_launch, record);
@@ -1119,8 +1132,11 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     a.pid_calls = sat_pid_calls(h->pid_calls);
     a.ring_slot = ring_slot_of(h->step);
     set_weight_row(h, a);
-    StepKernel kern = select_step_kernel(h, k);
-    const dim3 block(step_block_threads(h, k));
+    // a launch over a command schedule always runs on the several-steps kernel, even for one step: only that one reads the
+    // schedule, its mailbox and kFlagPublishAll
+    const int kk = h->sched_refresh ? std::max(k, 2) : k;
+    StepKernel kern = select_step_kernel(h, kk);
+    const dim3 block(step_block_threads(h, kk));
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
@@ -1183,6 +1199,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
       a.sched_refresh = h->sched_refresh;
       a.sched_stride = (size_t)h->batch * h->n;
       a.sched_ready = h->sched_ready;
+      a.fault = h->d_fault;
       h->prev_publish = sim_time(h->step + (uint64_t)k - 1, h->cfg.dt);
     } else {
       for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
@@ -1268,6 +1285,15 @@ int cdpr_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int cdpr_device_pci_bus_id(int device, char* out, size_t len) {
+  if (!out || len < 13) return CDPR_ERR_INVALID;
+  out[0] = 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CDPR_ERR_INVALID;
+  if (hipDeviceGetPCIBusId(out, (int)len, device) != hipSuccess) return CDPR_ERR_DEVICE;
+  return CDPR_OK;
 }
 
 size_t cdpr_bytes_per_state_step(const cdpr_config_t* cfg) {
@@ -1835,20 +1861,38 @@ int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void* 
   return run_steps(h, nsteps, steps_per_launch, static_cast<float4*>(d_record));
 }
 
-int cdpr_update_scheduled(cdpr_handle_t h, int nsteps, int refresh_steps, const float* d_commands, const uint32_t* d_ready, void* d_record,
-                          size_t record_bytes) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (h->general || h->fp64 || h->per_robot || h->lane_cable) {
-    h->err = "cdpr_update_scheduled: uniform-mode handles on the register-resident path, one or two lanes per robot, only";
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  if (h->cfg.publish_period != 0.0) {
-    h->err = "cdpr_update_scheduled needs publish_period == 0 (every step published)";
-    return CDPR_ERR_UNSUPPORTED;
+// A command schedule resident in HBM, any kind of command, any handle.  Semantics: for j = 0 ..: the callback of `kind`
+// with batch j (for the robots of mask j), then refresh_steps x update().  Two forms serve it:
+//   * in the launch: uniform-mode handles on the register-resident path with one or two lanes per robot run the whole
+//     schedule in ONE launch of the several-steps kernel (the lanes read batch j at step j * refresh_steps themselves;
+//     state, windows and integrals stay on chip);
+//   * as a chain: every other handle (general controller path, per-robot modes with or without masks, precision = 64,
+//     one lane per cable) latches batch j from the caller's buffers in place and queues its steps, batch after batch,
+//     without a host round trip; a mailbox is honoured by a one-thread wait kernel in front of the batch's latch.
+// A command of another kind pending at the call is latched with batch 0 in update()'s usual order (velocity, position,
+// force): batch 0 then goes the chain's way, so that a mode change between batch 0 and batch 1 is what the call sequence
+// would do (the schedule's rows must never be read as targets of another mode).
+static int scheduled_update(cdpr_engine* h, uint32_t kind, int nsteps, int refresh_steps, const float* d_commands, const uint32_t* d_ready,
+                            const uint8_t* d_masks, void* d_record, size_t record_bytes) {
+  if (kind > 2u) {
+    h->err = "cdpr_update_scheduled_kind: kind must be CDPR_COMMAND_VELOCITY, _POSITION or _FORCE";
+    return CDPR_ERR_INVALID;
   }
   if (nsteps < 0 || refresh_steps < 1 || !d_commands) {
     h->err = "cdpr_update_scheduled: nsteps >= 0, refresh_steps >= 1 and the command schedule are required";
     return CDPR_ERR_INVALID;
+  }
+  if (d_masks && !h->per_robot) {
+    h->err = "cdpr_update_scheduled_kind: robot masks need a handle created with per_robot_commands = 1";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (d_record && h->fp64) {
+    h->err = "cdpr_update_scheduled: trajectory records are fp32-only";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  if (h->cfg.publish_period != 0.0 && d_record) {
+    h->err = "cdpr_update_scheduled: a trajectory record needs publish_period == 0 (every step published)";
+    return CDPR_ERR_UNSUPPORTED;
   }
   const size_t image = (size_t)h->n_obs * h->stride;
   if (d_record && record_bytes < image * sizeof(float4) * (size_t)nsteps) {
@@ -1857,21 +1901,72 @@ int cdpr_update_scheduled(cdpr_handle_t h, int nsteps, int refresh_steps, const 
   }
   if (nsteps == 0) return CDPR_OK;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  // the first Joy of the schedule arrives as any jointVelocities Joy does: pending commands of the other kinds are latched
-  // first (run_steps' order), then this one; entering Velocity mode resets the Pid (JFC.cpp:113-115)
-  h->ext_vel[1] = d_commands;
-  h->vel_pending = true;
-  h->vel_masked = false;
-  // one launch: latch + nsteps steps with the schedule's refresh inside the kernel
-  h->sched_refresh = refresh_steps;
-  h->sched_ready = d_ready;
-  const int rc = run_steps(h, nsteps, nsteps, static_cast<float4*>(d_record));
-  h->sched_refresh = 0;
-  h->sched_ready = nullptr;
-  if (rc != CDPR_OK) return rc;
-  const int last = (nsteps - 1) / refresh_steps;
-  if (h->mode == kModeVelocity) h->ext_vel[0] = d_commands + (size_t)last * h->batch * h->n;  // the batch that stays latched
+  if (d_ready && !h->h_fault) {  // the status word a mailbox that never delivers is reported through
+    HIP_TRY(h, hipHostMalloc((void**)&h->h_fault, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    *h->h_fault = 0u;
+    HIP_TRY(h, hipHostGetDevicePointer((void**)&h->d_fault, h->h_fault, 0));
+  }
+  float4* const record = static_cast<float4*>(d_record);
+  const size_t batch_floats = (size_t)h->batch * h->n;
+  bool* pending[3] = {&h->vel_pending, &h->pos_pending, &h->frc_pending};
+  bool* masked[3] = {&h->vel_masked, &h->pos_masked, &h->frc_masked};
+  const float** ext[3] = {h->ext_vel, h->ext_pos, h->ext_frc};
+  const int nbatches = (nsteps + refresh_steps - 1) / refresh_steps;
+  // batch j becomes the pending command of `kind`, in place
+  auto stage_batch = [&](int j) {
+    const float* rows = d_commands + (size_t)j * batch_floats;
+    if (h->per_robot) {
+      h->sched_rows[kind] = rows;
+      h->sched_mask[kind] = d_masks ? d_masks + (size_t)j * h->batch : nullptr;
+    } else {
+      ext[kind][1] = rows;
+    }
+    *pending[kind] = true;
+    *masked[kind] = false;
+  };
+  const bool in_launch = !(h->general || h->fp64 || h->per_robot || h->lane_cable) && h->cfg.publish_period == 0.0;
+  bool others = false;
+  for (uint32_t k = 0; k < 3; ++k) others = others || (k != kind && *pending[k]);
+  int j = 0, done = 0;
+  // ---- the chain: every batch of a handle the launch form does not serve; batch 0 where another command is pending
+  const int chain_spl = ((size_t)h->batch * h->n <= 131072u) ? std::min(refresh_steps, 64) : 1;  // small batches: the hold in one launch
+  while (j < nbatches && (!in_launch || (j == 0 && others))) {
+    if (d_ready) {
+      hipLaunchKernelGGL(cdpr_mailbox_wait_kernel, dim3(1), dim3(1), 0, h->stream, d_ready + j, h->d_fault);
+      HIP_TRY(h, hipGetLastError());
+    }
+    stage_batch(j);
+    const int k = std::min(refresh_steps, nsteps - done);
+    if (int rc = run_steps(h, k, chain_spl, record ? record + (size_t)done * image : nullptr)) return rc;
+    done += k;
+    ++j;
+  }
+  if (j < nbatches) {
+    // ---- the rest in one launch: batch j is latched as any command of its kind is (entering the mode resets its Pid,
+    //      JFC.cpp:101-103,113-115), the later ones are read by the kernel
+    stage_batch(j);
+    h->sched_refresh = refresh_steps;
+    h->sched_ready = d_ready ? d_ready + j : nullptr;
+    const int rest = nsteps - done;
+    const int rc = run_steps(h, rest, rest, record ? record + (size_t)done * image : nullptr);
+    h->sched_refresh = 0;
+    h->sched_ready = nullptr;
+    if (rc != CDPR_OK) return rc;
+    ext[kind][0] = d_commands + (size_t)(nbatches - 1) * batch_floats;  // the batch that stays latched
+  }
   return CDPR_OK;
+}
+
+int cdpr_update_scheduled(cdpr_handle_t h, int nsteps, int refresh_steps, const float* d_commands, const uint32_t* d_ready, void* d_record,
+                          size_t record_bytes) {
+  if (!h) return CDPR_ERR_INVALID;
+  return scheduled_update(h, CDPR_COMMAND_VELOCITY, nsteps, refresh_steps, d_commands, d_ready, nullptr, d_record, record_bytes);
+}
+
+int cdpr_update_scheduled_kind(cdpr_handle_t h, uint32_t kind, int nsteps, int refresh_steps, const float* d_commands, const uint32_t* d_ready,
+                               const uint8_t* d_robot_masks, void* d_record, size_t record_bytes) {
+  if (!h) return CDPR_ERR_INVALID;
+  return scheduled_update(h, kind, nsteps, refresh_steps, d_commands, d_ready, d_robot_masks, d_record, record_bytes);
 }
 
 int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position, float* velocity, float* effort,
@@ -1925,11 +2020,22 @@ static hipError_t wait_stream(cdpr_engine* h) {
   return hipStreamSynchronize(h->stream);
 }
 
+// A schedule mailbox that never delivered (cdpr_update_scheduled with d_ready): the waiting kernel gave up after its poll
+// budget, raised the handle's status word and went on with whatever the schedule held - the trajectory is not what the
+// caller asked for, and every call that hands results out says so until cdpr_reset.
+static int check_fault(cdpr_engine* h) {
+  if (h->h_fault && *(volatile uint32_t*)h->h_fault != 0u) {
+    h->err = "a command schedule's mailbox timed out (d_ready never became non-zero): the steps since are not the scheduled trajectory; cdpr_reset clears this";
+    return CDPR_ERR_DEVICE;
+  }
+  return CDPR_OK;
+}
+
 int cdpr_synchronize(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
+  return check_fault(h);
 }
 
 uint32_t cdpr_mapping(cdpr_handle_t h) {
@@ -1950,7 +2056,7 @@ int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, flo
     int rc = fetch_fields(h, h->d_obs, fields, dst[f]);
     if (rc != CDPR_OK) return rc;
   }
-  return CDPR_OK;
+  return check_fault(h);
 }
 
 // JointState + PlatformState of the last published step in ONE device round trip (PLG.cpp:248-280 publishes both every
@@ -2053,14 +2159,15 @@ int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, floa
   if (effort) std::memcpy(effort, src + 2 * bn, bn * sizeof(float));
   if (pose7) std::memcpy(pose7, src + 3 * bn, (size_t)h->batch * 7 * sizeof(float));
   if (twist6) std::memcpy(twist6, src + 3 * bn + (size_t)h->batch * 7, (size_t)h->batch * 6 * sizeof(float));
-  return CDPR_OK;
+  return check_fault(h);
 }
 
 int cdpr_get_platform_state(cdpr_handle_t h, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   if (h->fp64) return fetch_observables64(h, nullptr, nullptr, nullptr, pose7, twist6, true);
-  return fetch_platform(h, h->d_obs, pose7, twist6);
+  const int rc = fetch_platform(h, h->d_obs, pose7, twist6);
+  return rc != CDPR_OK ? rc : check_fault(h);
 }
 
 int cdpr_get_raw_state(cdpr_handle_t h, float* pose7, float* twist6) {
@@ -2070,7 +2177,8 @@ int cdpr_get_raw_state(cdpr_handle_t h, float* pose7, float* twist6) {
     int rc = fetch_rows64(h, h->d_state64, 0, 7, pose7, true);
     return rc != CDPR_OK ? rc : fetch_rows64(h, h->d_state64, 7, 6, twist6, true);
   }
-  return fetch_platform(h, h->d_state, pose7, twist6);
+  const int rc = fetch_platform(h, h->d_state, pose7, twist6);
+  return rc != CDPR_OK ? rc : check_fault(h);
 }
 
 static int need_fp64(cdpr_engine* h, const char* what) {

@@ -140,9 +140,14 @@ struct GenBuf {
     const f4 v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (uint32_t)slot * rs16, 0));
     return make_float4(v.x, v.y, v.z, v.w);
   }
+  // (The row goes into the VECTOR offset, soffset stays the immediate 0: gfx950 needs a wait state between a 128-bit
+  //  buffer store whose soffset is an SGPR and a VALU write of its data registers - lanes 12-15 of every 16 otherwise
+  //  store the new value now and then (scripts/micro/store_hazard.hip, profiles/r05_store_hazard.txt) - and LLVM's hazard
+  //  recognizer inserts none in that case (the ISA manual exempts it); with an immediate soffset it inserts the two wait
+  //  states the part needs.  scripts/exec_lint.py fails the build's test if the pattern appears anywhere.)
   CDPR_DEV void store4_if(bool on, int slot, uint32_t voff, const float4& v) const {
     const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, on ? voff : 0xFFFFFFFFu, (uint32_t)slot * rs16, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, on ? voff + (uint32_t)slot * rs16 : 0xFFFFFFFFu, 0, 0);
   }
   // global -> LDS without a register destination: lane l's 16 bytes land at dst_row + 16 l
   CDPR_DEV void slot_to_lds(int slot, uint32_t voff, float4* dst_row) const {
@@ -292,7 +297,8 @@ CDPR_DEV float gen_finish(const GenBuf& RB, const GenSel c, int slot_h, int row_
 // force into force[], the `pid` topic's terms of cable 0 into dbg.  Shared by the one-wave stepping kernel and the
 // controller wave of the role-split kernel.  LDS working set: `cab` = per cable NV + 1 DMA-staged slots of 64 float4 (the
 // values, then H); seen as rows of 64 floats, a cable's rows 0-6 double as the parking place of a cable that waits for the
-// fit and rows 7-9 as the fit queue (item, new sample, result) once the values are done with; `hold` = the staged
+// fit and rows 7-9 as the fit queue (item, new sample, result) once the values are done with (rows 10-11: dump words of the
+// lanes a predicated LDS store does not concern); `hold` = the staged
 // hold-position slots.
 // Only q, qd and the force live across the cables: a cable whose derivative is known at once (uniform window: the FIR;
 // window not full: 0) runs its whole Pid::update in the first loop; one that needs the fit parks seven numbers and
@@ -338,7 +344,7 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   constexpr int kCab = (NV + 1) * 64;    // float4 elements between the slot sets of consecutive cables
   constexpr int kCabF = kCab * 4;        // the same in floats
   constexpr int LP = (N + 3) / 4;
-  static_assert((NV + 1) * 4 >= 10, "parking and queue rows");
+  static_assert((NV + 1) * 4 >= 12, "parking, queue and dump rows");
   float* const cabf = reinterpret_cast<float*>(cab);
   const int pcas_max = kc.pcas_max, dcas_max = kc.dcas_max;
   const bool filters = (pcas_max | dcas_max) != 0;
@@ -376,7 +382,11 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     }
     simple = (neg >= 0) && (nz == 0u) && (was & 1u) != 0u;
   }
-  if (__builtin_amdgcn_ballot_w64(!simple) == 0ull) {  // (wave-uniform; a __builtin_expect layout hint here changed results: left alone)
+#ifdef CDPR_EXPECT_STEADY  // build variant (scripts/build_variants.sh): the branch-layout hint; results must not depend on it
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!simple) == 0ull, 1)) {
+#else
+  if (__builtin_amdgcn_ballot_w64(!simple) == 0ull) {  // (wave-uniform)
+#endif
     GEN_CTL_STAMP(1);
     // same window for both Pids and consecutive steps everywhere: ONE ring head for the whole wave (now mod nbuf, a
     // scalar), one row of weights, static LDS addresses; the table weighs the head slot with 0 and the new sample enters
@@ -455,22 +465,18 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           force[i] = out;
           float4 o = vs[j];
           o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
-          if (live) {
-            RB.store4_if(true, sa + q4, va, o);
-            RB.storei_if(true, rb + nhead, vb, now);
-            RB.store4_if(true, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
-          }
+          RB.store4_if(live, sa + q4, va, o);
+          RB.storei_if(live, rb + nhead, vb, now);
+          RB.store4_if(live, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
         }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     GEN_CTL_STAMP(3);
-    if (live) {
 #pragma unroll
-      for (int g4 = 0; g4 < LP; ++g4)
-        RB.store4_if(true, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
-                                                      (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
-    }
+    for (int g4 = 0; g4 < LP; ++g4)
+      RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
+                                                    (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
     return;
   }
 
@@ -581,9 +587,12 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     }
     force[i] = is_force ? target[i] : ((runs && !queued) ? out : 0.f);
     need |= queued ? (1u << i) : 0u;
-    if (queued) {  // park what the rest of Pid::update needs in the cable's own staged rows (the values there are done with)
-      park[0 * 64] = error, park[1 * 64] = dt, park[2 * 64] = pre, park[3 * 64] = ie, park[4 * 64] = prev_ierr, park[5 * 64] = old_cmd;
-      park[6 * 64] = __uint_as_float(nmeta);
+    {  // park what the rest of Pid::update needs in the cable's own staged rows (the values there are done with).  No branch:
+       // a lane that is not queued writes the same seven numbers to its dump word (row 10 of the cable's block, unused)
+      float* const pk = queued ? park : park + 10 * 64;
+      const int ps = queued ? 64 : 0;
+      pk[0 * ps] = error, pk[1 * ps] = dt, pk[2 * ps] = pre, pk[3 * ps] = ie, pk[4 * ps] = prev_ierr, pk[5 * ps] = old_cmd;
+      pk[6 * ps] = __uint_as_float(nmeta);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -599,18 +608,20 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    // (no divergent branches from here to the end of the function: per-lane cases are address selects - a lane without an
+    //  item writes to its dump word, row 11 of cable 0's block - see the note on exec restores in DESIGN.md section 4)
     const uint32_t cnt = (uint32_t)__builtin_popcount(need);
-    uint32_t slot = 0u;
-    if (cnt) slot = __hip_atomic_fetch_add(q_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t slot = __hip_atomic_fetch_add(q_count, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      if (need & (1u << i)) {
-        const float* park = cabf + i * kCabF + lane;
-        const uint32_t hd = (__float_as_uint(park[6 * 64]) >> kGmHeadShift) & kGmField;
-        *qitem(slot) = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | (hd << 10);
-        *qerr(slot) = park[0];
-        ++slot;
-      }
+      const bool has = (need & (1u << i)) != 0u;
+      const float* park = cabf + i * kCabF + lane;
+      const uint32_t hd = (__float_as_uint(park[6 * 64]) >> kGmHeadShift) & kGmField;
+      uint32_t* const qi = has ? qitem(slot) : reinterpret_cast<uint32_t*>(cabf + 11 * 64 + lane);
+      float* const qe = has ? qerr(slot) : cabf + 11 * 64 + lane;
+      *qi = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | (hd << 10);
+      *qe = park[0];
+      slot += has ? 1u : 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -649,9 +660,9 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
         t_old = ((uint32_t)j == old) ? t[j] : t_old;
       }
       const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
-      if (mine) cabf[ci * kCabF + 9 * 64 + ol] = res;
+      *(mine ? cabf + ci * kCabF + 9 * 64 + ol : cabf + 11 * 64 + lane) = res;
     }
-    if (lane == 0) *q_count = 0u;  // for the next step
+    *q_count = 0u;  // for the next step (every lane writes the same word)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1046,6 +1057,11 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     }
     nm0 = (nm0 + 1 == g.nbuf0) ? 0 : nm0 + 1;
     nm1 = (nm1 + 1 == g.nbuf1) ? 0 : nm1 + 1;
+#ifdef CDPR_HYP_STEP_FENCE  // diagnosis: everything of this step (global and LDS) complete before the next one starts
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_barrier();
+#endif
   }
   if (ROLLOUT) {
     if (live) a.roll_cost[r] = cost;

@@ -37,4 +37,8 @@ __global__ __launch_bounds__(256) void cdpr_latch_fast_kernel(const LatchFastArg
   a.meta[r] = (uint8_t)m;
 }
 
+// cdpr_update_scheduled_kind served as a chain of launches: one thread waits for the mailbox word of the next batch in front
+// of the batch's latch (what sched_wait does inside a launch that carries the schedule itself).
+__global__ void cdpr_mailbox_wait_kernel(const uint32_t* word, uint32_t* fault) { mailbox_wait(word, fault); }
+
 }  // namespace cdpr

@@ -135,6 +135,7 @@ struct StepArgs {
   int sched_refresh;
   size_t sched_stride;
   const uint32_t* sched_ready;
+  uint32_t* fault;  // with a mailbox: the handle's status word (device-mapped host memory); a wait that gives up ORs bit 0 into it
 };
 
 __host__ __device__ constexpr int plat_slots(bool fk) { return fk ? 5 : 4; }
@@ -152,14 +153,23 @@ CDPR_DEV bool step_published(const StepArgs& a, int step) {
   return ((a.publish_mask >> step) & 1ull) != 0ull;
 }
 // The mailbox of a scheduled launch: wait until Joy batch j is there (the host, or a producer kernel on another stream, sets
-// the word after it has written the batch)
-CDPR_DEV void sched_wait(const StepArgs& a, int j) {
-  if (a.sched_ready) {
-    // (bounded: ~2^23 polls of ~0.5 us; a producer that never delivers must not hang the GPU - the launch then goes on with
-    //  whatever the schedule holds)
-    for (uint32_t spins = 0; spins < (1u << 23) && __hip_atomic_load(a.sched_ready + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u; ++spins)
-      __builtin_amdgcn_s_sleep(16);
+// the word after it has written the batch).  Bounded: ~2^23 polls of ~0.5 us; a producer that never delivers must not hang
+// the GPU.  A wait that gives up raises the handle's status word (the host reports CDPR_ERR_DEVICE from cdpr_synchronize
+// and the getters on) and every later wait of the launch returns at once: the launch ends in milliseconds, its results
+// are declared invalid.
+CDPR_DEV void mailbox_wait(const uint32_t* word, uint32_t* fault) {
+  if (fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+  uint32_t spins = 0;
+  while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+    if (++spins >= (1u << 23)) {
+      if (fault) __hip_atomic_fetch_or(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(16);
   }
+}
+CDPR_DEV void sched_wait(const StepArgs& a, int j) {
+  if (a.sched_ready) mailbox_wait(a.sched_ready + j, a.fault);
 }
 
 
@@ -736,11 +746,18 @@ CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, co
 #if CDPR_STORE_AUX == 0
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base + (size_t)slot * stride) + off) = v;
 #else
-  // one buffer descriptor per slot row (wave-uniform: SGPRs only), 32-bit lane offset, explicit cache policy
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)slot * stride, 0, (int)(stride * sizeof(float4)), 0x00020000);
   const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
                    __builtin_bit_cast(unsigned, v.w)};
+#ifdef CDPR_DESC_PER_BUFFER
+  // diagnosis build (round 2's experiment, scripts/build_variants.sh descbuf): one descriptor per BUFFER, the row as the
+  // scalar offset operand
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off, (uint32_t)((size_t)slot * stride * sizeof(float4)), CDPR_STORE_AUX);
+#else
+  // one buffer descriptor per slot row (wave-uniform: SGPRs only), 32-bit lane offset, explicit cache policy
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)slot * stride, 0, (int)(stride * sizeof(float4)), 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, off, 0, CDPR_STORE_AUX);
+#endif
 #endif
 }
 

@@ -136,12 +136,18 @@ class Engine:
         """As update_record, into a caller-owned device buffer (nothing is copied back)."""
         self._check(lib().cdpr_update_record(self._h, int(nsteps), int(steps_per_launch), C.c_void_p(d_record), record_bytes))
 
-    def update_scheduled(self, nsteps: int, refresh_steps: int, d_commands: int, d_record: int = 0, record_bytes: int = 0, d_ready: int = 0) -> None:
-        """A whole jointVelocities schedule in one launch: Joy batch j (device buffer float[batches][B][n] at d_commands) is
-        latched at step j * refresh_steps; every step's observables go to the record (device buffer) if one is given.
-        d_ready: optional device-visible uint32[batches] mailbox (batch j is taken once d_ready[j] != 0)."""
-        self._check(lib().cdpr_update_scheduled(self._h, int(nsteps), int(refresh_steps), C.c_void_p(d_commands), C.c_void_p(d_ready) if d_ready else None,
-                                                C.c_void_p(d_record) if d_record else None, int(record_bytes)))
+    def update_scheduled(self, nsteps: int, refresh_steps: int, d_commands: int, d_record: int = 0, record_bytes: int = 0, d_ready: int = 0,
+                         kind: str = "velocity", d_robot_masks: int = 0) -> None:
+        """A whole command schedule resident in HBM, queued with one call: Joy batch j (device buffer float[batches][B][n] at
+        d_commands) is latched at step j * refresh_steps as a `kind` command ("velocity" = jointVelocities, "position" =
+        jointPositions, "force" = setForce); every step's observables go to the record (device buffer) if one is given.
+        d_ready: optional device-visible uint32[batches] mailbox (batch j is taken once d_ready[j] != 0).  d_robot_masks
+        (Config.perRobotCommands): device buffer uint8[batches][B], batch j reaches only the robots of its mask.
+        Uniform-mode handles on the register-resident path run it in ONE launch; every other handle as a chain of launches
+        queued back to back (same results: cdpr_update_scheduled_kind)."""
+        k = {"velocity": _abi.COMMAND_VELOCITY, "position": _abi.COMMAND_POSITION, "force": _abi.COMMAND_FORCE}[kind]
+        self._check(lib().cdpr_update_scheduled_kind(self._h, k, int(nsteps), int(refresh_steps), C.c_void_p(d_commands), C.c_void_p(d_ready) if d_ready else None,
+                                                     C.c_void_p(d_robot_masks) if d_robot_masks else None, C.c_void_p(d_record) if d_record else None, int(record_bytes)))
 
     def update_record(self, nsteps: int, steps_per_launch: int = 10):
         """Advance nsteps world steps (fused launches) and return the observables of EVERY step:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CDPR_ABI_VERSION 4u
+#define CDPR_ABI_VERSION 5u   /* 5 = 4 + cdpr_update_scheduled_kind, cdpr_device_pci_bus_id (cdpr_config_t unchanged) */
 #define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
 #define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
 #define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
@@ -173,6 +173,9 @@ typedef struct cdpr_engine *cdpr_handle_t;
 uint32_t cdpr_abi_version(void);
 size_t cdpr_config_size(void);                       /* sizeof(cdpr_config_t) as compiled */
 int cdpr_device_count(void);                         /* visible GPUs, 0 if none */
+/* PCI address "dddd:bb:dd.f" of HIP ordinal `device` (len >= 13): a multi-process host that also runs another GPU runtime
+ * (bench.py: torch.distributed over RCCL) checks with it that both runtimes mean the same GPU by ordinal r. */
+int cdpr_device_pci_bus_id(int device, char *out, size_t len);
 /* Algorithmic HBM bytes one robot moves per state-step for this configuration
  * (state round trip + command read + observables written); see DESIGN.md. */
 size_t cdpr_bytes_per_state_step(const cdpr_config_t *cfg);
@@ -253,19 +256,38 @@ int cdpr_observable_image_bytes(cdpr_handle_t h, size_t *bytes);
 int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void *d_record, size_t record_bytes);
 int cdpr_decode_observables(cdpr_handle_t h, const void *image, float *position, float *velocity, float *effort,
                             float *pose7, float *twist6);
-/* A whole command schedule in ONE launch: what `for j: cableVelocityCommandCallback(batch j); refresh_steps x update()`
- * does (the reference's 100 Hz publishers against the 1 kHz world: a Joy every 10 world steps, PLG.cpp:206-211 +
- * sinevelocitytest.cpp:34-48), for callers whose batch is too small for a launch per step to pay (a 4 096 x 4-cable step
- * is 1.4 us of work behind 3-4 us of launch).  d_commands: DEVICE buffer float[ceil(nsteps / refresh_steps)][B][n], Joy
- * batch j is latched at world step first + j * refresh_steps.  d_ready: optional DEVICE-visible mailbox uint32[batches]:
- * the launch takes batch j only once d_ready[j] != 0 (a host or a producer kernel that fills the schedule while the
- * launch runs; pinned host memory mapped to the device works); NULL = the whole schedule is there.  d_record: as
- * cdpr_update_record (every step's observable image kept), or NULL (each published step overwrites the last, as the topic
- * does).  Bit-identical to the call sequence above (tested).  Afterwards the last batch stays latched (it must stay valid
- * like a bound buffer).  Needs publish_period == 0, a uniform-mode handle on the register-resident path with one lane or two
- * lanes per robot; CDPR_ERR_UNSUPPORTED otherwise.  Asynchronous. */
+/* A whole command schedule resident in HBM, queued with one call: what
+ *   for j: cableVelocityCommandCallback(batch j); refresh_steps x update()
+ * does (the reference's 100 Hz / 10 Hz publishers against the 1 kHz world: a Joy every 10 or 100 world steps, PLG.cpp:206-211
+ * + sinevelocitytest.cpp:34-48, squarevelocitytest.cpp:20-34, squarepositiontest.cpp:21-35), for callers whose batch is too
+ * small for a launch per step to pay (a 4 096 x 4-cable step is 1.4 us of work behind 3-4 us of launch).
+ * d_commands: DEVICE buffer float[ceil(nsteps / refresh_steps)][B][n], batch j is latched at world step first + j *
+ * refresh_steps.  d_ready: optional DEVICE-visible mailbox uint32[batches]: batch j is taken only once d_ready[j] != 0 (a
+ * host or a producer kernel that fills the schedule while the work runs; pinned host memory mapped to the device works);
+ * NULL = the whole schedule is there.  The wait is bounded (~2^23 polls, a few seconds): a mailbox that never delivers
+ * does not hang the GPU - the handle's status word is raised instead and cdpr_synchronize and the getters return
+ * CDPR_ERR_DEVICE until cdpr_reset.  d_record: as cdpr_update_record (every step's observable image kept; needs
+ * publish_period == 0), or NULL (each published step overwrites the last, as the topic does).
+ * Bit-identical to the call sequence above (tested).  Afterwards the last batch stays latched (on uniform-mode handles it
+ * is read in place and must stay valid like a bound buffer).  Asynchronous.
+ *
+ * cdpr_update_scheduled_kind: the same for any command kind - jointVelocities, jointPositions (squarepositiontest) or
+ * setForce (JFC.h:92-95; a tension-distribution / MPC caller) - and, on per_robot_commands handles, with one robot mask per
+ * batch (d_robot_masks: DEVICE buffer uint8[batches][B], batch j reaches the robots with mask[j][b] != 0; NULL = every
+ * robot), i.e. for j: cdpr_set_<kind>_command_masked(batch j, mask j); refresh_steps x update().
+ * Every handle type is served.  Uniform-mode handles on the register-resident path with one or two lanes per robot run the
+ * schedule in ONE launch (the lanes read batch j themselves; state, windows and integrals stay on chip); the others
+ * (general controller path, per-robot modes, precision = 64, one lane per cable) latch batch j from the caller's buffers in
+ * place and queue its steps, batch after batch, without a host round trip.  A command of ANOTHER kind that is pending at
+ * the call is latched together with batch 0 in update()'s order (velocity, position, force: PLG.cpp:206-219), exactly as
+ * the call sequence would. */
+#define CDPR_COMMAND_VELOCITY 0u    /* jointVelocities, cableVelocityCommandCallback (PLG.cpp:67-74) */
+#define CDPR_COMMAND_POSITION 1u    /* jointPositions, cablePositionCommandCallback (PLG.cpp:76-83)  */
+#define CDPR_COMMAND_FORCE 2u       /* JointForceCalculator::setForce (JFC.h:92-95)                   */
 int cdpr_update_scheduled(cdpr_handle_t h, int nsteps, int refresh_steps, const float *d_commands, const uint32_t *d_ready,
                           void *d_record, size_t record_bytes);
+int cdpr_update_scheduled_kind(cdpr_handle_t h, uint32_t kind, int nsteps, int refresh_steps, const float *d_commands,
+                               const uint32_t *d_ready, const uint8_t *d_robot_masks, void *d_record, size_t record_bytes);
 /* Waits until everything queued on the handle has completed.  Every wait of the library polls the stream for up to 2 ms
  * before it blocks (a blocked host thread wakes up 15-25 us late, two step kernels; environment CDPR_SYNC_SPIN_US
  * overrides, 0 = always block). */

@@ -85,6 +85,10 @@ def test_bench_gpus_8_dry_run_pins_and_reports_every_rank():
     out = _run_bench(["--gpus", "8", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--dry-run"], timeout=600)
     assert out["n_gpus"] == 8 and out["dry_run"] is True
     assert [r["rank"] for r in out["per_rank"]] == list(range(8))
+    # the pre-flight's fields: the rendezvous backend and why it is not RCCL on this GPU-less box, and
+    # every rank's device identity (no device here: None, but the keys are there)
+    assert out["rendezvous"] == "gloo" and "no GPU" in out["rendezvous_fallback"]
+    assert all({"device", "pci", "torch_pci"} <= set(r) for r in out["per_rank"])
     ncpu = len(os.sched_getaffinity(0))
     if ncpu >= 8:
         assert all(r["cpus"] == ncpu // 8 for r in out["per_rank"])

@@ -344,7 +344,10 @@ def test_bench_gpus_2_is_its_own_launcher_on_the_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["state_finite"] is True
+    # (a loose floor, ADVICE r04: two ranks of 8 192 robots sharing one GPU reach ~1e9; an order-of-magnitude regression of
+    #  the multi-rank path - host placement, blocking waits starving the launch loops - must not pass)
+    assert out["n_gpus"] == 2 and out["value"] > 2e7 and out["config"]["state_finite"] is True
+    assert all(p["value"] > 1e7 and p["pci"] for p in out["per_rank"]) and out["config"]["rendezvous"] in ("nccl", "gloo")
     assert out["rollout"]["cost_finite"] is True and "config5: 2 x 512" in out["rollout"]["workload"]
     assert out["parity_check"]["ok_all_ranks"] and out["rollout"]["parity_check"]["ok_all_ranks"] and len(out["per_rank"]) == 2
 
@@ -369,12 +372,14 @@ def test_bench_gpus_8_on_the_one_gpu():
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["value"] > 0 and out["config"]["state_finite"] is True
-    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and all(p["value"] > 0 for p in out["per_rank"])
+    # (loose floors, ADVICE r04: eight ranks of 4 096 robots on ONE GPU and a cgroup of a few CPUs still reach > 1e8 together)
+    floor = 2e7 if out["placement"]["cpus_effective"] >= 8 else 2e6
+    assert out["n_gpus"] == 8 and out["value"] > floor and out["config"]["state_finite"] is True
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and all(p["value"] > floor / 8 and p["pci"] for p in out["per_rank"])
     assert out["parity_check"]["ok"] and out["parity_check"]["ok_all_ranks"]
     assert out["rollout"]["parity_check"]["ok_all_ranks"] and out["rollout"]["value_device_resident"] > 0
-    # (no assertion on the wall time: it depends on the box's load and its cgroup CPU quota, not on correctness; the
-    #  subprocess timeout above is the only clock)
+    # (the wall time depends on the box's load and its cgroup CPU quota: bounded generously, reported)
+    assert took < 600, f"eight ranks on one GPU took {took:.0f} s"
     print(f"eight ranks on one GPU took {took:.0f} s")
 
 

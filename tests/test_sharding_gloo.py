@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -102,6 +103,38 @@ def test_spin_barrier_is_taken_by_all_ranks_or_none(tmp_path):
     w1, spin1 = eval((tmp_path / "fb1.txt").read_text())
     assert not spin0 and not spin1 and w0 >= 0.29  # nobody spins, and the fallback barrier still holds rank 0 back
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("cdpr_bench_barrier_") and f.endswith("_29519")]
+
+
+RCCL_FALLBACK_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+from cdpr_simulation_amd.sharding import RankContext
+
+ctx = RankContext.from_env(backend="nccl")
+m = ctx.max_over_ranks(float(ctx.rank))
+names = ctx.gather_strings(f"rank{{ctx.rank}}")
+ctx.barrier()
+open(os.path.join({out!r}, f"rf{{ctx.rank}}.txt"), "w").write(repr((ctx.backend_name(), ctx.fallback, m, names)))
+ctx.close()
+"""
+
+
+@pytest.mark.parametrize("assume_gpus", ["0", "1"])
+def test_rendezvous_falls_back_to_gloo_on_every_rank_when_rccl_cannot_come_up(tmp_path, assume_gpus):
+    """the rendezvous carries a barrier and a max - when RCCL cannot come up it must not take the run
+    down.  On this GPU-less box, "0": the ranks agree up front that nobody can try RCCL; "1": every rank TRIES (as on a GPU
+    box), the initialisation fails, the ranks agree on the outcome over the TCP store and all take gloo."""
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL_FALLBACK_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, OMP_NUM_THREADS="1", CDPR_RENDEZVOUS_ASSUME_GPUS=assume_gpus)
+    port = "29523" if assume_gpus == "0" else "29527"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", port, str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for rank in (0, 1):
+        backend, fallback, m, names = eval((tmp_path / f"rf{rank}.txt").read_text())
+        assert backend == "gloo" and m == 1.0 and names == ["rank0", "rank1"]
+        assert fallback and ("no GPU" in fallback if assume_gpus == "0" else "RCCL group did not come up" in fallback)
 
 
 def test_shard_range_covers_everything(pkg):
