@@ -58,6 +58,8 @@ struct cdpr_engine {
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
   bool gen_split = false;   // general path: one-step launches use the role-split kernel (FK + TD, n >= 6, windows <= 11, <= 2 workgroups per CU)
+  bool gen_lean = false;    // general path, larger batches: one-step launches use the lean role-split kernel (two waves per SIMD, the rare
+                            // controller paths by call: cdpr_general_split.hpp)
   bool persist = false;     // one-step launches use the persistent one-wave kernel: one wave per SIMD walks over blocks of 64
                             // robots, the next block's rows in flight under the current block's arithmetic (large batches)
   uint32_t persist_grid = 0;  // waves of such a launch: SIMDs of the device
@@ -689,13 +691,15 @@ int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record
   // where the role-split one-step kernel serves the handle, its launches beat the one-wave kernel's multi-step ones
   // (16 384 x 8: 9.2 against 13.7 us per step, 32 768: 10.1 against 21.6; same bits): fused updates and the trajectory
   // record then run as one-step launches
-  if (h->gen_split) per_launch = 1;
+  if (h->gen_split || h->gen_lean) per_launch = 1;  // (likewise where the lean kernel + one-wave kernel pair steps the handle)
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
     // one step per launch on FK + TD handles up to two workgroups per CU: the role-split form (cdpr_general_split.hpp)
     const bool gsplit = h->gen_split && k == 1;
-    GenKernel kern = gsplit ? pick_gen_split11(h->n) : pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11, k == 1);
+    // ... and beyond: the lean role-split kernel (two waves per SIMD; the rare controller paths by call)
+    const bool glean = h->gen_lean && k == 1 && h->step != 0;  // (world step 0 runs no controller: the one-wave kernel's case)
+    GenKernel kern = gsplit ? pick_gen_split11(h->n) : glean ? pick_gen_lean11(h->n) : pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11, k == 1);
     a.nsteps = k;
     a.flags = (h->step == 0) ? kFlagFirstWorldStep : 0u;
     g.now_step = (int)h->step;
@@ -708,7 +712,7 @@ int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record
         a.publish_mask |= (1ull << j);
       }
     }
-    hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(gsplit ? 128 : 64), 0, h->stream, a, g);
+    hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3((gsplit || glean) ? 128 : 64), 0, h->stream, a, g);
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;
@@ -1553,6 +1557,13 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
       const bool can = h->fk && h->td && h->n >= 6 && h->glay.nb <= 11;
       h->gen_split = can && cfg->batch <= (uint32_t)cus * 128u;
       if (const char* gs = std::getenv("CDPR_GEN_SPLIT")) h->gen_split = can && gs[0] == '1';
+      // beyond that: the lean role-split kernel (not with the optional physics: it carries none); CDPR_GEN_LEAN=0|1 overrides
+      // (A/B; 1 also below the role-split kernel's limit)
+      h->gen_lean = can && !h->phys && !h->gen_split;
+      if (const char* gl = std::getenv("CDPR_GEN_LEAN")) {
+        h->gen_lean = can && !h->phys && gl[0] == '1';
+        if (h->gen_lean) h->gen_split = false;
+      }
     }
     const size_t rec_bytes = h->glay.bytes(h->stride);
     if (rec_bytes >= (1ull << 32)) {  // the record buffer is addressed with 32-bit offsets (one buffer resource)

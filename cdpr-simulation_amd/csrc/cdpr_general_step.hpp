@@ -334,8 +334,10 @@ struct GenDbg {
   float p, i, d, des;
   bool pi, dw;
 };
-template <int N, int NBMAX>
-CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, uint32_t first_unit,
+// STEADY_ONLY: only the steady-state branch is compiled (the lean role-split kernel inlines this much and calls
+// gen_controller_cold for the rest); returns false - having stored nothing - when the wave is not in the steady state.
+template <int N, int NBMAX, bool STEADY_ONLY = false>
+CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, uint32_t first_unit,
                              uint32_t units, int mode, int now, const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)],
                              const v2f (&qd)[cable_pairs(N)], float4* cab, const float4* hold_slots, const float* wrot,
                              const float4 (*ptab)[kGenPidFloats / 4], uint32_t* q_count, float (&force)[N], GenDbg& dbg) {
@@ -436,8 +438,8 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           const float desired = hold ? held : target[i];  // JFC.cpp:81
           newpos[i] = hold ? held : qi;                    // JFC.cpp:75,87
           const float error = desired - ((mode == 2 && sv) ? qdi : qi);
-          const uint32_t va = col * 16u + (sv ? pid_a : 0u), vb = col * 4u + (sv ? pid_b : 0u);
-          const int sa = L.block_a(0, i), rb = L.block_b(0, i);
+          const uint32_t va = col * 16u + (sv ? pid_a : 0u);
+          const int sa = L.block_a(0, i);
           const uint32_t meta = __float_as_uint(hh[j].x);
           const int run = (int)((meta >> kGmRunShift) & kGmField);
           const uint32_t nmeta = meta_lo | ((uint32_t)min(run + 1, (int)kGmField) << kGmRunShift);
@@ -466,7 +468,8 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           float4 o = vs[j];
           o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
           RB.store4_if(live, sa + q4, va, o);
-          RB.storei_if(live, rb + nhead, vb, now);
+          // (no stamp store: the stamps of a run of consecutive steps are implied by mLastTime and `run`; the first call after
+          //  a gap writes them out - see "lazy stamps" below.  4 B per cable and step less, 32 of 1 216 B per robot-step)
           RB.store4_if(live, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
         }
       }
@@ -477,8 +480,9 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     for (int g4 = 0; g4 < LP; ++g4)
       RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
                                                     (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
-    return;
+    return true;
   }
+  if constexpr (STEADY_ONLY) return false;
 
   uint32_t need = 0u;  // cables whose derivative comes from the fit queue
   bool any_rot = false;  // some ring of this wave turned this step (wave-uniform)
@@ -533,9 +537,14 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     const int nhead = sv ? kc.nm1 : kc.nm0;
     int shift = nhead - 1 - head;
     shift += (shift < 0) ? nbuf : 0;
-    const bool rot = runs && count > 0 && shift != 0;
+    // Lazy stamps: the steady-state branch above stores no stamp (mDbufferX): the newest run + 1 samples were taken on
+    // consecutive steps ending at mLastTime, so their stamps are mLastTime - age.  The first call after a GAP (now - last
+    // != 1: the run ends) writes the window's stamps out - the implied ones computed, the older ones as stored - turned
+    // with the ring where the ring turns; from then on `run` starts again at 0 and every stamp of the window is in memory.
+    const bool gap = runs && count > 0 && (now - last) != 1;
+    const bool rot = gap && shift != 0;
     shift = rot ? shift : 0;
-    if (__builtin_amdgcn_ballot_w64(rot) != 0ull) {  // (wave-uniform; lanes that do not turn move every sample onto itself)
+    if (__builtin_amdgcn_ballot_w64(gap) != 0ull) {  // (wave-uniform; lanes that do not turn move every sample onto itself)
       any_rot = true;
       float tv[NBMAX];
       int ts[NBMAX];
@@ -545,12 +554,15 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
         src += (src < 0) ? nbuf : 0;
         src = (j < nbuf) ? src : j;
         tv[j] = park[(src >> 2) * 256 + lane * 3 + (src & 3)];
-        ts[j] = RB.loadi(rb, vb + (uint32_t)min(src, L.nb - 1) * RB.rs4);
+        int age = head - src;  // of the sample in ring slot `src`, in calls before the newest one
+        age += (age < 0) ? nbuf : 0;
+        const int stored = RB.loadi(rb, vb + (uint32_t)min(src, L.nb - 1) * RB.rs4);
+        ts[j] = (age <= run && age < count) ? last - age : stored;
       }
 #pragma unroll
       for (int j = 0; j < NBMAX; ++j) park[(j >> 2) * 256 + lane * 3 + (j & 3)] = tv[j];
 #pragma unroll
-      for (int j = 0; j < NBMAX; ++j) RB.storei_if(live && rot && j < nbuf && j != nhead, rb + min(j, L.nb - 1), vb, ts[j]);
+      for (int j = 0; j < NBMAX; ++j) RB.storei_if(live && gap && j < nbuf && j != nhead, rb + min(j, L.nb - 1), vb, ts[j]);
 #pragma unroll
       for (int s4 = 0; s4 < NV; ++s4) RB.store4_if(live && rot && s4 != (nhead >> 2) && s4 < L.nv(), sa + min(s4, L.nv() - 1), va, cs[s4 * 64]);
     }
@@ -619,7 +631,7 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       const uint32_t hd = (__float_as_uint(park[6 * 64]) >> kGmHeadShift) & kGmField;
       uint32_t* const qi = has ? qitem(slot) : reinterpret_cast<uint32_t*>(cabf + 11 * 64 + lane);
       float* const qe = has ? qerr(slot) : cabf + 11 * 64 + lane;
-      *qi = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | (hd << 10);
+      *qi = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | (hd << 10) | (((__float_as_uint(park[6 * 64]) >> kGmRunShift) & kGmField) << 16);
       *qe = park[0];
       slot += has ? 1u : 0u;
     }
@@ -634,6 +646,7 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       const uint32_t it = *qitem(mine ? idx : 0u);
       const float e_new = *qerr(mine ? idx : 0u);
       const uint32_t ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u, hd = (it >> 10) & 63u;
+      const int irun = (int)((it >> 16) & 63u);  // consecutive steps ending at the sample just pushed: those stamps are implied
       const uint32_t ro = first_unit + ol;
       const uint32_t ocol = (ro < units) ? ro : (units - 1u);
       // the item's Pid of its cable, its owner's column: everything per lane goes into the vector offsets
@@ -656,7 +669,9 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
 #pragma unroll
       for (int j = 0; j < NBMAX; ++j) {
         y[j] = ((uint32_t)j == hd) ? e_new : ((j < nbuf) ? y[j] : 0.f);  // the sample just pushed (its store may still be in flight)
-        t[j] = ((uint32_t)j == hd || j >= nbuf) ? now : t[j];
+        int age = (int)hd - j;
+        age += (age < 0) ? nbuf : 0;
+        t[j] = (j >= nbuf) ? now : ((age <= irun) ? now - age : t[j]);  // (age 0: the sample just pushed)
         t_old = ((uint32_t)j == old) ? t[j] : t_old;
       }
       const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
@@ -683,20 +698,73 @@ CDPR_DEV void gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       force[i] = queued ? out : force[i];
     }
   }
+  return true;
+}
+
+// The general controller's rare paths as a CALL: gen_controller with its ring rotation, fit queue and fp64 fit needs ~100
+// registers more than its steady-state branch, and inlined into a kernel that must fit two waves per SIMD (the lean
+// role-split kernel, cdpr_general_split.hpp) that pressure spills on the steady path too (224 B of scratch per lane, 81
+// spilled SGPRs: measured).  As a function of its own it gets its own register allocation; the caller's live registers go
+// to the stack around the call - on the steps that need it, not on the others.  Arguments travel by value (arrays by
+// reference would put the caller's copies into scratch for good); wave-uniform ones are made scalars again on entry
+// (a callee receives every argument in vector registers), LDS arrays come as their LDS addresses.
+template <int N>
+struct GenColdIn {
+  float target[N];
+  int sel[N];
+  v2f q[cable_pairs(N)], qd[cable_pairs(N)];
+};
+template <int N>
+struct GenColdOut {
+  float force[N];
+  GenDbg dbg;
+};
+CDPR_DEV uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+template <typename T>
+CDPR_DEV T* lds_pointer(uint32_t addr) { return (T*)(__attribute__((address_space(3))) T*)(uintptr_t)addr; }
+CDPR_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+CDPR_DEV int uni(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
+CDPR_DEV float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+
+template <int N, int NBMAX>
+__device__ __attribute__((noinline)) GenColdOut<N> gen_controller_cold(GenCtlConst kc_v, uint64_t rec_v, uint32_t rstride_v, uint32_t rec_bytes_v, GenLayout L_v, uint32_t lane, bool live,
+                                                                         uint32_t col, uint32_t first_unit_v, uint32_t units_v, int mode, int now_v, GenColdIn<N> in, uint32_t lds_cab,
+                                                                         uint32_t lds_hold, uint32_t lds_wrot, uint32_t lds_ptab, uint32_t lds_qcount) {
+  GenCtlConst kc;
+  kc.pcas_max = uni(kc_v.pcas_max), kc.dcas_max = uni(kc_v.dcas_max), kc.dt = uni(kc_v.dt), kc.inv_dt = uni(kc_v.inv_dt);
+  kc.nm0 = uni(kc_v.nm0), kc.nm1 = uni(kc_v.nm1), kc.nbuf0 = uni(kc_v.nbuf0), kc.simple_ok = false;  // (the steady branch was the caller's)
+#ifdef CDPR_STAMPS
+  kc.stamps = nullptr;
+#endif
+  GenLayout L;
+  L.n = uni(L_v.n), L.nb = uni(L_v.nb), L.ncas = uni(L_v.ncas);
+  const uint64_t rec = ((uint64_t)uni((uint32_t)(rec_v >> 32)) << 32) | uni((uint32_t)rec_v);
+  const GenBuf RB = gen_buffer(reinterpret_cast<float*>(rec), uni(rstride_v), uni(rec_bytes_v), L);
+  GenColdOut<N> out;
+#pragma unroll
+  for (int i = 0; i < N; ++i) out.force[i] = 0.f;
+  out.dbg = GenDbg{0.f, 0.f, 0.f, 0.f, false, false};
+  gen_controller<N, NBMAX, false>(kc, RB, L, lane, live, col, uni(first_unit_v), uni(units_v), mode, uni(now_v), in.target, in.sel, in.q, in.qd,
+                                  lds_pointer<float4>(uni(lds_cab)), lds_pointer<const float4>(uni(lds_hold)), lds_pointer<const float>(uni(lds_wrot)),
+                                  reinterpret_cast<const float4(*)[kGenPidFloats / 4]>(lds_pointer<const float4>(uni(lds_ptab))), lds_pointer<uint32_t>(uni(lds_qcount)),
+                                  out.force, out.dbg);
+  return out;
 }
 
 // Issue the LDS-DMA of one wave's record slots for this step: per cable the selected Pid's NV value slots and H, plus the
 // hold-position slots.  `keep`: a value every ordinary load issued so far feeds (hipcc drains every outstanding VMEM
 // operation at the first use of an ordinary load's result while an LDS-DMA is pending).
 template <int N, int NBMAX>
-CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t col, const int (&sel)[N], float4* cab, float4* hold_slots, float keep) {
+CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t col, const int (&sel)[N], float4* cab, float4* hold_slots, float keep, bool need_hold) {
   constexpr int NV = gen_nv(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
   constexpr int LP = (N + 3) / 4;
   asm volatile("" ::"v"(keep));
   const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16;
+  if (need_hold) {  // (wave-uniform) mLastPosition is only read by a cable in the hold branch (JFC.cpp:81)
 #pragma unroll
-  for (int g4 = 0; g4 < LP; ++g4) RB.slot_to_lds(g4, col * 16u, hold_slots + g4 * 64);
+    for (int g4 = 0; g4 < LP; ++g4) RB.slot_to_lds(g4, col * 16u, hold_slots + g4 * 64);
+  }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const uint32_t va = col * 16u + (sel[i] ? pid_a : 0u);
@@ -867,7 +935,10 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       float keep = (s.px + s.qy) + (s.vy + s.wz) + fkqw;
 #pragma unroll
       for (int i = 0; i < N; ++i) keep += target[i];
-      gen_stage_records<N, NBMAX>(RB, L, col, sel, &stage[0][0][0], &hold_slots[0][0], keep);
+      bool holds = false;  // some cable of this lane is in the hold branch (JFC.cpp:78-82)
+#pragma unroll
+      for (int i = 0; i < N; ++i) holds = holds || (mode == 2 && sel[i] == 0);
+      gen_stage_records<N, NBMAX>(RB, L, col, sel, &stage[0][0][0], &hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull);
     }
     GEN_PHASE_STAMP(1);
 

@@ -53,6 +53,7 @@ StepKernel pick_pair_kernel(bool single, uint32_t n, bool fk, bool td);
 StepKernel pick_cable_kernel(uint32_t n, bool fk, bool td);
 // k_gen.hip: the general controller path (cdpr_general_step.hpp); long_window: derivative windows of 12 .. 32 samples
 GenKernel pick_gen_kernel(uint32_t n, bool fk, bool td, bool rollout, bool long_window, bool single);
+GenKernel pick_gen_lean11(uint32_t n);   // k_gen_split.hip: the same for larger batches: two waves per SIMD, the rare controller paths by call (cdpr_gen_lean_kernel)
 GenKernel pick_gen_split11(uint32_t n);  // k_gen_split.hip: one step per launch, two waves per 64 robots split by role (FK + TD, n >= 6, windows <= 11)
 // k_f64.hip: precision = 64
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean);  // lean: nothing cached in LDS (four workgroups per CU)

@@ -10,4 +10,12 @@ GenKernel pick_gen_split11(uint32_t n) {
   }
   return nullptr;
 }
+GenKernel pick_gen_lean11(uint32_t n) {
+  switch (n) {
+    case 6: return cdpr_gen_lean_kernel<6>;
+    case 7: return cdpr_gen_lean_kernel<7>;
+    case 8: return cdpr_gen_lean_kernel<8>;
+  }
+  return nullptr;
+}
 }  // namespace cdpr

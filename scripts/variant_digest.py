@@ -139,8 +139,8 @@ def sc_mapping(pkg, c, mapping):
         undo()
 
 
-def sc_hold(pkg, c, split, per_robot=False, B=1500):
-    undo = env(CDPR_GEN_SPLIT=split)
+def sc_hold(pkg, c, split, per_robot=False, B=1500, lean=None):
+    undo = env(CDPR_GEN_SPLIT=split, CDPR_GEN_LEAN=lean)
     try:
         eps, n = 0.004, 8
         rng = np.random.default_rng(41)
@@ -276,6 +276,8 @@ SCENARIOS = {
     "lane_per_cable": lambda pkg, c: sc_mapping(pkg, c, 3),
     "hold_one_wave": lambda pkg, c: sc_hold(pkg, c, 0),
     "hold_role_split": lambda pkg, c: sc_hold(pkg, c, 1),
+    "hold_lean": lambda pkg, c: sc_hold(pkg, c, None, lean=1),                      # lean role-split kernel: the rare controller paths by call
+    "hold_per_robot_lean": lambda pkg, c: sc_hold(pkg, c, None, per_robot=True, lean=1),
     "hold_per_robot_one_wave": lambda pkg, c: sc_hold(pkg, c, 0, per_robot=True),
     "hold_per_robot_role_split": lambda pkg, c: sc_hold(pkg, c, 1, per_robot=True),
     "general_kinds": sc_general_kinds,
