@@ -478,6 +478,8 @@ int upload_home64(cdpr_engine* h) {
   HIP_TRY(h, hipMemcpyAsync(h->d_state64, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_obs64, o.data(), o.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->d_dbg64) HIP_TRY(h, hipMemsetAsync(h->d_dbg64, 0, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(double), h->stream));
+  if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157 (call count 0)
+  if (h->d_target) HIP_TRY(h, hipMemsetAsync(h->d_target, 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
   for (int i = 0; i < 2; ++i) {
     HIP_TRY(h, hipMemsetAsync(h->d_vel[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
@@ -801,29 +803,40 @@ void fill_pid64(const cdpr_pid_params_t& p, double dt, F64Args& k) {
 }
 
 // precision = 64: the same host logic (commands are latched by run_steps before this is reached), the fp64 kernel
-int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
+int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, double* record = nullptr) {
   const uint32_t n = h->n;
   if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller row
     h->pid_calls = 0;
     HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)11 * n * h->stride * sizeof(double), h->stream));
   }
   F64Args a = h->base64;
-  const bool vel = h->mode == kModeVelocity, frc = h->mode == kModeForce;
+  const bool pr = h->per_robot;
+  const bool vel = pr || h->mode == kModeVelocity, frc = !pr && h->mode == kModeForce;
   fill_pid64(vel ? h->cfg.velocity_pid : h->cfg.position_pid, h->cfg.dt, a);
-  a.cmd = frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0])
-              : vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
+  a.cmd = pr ? h->d_target
+             : frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0])
+                   : vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
   a.wtab = h->d_wtab64 + (vel ? 0 : kWin * (kWin + 2));
+  if (pr) {  // mode, Pid call count and so the Pid per lane: the velocity Pid in the primary fields, the position Pid in alt_*
+    F64Args p = h->base64;
+    fill_pid64(h->cfg.position_pid, h->cfg.dt, p);
+    a.alt_kf = p.kf, a.alt_kp = p.kp, a.alt_ki = p.ki, a.alt_kd = p.kd;
+    a.alt_imax = p.imax, a.alt_imin = p.imin, a.alt_cmax = p.cmax, a.alt_cmin = p.cmin, a.alt_clamp_cmd = p.clamp_cmd;
+    a.meta = h->d_mode;
+  }
+  const size_t image64 = (size_t)f64_obs_rows((int)n) * h->stride;  // doubles per observable image
+  a.obs_step_stride = record ? image64 : 0;
   // the rings in LDS (64 KiB per wave at n = 8: two waves per CU) while the batch leaves CUs to spare
   const int ring_env = [] { const char* v = std::getenv("CDPR_F64_RING_LDS"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
   const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
-  F64Kernel kern = pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
+  F64Kernel kern = pr ? pick_f64_pr_kernel(n, ring_lds) : pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
   const bool sp_lean = sp_env >= 0 ? sp_env == 2 : h->batch > 16384u;
-  F64Kernel split_kern = (a.fk && a.td && sp_env != 0) ? pick_f64_split_kernel(n, sp_lean) : nullptr;
+  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr) ? pick_f64_split_kernel(n, sp_lean) : nullptr;  // (per-robot handles: the one-wave kernel)
   // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
   // (14.4 against 20.8 us per step at one robot x 8, same bits): a fused update then runs as one-step launches
   if (split_kern && !sp_lean) per_launch = 1;
@@ -831,9 +844,10 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
     a.nsteps = k;
-    a.flags = vel ? kFlagActualIsVelocity : (frc ? kFlagForceMode : 0u);
+    a.flags = pr ? 0u : (vel ? kFlagActualIsVelocity : (frc ? kFlagForceMode : 0u));
     const bool first_world = (h->step == 0);
     if (first_world) a.flags |= kFlagFirstWorldStep;
+    if (record) a.obs = record + (size_t)done * image64;
     a.pid_calls = sat_pid_calls(h->pid_calls);
     a.ring_slot = ring_slot_of(h->step);
     a.publish_mask = 0;
@@ -851,9 +865,11 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid) {
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;
-    h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));
+    if (!frc) h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));  // (no Pid call in Force mode)
     done += k;
   }
+  if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
+    HIP_TRY(h, hipMemcpyAsync(h->d_obs64, record + (size_t)(nsteps - 1) * image64, image64 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
   return CDPR_OK;
 }
 
@@ -977,6 +993,21 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   if (h->per_robot) {
     // every robot has its own mode: commands (masked or not) are latched on the device, robot by robot
     auto latch = [&](float* pending, float* latched, const uint8_t* mask, int which, int new_mode) -> int {
+      if (h->fp64) {  // precision = 64: the same on the double state (integral rows 20 + 11 i + 10)
+        LatchF64Args lf{};
+        lf.mask = mask;
+        lf.meta = h->d_mode;
+        lf.pending = pending;
+        lf.target = h->d_target;
+        lf.state = h->d_state64;
+        lf.stride = h->stride;
+        lf.batch = h->batch;
+        lf.n = h->n;
+        lf.new_mode = (new_mode == kModeVelocity) ? kMetaVelocity : (new_mode == kModePosition) ? kMetaPosition : kMetaForce;
+        hipLaunchKernelGGL(cdpr_latch_f64_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, lf);
+        HIP_TRY(h, hipGetLastError());
+        return CDPR_OK;
+      }
       if (!h->general) {  // register-resident path: one active target row and one Pid record per robot
         LatchFastArgs lf{};
         lf.mask = mask;
@@ -1034,6 +1065,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     if (int rc = mark_free()) return rc;
     touched[0] = touched[1] = touched[2] = false;  // recorded; nothing below latches on a per-robot handle
     if (h->general) return run_steps_general(h, nsteps, per_launch, record);
+    if (h->fp64) return run_steps_f64(h, nsteps, per_launch, false, reinterpret_cast<double*>(record));
   }
   if (h->vel_pending) {
     if (h->ext_vel[1]) {  // bound caller buffer: latched by pointer, nothing copied
@@ -1080,13 +1112,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   }
   if (int rc = mark_free()) return rc;
   if (h->general) return run_steps_general(h, nsteps, per_launch, record);
-  if (h->fp64) {
-    if (record) {
-      h->err = "trajectory records are fp32-only";
-      return CDPR_ERR_UNSUPPORTED;
-    }
-    return run_steps_f64(h, nsteps, per_launch, reset_pid);
-  }
+  if (h->fp64) return run_steps_f64(h, nsteps, per_launch, reset_pid, reinterpret_cast<double*>(record));
 
   if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller record; rare, so done outside the step kernel
     h->pid_calls = 0;
@@ -1273,6 +1299,25 @@ int fetch_platform(cdpr_engine* h, const float4* rows, float* pose7, float* twis
   return fetch_fields(h, rows, kTwistFields, twist6);
 }
 
+// image of a precision = 64 handle -> robot-major arrays, as double or rounded to float
+template <typename T>
+void decode_image64(const cdpr_engine* h, const double* o, T* position, T* velocity, T* effort, T* pose7, T* twist6) {
+  const size_t st = h->stride;
+  const uint32_t n = h->n;
+  T* dst[3] = {position, velocity, effort};
+  for (int f = 0; f < 3; ++f) {
+    if (!dst[f]) continue;
+    for (uint32_t r = 0; r < h->batch; ++r)
+      for (uint32_t i = 0; i < n; ++i) dst[f][(size_t)r * n + i] = (T)o[(size_t)(16 + f * n + i) * st + r];
+  }
+  for (uint32_t r = 0; r < h->batch; ++r) {
+    if (pose7)
+      for (int c = 0; c < 7; ++c) pose7[(size_t)r * 7 + c] = (T)o[(size_t)c * st + r];
+    if (twist6)
+      for (int c = 0; c < 6; ++c) twist6[(size_t)r * 6 + c] = (T)o[(size_t)(7 + c) * st + r];
+  }
+}
+
 inline float comp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 
 }  // namespace
@@ -1342,10 +1387,11 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     g_create_error = "internal: per-robot handle routed to the register-resident path with windows it cannot hold";
     return CDPR_ERR_UNSUPPORTED;
   }
-  if (cfg->precision == 64 && (general || cfg->per_robot_commands != 0 || phys_cfg)) {
-    g_create_error = "precision = 64 covers uniform-mode handles on the register-resident path only (no per_robot_commands, lumped legs, "
-                     "travel_stop, hold branch, cascades, long windows or cmd_limit 0): " +
-                     (general ? fast_path_obstacle(*cfg) : std::string("per-robot modes / optional physics"));
+  if (cfg->precision == 64 && (general || phys_cfg)) {
+    g_create_error = "precision = 64 covers the register-resident path only (no lumped legs, travel_stop, hold branch, cascades, long windows, "
+                     "cmd_limit 0, or per-robot modes with two different derivative windows): " +
+                     (general ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
+                              : std::string("optional physics"));
     return CDPR_ERR_UNSUPPORTED;
   }
   int ndev = 0;
@@ -1844,27 +1890,24 @@ int cdpr_update(cdpr_handle_t h, int nsteps) { return run_steps(h, nsteps, 1); }
 
 int cdpr_update_fused(cdpr_handle_t h, int nsteps, int steps_per_launch) { return run_steps(h, nsteps, steps_per_launch); }
 
+// One observable image: fp32 handles n_obs float4 slot rows, precision = 64 handles f64_obs_rows(n) rows of doubles
+static size_t image_bytes(const cdpr_engine* h) {
+  return h->fp64 ? (size_t)f64_obs_rows((int)h->n) * h->stride * sizeof(double) : (size_t)h->n_obs * h->stride * sizeof(float4);
+}
+
 int cdpr_observable_image_bytes(cdpr_handle_t h, size_t* bytes) {
   if (!h || !bytes) return CDPR_ERR_INVALID;
-  if (h->fp64) {
-    h->err = "observable images / trajectory records are fp32-only";
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  *bytes = (size_t)h->n_obs * h->stride * sizeof(float4);
+  *bytes = image_bytes(h);
   return CDPR_OK;
 }
 
 int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void* d_record, size_t record_bytes) {
   if (!h) return CDPR_ERR_INVALID;
-  if (h->fp64) {
-    h->err = "cdpr_update_record: not available with precision = 64";
-    return CDPR_ERR_UNSUPPORTED;
-  }
   if (h->cfg.publish_period != 0.0) {
     h->err = "cdpr_update_record needs publish_period == 0 (every step published)";
     return CDPR_ERR_UNSUPPORTED;
   }
-  const size_t image = (size_t)h->n_obs * h->stride * sizeof(float4);
+  const size_t image = image_bytes(h);
   if (!d_record || nsteps < 0 || record_bytes < image * (size_t)nsteps) {
     h->err = "cdpr_update_record: record buffer missing or smaller than nsteps observable images";
     return CDPR_ERR_INVALID;
@@ -1897,16 +1940,12 @@ static int scheduled_update(cdpr_engine* h, uint32_t kind, int nsteps, int refre
     h->err = "cdpr_update_scheduled_kind: robot masks need a handle created with per_robot_commands = 1";
     return CDPR_ERR_UNSUPPORTED;
   }
-  if (d_record && h->fp64) {
-    h->err = "cdpr_update_scheduled: trajectory records are fp32-only";
-    return CDPR_ERR_UNSUPPORTED;
-  }
   if (h->cfg.publish_period != 0.0 && d_record) {
     h->err = "cdpr_update_scheduled: a trajectory record needs publish_period == 0 (every step published)";
     return CDPR_ERR_UNSUPPORTED;
   }
-  const size_t image = (size_t)h->n_obs * h->stride;
-  if (d_record && record_bytes < image * sizeof(float4) * (size_t)nsteps) {
+  const size_t image = image_bytes(h) / sizeof(float4);  // in float4 units (both image kinds are multiples of 16 B: stride is a multiple of 64)
+  if (d_record && record_bytes < image_bytes(h) * (size_t)nsteps) {
     h->err = "cdpr_update_scheduled: record buffer smaller than nsteps observable images";
     return CDPR_ERR_INVALID;
   }
@@ -1980,12 +2019,22 @@ int cdpr_update_scheduled_kind(cdpr_handle_t h, uint32_t kind, int nsteps, int r
   return scheduled_update(h, kind, nsteps, refresh_steps, d_commands, d_ready, d_robot_masks, d_record, record_bytes);
 }
 
+int cdpr_decode_observables_f64(cdpr_handle_t h, const void* image, double* position, double* velocity, double* effort, double* pose7, double* twist6) {
+  if (!h || !image) return CDPR_ERR_INVALID;
+  if (!h->fp64) {
+    h->err = "cdpr_decode_observables_f64: the handle was not created with precision = 64";
+    return CDPR_ERR_UNSUPPORTED;
+  }
+  decode_image64(h, static_cast<const double*>(image), position, velocity, effort, pose7, twist6);
+  return CDPR_OK;
+}
+
 int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position, float* velocity, float* effort,
                             float* pose7, float* twist6) {
   if (!h || !image) return CDPR_ERR_INVALID;
-  if (h->fp64) {
-    h->err = "observable images / trajectory records are fp32-only";
-    return CDPR_ERR_UNSUPPORTED;
+  if (h->fp64) {  // (the float getters of a precision = 64 handle round)
+    decode_image64(h, static_cast<const double*>(image), position, velocity, effort, pose7, twist6);
+    return CDPR_OK;
   }
   const float4* o = static_cast<const float4*>(image);
   const size_t st = h->stride;

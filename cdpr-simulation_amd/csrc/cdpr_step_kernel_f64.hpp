@@ -9,8 +9,9 @@
 // fp64), no role split, no LDS: clarity over speed.  It covers what the register-resident fp32 path covers for a
 // uniform-mode handle (IK, Pid, optional Newton-Raphson FK and tension distribution, SetForce limits, velocity limit,
 // unilateral cables, observables with publish decimation, travel-limit flags, world step, any number of steps per
-// launch); everything else (general controller path, per-robot modes, lumped legs, rollout, trajectory record) stays
-// fp32-only and cdpr_create refuses the combination.
+// launch; round 5: the trajectory record and per-robot modes - PR instantiations: mode, Pid call count and so the Pid in use
+// per lane, as in the fp32 PR kernels); everything else (general controller path, lumped legs, rollout) stays fp32-only and
+// cdpr_create refuses the combination.
 //
 // HBM layout (doubles, struct of arrays over the batch, row r of the state at state[r * stride + robot]):
 //   state: 0-6 pose (x y z qx qy qz qw) | 7-12 twist (v, w) | 13-19 FK estimate (pose7) | per cable i: 20 + 11 i + j,
@@ -54,6 +55,14 @@ struct F64Args {
   double td_min, td_max, td_mid;
   double kf, kp, ki, kd, imax, imin, cmax, cmin, inv_dt;
   int nbuf, clamp_cmd;
+  size_t obs_step_stride;  // doubles between the observable images of consecutive steps (0: every step overwrites the same image;
+                           // > 0: a trajectory record keeps them all, cdpr_update_record)
+  // per-robot handles (PR instantiations): meta[r] as StepArgs::meta (bits 0-1 mode, bits 2-7 Pid calls since the robot's last
+  // reset, saturating); `cmd` is then the robot's ACTIVE target row, the fields above hold the VELOCITY Pid and these the
+  // POSITION Pid's (the two share one derivative window on such handles: one weight table, one nbuf)
+  uint8_t* meta;
+  double alt_kf, alt_kp, alt_ki, alt_kd, alt_imax, alt_imin, alt_cmax, alt_cmin;
+  int alt_clamp_cmd;
 };
 
 __host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
@@ -228,7 +237,7 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 // needed again - the rows at the true pose (IK stage) for the world step, the rows at the estimate (the Newton stage's
 // closing evaluation) for both passes of the tension distribution - instead of being recomputed: 48 row evaluations per
 // step instead of 72 at n = 8 (a row is ~60 fp64 instructions, a reload 6 LDS reads).  Same values, same bits.
-template <int N, bool RING_LDS = false, bool JCACHE = false>
+template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   // cables per pass of the loops over the cables.  One lane's step is a dependent chain (rotate the anchor, length,
   // reciprocal square root, row, accumulate): with a single wave per SIMD a dependent fp64 instruction waits ~8 cycles for
@@ -261,12 +270,20 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       for (int k = 0; k < kWin; ++k) c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] = S[(size_t)(20 + 11 * i + k) * st];
     }
   }
-  const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
-  int calls = a.pid_calls;
+  // uniform handles: mode and call count are launch arguments; PR: this robot's own (per lane)
+  uint32_t meta = 0u;
+  if (PR) meta = a.meta[r];
+  const bool actual_is_vel = PR ? ((meta & kMetaModeMask) == kMetaVelocity) : ((a.flags & kFlagActualIsVelocity) != 0u);
+  int calls = PR ? (int)(meta >> kMetaCallShift) : a.pid_calls;
+  // the Pid this lane runs (PR: the velocity Pid's gains in the primary fields, the position Pid's in alt_*)
+  const bool alt = PR && !actual_is_vel;
+  const double kf = alt ? a.alt_kf : a.kf, kp = alt ? a.alt_kp : a.kp, ki = alt ? a.alt_ki : a.ki, kd = alt ? a.alt_kd : a.kd;
+  const double imax = alt ? a.alt_imax : a.imax, imin = alt ? a.alt_imin : a.imin, cmax = alt ? a.alt_cmax : a.cmax, cmin = alt ? a.alt_cmin : a.cmin;
+  const bool clamp_cmd = (alt ? a.alt_clamp_cmd : a.clamp_cmd) != 0;
 
   for (int step = 0; step < a.nsteps; ++step) {
     const bool first_world = (step == 0) && (a.flags & kFlagFirstWorldStep);
-    const bool force_mode = (a.flags & kFlagForceMode) != 0u;      // UpdateMode::Force (JFC.cpp:67-70): no Pid
+    const bool force_mode = PR ? ((meta & kMetaModeMask) == kMetaForce) : ((a.flags & kFlagForceMode) != 0u);  // UpdateMode::Force (JFC.cpp:67-70): no Pid
     const bool run_pid = !first_world && !force_mode && calls != 0;  // Pid.cpp:123-126: the first call since reset returns 0
     const bool full = calls >= a.nbuf;
     const int ring_slot = (a.ring_slot + step) % kWin;
@@ -295,25 +312,25 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           double acc = wt[kWin] * error;
 #pragma unroll
           for (int k = 0; k < kWin; ++k) acc = fma(wt[k], RING_LDS ? c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] : S[(size_t)(20 + 11 * i + k) * st], acc);
-          const double p_term = a.kp * error;
+          const double p_term = kp * error;
           const double prev_ierr = c_ierr[i][lane];
           double ie = fma(a.dt, error, prev_ierr);
-          double i_term = a.ki * ie;
+          double i_term = ki * ie;
           const double i_raw = i_term;
-          if (i_term > a.imax) {  // Pid.cpp:143-152
-            i_term = a.imax;
-            ie = i_term / a.ki;
-          } else if (i_term < a.imin) {
-            i_term = a.imin;
-            ie = i_term / a.ki;
+          if (i_term > imax) {  // Pid.cpp:143-152
+            i_term = imax;
+            ie = i_term / ki;
+          } else if (i_term < imin) {
+            i_term = imin;
+            ie = i_term / ki;
           }
           const double derived = full ? acc * a.inv_dt : 0.0;
-          const double d_term = a.kd * derived;
-          const double cmd = fma(a.kf, desired, p_term) + i_term + d_term;
-          double out = a.clamp_cmd ? fmax(fmin(cmd, a.cmax), a.cmin) : cmd;  // Pid.cpp:175-177
-          if (out != cmd) {                                                    // Pid.cpp:181-184
+          const double d_term = kd * derived;
+          const double cmd = fma(kf, desired, p_term) + i_term + d_term;
+          double out = clamp_cmd ? fmax(fmin(cmd, cmax), cmin) : cmd;  // Pid.cpp:175-177
+          if (out != cmd) {                                              // Pid.cpp:181-184
             ie = prev_ierr;
-            out = fma(a.dt * error, a.ki, out);
+            out = fma(a.dt * error, ki, out);
           }
           c_ierr[i][lane] = ie;
           force = out;
@@ -329,7 +346,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         }
         c_f[i][lane] = force;
       }
-      if (!first_world) ++calls;
+      // (PR: the count saturates where the meta byte does; a robot in Force mode calls no Pid)
+      if (!first_world) calls = PR ? (force_mode ? calls : min(calls + 1, (int)kMetaCallMax)) : calls + 1;
     }
     // ---- Newton-Raphson forward kinematics ([NEW] SURVEY 8(a) row 14)
     double fk_res = 0.0;
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     }
     // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
     if ((a.publish_mask >> step) & 1ull) {
-      double* const O = a.obs + r;
+      double* const O = a.obs + (size_t)step * a.obs_step_stride + r;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         O[(size_t)c * st] = p[c];
@@ -540,6 +558,35 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       for (int k = 0; k < kWin; ++k) S[(size_t)(20 + 11 * i + k) * st] = c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane];
     }
   }
+  if (PR) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)calls << kMetaCallShift));
+}
+
+// Per-robot command arrival on a precision = 64 handle (cdpr_set_*_command_masked; PLG.cpp:206-219 per model): what
+// cdpr_latch_fast_kernel does on the fp32 state - the Joy's row becomes the robot's active target, entering the mode from
+// another one resets its Pid (JFC.cpp:101-103,113-115: integral 0, call count 0), setForce resets nothing.
+struct LatchF64Args {
+  const uint8_t* mask;   // uint8[B], or nullptr = every robot
+  uint8_t* meta;
+  const float* pending;  // float[B][n]
+  float* target;         // float[B][n]
+  double* state;
+  size_t stride;
+  uint32_t batch, n;
+  uint32_t new_mode;     // kMetaForce / kMetaPosition / kMetaVelocity
+};
+static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF64Args a) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= a.batch) return;
+  if (a.mask && !a.mask[r]) return;
+  for (uint32_t i = 0; i < a.n; ++i) a.target[(size_t)r * a.n + i] = a.pending[(size_t)r * a.n + i];
+  uint32_t m = a.meta[r];
+  if (a.new_mode == kMetaForce) {
+    m = (m & ~kMetaModeMask) | kMetaForce;
+  } else if ((m & kMetaModeMask) != a.new_mode) {
+    for (uint32_t i = 0; i < a.n; ++i) a.state[(size_t)(20 + 11 * i + 10) * a.stride + r] = 0.0;
+    m = a.new_mode;  // call count 0
+  }
+  a.meta[r] = (uint8_t)m;
 }
 
 // cdpr_split_kernel_f64 - one step per launch with TWO waves per 64 robots, split by role like cdpr_split_kernel: FK + TD

@@ -2,12 +2,14 @@
 #include "cdpr_kernels.hpp"
 namespace cdpr {
 namespace {
+template <int N> F64Kernel f64_pr_n(bool ring_lds) { return ring_lds ? cdpr_step_kernel_f64<N, true, false, true> : cdpr_step_kernel_f64<N, false, false, true>; }
 template <int N> F64Kernel f64_n(bool ring_lds, bool jcache) {
   if (jcache) return cdpr_step_kernel_f64<N, true, true>;  // (112 KiB of LDS per wave at n = 8: one workgroup per CU)
   return ring_lds ? cdpr_step_kernel_f64<N, true> : cdpr_step_kernel_f64<N, false>;
 }
 }  // namespace
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }
+F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds) { CDPR_PICK_CABLES(f64_pr_n, ring_lds); }  // per-robot modes (PR)
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean) {
   if (lean) {
     switch (n) {

@@ -163,11 +163,16 @@ class Engine:
             self._check(lib().cdpr_device_download(self._h, raw.ctypes.data_as(C.c_void_p), dptr, raw.nbytes))
         finally:
             lib().cdpr_device_free(self._h, dptr)
-        out = {k: np.empty((nsteps, self.B, w), dtype=np.float32) for k, w in (("position", self.n), ("velocity", self.n), ("effort", self.n), ("pose", 7), ("twist", 6))}
+        f64 = int(self.config.precision) == 64  # precision = 64 handles record doubles and hand out float64 arrays
+        out = {k: np.empty((nsteps, self.B, w), dtype=np.float64 if f64 else np.float32) for k, w in (("position", self.n), ("velocity", self.n), ("effort", self.n), ("pose", 7), ("twist", 6))}
         for j in range(nsteps):
             img = raw[j * image:(j + 1) * image]
-            self._check(lib().cdpr_decode_observables(self._h, img.ctypes.data_as(C.c_void_p), _fp(out["position"][j]), _fp(out["velocity"][j]),
-                                                      _fp(out["effort"][j]), _fp(out["pose"][j]), _fp(out["twist"][j])))
+            if f64:
+                self._check(lib().cdpr_decode_observables_f64(self._h, img.ctypes.data_as(C.c_void_p), self._dp(out["position"][j]), self._dp(out["velocity"][j]),
+                                                              self._dp(out["effort"][j]), self._dp(out["pose"][j]), self._dp(out["twist"][j])))
+            else:
+                self._check(lib().cdpr_decode_observables(self._h, img.ctypes.data_as(C.c_void_p), _fp(out["position"][j]), _fp(out["velocity"][j]),
+                                                          _fp(out["effort"][j]), _fp(out["pose"][j]), _fp(out["twist"][j])))
         return out
 
     def decode_observables(self, image: np.ndarray):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CDPR_ABI_VERSION 5u   /* 5 = 4 + cdpr_update_scheduled_kind, cdpr_device_pci_bus_id (cdpr_config_t unchanged) */
+#define CDPR_ABI_VERSION 5u   /* 5 = 4 + cdpr_update_scheduled_kind, cdpr_device_pci_bus_id, cdpr_decode_observables_f64 (cdpr_config_t unchanged) */
 #define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
 #define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
 #define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
@@ -116,10 +116,10 @@ typedef struct cdpr_config {
   uint32_t unilateral_cables;       /* 1: a cable cannot push, axial force max(T, 0) ([NEW]; the reference has no slack model) */
   uint32_t precision;               /* 0 or 32: fp32 kernels (what every throughput figure is quoted on).  64: the step in the
                                        reference's own precision (Pid.h, Gazebo/ODE compute in double): one plain fp64 kernel for
-                                       uniform-mode handles (IK, Pid, FK, TD, limits, observables, world step; any steps per launch),
-                                       meant for one robot / small batches; read it out with the *_f64 getters.  Not with
-                                       per_robot_commands, the general controller path, the lumped legs, travel_stop, rollouts or
-                                       trajectory records (cdpr_create / the call return CDPR_ERR_UNSUPPORTED) */
+                                       handles on the register-resident path (IK, Pid, FK, TD, limits, observables, world step; any steps
+                                       per launch; trajectory records, command schedules and per_robot_commands since ABI 5), meant for
+                                       one robot / small batches; read it out with the *_f64 getters.  Not with the general controller
+                                       path, the lumped legs, travel_stop or rollouts (cdpr_create / the call return CDPR_ERR_UNSUPPORTED) */
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */
@@ -256,6 +256,10 @@ int cdpr_observable_image_bytes(cdpr_handle_t h, size_t *bytes);
 int cdpr_update_record(cdpr_handle_t h, int nsteps, int steps_per_launch, void *d_record, size_t record_bytes);
 int cdpr_decode_observables(cdpr_handle_t h, const void *image, float *position, float *velocity, float *effort,
                             float *pose7, float *twist6);
+/* precision = 64 handles: their images hold doubles (cdpr_observable_image_bytes says how many bytes); this decodes without
+ * the rounding to float (cdpr_decode_observables works on them too and rounds).  CDPR_ERR_UNSUPPORTED on fp32 handles. */
+int cdpr_decode_observables_f64(cdpr_handle_t h, const void *image, double *position, double *velocity, double *effort,
+                                double *pose7, double *twist6);
 /* A whole command schedule resident in HBM, queued with one call: what
  *   for j: cableVelocityCommandCallback(batch j); refresh_steps x update()
  * does (the reference's 100 Hz / 10 Hz publishers against the 1 kHz world: a Joy every 10 or 100 world steps, PLG.cpp:206-211

@@ -57,11 +57,11 @@ def test_config_switch_selects_the_baseline_shapes():
     assert (a.batch, a.cables) == (128, 4)
 
 
-def _run_bench(extra, timeout=300):
+def _run_bench(extra, timeout=300, backend="gloo"):
     import json
     import subprocess
 
-    env = dict(os.environ, CDPR_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env = dict(os.environ, CDPR_BENCH_BACKEND=backend, OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
@@ -82,7 +82,8 @@ def test_bench_gpus_2_spawns_its_own_ranks():
 def test_bench_gpus_8_dry_run_pins_and_reports_every_rank():
     """The driver's N = 8 launch, rank plumbing only: eight ranks, disjoint core sets (when the box has at least eight
     CPUs), one JSON line carrying every rank's own figure."""
-    out = _run_bench(["--gpus", "8", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--dry-run"], timeout=600)
+    # (the driver's own backend request, "nccl" = RCCL: on this GPU-less box the pre-flight must end on gloo)
+    out = _run_bench(["--gpus", "8", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--dry-run"], timeout=600, backend="nccl")
     assert out["n_gpus"] == 8 and out["dry_run"] is True
     assert [r["rank"] for r in out["per_rank"]] == list(range(8))
     # the pre-flight's fields (VERDICT r04 next 8): the rendezvous backend and why it is not RCCL on this GPU-less box, and

@@ -152,8 +152,120 @@ def test_fp64_facade_publishes_doubles(pkg, oracle):
     assert np.abs(ps.pose.position - op[:, :3]).max() < TOL64["pose"] and np.abs(ps.velocity.angular - ot[:, 3:]).max() < TOL64["twist"]
 
 
+@pytest.mark.parametrize("cables,stages,B", [(8, 3, 130), (4, 0, 70), (8, 3, 40000)])
+def test_fp64_per_robot_modes(pkg, oracle, cables, stages, B):
+    """precision = 64 with per_robot_commands (round 5): every robot has its own JointForceCalculator mode and Pid call
+    history (PLG.cpp:206-219 runs per model) - velocity, position and setForce commands reaching subsets of the robots, mode
+    changes resetting the Pid of the robots they reach, one step and several steps per launch - against the oracle at fp64
+    tolerances; 40 000 robots: the large-batch variant of the kernel (rings read from HBM)."""
+    rng = np.random.default_rng(84 + cables)
+    model = pkg.eight_cable_model() if cables == 8 else pkg.cube_model()
+    cfg = pkg.Config(model=model, batch=B, stages=stages, precision=64, perRobotCommands=True)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05))
+    eng.update(11), ora.update(11)
+    compare64(eng, ora, "position mode from Load")
+    grp = np.arange(B) % 4
+    steps = iter([13, 1, 24, 7, 30, 12, 19])
+    for rnd in range(2):
+        v = rng.uniform(-0.03, 0.03, (B, cables)).astype(np.float32)
+        f = ((7.0 if cables == 8 else 3.97) + rng.uniform(-0.5, 0.5, (B, cables))).astype(np.float32)
+        p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+        for e in (eng, ora):
+            e.set_velocity_command(v, mask=(grp <= 1).astype(np.uint8))       # groups 0, 1 -> Velocity
+            e.set_force_command(f, mask=(grp == 2).astype(np.uint8))          # group 2 -> Force; group 3 stays in Position mode
+        k = next(steps)
+        eng.update(k, 1), ora.update(k)
+        compare64(eng, ora, f"round {rnd}: velocity + force subsets")
+        for e in (eng, ora):
+            e.set_position_command(p, mask=(grp == 1).astype(np.uint8))       # group 1 back to Position: its Pid is reset
+        k = next(steps)
+        eng.update(k, 5), ora.update(k)
+        compare64(eng, ora, f"round {rnd}: position subset (fused launches)")
+        for e in (eng, ora):
+            e.set_velocity_command(v[::-1].copy(), mask=(grp >= 2).astype(np.uint8))  # Force -> Velocity resets the velocity Pid
+        k = next(steps)
+        eng.update(k, 1), ora.update(k)
+        compare64(eng, ora, f"round {rnd}: leaving Force mode")
+    # an unmasked Joy reaches everybody
+    v = rng.uniform(-0.02, 0.02, (B, cables)).astype(np.float32)
+    eng.set_velocity_command(v), ora.set_velocity_command(v)
+    eng.update(15, 3), ora.update(15)
+    compare64(eng, ora, "unmasked Joy at the end")
+
+
+@pytest.mark.parametrize("per_robot", [False, True])
+def test_fp64_trajectory_record_and_schedule(pkg, oracle, per_robot):
+    """cdpr_update_record on precision = 64 handles (round 5): every step's observables kept, in double, equal to what step-
+    by-step read-outs give (same kernels, same bits) - the role-split kernel's one-step launches (uniform FK + TD handle) and
+    the one-wave kernel's fused launches (per-robot handle) - and a jointVelocities schedule queued with one call."""
+    B, n, T = 70, 8, 37
+    rng = np.random.default_rng(86)
+    model = pkg.eight_cable_model()
+    cfg = pkg.Config(model=model, batch=B, stages=3, precision=64, perRobotCommands=per_robot)
+    pose = perturbed_poses(model, B, rng, 0.02, 0.05)
+    a, ora = pair64(pkg, oracle, cfg, pose)
+    b, _ = pair64(pkg, oracle, cfg, pose)
+    v = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+    for e in (a, b, ora):
+        e.update(6)
+        e.set_velocity_command(v)
+    rec = a.update_record(T, 5)
+    assert rec["pose"].dtype == np.float64 and rec["effort"].shape == (T, B, n)
+    for j in range(T):
+        b.update(1), ora.update(1)
+        q, qd, eff, p7, t6 = b.observables_f64()
+        assert np.array_equal(rec["effort"][j], eff) and np.array_equal(rec["pose"][j], p7) and np.array_equal(rec["velocity"][j], qd), j
+        if j % 9 == 0:
+            assert np.abs(rec["effort"][j] - ora.joint_states()[2]).max() <= TOL64["eff"]
+    for x, y in zip(a.observables_f64() + a.raw_state_f64(), b.observables_f64() + b.raw_state_f64()):
+        assert np.array_equal(x, y)
+    compare64(a, ora, "after the record")
+    # a schedule of 4 batches, 10 steps each, with its record
+    sched = rng.uniform(-0.03, 0.03, (4, B, n)).astype(np.float32)
+    image = a.observable_image_bytes()
+    d_sched, d_rec = a.device_upload(sched), a.device_alloc(image * 40)
+    a.update_scheduled(40, 10, d_sched, d_rec, image * 40)
+    for j in range(4):
+        b.set_velocity_command(sched[j]), ora.set_velocity_command(sched[j])
+        b.update(10), ora.update(10)
+    for x, y in zip(a.observables_f64() + a.raw_state_f64(), b.observables_f64() + b.raw_state_f64()):
+        assert np.array_equal(x, y)
+    last = a.device_download(d_rec, (40, image), dtype=np.uint8)[39]
+    import ctypes as C
+
+    from cdpr_simulation_amd._native import lib
+
+    eff = np.empty((B, n))
+    assert lib().cdpr_decode_observables_f64(a._h, last.ctypes.data_as(C.c_void_p), None, None, eff.ctypes.data_as(C.POINTER(C.c_double)), None, None) == 0
+    assert np.array_equal(eff, a.observables_f64()[2])
+    compare64(a, ora, "after the schedule")
+
+
+def test_fp64_facade_runs_n_steps_as_one_launch_chain(pkg, oracle):
+    """The facade's update(n) on a precision = 64 handle: one launch chain into a trajectory record of doubles, n messages
+    per topic (round 4: n device round trips), float64 arrays equal to the step-by-step facade's."""
+    cfg = pkg.Config(batch=3, precision=64)
+    plugs = [pkg.CdprGazeboPlugin(), pkg.CdprGazeboPlugin()]
+    got = [[], []]
+    for pl, g in zip(plugs, got):
+        pl.Load(cfg)
+        pl.bus.subscribe("jointStates", g.append)
+    gen = pkg.stimulus.sine_velocity(4)
+    for k in range(6):
+        cmd = next(gen)
+        for pl in plugs:
+            pl.bus.publish("jointVelocities", pkg.Joy(axes=cmd))
+        plugs[0].update(25)
+        for _ in range(25):
+            plugs[1].update(1)
+    assert len(got[0]) == len(got[1]) == 149
+    for m0, m1 in zip(got[0], got[1]):
+        assert m0.header.stamp == m1.header.stamp and m0.effort.dtype == np.float64
+        assert np.array_equal(m0.effort, m1.effort) and np.array_equal(m0.position, m1.position)
+
+
 def test_fp64_refuses_what_it_does_not_cover(pkg):
-    for kw in (dict(perRobotCommands=True), dict(velocityEpsilon=0.01)):
+    for kw in (dict(velocityEpsilon=0.01), dict(perRobotCommands=True, velocityEpsilon=0.01)):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(pkg.Config(batch=4, precision=64, **kw), 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
@@ -165,8 +277,6 @@ def test_fp64_refuses_what_it_does_not_cover(pkg):
     with pytest.raises(pkg.CdprError) as ei:
         eng.rollout_velocity(np.zeros((4, 3, 2, 8), np.float32), np.zeros((4, 3), np.float32))
     assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
-    with pytest.raises(pkg.CdprError):
-        eng.update_record(5, 5)
     plain = pkg.Engine(pkg.Config(batch=2), 0)
     with pytest.raises(pkg.CdprError) as ei:
         plain.observables_f64()
