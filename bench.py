@@ -46,9 +46,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-HBM_COPY_GBS = 6290.0  # what a plain row-copy kernel reaches on this part (scripts/micro/rowcopy.hip): the practical ceiling
+HBM_COPY_GBS = 6290.0  # what a plain row-copy kernel reaches on this part (scripts/micro/rowcopy.hip, HISTORY.md section 6): the practical ceiling
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # same guide
-# flop per state-step counted from the gfx950 ISA of the shipped kernels
+# flop per state-step counted from the gfx950 ISA of the shipped kernels (HISTORY.md section 4)
 FLOP_PER_STATE_STEP = {8: 6325, 4: 648}
 METRIC = "CDPR sim-steps/sec (whole node), 65 536 parallel 8-cable robots, 1 ms dt"
 CONFIGS = {2: dict(batch=4096, cables=4), 3: dict(batch=65536, cables=8)}

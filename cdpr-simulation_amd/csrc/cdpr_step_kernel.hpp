@@ -187,21 +187,28 @@ CDPR_DEV void sched_wait(const StepArgs& a, int j) {
 #define CDPR_STAMP(i) do { } while (0)
 #endif
 
-CDPR_DEV v2f splat(float s) { return (v2f){s, s}; }
-CDPR_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-CDPR_DEV v2f fma2(float a, v2f b, v2f c) { return __builtin_elementwise_fma(splat(a), b, c); }
+// leaf helpers: without debug locations in the instruction-budget build (scripts/region_budget.py), so that their
+// instructions count for the region that calls them
+#ifdef CDPR_LEAF_NODEBUG
+#define CDPR_LEAF __device__ __forceinline__ __attribute__((nodebug))
+#else
+#define CDPR_LEAF CDPR_DEV
+#endif
+CDPR_LEAF v2f splat(float s) { return (v2f){s, s}; }
+CDPR_LEAF v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+CDPR_LEAF v2f fma2(float a, v2f b, v2f c) { return __builtin_elementwise_fma(splat(a), b, c); }
 // x + y of a pair as ONE v_add_f32 on the two halves.  Written as `v.x + v.y` the backend pairs neighbouring sums up into
 // v_pk_add_f32 and pays three v_mov_b32 per pair to line the halves up (12 instructions for six sums instead of 6).
-CDPR_DEV float hsum(v2f v) {
+CDPR_LEAF float hsum(v2f v) {
   float r;
   asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y));
   return r;
 }
 CDPR_DEV v2f rsq2(v2f v) { return (v2f){__frsqrt_rn(v.x), __frsqrt_rn(v.y)}; }
-CDPR_DEV v2f min2(v2f a, v2f b) { return (v2f){fminf(a.x, b.x), fminf(a.y, b.y)}; }
-CDPR_DEV v2f max2(v2f a, v2f b) { return (v2f){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
-CDPR_DEV v2f abs2(v2f a) { return (v2f){fabsf(a.x), fabsf(a.y)}; }
-CDPR_DEV float comp4(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+CDPR_LEAF v2f min2(v2f a, v2f b) { return (v2f){fminf(a.x, b.x), fminf(a.y, b.y)}; }
+CDPR_LEAF v2f max2(v2f a, v2f b) { return (v2f){fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+CDPR_LEAF v2f abs2(v2f a) { return (v2f){fabsf(a.x), fabsf(a.y)}; }
+CDPR_LEAF float comp4(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 
 struct Rot {
   float r00, r01, r02, r10, r11, r12, r20, r21, r22;
@@ -228,16 +235,17 @@ CDPR_DEV Rot quat_to_rot(float x, float y, float z, float w) {
 // q <- exp(theta / 2) (x) q, world-frame rotation increment, renormalised.
 CDPR_DEV void quat_apply_rotvec(float& qx, float& qy, float& qz, float& qw, float tx, float ty, float tz) {
   const float a2 = fmaf(tz, tz, fmaf(ty, ty, tx * tx));
-  float k, cw;
-  if (a2 < 1e-8f) {  // |theta| < 1e-4: series (exact to fp32)
-    k = fmaf(a2, -1.f / 48.f, 0.5f);
-    cw = fmaf(a2, -0.125f, 1.f);
-  } else {
-    const float a = sqrtf(a2);
-    float s;
-    __sincosf(0.5f * a, &s, &cw);
-    k = s / a;
-  }
+  // k = sin(|theta| / 2) / |theta|, cw = cos(|theta| / 2).  Round 5 (scripts/region_budget.py: this update was 73 vector
+  // instructions per Newton iteration, 292 of a step's 3 174, against ~40 of arithmetic): |theta| = a2 * rsq(a2) and
+  // k = s * rsq(a2) from ONE v_rsq_f32 instead of a correctly rounded sqrtf and a correctly rounded division (both expand to
+  // ~10 instructions), and the small-angle series as a select instead of a divergent branch.  |theta| < 1e-4: series
+  // (exact to fp32; also keeps rsq(0) = inf out of the result).
+  const float inv_a = __frsqrt_rn(fmaxf(a2, 1e-30f));
+  float s, c;
+  __sincosf(0.5f * (a2 * inv_a), &s, &c);
+  const bool tiny = a2 < 1e-8f;
+  const float k = tiny ? fmaf(a2, -1.f / 48.f, 0.5f) : s * inv_a;
+  const float cw = tiny ? fmaf(a2, -0.125f, 1.f) : c;
   const float dx = k * tx, dy = k * ty, dz = k * tz;
   const float nw = fmaf(-dz, qz, fmaf(-dy, qy, fmaf(-dx, qx, cw * qw)));
   const float nx = fmaf(-dz, qy, fmaf(dy, qz, fmaf(qw, dx, cw * qx)));
@@ -571,6 +579,11 @@ CDPR_DEV float pack_flags(int td_flag, uint32_t limit_mask) { return (float)((ui
 template <int N>
 CDPR_DEV void apply_travel_stop(const StepArgs& a, Platform& s, const v2f (&q)[cable_pairs(N)], const v2f (&jac)[cable_pairs(N)][6]) {
   const Rot r = quat_to_rot(s.qx, s.qy, s.qz, s.qw);
+  // (the twist in locals over the sweeps.  Round 5 note: in most PHYS instantiations LLVM leaves the slice {vx, vy, vz, wx} of
+  //  the Platform struct in scratch memory (16 B + 8 B per lane; with a stack object in the frame the spilled scalars go to
+  //  memory as well).  Neither these locals nor -fno-slp-vectorize change that; the instantiation decides (n = 3, 4 with
+  //  ROLLOUT and the general kernels at n = 4, 7, 8 are free of it).  Open: profiles/r05_resource_usage.txt.)
+  float vx = s.vx, vy = s.vy, vz = s.vz, wx = s.wx, wy = s.wy, wz = s.wz;
   for (int sweep = 0; sweep < a.travel_stop; ++sweep)
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -579,7 +592,7 @@ CDPR_DEV void apply_travel_stop(const StepArgs& a, Platform& s, const v2f (&q)[c
 #pragma unroll
     for (int c = 0; c < 6; ++c) j[c] = (i & 1) ? jac[k][c].y : jac[k][c].x;
     const float qi = (i & 1) ? q[k].y : q[k].x;
-    const float qdn = -fmaf(j[5], s.wz, fmaf(j[4], s.wy, fmaf(j[3], s.wx, fmaf(j[2], s.vz, fmaf(j[1], s.vy, j[0] * s.vx)))));
+    const float qdn = -fmaf(j[5], wz, fmaf(j[4], wy, fmaf(j[3], wx, fmaf(j[2], vz, fmaf(j[1], vy, j[0] * vx)))));
     const bool hit = (qi >= a.travel_hi && qdn > 0.f) || (qi <= a.travel_lo && qdn < 0.f);
     // Iw^-1 (rb x u) = R Ib^-1 R^T (rb x u)
     const float tbx = fmaf(r.r20, j[5], fmaf(r.r10, j[4], r.r00 * j[3]));
@@ -594,13 +607,14 @@ CDPR_DEV void apply_travel_stop(const StepArgs& a, Platform& s, const v2f (&q)[c
     const float d = fmaf(j[5], awz, fmaf(j[4], awy, fmaf(j[3], awx, fmaf(j[2], j[2], fmaf(j[1], j[1], j[0] * j[0])) * a.inv_mass)));
     const float lam = hit ? qdn / d : 0.f;
     const float lm = lam * a.inv_mass;
-    s.vx = fmaf(lm, j[0], s.vx);
-    s.vy = fmaf(lm, j[1], s.vy);
-    s.vz = fmaf(lm, j[2], s.vz);
-    s.wx = fmaf(lam, awx, s.wx);
-    s.wy = fmaf(lam, awy, s.wy);
-    s.wz = fmaf(lam, awz, s.wz);
+    vx = fmaf(lm, j[0], vx);
+    vy = fmaf(lm, j[1], vy);
+    vz = fmaf(lm, j[2], vz);
+    wx = fmaf(lam, awx, wx);
+    wy = fmaf(lam, awy, wy);
+    wz = fmaf(lam, awz, wz);
   }
+  s.vx = vx, s.vy = vy, s.vz = vz, s.wx = wx, s.wy = wy, s.wz = wz;
 }
 
 // World step with the lumped legs ([EXT] -> reduced; closed forms in DESIGN.md section 1).  Leg i turns about its frame anchor with angular velocity (u x vP)/L, vP = v + omega x rb.  The
@@ -1202,6 +1216,22 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
 #pragma unroll
       for (int k = 0; k < NP; ++k) applied[k] = f[k];
     }
+    if (LOWREG && FK) {
+      // rebuild the true structure matrix - and with it the joint positions and rates - HERE, behind the tension distribution:
+      // none of the three is needed between the Pid and this point, so none rides through the Newton stage (q and qd were the
+      // 16 registers that made this kernel spill 2-3 of its 256: 12-20 B of scratch per lane).  Same expressions on the same
+      // inputs: same bits; the opaque LDS offset keeps the compiler from re-using (and so keeping alive) the first evaluation.
+      uint32_t again = 0;
+      asm volatile("" : "+v"(again));
+      v2f len2[NP], l02[NP];
+      ik_pairs<N, true>(lds + again, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len2, jac, l02);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        q[k] = l02[k] - len2[k];
+        qd[k] = -fma2(s.wz, jac[k][5], fma2(s.wy, jac[k][4], fma2(s.wx, jac[k][3],
+                      fma2(s.vz, jac[k][2], fma2(s.vy, jac[k][1], splat(s.vx) * jac[k][0])))));
+      }
+    }
     if (a.vel_limit > 0.f) {  // Joint::SetForce velocity truncation [EXT]: no pushing a runaway joint further out
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
@@ -1256,12 +1286,9 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
         tens[k] = fma2(-a.damping, qd[k], applied[k]);
         if (a.unilateral) tens[k] = max2(tens[k], splat(0.f));  // [NEW] option: a cable cannot push
       }
-      if (LOWREG && FK) {  // rebuild the true structure matrix (it was not kept alive through the Newton stage)
-        // (measured for multi-step and rollout launches too, with and without per-iteration geometry reads: 330 -> 33
-        //  v_accvgpr moves per step, yet 3-9 % slower: profiles/r02l_multistep_register_pressure_ab.txt)
-        v2f len2[NP], l02[NP];
-        ik_pairs<N, false>(lds, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len2, jac, l02);
-      }
+      // (LOWREG: the true structure matrix was rebuilt behind the tension distribution, see there.  Rebuilding it was measured
+      //  for multi-step and rollout launches too, with and without per-iteration geometry reads: 330 -> 33 v_accvgpr moves
+      //  per step, yet 3-9 % slower: profiles/r02l_multistep_register_pressure_ab.txt)
       float w[6];
       jt_times<NP>(jac, tens, w);
       w[0] = a.fgx - w[0];

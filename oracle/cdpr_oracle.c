@@ -827,7 +827,7 @@ static void robot_step(const orc_sim *s, orc_robot *r, uint64_t k, int publish) 
     for (int a = 0; a < 3; ++a) aw[a] = rm[3 * a] * ab[0] + rm[3 * a + 1] * ab[1] + rm[3 * a + 2] * ab[2];
     for (int a = 0; a < 3; ++a) om[a] += cfg->dt * aw[a];
   } else {
-    /* Lumped legs ([EXT] -> reduced).  Leg i turns about its frame anchor with angular velocity
+    /* Lumped legs ([EXT] -> reduced, HISTORY.md section 1).  Leg i turns about its frame anchor with angular velocity
      * (u x vP)/L, vP = v + omega x rb the velocity of its platform anchor.  Massless-leg torque balance gives the force
      * the passive joint dampers put on the platform at the anchor, Fd = -(c/L) (2 vt/L - omega x u), vt the part of vP
      * across the cable, plus the spherical joint's torque c ((u x vP)/L - omega).  The links' inertia appears at the

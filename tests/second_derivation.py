@@ -174,7 +174,7 @@ def world_step(model, dt, gravity, p, rot, v, w, tension_axial, u, rb):
 
 def lumped_leg_terms(model, p, rot, v, w, frame_anchors, platform_anchors):
     """The lumped legs from ENERGY functions instead of force balances (the oracle and the kernels use closed-form
-    forces and a closed-form mass matrix): kinetic energy T(xi) and Rayleigh dissipation D(xi) of
+    forces and a closed-form mass matrix, HISTORY.md section 1): kinetic energy T(xi) and Rayleigh dissipation D(xi) of
     the leg links and passive joint dampers as quadratic functions of the platform twist xi = [v; omega] at the current
     pose; the added mass matrix is the Hessian of T, the damper wrench is -grad D, both by central differences (exact
     for quadratics).  Leg i turns about its frame anchor with angular velocity (u x vP)/L, vP = v + omega x rb."""
