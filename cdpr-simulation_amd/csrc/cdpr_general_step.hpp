@@ -58,6 +58,7 @@ namespace cdpr {
 constexpr int kGenMaxBuf = 32;   // CDPR_MAX_D_BUFFER
 constexpr int kGenMaxDeg = 4;    // CDPR_MAX_D_DEGREE
 constexpr int kGenMaxCas = 4;    // CDPR_MAX_CASCADE
+constexpr int kGenQueueWords = 4 + 4 * 64;  // a wave's fit-queue counter, then four rows of 64 words (gen_controller, tier 1)
 
 struct GenLayout {
   int n, nb, ncas;  // cables, longest window of the two Pids, deepest cascade
@@ -330,12 +331,200 @@ struct GenCtlConst {
 #define GEN_CTL_STAMP(i) do { } while (0)
 #define GEN_PHASE_STAMP(i) CDPR_STAMP(i)
 #endif
+// diagnostic build with -DCDPR_STAMPS_COLD (scripts/stamp_probe_cold.py): the rare paths' own timeline and queue length, in a
+// second block of eight words per workgroup behind the phase stamps
+#if defined(CDPR_STAMPS) && defined(CDPR_STAMPS_COLD)
+#define GEN_COLD_STAMP(i, v)                                                                  \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if (kc.stamps && lane == 0) kc.stamps[i] = (v);                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  } while (0)
+#else
+#define GEN_COLD_STAMP(i, v) do { } while (0)
+#endif
 struct GenDbg {
   float p, i, d, des;
   bool pi, dw;
 };
-// STEADY_ONLY: only the steady-state branch is compiled (the lean role-split kernel inlines this much and calls
-// gen_controller_cold for the rest); returns false - having stored nothing - when the wave is not in the steady state.
+// Pid::update of every cable of a wave whose calls are all CONSECUTIVE (each Pid called one world step ago, mWasLastTime
+// set, no cascades, command clamp, iMin <= iMax, one window length for both Pids): ONE ring head for the whole wave (now
+// mod nbuf, a scalar), one row of weights, static LDS addresses; the table weighs the head slot with 0 and the new sample
+// enters the FIR from its register, so nothing is written to the staged window before it is read.  No stamp is stored:
+// the stamps of a run of consecutive steps are implied by mLastTime and `run` (lazy stamps, see the general loop).
+//   PASS 0  no cable waits for the fit (need == 0): everything is done here
+//   PASS 1  the cables of `need` (a per-lane mask) wait for the fit: their new error goes to the queue's error row
+//           (qrows + 64, at the item's index: qslot0 + its rank among the lane's items), H and force are left to pass 2
+//   PASS 2  the cables of `need` only, the derivative from the queue's result row (qrows + 128)
+// Arithmetic and its order are gen_finish's and the general loop's: the same bits on the same inputs.
+template <int N, int NBMAX, int PASS, int GWIDE = 4>
+CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, int mode, int now,
+                              const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)], const v2f (&qd)[cable_pairs(N)],
+                              const float4* cab, const float4 (&held4)[(N + 3) / 4], const float* wrot, const float4 (*ptab)[kGenPidFloats / 4],
+                              uint32_t need, uint32_t qslot0, float* qrows, float (&force)[N], float (&newpos)[N], GenDbg& dbg) {
+  constexpr int NV = gen_nv(NBMAX);
+  constexpr int NBP = gen_nbp(NBMAX);
+  constexpr int kCab = (NV + 1) * 64;
+  const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16;
+  const int nhead = kc.nm0, nbuf = kc.nbuf0;
+  const int q4 = nhead >> 2, qc = nhead & 3;
+  const uint32_t meta_lo = kGmWasLast | ((uint32_t)nhead << kGmHeadShift);
+  float4 w[NV];
+  if constexpr (PASS != 2) {
+    const float4* wr = reinterpret_cast<const float4*>(wrot + nhead * NBP);
+#pragma unroll
+    for (int s4 = 0; s4 < NV; ++s4) w[s4] = wr[s4];
+  }
+  // cables per group: 4 NV + 20 registers per cable; groups of 2 or 8 and no scheduling barrier between the groups were
+  // measured too (+-0.05 us: the phase is bound by the instruction count, ~2.5 ns per instruction of any kind)
+  constexpr int GW = (PASS == 2) ? 1 : ((NV > 3) ? 2 : GWIDE);
+  constexpr int G = (N < GW) ? N : GW;
+#pragma unroll
+  for (int b = 0; b < N; b += G) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (PASS == 0 && b == G) GEN_CTL_STAMP(2);
+    if constexpr (PASS == 2) {  // (wave-uniform) no lane waits for this cable's fit
+      if (__builtin_amdgcn_ballot_w64(((need >> b) & 1u) != 0u) == 0ull) continue;
+    }
+    float4 g0[G], g1[G], g2[G];  // kf kp ki kd | imax imin cmax cmin | nbuf . . 1/ki
+    float wn[G];
+    float4 v[G][NV], vs[G], hh[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int i = b + j;
+      if (i < N) {
+        hh[j] = cab[i * kCab + NV * 64 + lane];
+        const float4* pt = ptab[sel[i] ? 1 : 0];
+        g0[j] = pt[0], g1[j] = pt[1], g2[j] = pt[2], wn[j] = pt[5].w;
+        if constexpr (PASS != 2) {
+          const float4* cs = cab + i * kCab + lane;
+#pragma unroll
+          for (int s4 = 0; s4 < NV; ++s4) v[j][s4] = cs[s4 * 64];
+          vs[j] = cs[q4 * 64];  // the slot that takes the new sample
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const int i = b + j;
+      if (i < N) {
+        const float qi = (i & 1) ? q[i / 2].y : q[i / 2].x;
+        const float qdi = (i & 1) ? qd[i / 2].y : qd[i / 2].x;
+        const bool sv = sel[i] != 0;
+        const bool hold = (mode == 2) && !sv;
+        const float held = comp4(held4[i / 4], i % 4);
+        const float desired = hold ? held : target[i];  // JFC.cpp:81
+        if constexpr (PASS != 2) newpos[i] = hold ? held : qi;  // JFC.cpp:75,87
+        const float error = desired - ((mode == 2 && sv) ? qdi : qi);
+        const uint32_t va = col * 16u + (sv ? pid_a : 0u);
+        const int sa = L.block_a(0, i);
+        const uint32_t meta = __float_as_uint(hh[j].x);
+        const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
+        const int ncount = min(count + 1, nbuf);
+        const int nrun = (count > 0) ? min(run + 1, (int)kGmField) : 0;
+        const uint32_t nmeta = meta_lo | ((uint32_t)ncount << kGmCountShift) | ((uint32_t)nrun << kGmRunShift);
+        const bool waits = (PASS != 0) && ((need >> i) & 1u) != 0u;  // this lane's cable i goes through the fit queue
+        const uint32_t qslot = (PASS != 0) ? qslot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u)) : 0u;
+        const float prev_ierr = hh[j].z;
+        const float p_term = g0[j].y * error;
+        float ie = fmaf(kc.dt, error, prev_ierr);  // dt = one world step
+        const float i_term = g0[j].z * ie;
+        if (i == 0 && PASS != 2) dbg.p = p_term, dbg.i = i_term, dbg.des = desired, dbg.pi = true;
+        const float i_cl = __builtin_amdgcn_fmed3f(i_term, g1[j].y, g1[j].x);  // Pid.cpp:143-152 (iMin <= iMax here)
+        ie = (i_cl != i_term) ? i_cl * g2[j].w : ie;
+        float derived;
+        if constexpr (PASS != 2) {
+          float acc = 0.f;
+#pragma unroll
+          for (int s4 = 0; s4 < NV; ++s4)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (4 * s4 + k < NBMAX) acc = fmaf(comp4(w[s4], k), comp4(v[j][s4], k), acc);
+          acc = fmaf(wn[j], error, acc);
+          derived = (ncount >= nbuf) ? acc * kc.inv_dt : 0.f;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
+        } else {
+          derived = qrows[128 + (waits ? qslot : 0u)];
+        }
+        const float d_term = g0[j].w * derived;
+        if (i == 0) {
+          if constexpr (PASS == 0) dbg.d = d_term, dbg.dw = true;
+          if constexpr (PASS == 1) dbg.d = waits ? dbg.d : d_term, dbg.dw = !waits;
+          if constexpr (PASS == 2) dbg.d = waits ? d_term : dbg.d, dbg.dw = dbg.dw || waits;
+        }
+        const float cmd = ((g0[j].x * desired + p_term) + i_cl) + d_term;  // Pid.cpp:170
+        float out = __builtin_amdgcn_fmed3f(cmd, g1[j].w, g1[j].z);          // Pid.cpp:175-177 (cmdMin < cmdMax here)
+        const bool wind = out != cmd;                                         // Pid.cpp:181-184
+        ie = wind ? prev_ierr : ie;
+        out = wind ? fmaf(kc.dt * error, g0[j].z, out) : out;
+        if constexpr (PASS == 0) force[i] = out;
+        if constexpr (PASS == 1) force[i] = waits ? 0.f : out;
+        if constexpr (PASS == 2) force[i] = waits ? out : force[i];
+        if constexpr (PASS != 2) {
+          float4 o = vs[j];
+          o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
+          RB.store4_if(live, sa + q4, va, o);
+        }
+        if constexpr (PASS == 1) qrows[waits ? 64u + qslot : 192u + lane] = error;  // (no branch: a lane without an item writes its dump word)
+        const bool writes_h = (PASS == 0) ? live : ((PASS == 1) ? (live && !waits) : (live && waits));
+        RB.store4_if(writes_h, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// STEADY_ONLY: only the first branch is compiled (the lean role-split kernel inlines this much and leaves the rest to
+// gen_lean_cold_tail); returns false - having stored nothing - when the wave does not qualify for it.
+// Which branch of gen_controller serves this lane's cables (see there): `consec` - every cable calls a Pid that was called one
+// world step ago (mWasLastTime set, not Force mode); `simple` - and none of them needs the fit (a uniform or a filling window).
+template <int N, int NBMAX>
+CDPR_DEV void gen_consecutive_test(const GenCtlConst kc, const float4* cab, uint32_t lane, int mode, int now, bool& simple, bool& consec) {
+  constexpr int NV = gen_nv(NBMAX);
+  constexpr int kCab = (NV + 1) * 64;
+  simple = false, consec = false;
+  if (kc.simple_ok) {  // (scalar: no cascades, one window for both Pids, both with a command clamp and iMin <= iMax)
+    // all-integer, no per-cable lane masks: a sign bit collects "the window is full after this push and not a uniform grid",
+    // any bit collects "not called one step ago", an AND collects mWasLastTime
+    const int nbuf = kc.nbuf0;
+    int neg = 0;
+    uint32_t nz = (mode == 0) ? 1u : 0u, was = 1u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float2 ml = *reinterpret_cast<const float2*>(&cab[i * kCab + NV * 64 + lane]);
+      const uint32_t meta = __float_as_uint(ml.x);
+      const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
+      neg |= ~(count + 1 - nbuf) & (run + 2 - nbuf);
+      nz |= (uint32_t)(now - 1 - __float_as_int(ml.y));
+      was &= meta;
+    }
+    consec = (nz == 0u) && (was & 1u) != 0u;
+    simple = consec && (neg >= 0);
+  }
+}
+
+// gen_controller's first branch: every cable of the wave on a uniform or a filling window (gen_consecutive<0>), then
+// mLastPosition back.
+template <int N, int NBMAX, int GWIDE>
+CDPR_DEV void gen_steady(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, int mode, int now, const float (&target)[N],
+                         const int (&sel)[N], const v2f (&q)[cable_pairs(N)], const v2f (&qd)[cable_pairs(N)], const float4* cab, const float4* hold_slots,
+                         const float* wrot, const float4 (*ptab)[kGenPidFloats / 4], float (&force)[N], GenDbg& dbg) {
+  constexpr int LP = (N + 3) / 4;
+  float4 held4[LP];
+#pragma unroll
+  for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
+  float newpos[N];
+  GEN_CTL_STAMP(1);
+  gen_consecutive<N, NBMAX, 0, GWIDE>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, 0u, 0u, nullptr, force, newpos, dbg);
+  GEN_CTL_STAMP(3);
+#pragma unroll
+  for (int g4 = 0; g4 < LP; ++g4)
+    RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
+                                                  (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
+}
+
+#ifndef CDPR_LEAN_GROUP
+#define CDPR_LEAN_GROUP 2  // cables per group in the branch the lean role-split kernel inlines (register pressure: 32 registers per cable of a group)
+#endif
 template <int N, int NBMAX, bool STEADY_ONLY = false>
 CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, uint32_t first_unit,
                              uint32_t units, int mode, int now, const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)],
@@ -358,134 +547,123 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
   float newpos[N];
 
-  // ---- the steady state, decided for the whole wave: every cable of every robot calls a Pid that was called one world step
-  //      ago and whose window is a full uniform grid, no cascades, a command clamp - what a handle does on all steps but the
-  //      dozen after a mode change or a switch between the two Pids of a hold-branch cable.  Then Pid::update is the fast
-  //      path's arithmetic (Pid.cpp:128-186 with derive() as the closed-form FIR) plus the ring bookkeeping, without any of
-  //      the per-lane case selection below: ~95 instructions of all kinds per cable (46 of them the Pid's own vector
-  //      arithmetic) instead of ~300.
+  // ---- consecutive calls, decided for the whole wave: every cable of every robot calls a Pid that was called one world step
+  //      ago, no cascades, a command clamp - what a handle does on all steps but the one of a mode change or of a switch
+  //      between the two Pids of a hold-branch cable.  Then Pid::update is the fast path's arithmetic (Pid.cpp:128-186) plus the
+  //      ring bookkeeping, without any of the per-lane case selection of the general loop below: ~100 instructions of all
+  //      kinds per cable instead of ~300.  The derivative of a cable is then one of three things:
+  //        S  a full window on a uniform grid: the closed-form FIR;
+  //        F  a window that is still filling (count + 1 < nbuf): 0, as derive() returns it (Pid.cpp:200-203);
+  //        Q  a full window with a gap in it (the nbuf - 1 steps after a switch between the two Pids): the least-squares fit
+  //           on the real stamps, through the wave's fit queue.
+  //      Waves with S and F cables only take the first branch below (gen_consecutive<0>: the lean role-split kernel inlines
+  //      this much); waves with some Q cable the second one (tier 1).
   // (a single wave per SIMD hides nothing: every dependent LDS round trip costs ~50 ns, so the reads of a phase are issued
   //  for a group of cables together and the group then pays the latency once)
-  bool simple = false;
-  if (kc.simple_ok) {  // (scalar: no cascades, one window for both Pids, both with a command clamp and iMin <= iMax)
-    // all-integer, no per-cable lane masks: sign bits collect "count < nbuf" and "run + 1 < nbuf - 1", any bit collects
-    // "not called one step ago", an AND collects mWasLastTime
-    const int nbuf = kc.nbuf0;
-    int neg = 0;
-    uint32_t nz = (mode == 0) ? 1u : 0u, was = 1u;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const float2 ml = *reinterpret_cast<const float2*>(&cab[i * kCab + NV * 64 + lane]);
-      const uint32_t meta = __float_as_uint(ml.x);
-      const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
-      neg |= (count - nbuf) | (run + 2 - nbuf);
-      nz |= (uint32_t)(now - 1 - __float_as_int(ml.y));
-      was &= meta;
-    }
-    simple = (neg >= 0) && (nz == 0u) && (was & 1u) != 0u;
-  }
+  bool simple = false, consec = false;
+  gen_consecutive_test<N, NBMAX>(kc, cab, lane, mode, now, simple, consec);
 #ifdef CDPR_EXPECT_STEADY  // build variant (scripts/build_variants.sh): the branch-layout hint; results must not depend on it
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(!simple) == 0ull, 1)) {
 #else
   if (__builtin_amdgcn_ballot_w64(!simple) == 0ull) {  // (wave-uniform)
 #endif
-    GEN_CTL_STAMP(1);
-    // same window for both Pids and consecutive steps everywhere: ONE ring head for the whole wave (now mod nbuf, a
-    // scalar), one row of weights, static LDS addresses; the table weighs the head slot with 0 and the new sample enters
-    // the FIR from its register, so nothing is written to the staged window before it is read
-    const int nhead = kc.nm0, nbuf = kc.nbuf0;
-    const int q4 = nhead >> 2, qc = nhead & 3;
-    const uint32_t meta_lo = kGmWasLast | ((uint32_t)nbuf << kGmCountShift) | ((uint32_t)nhead << kGmHeadShift);
-    float4 w[NV];
-    {
-      const float4* wr = reinterpret_cast<const float4*>(wrot + nhead * NBP);
-#pragma unroll
-      for (int s4 = 0; s4 < NV; ++s4) w[s4] = wr[s4];
-    }
-    // cables per group: 4 NV + 20 registers per cable; groups of 2 or 8 and no scheduling barrier between the groups were
-    // measured too (+-0.05 us: the phase is bound by the instruction count, ~2.5 ns per instruction of any kind)
-    constexpr int GW = (NV > 3) ? 2 : 4;
-    constexpr int G = (N < GW) ? N : GW;
-#pragma unroll
-    for (int b = 0; b < N; b += G) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (b == G) GEN_CTL_STAMP(2);
-      float4 g0[G], g1[G], g2[G];  // kf kp ki kd | imax imin cmax cmin | nbuf . . 1/ki
-      float wn[G];
-      float4 v[G][NV], vs[G], hh[G];
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int i = b + j;
-        if (i < N) {
-          hh[j] = cab[i * kCab + NV * 64 + lane];
-          const float4* pt = ptab[sel[i] ? 1 : 0];
-          g0[j] = pt[0], g1[j] = pt[1], g2[j] = pt[2], wn[j] = pt[5].w;
-          const float4* cs = cab + i * kCab + lane;
-#pragma unroll
-          for (int s4 = 0; s4 < NV; ++s4) v[j][s4] = cs[s4 * 64];
-          vs[j] = cs[q4 * 64];  // the slot that takes the new sample
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < G; ++j) {
-        const int i = b + j;
-        if (i < N) {
-          const float qi = (i & 1) ? q[i / 2].y : q[i / 2].x;
-          const float qdi = (i & 1) ? qd[i / 2].y : qd[i / 2].x;
-          const bool sv = sel[i] != 0;
-          const bool hold = (mode == 2) && !sv;
-          const float held = comp4(held4[i / 4], i % 4);
-          const float desired = hold ? held : target[i];  // JFC.cpp:81
-          newpos[i] = hold ? held : qi;                    // JFC.cpp:75,87
-          const float error = desired - ((mode == 2 && sv) ? qdi : qi);
-          const uint32_t va = col * 16u + (sv ? pid_a : 0u);
-          const int sa = L.block_a(0, i);
-          const uint32_t meta = __float_as_uint(hh[j].x);
-          const int run = (int)((meta >> kGmRunShift) & kGmField);
-          const uint32_t nmeta = meta_lo | ((uint32_t)min(run + 1, (int)kGmField) << kGmRunShift);
-          const float prev_ierr = hh[j].z;
-          const float p_term = g0[j].y * error;
-          float ie = fmaf(kc.dt, error, prev_ierr);  // dt = one world step
-          const float i_term = g0[j].z * ie;
-          if (i == 0) dbg.p = p_term, dbg.i = i_term, dbg.des = desired, dbg.pi = true;
-          const float i_cl = __builtin_amdgcn_fmed3f(i_term, g1[j].y, g1[j].x);  // Pid.cpp:143-152 (iMin <= iMax here)
-          ie = (i_cl != i_term) ? i_cl * g2[j].w : ie;
-          float acc = 0.f;
-#pragma unroll
-          for (int s4 = 0; s4 < NV; ++s4)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              if (4 * s4 + k < NBMAX) acc = fmaf(comp4(w[s4], k), comp4(v[j][s4], k), acc);
-          acc = fmaf(wn[j], error, acc);
-          const float d_term = g0[j].w * (acc * kc.inv_dt);
-          if (i == 0) dbg.d = d_term, dbg.dw = true;
-          const float cmd = ((g0[j].x * desired + p_term) + i_cl) + d_term;  // Pid.cpp:170
-          float out = __builtin_amdgcn_fmed3f(cmd, g1[j].w, g1[j].z);          // Pid.cpp:175-177 (cmdMin < cmdMax here)
-          const bool wind = out != cmd;                                         // Pid.cpp:181-184
-          ie = wind ? prev_ierr : ie;
-          out = wind ? fmaf(kc.dt * error, g0[j].z, out) : out;
-          force[i] = out;
-          float4 o = vs[j];
-          o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
-          RB.store4_if(live, sa + q4, va, o);
-          // (no stamp store: the stamps of a run of consecutive steps are implied by mLastTime and `run`; the first call after
-          //  a gap writes them out - see "lazy stamps" below.  4 B per cable and step less, 32 of 1 216 B per robot-step)
-          RB.store4_if(live, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    GEN_CTL_STAMP(3);
-#pragma unroll
-    for (int g4 = 0; g4 < LP; ++g4)
-      RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
-                                                    (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
+    gen_steady<N, NBMAX, STEADY_ONLY ? CDPR_LEAN_GROUP : 4>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, hold_slots, wrot, ptab, force, dbg);
     return true;
   }
+  GEN_COLD_STAMP(0, __builtin_amdgcn_s_memrealtime());
   if constexpr (STEADY_ONLY) return false;
+
+  // ---- tier 1: consecutive calls everywhere and some windows with a gap in them (the nbuf - 1 steps after a switch between
+  //      the two Pids).  The queue is built FIRST, from the staged H slots alone, so that the stamps a fit needs - the only
+  //      thing it reads from memory: the window values are the owner's staged slots in LDS - are in flight under the
+  //      Pid arithmetic of the whole wave (gen_consecutive<1>); the waiting cables are finished after the fit by a second pass
+  //      over them alone (gen_consecutive<2>).  One pass of the queue (<= 64 items per wave); a wave with more takes the
+  //      general loop below.  `q_count` is followed by four rows of 64 words: items, new errors, results, dump words.
+  if (kc.simple_ok && __builtin_amdgcn_ballot_w64(!consec) == 0ull) {  // (wave-uniform)
+    uint32_t* const qitems = q_count + 4;
+    float* const qrows = reinterpret_cast<float*>(q_count + 4);
+    const int nbuf = kc.nbuf0, nhead = kc.nm0;
+    uint32_t need = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t meta = __float_as_uint(cabf[i * kCabF + NV * 256 + lane * 4]);
+      const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
+      need |= ((count + 1 >= nbuf) && (run + 2 < nbuf)) ? (1u << i) : 0u;
+    }
+    const uint32_t slot0 = __hip_atomic_fetch_add(q_count, (uint32_t)__builtin_popcount(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t meta = __float_as_uint(cabf[i * kCabF + NV * 256 + lane * 4]);
+      const uint32_t nrun = (uint32_t)min((int)((meta >> kGmRunShift) & kGmField) + 1, (int)kGmField);
+      const uint32_t sl = slot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u));
+      const bool has = ((need >> i) & 1u) != 0u && sl < 64u;
+      qitems[has ? sl : 192u + lane] = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | (nrun << 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t total = *q_count;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    *q_count = 0u;  // for the general loop or the next step (every lane writes the same word)
+    GEN_COLD_STAMP(4, (unsigned long long)total | (2ull << 32));
+    if (total <= 64u) {  // (wave-uniform)
+      const bool mine = lane < total;
+      const uint32_t it = qitems[mine ? lane : 0u];
+      const uint32_t ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u;
+      const int irun = (int)((it >> 16) & 63u);
+      const uint32_t ro = first_unit + ol;
+      const uint32_t ocol = (ro < units) ? ro : (units - 1u);
+      const uint32_t ob = ocol * 4u + (uint32_t)L.block_b(0, (int)ci) * RB.rs4 + (sp ? pid_b : 0u);
+      int t[NBMAX];
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
+      GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
+      gen_consecutive<N, NBMAX, 1>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      GEN_COLD_STAMP(2, __builtin_amdgcn_s_memrealtime());
+      const float e_new = qrows[64u + (mine ? lane : 0u)];
+      float y[NBMAX];
+#pragma unroll
+      for (int s4 = 0; s4 < NV; ++s4) {
+        const float4 v = cab[ci * kCab + s4 * 64 + ol];  // the owner's staged window
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * s4 + k < NBMAX) y[4 * s4 + k] = comp4(v, k);
+      }
+      const uint32_t hd = (uint32_t)nhead;
+      const uint32_t old = (hd + 1u == (uint32_t)nbuf) ? 0u : hd + 1u;  // the oldest sample sits right after the head
+      const int degree = __float_as_int(ptab[sp][5].z);
+      int t_old = now;
+#pragma unroll
+      for (int j = 0; j < NBMAX; ++j) {
+        y[j] = ((uint32_t)j == hd) ? e_new : ((j < nbuf) ? y[j] : 0.f);
+        int age = (int)hd - j;
+        age += (age < 0) ? nbuf : 0;
+        t[j] = (j >= nbuf) ? now : ((age <= irun) ? now - age : t[j]);
+        t_old = ((uint32_t)j == old) ? t[j] : t_old;
+      }
+      const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
+      qrows[mine ? 128u + lane : 192u + lane] = res;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      gen_consecutive<N, NBMAX, 2>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
+#pragma unroll
+      for (int g4 = 0; g4 < LP; ++g4)
+        RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
+                                                      (4 * g4 + 3 < N) ? newpos[4 * g4 + 3] : 0.f));
+      GEN_COLD_STAMP(3, __builtin_amdgcn_s_memrealtime());
+      return true;
+    }
+  }
 
   uint32_t need = 0u;  // cables whose derivative comes from the fit queue
   bool any_rot = false;  // some ring of this wave turned this step (wave-uniform)
+  GEN_COLD_STAMP(4, 0ull);
+  GEN_COLD_STAMP(2, 0ull);
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     __builtin_amdgcn_sched_barrier(0);  // one cable at a time: hoisting every cable's staged slots costs 128 registers (letting the
@@ -608,6 +786,7 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
   // mLastPosition of every cable back (whole slots: a held cable keeps what it had)
 #pragma unroll
   for (int g4 = 0; g4 < LP; ++g4)
@@ -639,6 +818,8 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const uint32_t total = *q_count;
+    GEN_COLD_STAMP(2, __builtin_amdgcn_s_memrealtime());
+    GEN_COLD_STAMP(4, (unsigned long long)total | (any_rot ? (1ull << 32) : 0ull));
     for (uint32_t first = 0; first < total; first += 64u) {  // (wave-uniform trip count)
       // every lane runs the fit - lanes past the end of the queue on a copy of item 0 - and only the result is predicated
       const uint32_t idx = first + lane;
@@ -698,58 +879,18 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       force[i] = queued ? out : force[i];
     }
   }
+  GEN_COLD_STAMP(3, __builtin_amdgcn_s_memrealtime());
   return true;
 }
 
-// The general controller's rare paths as a CALL: gen_controller with its ring rotation, fit queue and fp64 fit needs ~100
-// registers more than its steady-state branch, and inlined into a kernel that must fit two waves per SIMD (the lean
-// role-split kernel, cdpr_general_split.hpp) that pressure spills on the steady path too (224 B of scratch per lane, 81
-// spilled SGPRs: measured).  As a function of its own it gets its own register allocation; the caller's live registers go
-// to the stack around the call - on the steps that need it, not on the others.  Arguments travel by value (arrays by
-// reference would put the caller's copies into scratch for good); wave-uniform ones are made scalars again on entry
-// (a callee receives every argument in vector registers), LDS arrays come as their LDS addresses.
-template <int N>
-struct GenColdIn {
-  float target[N];
-  int sel[N];
-  v2f q[cable_pairs(N)], qd[cable_pairs(N)];
-};
-template <int N>
-struct GenColdOut {
-  float force[N];
-  GenDbg dbg;
-};
+// Helpers of the lean role-split kernel's cold tail (cdpr_general_split.hpp): a function called from a kernel receives every
+// argument in vector registers; wave-uniform ones are made scalars again, LDS objects travel as their LDS addresses.
 CDPR_DEV uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
 template <typename T>
 CDPR_DEV T* lds_pointer(uint32_t addr) { return (T*)(__attribute__((address_space(3))) T*)(uintptr_t)addr; }
 CDPR_DEV uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 CDPR_DEV int uni(int v) { return (int)__builtin_amdgcn_readfirstlane((uint32_t)v); }
 CDPR_DEV float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
-
-template <int N, int NBMAX>
-__device__ __attribute__((noinline)) GenColdOut<N> gen_controller_cold(GenCtlConst kc_v, uint64_t rec_v, uint32_t rstride_v, uint32_t rec_bytes_v, GenLayout L_v, uint32_t lane, bool live,
-                                                                         uint32_t col, uint32_t first_unit_v, uint32_t units_v, int mode, int now_v, GenColdIn<N> in, uint32_t lds_cab,
-                                                                         uint32_t lds_hold, uint32_t lds_wrot, uint32_t lds_ptab, uint32_t lds_qcount) {
-  GenCtlConst kc;
-  kc.pcas_max = uni(kc_v.pcas_max), kc.dcas_max = uni(kc_v.dcas_max), kc.dt = uni(kc_v.dt), kc.inv_dt = uni(kc_v.inv_dt);
-  kc.nm0 = uni(kc_v.nm0), kc.nm1 = uni(kc_v.nm1), kc.nbuf0 = uni(kc_v.nbuf0), kc.simple_ok = false;  // (the steady branch was the caller's)
-#ifdef CDPR_STAMPS
-  kc.stamps = nullptr;
-#endif
-  GenLayout L;
-  L.n = uni(L_v.n), L.nb = uni(L_v.nb), L.ncas = uni(L_v.ncas);
-  const uint64_t rec = ((uint64_t)uni((uint32_t)(rec_v >> 32)) << 32) | uni((uint32_t)rec_v);
-  const GenBuf RB = gen_buffer(reinterpret_cast<float*>(rec), uni(rstride_v), uni(rec_bytes_v), L);
-  GenColdOut<N> out;
-#pragma unroll
-  for (int i = 0; i < N; ++i) out.force[i] = 0.f;
-  out.dbg = GenDbg{0.f, 0.f, 0.f, 0.f, false, false};
-  gen_controller<N, NBMAX, false>(kc, RB, L, lane, live, col, uni(first_unit_v), uni(units_v), mode, uni(now_v), in.target, in.sel, in.q, in.qd,
-                                  lds_pointer<float4>(uni(lds_cab)), lds_pointer<const float4>(uni(lds_hold)), lds_pointer<const float>(uni(lds_wrot)),
-                                  reinterpret_cast<const float4(*)[kGenPidFloats / 4]>(lds_pointer<const float4>(uni(lds_ptab))), lds_pointer<uint32_t>(uni(lds_qcount)),
-                                  out.force, out.dbg);
-  return out;
-}
 
 // Issue the LDS-DMA of one wave's record slots for this step: per cable the selected Pid's NV value slots and H, plus the
 // hold-position slots.  `keep`: a value every ordinary load issued so far feeds (hipcc drains every outstanding VMEM
@@ -789,7 +930,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
   __shared__ __attribute__((aligned(16))) float wrot[2][NBMAX][NBP];
   __shared__ float4 stage[N][NV + 1][64];  // gen_controller's working set: the DMA-staged value slots and H of every cable
   __shared__ float4 hold_slots[LP][64];
-  __shared__ uint32_t q_count;
+  __shared__ uint32_t q_count[kGenQueueWords];
   __shared__ float4 ptab[2][kGenPidFloats / 4];
 
   const uint32_t lane = threadIdx.x;
@@ -852,7 +993,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
 #pragma unroll
   for (int j = 0; j < kWPass; ++j)
     if (lane + 64u * j < kW4) reinterpret_cast<float4*>(&wrot[0][0][0])[lane + 64u * j] = wv[j];
-  if (lane == 0) q_count = 0u;
+  if (lane == 0) q_count[0] = 0u;
   if (lane < 2 * kGenPidFloats) (&ptab[0][0].x)[lane] = pv;
 
   if (ROLLOUT) {
@@ -1022,7 +1163,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       cc.stamps = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
 #endif
       gen_controller<N, NBMAX>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &stage[0][0][0], &hold_slots[0][0],
-                               &wrot[0][0][0], ptab, &q_count, force, dbg);
+                               &wrot[0][0][0], ptab, q_count, force, dbg);
     }
     CDPR_STAMP(5);
     v2f f[NP];

@@ -776,6 +776,15 @@ CDPR_DEV void store_slot(float4* base, size_t stride, int slot, uint32_t off, co
 }
 
 // Row store with the cache policy as a template argument (experiments on single rows; see CDPR_STORE_AUX for the values)
+// store_slot for the lanes with `on` only, WITHOUT a branch: the row's buffer descriptor covers `stride` columns, an offset
+// of all ones fails its range check and the store is dropped.  (Where a divergent `if` around the stores would be the only
+// divergent branch of a region, LLVM structurizes the whole region because of it: see gen_lean_cold_tail.)
+CDPR_DEV void store_slot_if(bool on, float4* base, size_t stride, int slot, uint32_t off, const float4& v) {
+  const u32x4 d = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+                   __builtin_bit_cast(unsigned, v.w)};
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base + (size_t)slot * stride, 0, (int)(stride * sizeof(float4)), 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, on ? off : 0xFFFFFFFFu, 0, CDPR_STORE_AUX);
+}
 template <int AUX>
 CDPR_DEV void store_slot_aux(float4* base, size_t stride, int slot, uint32_t off, const float4& v) {
   if constexpr (AUX == 0) {
