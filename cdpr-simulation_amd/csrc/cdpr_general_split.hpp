@@ -262,8 +262,8 @@ __global__ __launch_bounds__(128, 1) void cdpr_gen_split_kernel(const StepArgs a
 // every other wave to gen_lean_cold_tail: a function with its own register allocation that FINISHES the controller wave's
 // work - general controller, hand-offs with the estimator wave, observables, world step, state - and ends the program.
 // It never returns, so nothing of the caller is saved around it, and it takes its few per-lane inputs in argument
-// registers (platform state, joint positions and rates: 30 VGPRs), reads the launch's arguments from the kernel-argument
-// segment itself and rebuilds the structure matrix behind the controller.  (First version of this round: an ordinary
+// registers (the platform state), joint positions, rates and the structure matrix through the lane's private memory, the
+// Joy targets and modes through LDS, and reads the launch's arguments from the kernel-argument segment itself.  (First version of this round: an ordinary
 // call, gen_controller_cold.  Its 75 argument words went through the stack, the caller saved 46 registers around it and
 // the callee's entry waits for vmcnt(0): 3.6 us on the way in and 1.4 - 2.7 us on the way out of a 5.6 us loop -
 // profiles/r05_cold_probe_before.txt.)  Two waves per SIMD fit, so at 65 536 robots a SIMD hosts an estimator wave and a
@@ -285,6 +285,8 @@ struct LeanShared {
   float4 ptab[2][kGenPidFloats / 4];
   uint32_t q_count[kGenQueueWords];
   float4 dump[64];  // where the lanes a predicated LDS store does not concern write (no divergent branch in the controller wave's prologue)
+  float4 tgt[2][64];  // the Joy targets of the wave's robots, for the cold tail (31 argument registers carry the state, q and qd)
+  int mode_row[64];   // and their modes (read from memory again, the tail's entry waits for every store in flight: vmcnt is one counter)
   // the hand-off buffers live in the staged record slots, which are done with when the controller returns
   static_assert(sizeof(float4) * N * (NV + 1) * 64 >= (2 * NP * 64) * sizeof(v2f) + 6 * 64 * sizeof(float), "hand-off buffers fit the staging area");
   CDPR_DEV v2f (*x_force())[64] { return reinterpret_cast<v2f(*)[64]>(&stage[0][0][0]); }
@@ -294,11 +296,12 @@ struct LeanShared {
 
 // What the controller wave does once the per-cable forces are known: forces to the estimator wave, observables, the
 // distributed tensions back, SetForce limits, world step, state.  Shared by the kernel and by gen_lean_cold_tail.
-// REBUILD: the structure matrix is not alive yet (the cold tail): built between the two barriers, while the estimator wave
-// runs the tension distribution.
+// REBUILD: the structure matrix is not in registers (the cold tail): read back from jac_src between the two barriers, while
+// the estimator wave runs the tension distribution.
 template <int N, bool REBUILD>
 CDPR_DEV void lean_controller_epilogue(const StepArgs& a, LeanShared<N>& sm, float* geo, uint32_t lane, uint32_t r, bool live, Platform s, const v2f (&q)[cable_pairs(N)],
-                                       const v2f (&qd)[cable_pairs(N)], v2f (&jac)[cable_pairs(N)][6], const float (&force)[N], const GenDbg dbg) {
+                                       const v2f (&qd)[cable_pairs(N)], v2f (&jac)[cable_pairs(N)][6], const float (&force)[N], const GenDbg dbg,
+                                       const float4* jac_src = nullptr) {
   constexpr int NP = cable_pairs(N);
   constexpr int G = joint_groups(N);
   const size_t st = a.stride;
@@ -331,9 +334,15 @@ CDPR_DEV void lean_controller_epilogue(const StepArgs& a, LeanShared<N>& sm, flo
       store_slot_if(live, obs, st, 4 + G + gI, woff, make_float4(qd[k0].x, qd[k0].y, has ? qd[k1].x : 0.f, has ? qd[k1].y : 0.f));
     }
   }
-  if constexpr (REBUILD) {
-    v2f len2[NP], l02[NP];
-    ik_pairs<N, true>(geo, s.px, s.py, s.pz, s.qx, s.qy, s.qz, s.qw, len2, jac, l02);
+  if constexpr (REBUILD) {  // the cold tail: the structure matrix comes back from the kernel's spill buffer (see gen_lean_cold_tail)
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) {
+        const float4 v = jac_src[(k * 6 + c) / 2];
+        jac[k][c] = (v2f){v.x, v.y};
+        jac[k][c + 1] = (v2f){v.z, v.w};
+      }
   }
   __builtin_amdgcn_s_barrier();        // #2: the estimator wave has finished the tension distribution
   CDPR_CTL_STAMP(5);
@@ -443,19 +452,19 @@ struct LeanKernArgs {
 //  prologue without a single divergent branch: predicated LDS stores go to dump words, loads to clamped addresses.)
 #define CDPR_LEAN_TAIL_ATTR __device__ __attribute__((noinline, noreturn))
 template <int N>
-CDPR_LEAN_TAIL_ATTR void gen_lean_cold_tail(lean_f4 s0, lean_f4 s1, lean_f4 s2, float s_wz, lean_f4 qa, lean_f4 qb, lean_f4 qda, lean_f4 qdb,
-                                                                        uint32_t sm_and_ka_hi, uint32_t ka_lo) {
+CDPR_LEAN_TAIL_ATTR void gen_lean_cold_tail(lean_f4 s0, lean_f4 s1, lean_f4 s2, float s_wz, const float4* spill, uint32_t sm_and_ka_hi, uint32_t ka_lo) {
   constexpr int NBMAX = 11;
   constexpr int NP = cable_pairs(N);
-  static_assert(N <= 8, "joint positions and rates travel in four float4 arguments");
   // (the kernel hands its kernel-argument segment over: __builtin_amdgcn_kernarg_segment_ptr() is null inside a function.  The
   //  cast to a generic pointer is undone by LLVM's address-space inference: the fields are read with scalar loads from the
   //  constant address space where they are used)
   const __attribute__((address_space(4))) void* const kap = (const __attribute__((address_space(4))) void*)(((uint64_t)(uni(sm_and_ka_hi) >> 16) << 32) | uni(ka_lo));
   const uint32_t sm_addr = sm_and_ka_hi & 0xFFFFu;  // (31 argument registers: the LDS address and the upper 16 bits of a 48-bit address share one)
   const LeanKernArgs& ka = *(const LeanKernArgs*)(const void*)kap;
-  const StepArgs& a = ka.a;
-  const GenCtl& g = ka.g;
+  // (copies: read through references the fields are loaded again at every use - eight scalar loads of velocityEpsilon, each
+  //  with its own wait, in front of the controller)
+  const StepArgs a = ka.a;
+  const GenCtl g = ka.g;
   LeanShared<N>& sm = *lds_pointer<LeanShared<N>>(uni(sm_addr));
   const uint32_t lane = threadIdx.x & 63u;
 #if defined(CDPR_STAMPS) && defined(CDPR_STAMPS_COLD)
@@ -469,19 +478,25 @@ CDPR_LEAN_TAIL_ATTR void gen_lean_cold_tail(lean_f4 s0, lean_f4 s1, lean_f4 s2, 
   GenLayout L;
   L.n = g.lay.n, L.nb = g.lay.nb, L.ncas = g.lay.ncas;
   const GenBuf RB = gen_buffer(g.rec, g.rstride, g.rec_bytes, L);
-  const int mode = g.mode_arr ? (int)g.mode_arr[rr] : g.mode;
+  const int mode = sm.mode_row[lane];
   float target[N];
-  lean_load_targets<N>(g, rr, mode, target);
+  {
+    const float4 ta = sm.tgt[0][lane], tb = sm.tgt[N > 4 ? 1 : 0][lane];
+    const float tv[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+    for (int i = 0; i < N; ++i) target[i] = tv[i];
+  }
   Platform s;
   s.px = s0.x; s.py = s0.y; s.pz = s0.z; s.qx = s0.w;
   s.qy = s1.x; s.qz = s1.y; s.qw = s1.z; s.vx = s1.w;
   s.vy = s2.x; s.vz = s2.y; s.wx = s2.z; s.wy = s2.w;
   s.wz = s_wz;
-  v2f q[NP], qd[NP];
-  {
-    const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w}, qdv[8] = {qda.x, qda.y, qda.z, qda.w, qdb.x, qdb.y, qdb.z, qdb.w};
+  v2f q[NP], qd[NP];  // pairs 2k, 2k+1 of q in spill[k / 2], of qd behind them, then the structure matrix (LeanSpill)
 #pragma unroll
-    for (int k = 0; k < NP; ++k) q[k] = (v2f){qv[2 * k], qv[2 * k + 1]}, qd[k] = (v2f){qdv[2 * k], qdv[2 * k + 1]};
+  for (int k = 0; k < NP; k += 2) {
+    const float4 a4 = spill[k / 2], b4 = spill[(NP + 1) / 2 + k / 2];
+    q[k] = (v2f){a4.x, a4.y}, qd[k] = (v2f){b4.x, b4.y};
+    if (k + 1 < NP) q[k + 1] = (v2f){a4.z, a4.w}, qd[k + 1] = (v2f){b4.z, b4.w};
   }
   const int now = g.now_step;
   int sel[N];
@@ -513,7 +528,7 @@ CDPR_LEAN_TAIL_ATTR void gen_lean_cold_tail(lean_f4 s0, lean_f4 s1, lean_f4 s2, 
   gen_controller<N, NBMAX, false>(cc, RB, L, lane, live, rr, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &sm.stage[0][0][0], &sm.hold_slots[0][0],
                                   &sm.wrot[0][0][0], sm.ptab, sm.q_count, force, dbg);
   v2f jac[NP][6];
-  lean_controller_epilogue<N, true>(a, sm, geo, lane, r, live, s, q, qd, jac, force, dbg);
+  lean_controller_epilogue<N, true>(a, sm, geo, lane, r, live, s, q, qd, jac, force, dbg, spill + 2 * ((NP + 1) / 2));
   // (as an instruction the compiler does not know: behind __builtin_amdgcn_endpgm it restores every callee-saved register it
   //  saved on entry first - a hundred loads nobody reads.  The function's own epilogue behind it is never executed.)
   asm volatile("s_endpgm");
@@ -561,6 +576,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   const int mode = g.mode_arr ? (int)g.mode_arr[rr] : g.mode;
   float target[N];
   lean_load_targets<N>(g, rr, mode, target);
+  sm.mode_row[lane] = mode;
+  sm.tgt[0][lane] = make_float4(target[0], (1 < N) ? target[1 < N ? 1 : 0] : 0.f, (2 < N) ? target[2 < N ? 2 : 0] : 0.f, (3 < N) ? target[3 < N ? 3 : 0] : 0.f);
+  if (N > 4) sm.tgt[1][lane] = make_float4(target[4 < N ? 4 : 0], (5 < N) ? target[5 < N ? 5 : 0] : 0.f, (6 < N) ? target[6 < N ? 6 : 0] : 0.f, (7 < N) ? target[7 < N ? 7 : 0] : 0.f);
   float* const dumpf = &sm.dump[0].x;
   *((lane < NP * kGeomFloatsPerPair) ? geo + lane : dumpf + lane) = gval;
 #pragma unroll
@@ -621,23 +639,40 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
 #ifdef CDPR_STAMPS
   cc.stamps = nullptr;
 #endif
-  bool simple, consec;
-  gen_consecutive_test<N, NBMAX>(cc, &sm.stage[0][0][0], lane, mode, now, simple, consec);
-  if (__builtin_amdgcn_ballot_w64(!simple) != 0ull) {  // (wave-uniform) the rare paths finish this wave's work in a function of their own and end the program there
-    const uint64_t kaddr = (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
-    float qv[8], qdv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      qv[i] = (i < N) ? ((i & 1) ? q[i / 2].y : q[i / 2].x) : 0.f;
-      qdv[i] = (i < N) ? ((i & 1) ? qd[i / 2].y : qd[i / 2].x) : 0.f;
-    }
-    gen_lean_cold_tail<N>((lean_f4){s.px, s.py, s.pz, s.qx}, (lean_f4){s.qy, s.qz, s.qw, s.vx}, (lean_f4){s.vy, s.vz, s.wx, s.wy}, s.wz,
-                          (lean_f4){qv[0], qv[1], qv[2], qv[3]}, (lean_f4){qv[4], qv[5], qv[6], qv[7]}, (lean_f4){qdv[0], qdv[1], qdv[2], qdv[3]},
-                          (lean_f4){qdv[4], qdv[5], qdv[6], qdv[7]}, lds_address(&sm) | ((uint32_t)(kaddr >> 32) << 16), (uint32_t)kaddr);
+  bool simple, fast, gaps;
+  gen_consecutive_test<N, NBMAX>(cc, &sm.stage[0][0][0], lane, mode, now, simple, fast, gaps);
+  // Two `if`s in sequence on the same wave-uniform decision, the second through a scalar the compiler cannot see through.  As ONE
+  // if / else LLVM's structurizer puts the call block FIRST and lets it flow into the block in front of the inlined branch:
+  // everything that branch and the epilogue read is then live across the call, the call block saves it (33 stores, 60
+  // v_writelane) and the tail's entry - s_waitcnt vmcnt(0) by the calling convention - waits for those stores.  Behind the
+  // inlined branch nothing is live any more but the tail's own arguments.
+  uint32_t cold = (__builtin_amdgcn_ballot_w64(!simple) != 0ull) ? 1u : 0u;
+  if (cold == 0u) {  // every cable on a uniform or a filling window: the first branch of gen_controller, inline
+    gen_steady<N, NBMAX, CDPR_LEAN_GROUP>(cc, RB, L, lane, live, col, mode, now, target, sel, q, qd, &sm.stage[0][0][0], &sm.hold_slots[0][0], &sm.wrot[0][0][0], sm.ptab,
+                                         force, dbg);
+    lean_controller_epilogue<N, false>(a, sm, geo, lane, r, live, s, q, qd, jac, force, dbg);
   }
-  gen_steady<N, NBMAX, CDPR_LEAN_GROUP>(cc, RB, L, lane, live, col, mode, now, target, sel, q, qd, &sm.stage[0][0][0], &sm.hold_slots[0][0], &sm.wrot[0][0][0], sm.ptab,
-                                       force, dbg);
-  lean_controller_epilogue<N, false>(a, sm, geo, lane, r, live, s, q, qd, jac, force, dbg);
+  cold = __builtin_amdgcn_readfirstlane(cold);
+  asm volatile("" : "+s"(cold));
+  if (cold != 0u) {  // the other paths finish this wave's work in a function of their own and end the program there
+    const uint64_t kaddr = (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
+    // q, qd and the structure matrix travel through the lane's private memory (a stack object of this kernel that only this
+    // block touches): the tail reads q and qd on entry and the matrix between the two barriers - rebuilding it there costs
+    // ~750 instructions the instruction cache has never seen (a wave alone on code runs at ~12 ns per instruction)
+    float4 spill[2 * ((NP + 1) / 2) + 3 * NP];
+#pragma unroll
+    for (int k = 0; k < NP; k += 2) {
+      const v2f qz = (k + 1 < NP) ? q[k + 1 < NP ? k + 1 : k] : (v2f){0.f, 0.f}, qdz = (k + 1 < NP) ? qd[k + 1 < NP ? k + 1 : k] : (v2f){0.f, 0.f};
+      spill[k / 2] = make_float4(q[k].x, q[k].y, qz.x, qz.y);
+      spill[(NP + 1) / 2 + k / 2] = make_float4(qd[k].x, qd[k].y, qdz.x, qdz.y);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) spill[2 * ((NP + 1) / 2) + (k * 6 + c) / 2] = make_float4(jac[k][c].x, jac[k][c].y, jac[k][c + 1].x, jac[k][c + 1].y);
+    gen_lean_cold_tail<N>((lean_f4){s.px, s.py, s.pz, s.qx}, (lean_f4){s.qy, s.qz, s.qw, s.vx}, (lean_f4){s.vy, s.vz, s.wx, s.wy}, s.wz, spill,
+                          lds_address(&sm) | ((uint32_t)(kaddr >> 32) << 16), (uint32_t)kaddr);
+  }
 }
 
 }  // namespace cdpr

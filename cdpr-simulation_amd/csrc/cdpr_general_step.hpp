@@ -179,56 +179,62 @@ CDPR_DEV GenBuf gen_buffer(float* rec, uint32_t rstride, uint32_t rec_bytes, con
 // alpha_k = sum x p_k^2 / sum p_k^2, beta_k = sum p_k^2 / sum p_{k-1}^2, fit = sum c_k p_k with c_k = sum y p_k / sum p_k^2.
 // Abscissae x_j = (t_j - t_new) / h, h = mean spacing: integers before the division, so exact for any stamps.
 // Returns d/dt in 1 / world steps (the caller divides by the step length).  Slots j >= nb are ignored.
+// STREAMING form (round 5): the polynomials' values on the sample points are not kept in arrays (2 x NBMAX doubles: 44
+// registers at the shipped window) but re-evaluated from the recurrence coefficients found so far - one pass over the
+// samples per degree, which yields sum p^2, sum y p and the next sum x p^2 together; one division per degree (1 / sum p^2
+// serves c_k, then alpha and beta of the next degree).  ~40 registers instead of ~110: the fit runs inside the kernels'
+// inlined controller branch; ~260 fp64 instructions at 11 samples, degree 2 (the array form: ~500, three divisions per degree).
 template <int NBMAX>
 CDPR_DEV double gen_fit(const float (&y)[NBMAX], const int (&t)[NBMAX], int nb, int degree, int t_new, int t_old) {
   double h = (double)(t_new - t_old) / (double)(nb - 1);
   if (!(h > 0.0)) h = 1.0;
   const double inv_h = 1.0 / h;
-  double pp[NBMAX], pc[NBMAX];  // p_{k-1}, p_k on the sample points
-  double sc = 0.0;              // sum p_k^2
+  int dx[NBMAX];  // stamps relative to the newest one (exact)
 #pragma unroll
-  for (int j = 0; j < NBMAX; ++j) {
-    pp[j] = 0.0;
-    pc[j] = (j < nb) ? 1.0 : 0.0;
-    sc += pc[j];
-  }
-  double sp = 1.0, beta = 0.0;
+  for (int j = 0; j < NBMAX; ++j) dx[j] = t[j] - t_new;
+  double sx = 0.0;  // sum x p_0^2
+#pragma unroll
+  for (int j = 0; j < NBMAX; ++j) sx += (j < nb) ? (double)dx[j] * inv_h : 0.0;
+  double r = 1.0 / (double)nb;  // 1 / sum p_k^2
+  double alpha[kGenMaxDeg], beta[kGenMaxDeg];
+  double bk = 0.0;            // beta_k
   double vp = 0.0, vc = 1.0;  // p_{k-1}(0), p_k(0): the newest stamp is x = 0
   double dp = 0.0, dc = 0.0;  // their derivatives at 0
   double deriv = 0.0;
 #pragma unroll
   for (int k = 0; k < kGenMaxDeg; ++k) {
     if (k < degree) {
-      double sx = 0.0;
+      alpha[k] = sx * r;
+      beta[k] = bk;
+      double sn = 0.0, bn = 0.0, sxn = 0.0;
 #pragma unroll
       for (int j = 0; j < NBMAX; ++j) {
-        const double x = (double)(t[j] - t_new) * inv_h;
-        sx = fma(x * pc[j], pc[j], sx);
-      }
-      const double alpha = sx / sc;
-      double sn = 0.0, bn = 0.0;
+        const double x = (double)dx[j] * inv_h;
+        double qm = 0.0, qc = 1.0;  // p_{i-1}(x), p_i(x)
 #pragma unroll
-      for (int j = 0; j < NBMAX; ++j) {
-        const double x = (double)(t[j] - t_new) * inv_h;
-        const double pn = (j < nb) ? fma(x - alpha, pc[j], -(beta * pp[j])) : 0.0;
-        pp[j] = pc[j];
-        pc[j] = pn;
+        for (int i = 0; i <= k; ++i) {
+          const double qn = fma(x - alpha[i], qc, -(beta[i] * qm));
+          qm = qc;
+          qc = qn;
+        }
+        const double pn = (j < nb) ? qc : 0.0;
         sn = fma(pn, pn, sn);
         bn = fma((double)y[j], pn, bn);
+        sxn = fma(x * pn, pn, sxn);
       }
-      const double vn = fma(-alpha, vc, -(beta * vp));
-      const double dn = vc + fma(-alpha, dc, -(beta * dp));
+      const double vn = fma(-alpha[k], vc, -(bk * vp));
+      const double dn = vc + fma(-alpha[k], dc, -(bk * dp));
       vp = vc;
       vc = vn;
       dp = dc;
       dc = dn;
-      deriv = fma(bn / sn, dn, deriv);
-      beta = sn / sc;
-      sp = sc;
-      sc = sn;
+      const double rn = 1.0 / sn;
+      deriv = fma(bn * rn, dn, deriv);
+      bk = sn * r;
+      r = rn;
+      sx = sxn;
     }
   }
-  (void)sp;
   return deriv * inv_h;
 }
 
@@ -356,8 +362,11 @@ struct GenDbg {
 //   PASS 1  the cables of `need` (a per-lane mask) wait for the fit: their new error goes to the queue's error row
 //           (qrows + 64, at the item's index: qslot0 + its rank among the lane's items), H and force are left to pass 2
 //   PASS 2  the cables of `need` only, the derivative from the queue's result row (qrows + 128)
+// GAPS (passes 1 and 2): some lane's Pid was NOT called one world step ago (the first call after a switch between the two Pids
+// of a hold-branch cable): its integrator step is now - mLastTime, its run of consecutive calls starts again at 0 - and its
+// ring has been turned already (gen_turn_rings) so that the wave's one ring head is this lane's head as well.
 // Arithmetic and its order are gen_finish's and the general loop's: the same bits on the same inputs.
-template <int N, int NBMAX, int PASS, int GWIDE = 4>
+template <int N, int NBMAX, int PASS, int GWIDE = 4, bool GAPS = false>
 CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, int mode, int now,
                               const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)], const v2f (&qd)[cable_pairs(N)],
                               const float4* cab, const float4 (&held4)[(N + 3) / 4], const float* wrot, const float4 (*ptab)[kGenPidFloats / 4],
@@ -421,15 +430,18 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
         const uint32_t meta = __float_as_uint(hh[j].x);
         const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
         const int ncount = min(count + 1, nbuf);
-        const int nrun = (count > 0) ? min(run + 1, (int)kGmField) : 0;
-        const uint32_t nmeta = meta_lo | ((uint32_t)ncount << kGmCountShift) | ((uint32_t)nrun << kGmRunShift);
+        const int since = GAPS ? now - __float_as_int(hh[j].y) : 1;  // world steps since this Pid's last call
+        const float dt = GAPS ? (float)since * kc.dt : kc.dt;          // (one step: the same bits)
+        const int nrun = (count > 0 && since == 1) ? min(run + 1, (int)kGmField) : 0;
+        const bool first = GAPS && !(meta & kGmWasLast);  // Pid.cpp:123-126: the first call since reset returns 0 and takes no sample
+        const uint32_t nmeta = first ? (meta | kGmWasLast) : (meta_lo | ((uint32_t)ncount << kGmCountShift) | ((uint32_t)nrun << kGmRunShift));
         const bool waits = (PASS != 0) && ((need >> i) & 1u) != 0u;  // this lane's cable i goes through the fit queue
         const uint32_t qslot = (PASS != 0) ? qslot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u)) : 0u;
         const float prev_ierr = hh[j].z;
         const float p_term = g0[j].y * error;
-        float ie = fmaf(kc.dt, error, prev_ierr);  // dt = one world step
+        float ie = fmaf(dt, error, prev_ierr);
         const float i_term = g0[j].z * ie;
-        if (i == 0 && PASS != 2) dbg.p = p_term, dbg.i = i_term, dbg.des = desired, dbg.pi = true;
+        if (i == 0 && PASS != 2) dbg.p = first ? dbg.p : p_term, dbg.i = first ? dbg.i : i_term, dbg.des = first ? dbg.des : desired, dbg.pi = !first;
         const float i_cl = __builtin_amdgcn_fmed3f(i_term, g1[j].y, g1[j].x);  // Pid.cpp:143-152 (iMin <= iMax here)
         ie = (i_cl != i_term) ? i_cl * g2[j].w : ie;
         float derived;
@@ -448,21 +460,25 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
         const float d_term = g0[j].w * derived;
         if (i == 0) {
           if constexpr (PASS == 0) dbg.d = d_term, dbg.dw = true;
-          if constexpr (PASS == 1) dbg.d = waits ? dbg.d : d_term, dbg.dw = !waits;
+          if constexpr (PASS == 1) dbg.d = (waits || first) ? dbg.d : d_term, dbg.dw = !waits && !first;
           if constexpr (PASS == 2) dbg.d = waits ? d_term : dbg.d, dbg.dw = dbg.dw || waits;
         }
         const float cmd = ((g0[j].x * desired + p_term) + i_cl) + d_term;  // Pid.cpp:170
         float out = __builtin_amdgcn_fmed3f(cmd, g1[j].w, g1[j].z);          // Pid.cpp:175-177 (cmdMin < cmdMax here)
         const bool wind = out != cmd;                                         // Pid.cpp:181-184
         ie = wind ? prev_ierr : ie;
-        out = wind ? fmaf(kc.dt * error, g0[j].z, out) : out;
+        out = wind ? fmaf(dt * error, g0[j].z, out) : out;
+        if constexpr (GAPS) {  // the first call: H = (meta | 1, now, mIerr as it was, the clamp of 0), no force (as the general loop leaves it)
+          ie = first ? prev_ierr : ie;
+          out = first ? __builtin_amdgcn_fmed3f(0.f, g1[j].w, g1[j].z) : out;
+        }
         if constexpr (PASS == 0) force[i] = out;
-        if constexpr (PASS == 1) force[i] = waits ? 0.f : out;
+        if constexpr (PASS == 1) force[i] = (waits || first) ? 0.f : out;
         if constexpr (PASS == 2) force[i] = waits ? out : force[i];
         if constexpr (PASS != 2) {
           float4 o = vs[j];
           o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
-          RB.store4_if(live, sa + q4, va, o);
+          RB.store4_if(live && !first, sa + q4, va, o);
         }
         if constexpr (PASS == 1) qrows[waits ? 64u + qslot : 192u + lane] = error;  // (no branch: a lane without an item writes its dump word)
         const bool writes_h = (PASS == 0) ? live : ((PASS == 1) ? (live && !waits) : (live && waits));
@@ -473,32 +489,95 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// TIER1 = false: the second branch (tier 1) is left out - inlined into the one-wave kernels it doubles the time of their first
+// branch (12.7 -> 27.1 us at 16 384 x 8, steady: scripts/one_wave_ab.py), so those go from the first branch to the general loop.
 // STEADY_ONLY: only the first branch is compiled (the lean role-split kernel inlines this much and leaves the rest to
 // gen_lean_cold_tail); returns false - having stored nothing - when the wave does not qualify for it.
-// Which branch of gen_controller serves this lane's cables (see there): `consec` - every cable calls a Pid that was called one
-// world step ago (mWasLastTime set, not Force mode); `simple` - and none of them needs the fit (a uniform or a filling window).
+// Which branch of gen_controller serves this lane's cables (see there):
+//   `simple`  every cable calls a Pid that was called one world step ago (mWasLastTime set, not Force mode) and none of them
+//             needs the fit (a uniform or a filling window): the first branch;
+//   `fast`    not Force mode, and where a cable's Pid was not called one step ago the stamps of its window are all implied
+//             (run + 1 >= count: no earlier gap in the window): the second branch (tier 1) serves it;
+//   `gaps`    some cable of this lane was not called one step ago, or never since its reset.
 template <int N, int NBMAX>
-CDPR_DEV void gen_consecutive_test(const GenCtlConst kc, const float4* cab, uint32_t lane, int mode, int now, bool& simple, bool& consec) {
+CDPR_DEV void gen_consecutive_test(const GenCtlConst kc, const float4* cab, uint32_t lane, int mode, int now, bool& simple, bool& fast, bool& gaps) {
   constexpr int NV = gen_nv(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
-  simple = false, consec = false;
+  simple = false, fast = false, gaps = false;
   if (kc.simple_ok) {  // (scalar: no cascades, one window for both Pids, both with a command clamp and iMin <= iMax)
-    // all-integer, no per-cable lane masks: a sign bit collects "the window is full after this push and not a uniform grid",
-    // any bit collects "not called one step ago", an AND collects mWasLastTime
+    // all-integer, no per-cable lane masks: sign bits collect "the window is full after this push and not a uniform grid" and
+    // "a gap now and an earlier one in the window", any bit collects "not called one step ago", an AND collects mWasLastTime
     const int nbuf = kc.nbuf0;
-    int neg = 0;
-    uint32_t nz = (mode == 0) ? 1u : 0u, was = 1u;
+    int neg = 0, old_gap = 0;
+    uint32_t nz = 0u, was = 1u;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const float2 ml = *reinterpret_cast<const float2*>(&cab[i * kCab + NV * 64 + lane]);
       const uint32_t meta = __float_as_uint(ml.x);
       const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
+      const int away = now - 1 - __float_as_int(ml.y);  // 0: called one step ago
       neg |= ~(count + 1 - nbuf) & (run + 2 - nbuf);
-      nz |= (uint32_t)(now - 1 - __float_as_int(ml.y));
+      old_gap |= (away != 0) ? ~(count - run - 2) : 0;  // sign bit: count >= run + 2 (a sample older than the run) at a gap
+      nz |= (uint32_t)away;
       was &= meta;
     }
-    consec = (nz == 0u) && (was & 1u) != 0u;
-    simple = consec && (neg >= 0);
+    const bool called = (was & 1u) != 0u;
+    gaps = nz != 0u || !called;  // (a Pid's first call since reset is served by the variant for gaps)
+    simple = called && mode != 0 && nz == 0u && (neg >= 0);
+    fast = mode != 0 && (old_gap >= 0);
+  }
+}
+
+// The rings of the lanes whose Pid was not called one world step ago, turned so that the ring slot of every sample is again
+// its stamp mod nbuf relative to THIS step (the previous sample right before the slot that takes the new one): values through
+// LDS (each lane gathers its own window, turned, and puts it back: a fit lane reads it there) and back to the records; the
+// stamps of the window - implied until now by mLastTime and `run` (lazy stamps) - written out, since the run ends here.
+// Per cable, skipped where no lane of the wave has a gap (wave-uniform).  Pid.cpp:193-217 keeps insertion order; the
+// layout here is an implementation choice that buys the one scalar ring head of the branches above.
+template <int N, int NBMAX>
+CDPR_DEV void gen_turn_rings(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, int now, const int (&sel)[N], float4* cab) {
+  constexpr int NV = gen_nv(NBMAX);
+  constexpr int kCab = (NV + 1) * 64;
+  constexpr int kCabF = kCab * 4;
+  float* const cabf = reinterpret_cast<float*>(cab);
+  const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16, pid_b = (uint32_t)L.pid_rows() * RB.rs4;
+  const int nhead = kc.nm0, nbuf = kc.nbuf0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float2 ml = *reinterpret_cast<const float2*>(&cab[i * kCab + NV * 64 + lane]);
+    const uint32_t meta = __float_as_uint(ml.x);
+    const int last = __float_as_int(ml.y);
+    const int count = (int)((meta >> kGmCountShift) & kGmField), head = (int)((meta >> kGmHeadShift) & kGmField);
+    const bool gap = count > 0 && (now - last) != 1;
+    if (__builtin_amdgcn_ballot_w64(gap) == 0ull) continue;  // (wave-uniform)
+    const bool sv = sel[i] != 0;
+    const uint32_t va = col * 16u + (sv ? pid_a : 0u), vb = col * 4u + (sv ? pid_b : 0u);
+    const int sa = L.block_a(0, i), rb = L.block_b(0, i);
+    int shift = nhead - 1 - head;
+    shift += (shift < 0) ? nbuf : 0;
+    const bool rot = gap && shift != 0;
+    shift = rot ? shift : 0;
+    float* const win = cabf + i * kCabF + lane * 4;  // the lane's float4 inside a slot row; slot rows 256 floats apart
+    float tv[NV * 4];
+#pragma unroll
+    for (int j = 0; j < NV * 4; ++j) {
+      int src = j - shift;
+      src += (src < 0) ? nbuf : 0;
+      src = (j < nbuf) ? src : j;
+      tv[j] = win[(src >> 2) * 256 + (src & 3)];
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < NV; ++s4) {
+      const float4 v = make_float4(tv[4 * s4], tv[4 * s4 + 1], tv[4 * s4 + 2], tv[4 * s4 + 3]);
+      cab[i * kCab + s4 * 64 + lane] = v;
+      RB.store4_if(live && rot && s4 < L.nv(), sa + min(s4, L.nv() - 1), va, v);
+    }
+#pragma unroll
+    for (int j = 0; j < NBMAX; ++j) {
+      int age = nhead - j;  // of ring slot j after this step's push, in calls before the new sample
+      age += (age < 0) ? nbuf : 0;
+      RB.storei_if(live && gap && j < nbuf && j != nhead && age - 1 < count, rb + min(j, L.nb - 1), vb, last - (age - 1));
+    }
   }
 }
 
@@ -525,7 +604,7 @@ CDPR_DEV void gen_steady(const GenCtlConst kc, const GenBuf& RB, const GenLayout
 #ifndef CDPR_LEAN_GROUP
 #define CDPR_LEAN_GROUP 2  // cables per group in the branch the lean role-split kernel inlines (register pressure: 32 registers per cable of a group)
 #endif
-template <int N, int NBMAX, bool STEADY_ONLY = false>
+template <int N, int NBMAX, bool STEADY_ONLY = false, bool TIER1 = true>
 CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, uint32_t first_unit,
                              uint32_t units, int mode, int now, const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)],
                              const v2f (&qd)[cable_pairs(N)], float4* cab, const float4* hold_slots, const float* wrot,
@@ -542,10 +621,6 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16, pid_b = (uint32_t)L.pid_rows() * RB.rs4;
   auto qitem = [&](uint32_t idx) -> uint32_t* { return reinterpret_cast<uint32_t*>(cabf + (idx >> 6) * kCabF + 7 * 64 + (idx & 63u)); };
   auto qerr = [&](uint32_t idx) -> float* { return cabf + (idx >> 6) * kCabF + 8 * 64 + (idx & 63u); };
-  float4 held4[LP];
-#pragma unroll
-  for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
-  float newpos[N];
 
   // ---- consecutive calls, decided for the whole wave: every cable of every robot calls a Pid that was called one world step
   //      ago, no cascades, a command clamp - what a handle does on all steps but the one of a mode change or of a switch
@@ -555,13 +630,14 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   //        S  a full window on a uniform grid: the closed-form FIR;
   //        F  a window that is still filling (count + 1 < nbuf): 0, as derive() returns it (Pid.cpp:200-203);
   //        Q  a full window with a gap in it (the nbuf - 1 steps after a switch between the two Pids): the least-squares fit
-  //           on the real stamps, through the wave's fit queue.
-  //      Waves with S and F cables only take the first branch below (gen_consecutive<0>: the lean role-split kernel inlines
-  //      this much); waves with some Q cable the second one (tier 1).
+  //           on the real stamps, through the wave's fit queue;
+  //      and a Pid that was NOT called one step ago (G: the step of the switch itself) has its ring turned first.
+  //      Waves with S and F cables only take the first branch below (gen_consecutive<0>); waves with some Q or G cable the
+  //      second one (tier 1).  STEADY_ONLY (the lean role-split kernel) compiles the first branch and nothing else.
   // (a single wave per SIMD hides nothing: every dependent LDS round trip costs ~50 ns, so the reads of a phase are issued
   //  for a group of cables together and the group then pays the latency once)
-  bool simple = false, consec = false;
-  gen_consecutive_test<N, NBMAX>(kc, cab, lane, mode, now, simple, consec);
+  bool simple, fast, gaps;
+  gen_consecutive_test<N, NBMAX>(kc, cab, lane, mode, now, simple, fast, gaps);
 #ifdef CDPR_EXPECT_STEADY  // build variant (scripts/build_variants.sh): the branch-layout hint; results must not depend on it
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(!simple) == 0ull, 1)) {
 #else
@@ -570,87 +646,118 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     gen_steady<N, NBMAX, STEADY_ONLY ? CDPR_LEAN_GROUP : 4>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, hold_slots, wrot, ptab, force, dbg);
     return true;
   }
-  GEN_COLD_STAMP(0, __builtin_amdgcn_s_memrealtime());
-  if constexpr (STEADY_ONLY) return false;
-
-  // ---- tier 1: consecutive calls everywhere and some windows with a gap in them (the nbuf - 1 steps after a switch between
-  //      the two Pids).  The queue is built FIRST, from the staged H slots alone, so that the stamps a fit needs - the only
-  //      thing it reads from memory: the window values are the owner's staged slots in LDS - are in flight under the
-  //      Pid arithmetic of the whole wave (gen_consecutive<1>); the waiting cables are finished after the fit by a second pass
-  //      over them alone (gen_consecutive<2>).  One pass of the queue (<= 64 items per wave); a wave with more takes the
-  //      general loop below.  `q_count` is followed by four rows of 64 words: items, new errors, results, dump words.
-  if (kc.simple_ok && __builtin_amdgcn_ballot_w64(!consec) == 0ull) {  // (wave-uniform)
+  // ---- tier 1: every Pid called with mWasLastTime set; some windows carry a gap (the nbuf - 1 steps after a switch between
+  //      the two Pids: the fit), some Pids are called for the first time after one (their rings are turned first,
+  //      gen_turn_rings).  The queue is built FIRST, from the staged H slots alone, so that the stamps a fit needs - the only
+  //      thing it reads from memory: the window values are the owner's staged slots in LDS - are in flight under the Pid
+  //      arithmetic of the whole wave (gen_consecutive<1>); the waiting cables are finished after the fit by a second pass
+  //      over them alone (gen_consecutive<2>).  One pass of the queue (<= 64 items per wave); a wave with more, or with a
+  //      lane that does not qualify, takes the general loop below (the lean role-split kernel: in its cold tail).
+  //      `q_count` is followed by four rows of 64 words: items, new errors, results, dump words.
+  if constexpr (STEADY_ONLY) return false;  // (inlined with tier 1 the lean kernel spills 332 registers, on the first branch's path too)
+  if constexpr (TIER1)
+  if (kc.simple_ok && __builtin_amdgcn_ballot_w64(!fast) == 0ull) {  // (wave-uniform)
+    GEN_COLD_STAMP(0, __builtin_amdgcn_s_memrealtime());
     uint32_t* const qitems = q_count + 4;
     float* const qrows = reinterpret_cast<float*>(q_count + 4);
     const int nbuf = kc.nbuf0, nhead = kc.nm0;
+    const bool any_gap = __builtin_amdgcn_ballot_w64(gaps) != 0ull;
     uint32_t need = 0u;
+    uint32_t word[N];  // the items' upper bits: gap flag (bit 15) and the run of consecutive calls ending at the new sample
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const uint32_t meta = __float_as_uint(cabf[i * kCabF + NV * 256 + lane * 4]);
+    for (int i = 0; i < N; ++i) {  // (every H read before the first queue word is written: the compiler must take them for aliases)
+      const float2 ml = *reinterpret_cast<const float2*>(&cab[i * kCab + NV * 64 + lane]);
+      const uint32_t meta = __float_as_uint(ml.x);
       const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
-      need |= ((count + 1 >= nbuf) && (run + 2 < nbuf)) ? (1u << i) : 0u;
+      const bool cons = (now - __float_as_int(ml.y)) == 1;
+      need |= ((count + 1 >= nbuf) && ((cons ? run + 2 : 1) < nbuf)) ? (1u << i) : 0u;  // full after this push, run + 1 (or 0) < nbuf - 1
+      word[i] = cons ? ((uint32_t)min(run + 1, (int)kGmField) << 16) : (1u << 15);
     }
-    const uint32_t slot0 = __hip_atomic_fetch_add(q_count, (uint32_t)__builtin_popcount(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t total = 0u, slot0 = 0u;
+    if (__builtin_amdgcn_ballot_w64(need != 0u) != 0ull) {  // (wave-uniform) some cable waits for the fit
+      slot0 = __hip_atomic_fetch_add(q_count, (uint32_t)__builtin_popcount(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const uint32_t meta = __float_as_uint(cabf[i * kCabF + NV * 256 + lane * 4]);
-      const uint32_t nrun = (uint32_t)min((int)((meta >> kGmRunShift) & kGmField) + 1, (int)kGmField);
-      const uint32_t sl = slot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u));
-      const bool has = ((need >> i) & 1u) != 0u && sl < 64u;
-      qitems[has ? sl : 192u + lane] = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | (nrun << 16);
+      for (int i = 0; i < N; ++i) {
+        const uint32_t sl = slot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u));
+        const bool has = ((need >> i) & 1u) != 0u && sl < 64u;
+        qitems[has ? sl : 192u + lane] = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | word[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      total = *q_count;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      *q_count = 0u;  // for the general loop or the next step (every lane writes the same word)
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t total = *q_count;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    *q_count = 0u;  // for the general loop or the next step (every lane writes the same word)
-    GEN_COLD_STAMP(4, (unsigned long long)total | (2ull << 32));
+    GEN_COLD_STAMP(4, (unsigned long long)total | ((any_gap ? 3ull : 2ull) << 32));
     if (total <= 64u) {  // (wave-uniform)
+      float4 held4[LP];
+#pragma unroll
+      for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
+      float newpos[N];
       const bool mine = lane < total;
-      const uint32_t it = qitems[mine ? lane : 0u];
-      const uint32_t ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u;
-      const int irun = (int)((it >> 16) & 63u);
-      const uint32_t ro = first_unit + ol;
-      const uint32_t ocol = (ro < units) ? ro : (units - 1u);
-      const uint32_t ob = ocol * 4u + (uint32_t)L.block_b(0, (int)ci) * RB.rs4 + (sp ? pid_b : 0u);
       int t[NBMAX];
+      uint32_t ol = 0u, ci = 0u, sp = 0u;
+      int irun = 0, t_gap = 0;
+      bool gapitem = false;
+      if (total != 0u) {  // (wave-uniform) the stamps of this lane's item on their way
+        const uint32_t it = qitems[mine ? lane : 0u];
+        ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u;
+        gapitem = ((it >> 15) & 1u) != 0u;
+        irun = (int)((it >> 16) & 63u);
+        t_gap = __float_as_int(cabf[ci * kCabF + NV * 256 + ol * 4 + 1]);  // the owner's mLastTime before this step
+        const uint32_t ro = first_unit + ol;
+        const uint32_t ocol = (ro < units) ? ro : (units - 1u);
+        const uint32_t ob = ocol * 4u + (uint32_t)L.block_b(0, (int)ci) * RB.rs4 + (sp ? pid_b : 0u);
 #pragma unroll
-      for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
+        for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
+      }
       GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
-      gen_consecutive<N, NBMAX, 1>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      GEN_COLD_STAMP(2, __builtin_amdgcn_s_memrealtime());
-      const float e_new = qrows[64u + (mine ? lane : 0u)];
-      float y[NBMAX];
-#pragma unroll
-      for (int s4 = 0; s4 < NV; ++s4) {
-        const float4 v = cab[ci * kCab + s4 * 64 + ol];  // the owner's staged window
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (4 * s4 + k < NBMAX) y[4 * s4 + k] = comp4(v, k);
+      if (any_gap) {  // (wave-uniform)
+        gen_turn_rings<N, NBMAX>(kc, RB, L, lane, live, col, now, sel, cab);
+        gen_consecutive<N, NBMAX, 1, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
+      } else {
+        gen_consecutive<N, NBMAX, 1, 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
       }
-      const uint32_t hd = (uint32_t)nhead;
-      const uint32_t old = (hd + 1u == (uint32_t)nbuf) ? 0u : hd + 1u;  // the oldest sample sits right after the head
-      const int degree = __float_as_int(ptab[sp][5].z);
-      int t_old = now;
+      if (total != 0u) {  // (wave-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GEN_COLD_STAMP(2, __builtin_amdgcn_s_memrealtime());
+        const float e_new = qrows[64u + (mine ? lane : 0u)];
+        float y[NBMAX];
 #pragma unroll
-      for (int j = 0; j < NBMAX; ++j) {
-        y[j] = ((uint32_t)j == hd) ? e_new : ((j < nbuf) ? y[j] : 0.f);
-        int age = (int)hd - j;
-        age += (age < 0) ? nbuf : 0;
-        t[j] = (j >= nbuf) ? now : ((age <= irun) ? now - age : t[j]);
-        t_old = ((uint32_t)j == old) ? t[j] : t_old;
+        for (int s4 = 0; s4 < NV; ++s4) {
+          const float4 v = cab[ci * kCab + s4 * 64 + ol];  // the owner's staged window (turned, where it had to be)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (4 * s4 + k < NBMAX) y[4 * s4 + k] = comp4(v, k);
+        }
+        const uint32_t hd = (uint32_t)nhead;
+        const uint32_t old = (hd + 1u == (uint32_t)nbuf) ? 0u : hd + 1u;  // the oldest sample sits right after the head
+        const int degree = __float_as_int(ptab[sp][5].z);
+        int t_old = now;
+#pragma unroll
+        for (int j = 0; j < NBMAX; ++j) {
+          y[j] = ((uint32_t)j == hd) ? e_new : ((j < nbuf) ? y[j] : 0.f);
+          int age = (int)hd - j;
+          age += (age < 0) ? nbuf : 0;
+          // the new sample and the run behind it: implied; the first call after a gap: the window's stamps were implied until
+          // this step (gen_consecutive_test: no earlier gap) and are on their way to memory only now; else: from memory
+          t[j] = (j >= nbuf) ? now : ((age <= irun) ? now - age : (gapitem ? t_gap - (age - 1) : t[j]));
+          t_old = ((uint32_t)j == old) ? t[j] : t_old;
+        }
+        const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
+        qrows[mine ? 128u + lane : 192u + lane] = res;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (any_gap)
+          gen_consecutive<N, NBMAX, 2, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
+        else
+          gen_consecutive<N, NBMAX, 2, 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
       }
-      const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
-      qrows[mine ? 128u + lane : 192u + lane] = res;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      gen_consecutive<N, NBMAX, 2>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
 #pragma unroll
       for (int g4 = 0; g4 < LP; ++g4)
         RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
@@ -659,7 +766,12 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       return true;
     }
   }
+  GEN_COLD_STAMP(0, __builtin_amdgcn_s_memrealtime());
 
+  float4 held4[LP];
+#pragma unroll
+  for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
+  float newpos[N];
   uint32_t need = 0u;  // cables whose derivative comes from the fit queue
   bool any_rot = false;  // some ring of this wave turned this step (wave-uniform)
   GEN_COLD_STAMP(4, 0ull);
@@ -1162,7 +1274,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
 #ifdef CDPR_STAMPS
       cc.stamps = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
 #endif
-      gen_controller<N, NBMAX>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &stage[0][0][0], &hold_slots[0][0],
+      gen_controller<N, NBMAX, false, false>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &stage[0][0][0], &hold_slots[0][0],
                                &wrot[0][0][0], ptab, q_count, force, dbg);
     }
     CDPR_STAMP(5);

@@ -34,7 +34,8 @@ for step in range(12):
     took = cold[:, 0] > 0
     c = cold[took].astype(np.float64) * 0.01
     qlen = (cold[took, 4] & 0xFFFFFFFF).astype(np.int64)
-    rot = ((cold[took, 4] >> 32) & 1).astype(np.int64)
+    kind = ((cold[took, 4] >> 32) & 3).astype(np.int64)  # 0 / 1: general loop (1: some ring turned); 2 / 3: tier 1 (3: some Pid called after a gap)
+    rot = (kind & 1)
     if took.sum() == 0:
         print(f"  step {step}: no workgroup in the cold path, span {span:.2f}"); continue
     loop = c[:, 1] - c[:, 0]
@@ -46,10 +47,10 @@ for step in range(12):
     e2 = c[:, 6] - c[:, 5]       # ... the Joy targets are back
     post = t[took, 4] - c[:, 3]  # return + registers back + forces to LDS
     ctl_s = (t[~took, 4] - t[~took, 7])
-    print(f"  step {step:2d}: {took.sum():4d}/{G} | q {np.median(qlen):5.0f} {np.percentile(qlen, 90):5.0f} {qlen.max():5d} | rot {rot.sum():4d} | "
+    print(f"  step {step:2d}: {took.sum():4d}/{G} (tier 1: {(kind >= 2).sum()}) | q {np.median(qlen):5.0f} {np.percentile(qlen, 90):5.0f} {qlen.max():5d} | rot {rot.sum():4d} | "
           f"loop {np.median(loop):5.2f} {loop.max():5.2f}  fit+finish {np.median(fit):5.2f} {fit.max():5.2f}  controller {np.median(ctl):5.2f} {ctl.max():5.2f} (entry {np.median(pre):5.2f} {pre.max():5.2f} [call {np.median(e1):4.2f}, targets {np.median(e2):4.2f}], exit {np.median(post):5.2f} {post.max():5.2f}; steady waves {np.median(ctl_s) if len(ctl_s) else 0:5.2f}) | span {span:.2f}")
     if step in (1, 5):
         order = np.argsort(-ctl)[:5]
         for o in order:
-            print(f"      worst: q {qlen[o]:4d} rot {rot[o]} loop {loop[o]:.2f} fit {fit[o]:.2f} controller {ctl[o]:.2f}")
+            print(f"      worst: kind {kind[o]} q {qlen[o]:4d} rot {rot[o]} loop {loop[o]:.2f} fit {fit[o]:.2f} controller {ctl[o]:.2f}")
 eng.close()
