@@ -655,10 +655,12 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   cold = __builtin_amdgcn_readfirstlane(cold);
   asm volatile("" : "+s"(cold));
   if (cold != 0u) {  // the other paths finish this wave's work in a function of their own and end the program there
+    // (this wave is late already and decides when the launch ends: it wins the SIMD's issue arbitration from here on)
+    __builtin_amdgcn_s_setprio(3);
     const uint64_t kaddr = (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
     // q, qd and the structure matrix travel through the lane's private memory (a stack object of this kernel that only this
-    // block touches): the tail reads q and qd on entry and the matrix between the two barriers - rebuilding it there costs
-    // ~750 instructions the instruction cache has never seen (a wave alone on code runs at ~12 ns per instruction)
+    // block touches): the tail reads q and qd on entry and the matrix between the two barriers (rebuilding it there:
+    // ~750 instructions; measured the same within the noise, 27.0 against 27.8 us per step with cables switching Pids)
     float4 spill[2 * ((NP + 1) / 2) + 3 * NP];
 #pragma unroll
     for (int k = 0; k < NP; k += 2) {

@@ -32,6 +32,13 @@ def main():
     table = json.load(open(tin)) if os.path.exists(tin) else {}
     table[key] = dom[1]
     table.setdefault("_sources", {})[key] = {"file": "profiles/" + os.path.basename(src), "kernel": dom[0]}
+    # L2 hit rate of the same kernel (separate PMC pass: TCC_HIT_sum / TCC_MISS_sum), keyed without the steps per launch:
+    # bench.py's roofline.residency
+    c = summary.get("pmc_per_dispatch", {}).get(dom[0], {})
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        hit, miss = c["TCC_HIT_sum"]["mean"], c["TCC_MISS_sum"]["mean"]
+        rkey = key.rsplit("_", 1)[0] if key.rsplit("_", 1)[-1].startswith(("spl", "sched")) else key
+        table.setdefault("_residency", {})[rkey] = {"tcc_hit_rate": hit / max(hit + miss, 1.0), "file": "profiles/" + os.path.basename(src)}
     json.dump(table, open(tout, "w"), indent=1)
     print(f"{key}: {dom[1]:.0f} B per launch ({dom[0]}) <- {src}")
 
