@@ -252,6 +252,20 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   __shared__ double c_je[JCACHE ? N : 1][JCACHE ? 6 : 1][64];  // rows at the FK estimate
   const uint32_t lane = threadIdx.x;
   const uint32_t r = blockIdx.x * 64u + lane;
+  // the geometry table (7 doubles per cable) in LDS: read through the argument pointer every row evaluation is 2 - 4 vector
+  // loads of a uniform address (the compiler does not make them scalar loads: stores lie between them) and each group of
+  // cables waits for them again - six evaluations per step
+  // (the large-batch variant only: 65 536 x 8 27.2 -> 24.4 us; with a workgroup per CU or less the loads hide and the copy is
+  //  a round trip more: one robot 14.4 -> 14.7 us)
+  constexpr bool kGeomLds = !RING_LDS;
+  __shared__ double c_geom_lds[kGeomLds ? N * 7 : 1];
+  if (kGeomLds) {
+    if (lane < N * 7) c_geom_lds[lane] = a.geom[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const double* const c_geom = kGeomLds ? c_geom_lds : a.geom;
   if (r >= a.batch) return;  // no barrier below: lanes are independent, LDS columns are private
   const size_t st = a.stride;
   double* const S = a.state + r;
@@ -295,8 +309,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
-        ik_row64(a.geom + i * 7, R, p, L, j);
-        const double q = a.geom[i * 7 + 6] - L;
+        ik_row64(c_geom + i * 7, R, p, L, j);
+        const double q = c_geom[i * 7 + 6] - L;
         const double qd = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
         c_len[i][lane] = L;
         c_q[i][lane] = q;
@@ -366,7 +380,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma clang loop unroll_count(kCableUnroll)
         for (int i = 0; i < N; ++i) {
           double L, j[6];
-          ik_row64(a.geom + i * 7, R, fkp, L, j);
+          ik_row64(c_geom + i * 7, R, fkp, L, j);
           const double res = c_len[i][lane] - L;
           rmax = fmax(rmax, fabs(res));
 #pragma unroll
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
-        ik_row64(a.geom + i * 7, R, fkp, L, j);
+        ik_row64(c_geom + i * 7, R, fkp, L, j);
         fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
         if (JCACHE) {
 #pragma unroll
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) j[c] = a.fk ? c_je[JCACHE ? i : 0][JCACHE ? c : 0][lane] : c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane];
           } else {
-            ik_row64(a.geom + i * 7, Rt, pt, L, j);
+            ik_row64(c_geom + i * 7, Rt, pt, L, j);
           }
           const double df = c_f[i][lane] - a.td_mid;
 #pragma unroll
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) j[c] = a.fk ? c_je[JCACHE ? i : 0][JCACHE ? c : 0][lane] : c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane];
           } else {
-            ik_row64(a.geom + i * 7, Rt, pt, L, j);
+            ik_row64(c_geom + i * 7, Rt, pt, L, j);
           }
           double t = a.td_mid;
 #pragma unroll
@@ -499,7 +513,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll
           for (int c = 0; c < 6; ++c) j[c] = c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane];
         } else {
-          ik_row64(a.geom + i * 7, R, p, L, j);
+          ik_row64(c_geom + i * 7, R, p, L, j);
         }
         double t = fma(-a.damping, c_qd[i][lane], c_f[i][lane]);
         if (a.unilateral) t = fmax(t, 0.0);
@@ -610,6 +624,14 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
                                                   // 65 536 x 8: 31.8 us with 2, 29.4 with 4, 44.9 with 8 (356 B of scratch)
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t r = blockIdx.x * 64u + lane;
+  __shared__ double c_geom_lds[LEAN ? N * 7 : 1];  // LEAN: the geometry table in LDS (see cdpr_step_kernel_f64); each wave writes all of it and reads what it wrote
+  if (LEAN) {
+    if (lane < N * 7) c_geom_lds[lane] = a.geom[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  const double* const c_geom = LEAN ? c_geom_lds : a.geom;
   const bool live = r < a.batch;  // (no early return: both waves meet at two barriers; tail lanes shadow the last robot)
   const size_t st = a.stride;
   double* const S = a.state + (live ? r : a.batch - 1u);
@@ -627,7 +649,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
 #pragma clang loop unroll_count(kU)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
-        ik_row64(a.geom + i * 7, R, p, L, j);
+        ik_row64(c_geom + i * 7, R, p, L, j);
         c_len[i][lane] = L;
       }
     }
@@ -647,7 +669,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
 #pragma clang loop unroll_count(kU)
         for (int i = 0; i < N; ++i) {
           double L, j[6];
-          ik_row64(a.geom + i * 7, R, fkp, L, j);
+          ik_row64(c_geom + i * 7, R, fkp, L, j);
           const double res = c_len[i][lane] - L;
           rmax = fmax(rmax, fabs(res));
 #pragma unroll
@@ -671,7 +693,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
 #pragma clang loop unroll_count(kU)
       for (int i = 0; i < N; ++i) {
         double L, j[6];
-        ik_row64(a.geom + i * 7, R, fkp, L, j);
+        ik_row64(c_geom + i * 7, R, fkp, L, j);
         fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
         if (!LEAN) {
 #pragma unroll
@@ -698,7 +720,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     for (int i = 0; i < N; ++i) {
       double L, j[6];
       if (LEAN) {
-        ik_row64(a.geom + i * 7, Rt, fkp, L, j);
+        ik_row64(c_geom + i * 7, Rt, fkp, L, j);
 #pragma unroll
         for (int c = 0; c < 6; ++c) jr[LEAN ? i : 0][c] = j[c];
       } else {
@@ -773,8 +795,8 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
 #pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
       double L, j[6];
-      ik_row64(a.geom + i * 7, R, p, L, j);
-      const double q = a.geom[i * 7 + 6] - L;
+      ik_row64(c_geom + i * 7, R, p, L, j);
+      const double q = c_geom[i * 7 + 6] - L;
       const double qd = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
       c_q[i][lane] = q;
       c_qd[i][lane] = qd;
@@ -882,7 +904,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     for (int i = 0; i < N; ++i) {
       double L, j[6];
       if (LEAN) {
-        ik_row64(a.geom + i * 7, R, p, L, j);
+        ik_row64(c_geom + i * 7, R, p, L, j);
       } else {
 #pragma unroll
         for (int c = 0; c < 6; ++c) j[c] = c_jt[LEAN ? 0 : i][LEAN ? 0 : c][lane];
