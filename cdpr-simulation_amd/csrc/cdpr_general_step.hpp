@@ -673,22 +673,29 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       need |= ((count + 1 >= nbuf) && ((cons ? run + 2 : 1) < nbuf)) ? (1u << i) : 0u;  // full after this push, run + 1 (or 0) < nbuf - 1
       word[i] = cons ? ((uint32_t)min(run + 1, (int)kGmField) << 16) : (1u << 15);
     }
+    // the items' places in the queue, lane by lane: an exclusive prefix sum of popcount(need) over the wave from four ballots
+    // (no LDS atomic, no barrier: `total` is a scalar at once; `q_count` is the general loop's alone)
     uint32_t total = 0u, slot0 = 0u;
-    if (__builtin_amdgcn_ballot_w64(need != 0u) != 0ull) {  // (wave-uniform) some cable waits for the fit
-      slot0 = __hip_atomic_fetch_add(q_count, (uint32_t)__builtin_popcount(need), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    {
+      const uint32_t cnt = (uint32_t)__builtin_popcount(need);
+      static_assert(N <= 15, "four bits of items per lane");
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(((cnt >> b) & 1u) != 0u);
+        slot0 += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b;
+        total += (uint32_t)__builtin_popcountll(m) << b;
+      }
+    }
+    if (total != 0u && total <= 64u) {  // (wave-uniform) some cable waits for the fit
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const uint32_t sl = slot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u));
-        const bool has = ((need >> i) & 1u) != 0u && sl < 64u;
+        const bool has = ((need >> i) & 1u) != 0u;
         qitems[has ? sl : 192u + lane] = lane | ((uint32_t)i << 6) | ((uint32_t)sel[i] << 9) | word[i];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      total = *q_count;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      *q_count = 0u;  // for the general loop or the next step (every lane writes the same word)
     }
     GEN_COLD_STAMP(4, (unsigned long long)total | ((any_gap ? 3ull : 2ull) << 32));
     if (total <= 64u) {  // (wave-uniform)
