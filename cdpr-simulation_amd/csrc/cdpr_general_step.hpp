@@ -78,6 +78,11 @@ struct GenLayout {
 };
 
 constexpr uint32_t kGmWasLast = 1u, kGmCountShift = 1u, kGmHeadShift = 7u, kGmRunShift = 13u, kGmField = 63u;
+// Two-run windows (round 5; handles whose configuration admits the consecutive-call branches: mCmd is not state there and the
+// H slot's fourth word is free): bit 25 says that the samples behind the newest run - ages run + 1 ... - were taken on
+// consecutive steps ending at the world step in H.w ("last2"), kGmRun2Shift holds that run's length - 1.  A window with ONE
+// gap in it (what a switch between the two Pids of a hold-branch cable leaves) then needs no stamp in memory at all.
+constexpr uint32_t kGmRun2Shift = 19u, kGmTwo = 1u << 25;
 
 struct GenPid {
   float kf, kp, ki, kd, imax, imin, cmax, cmin;
@@ -434,7 +439,14 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
         const float dt = GAPS ? (float)since * kc.dt : kc.dt;          // (one step: the same bits)
         const int nrun = (count > 0 && since == 1) ? min(run + 1, (int)kGmField) : 0;
         const bool first = GAPS && !(meta & kGmWasLast);  // Pid.cpp:123-126: the first call since reset returns 0 and takes no sample
-        const uint32_t nmeta = first ? (meta | kGmWasLast) : (meta_lo | ((uint32_t)ncount << kGmCountShift) | ((uint32_t)nrun << kGmRunShift));
+        // the run behind the newest one (two-run windows, see kGmTwo): kept while one of its samples is still in the window; a
+        // call after a gap starts a new newest run and makes the old one - the whole window: gen_consecutive_test - the second
+        const bool gapped = GAPS && since != 1 && count > 0;
+        const uint32_t run2 = gapped ? (uint32_t)run : ((meta >> kGmRun2Shift) & kGmField);
+        const int last2 = gapped ? __float_as_int(hh[j].y) : __float_as_int(hh[j].w);
+        const bool two = (gapped || (meta & kGmTwo) != 0u) && ncount > nrun + 1;
+        const uint32_t nmeta = first ? (meta | kGmWasLast)
+                                     : (meta_lo | ((uint32_t)ncount << kGmCountShift) | ((uint32_t)nrun << kGmRunShift) | (two ? (kGmTwo | (run2 << kGmRun2Shift)) : 0u));
         const bool waits = (PASS != 0) && ((need >> i) & 1u) != 0u;  // this lane's cable i goes through the fit queue
         const uint32_t qslot = (PASS != 0) ? qslot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u)) : 0u;
         const float prev_ierr = hh[j].z;
@@ -482,7 +494,7 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
         }
         if constexpr (PASS == 1) qrows[waits ? 64u + qslot : 192u + lane] = error;  // (no branch: a lane without an item writes its dump word)
         const bool writes_h = (PASS == 0) ? live : ((PASS == 1) ? (live && !waits) : (live && waits));
-        RB.store4_if(writes_h, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, out));
+        RB.store4_if(writes_h, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, (two && !first) ? __int_as_float(last2) : out));
       }
     }
   }
@@ -530,8 +542,8 @@ CDPR_DEV void gen_consecutive_test(const GenCtlConst kc, const float4* cab, uint
 
 // The rings of the lanes whose Pid was not called one world step ago, turned so that the ring slot of every sample is again
 // its stamp mod nbuf relative to THIS step (the previous sample right before the slot that takes the new one): values through
-// LDS (each lane gathers its own window, turned, and puts it back: a fit lane reads it there) and back to the records; the
-// stamps of the window - implied until now by mLastTime and `run` (lazy stamps) - written out, since the run ends here.
+// LDS (each lane gathers its own window, turned, and puts it back: a fit lane reads it there) and back to the records.  No
+// stamp is written: the window's stamps - implied until now by mLastTime and `run` - stay implied as its second run (kGmTwo).
 // Per cable, skipped where no lane of the wave has a gap (wave-uniform).  Pid.cpp:193-217 keeps insertion order; the
 // layout here is an implementation choice that buys the one scalar ring head of the branches above.
 template <int N, int NBMAX>
@@ -540,7 +552,7 @@ CDPR_DEV void gen_turn_rings(const GenCtlConst kc, const GenBuf& RB, const GenLa
   constexpr int kCab = (NV + 1) * 64;
   constexpr int kCabF = kCab * 4;
   float* const cabf = reinterpret_cast<float*>(cab);
-  const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16, pid_b = (uint32_t)L.pid_rows() * RB.rs4;
+  const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16;
   const int nhead = kc.nm0, nbuf = kc.nbuf0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -549,14 +561,14 @@ CDPR_DEV void gen_turn_rings(const GenCtlConst kc, const GenBuf& RB, const GenLa
     const int last = __float_as_int(ml.y);
     const int count = (int)((meta >> kGmCountShift) & kGmField), head = (int)((meta >> kGmHeadShift) & kGmField);
     const bool gap = count > 0 && (now - last) != 1;
-    if (__builtin_amdgcn_ballot_w64(gap) == 0ull) continue;  // (wave-uniform)
-    const bool sv = sel[i] != 0;
-    const uint32_t va = col * 16u + (sv ? pid_a : 0u), vb = col * 4u + (sv ? pid_b : 0u);
-    const int sa = L.block_a(0, i), rb = L.block_b(0, i);
     int shift = nhead - 1 - head;
     shift += (shift < 0) ? nbuf : 0;
     const bool rot = gap && shift != 0;
+    if (__builtin_amdgcn_ballot_w64(rot) == 0ull) continue;  // (wave-uniform)
     shift = rot ? shift : 0;
+    const bool sv = sel[i] != 0;
+    const uint32_t va = col * 16u + (sv ? pid_a : 0u);
+    const int sa = L.block_a(0, i);
     float* const win = cabf + i * kCabF + lane * 4;  // the lane's float4 inside a slot row; slot rows 256 floats apart
     float tv[NV * 4];
 #pragma unroll
@@ -571,12 +583,6 @@ CDPR_DEV void gen_turn_rings(const GenCtlConst kc, const GenBuf& RB, const GenLa
       const float4 v = make_float4(tv[4 * s4], tv[4 * s4 + 1], tv[4 * s4 + 2], tv[4 * s4 + 3]);
       cab[i * kCab + s4 * 64 + lane] = v;
       RB.store4_if(live && rot && s4 < L.nv(), sa + min(s4, L.nv() - 1), va, v);
-    }
-#pragma unroll
-    for (int j = 0; j < NBMAX; ++j) {
-      int age = nhead - j;  // of ring slot j after this step's push, in calls before the new sample
-      age += (age < 0) ? nbuf : 0;
-      RB.storei_if(live && gap && j < nbuf && j != nhead && age - 1 < count, rb + min(j, L.nb - 1), vb, last - (age - 1));
     }
   }
 }
@@ -671,7 +677,9 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
       const bool cons = (now - __float_as_int(ml.y)) == 1;
       need |= ((count + 1 >= nbuf) && ((cons ? run + 2 : 1) < nbuf)) ? (1u << i) : 0u;  // full after this push, run + 1 (or 0) < nbuf - 1
-      word[i] = cons ? ((uint32_t)min(run + 1, (int)kGmField) << 16) : (1u << 15);
+      // bit 15: the first call after a gap (the run behind the new sample ends at the owner's mLastTime); bit 14: the stamps behind
+      // the newest run are in memory (a window the general loop wrote out), not implied by a second run (kGmTwo)
+      word[i] = cons ? (((uint32_t)min(run + 1, (int)kGmField) << 16) | ((meta & kGmTwo) ? 0u : (1u << 14))) : (1u << 15);
     }
     // the items' places in the queue, lane by lane: an exclusive prefix sum of popcount(need) over the wave from four ballots
     // (no LDS atomic, no barrier: `total` is a scalar at once; `q_count` is the general loop's alone)
@@ -706,19 +714,25 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       const bool mine = lane < total;
       int t[NBMAX];
       uint32_t ol = 0u, ci = 0u, sp = 0u;
-      int irun = 0, t_gap = 0;
-      bool gapitem = false;
-      if (total != 0u) {  // (wave-uniform) the stamps of this lane's item on their way
+      int irun = 0, t_second = 0;
+      bool in_memory = false;
+      if (total != 0u) {  // (wave-uniform)
         const uint32_t it = qitems[mine ? lane : 0u];
         ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u;
-        gapitem = ((it >> 15) & 1u) != 0u;
+        in_memory = ((it >> 14) & 1u) != 0u;
         irun = (int)((it >> 16) & 63u);
-        t_gap = __float_as_int(cabf[ci * kCabF + NV * 256 + ol * 4 + 1]);  // the owner's mLastTime before this step
-        const uint32_t ro = first_unit + ol;
-        const uint32_t ocol = (ro < units) ? ro : (units - 1u);
-        const uint32_t ob = ocol * 4u + (uint32_t)L.block_b(0, (int)ci) * RB.rs4 + (sp ? pid_b : 0u);
+        // where the run behind the newest one ends: the owner's mLastTime before this step (first call after a gap) or its H.w
+        const float4 oh = cab[ci * kCab + NV * 64 + ol];
+        t_second = ((it >> 15) & 1u) ? __float_as_int(oh.y) : __float_as_int(oh.w);
 #pragma unroll
-        for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
+        for (int j = 0; j < NBMAX; ++j) t[j] = 0;
+        if (__builtin_amdgcn_ballot_w64(mine && in_memory) != 0ull) {  // (wave-uniform) a window whose stamps were written out: on their way
+          const uint32_t ro = first_unit + ol;
+          const uint32_t ocol = (ro < units) ? ro : (units - 1u);
+          const uint32_t ob = ocol * 4u + (uint32_t)L.block_b(0, (int)ci) * RB.rs4 + (sp ? pid_b : 0u);
+#pragma unroll
+          for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
+        }
       }
       GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
       if (any_gap) {  // (wave-uniform)
@@ -750,9 +764,9 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           y[j] = ((uint32_t)j == hd) ? e_new : ((j < nbuf) ? y[j] : 0.f);
           int age = (int)hd - j;
           age += (age < 0) ? nbuf : 0;
-          // the new sample and the run behind it: implied; the first call after a gap: the window's stamps were implied until
-          // this step (gen_consecutive_test: no earlier gap) and are on their way to memory only now; else: from memory
-          t[j] = (j >= nbuf) ? now : ((age <= irun) ? now - age : (gapitem ? t_gap - (age - 1) : t[j]));
+          // the new sample and the run behind it: implied by `now`; the samples behind that run: the window's second run, implied
+          // by the step it ends at - or, for a window the general loop wrote out, from memory
+          t[j] = (j >= nbuf) ? now : ((age <= irun) ? now - age : (in_memory ? t[j] : t_second - (age - irun - 1)));
           t_old = ((uint32_t)j == old) ? t[j] : t_old;
         }
         const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
@@ -810,6 +824,24 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     const bool runs = !is_force && !first;
     const float error = desired - actual;
     const float dt = (float)(now - last) * kc.dt;
+    // A two-run window (kGmTwo: written by the consecutive-call branches, maybe in another launch) is written out before this
+    // loop works on it: the stamps of its second run go to their rows, and from here on the window is what this loop knows -
+    // a newest run implied by mLastTime and `run`, everything older in memory (the H this call writes carries no kGmTwo).
+    if (__builtin_amdgcn_ballot_w64(runs && (meta & kGmTwo) != 0u) != 0ull) {  // (wave-uniform)
+      any_rot = true;  // (the fit reads other lanes' rows: the fence in front of it)
+      const int count0 = (int)((meta >> kGmCountShift) & kGmField), head0 = (int)((meta >> kGmHeadShift) & kGmField);
+      const int run0 = (int)((meta >> kGmRunShift) & kGmField), run2 = (int)((meta >> kGmRun2Shift) & kGmField);
+      const int last2 = __float_as_int(h.w);
+#pragma clang loop unroll(disable)  // (a rare path and no array indexed by j: kept as a loop, 12 instructions)
+      for (int j = 0; j < L.nb; ++j) {
+        int a = head0 - j;  // of ring slot j, in calls before the newest sample of the window as it stands
+        a += (a < 0) ? c.nbuf : 0;
+        const bool on = live && runs && (meta & kGmTwo) != 0u && j < c.nbuf && a > run0 && a < count0 && a - run0 - 1 <= run2;
+        RB.storei_if(on, rb + j, vb, last2 - (a - run0 - 1));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     float perr = error;
     if (pcas_max) perr = gen_cascade(RB, rb + L.r_pfilt(), vb, pcas_max, c.pcas, runs && live, c.pa0, c.pa1, c.pa2, c.pb1, c.pb2, error);
     const float p_term = c.kp * perr;
