@@ -365,8 +365,8 @@ struct GenDbg {
 // the stamps of a run of consecutive steps are implied by mLastTime and `run` (lazy stamps, see the general loop).
 //   PASS 0  no cable waits for the fit (need == 0): everything is done here
 //   PASS 1  the cables of `need` (a per-lane mask) wait for the fit: their new error goes to the queue's error row
-//           (qrows + 64, at the item's index: qslot0 + its rank among the lane's items), H and force are left to pass 2
-//   PASS 2  the cables of `need` only, the derivative from the queue's result row (qrows + 128)
+//           (qrows + 64, at the item's index: qslot0 + its rank among the lane's items) and six more numbers to the rows of
+//           `park`; the item's fit lane finishes the Pid::update (H, force) behind the fit (gen_controller, tier 1)
 // GAPS (passes 1 and 2): some lane's Pid was NOT called one world step ago (the first call after a switch between the two Pids
 // of a hold-branch cable): its integrator step is now - mLastTime, its run of consecutive calls starts again at 0 - and its
 // ring has been turned already (gen_turn_rings) so that the wave's one ring head is this lane's head as well.
@@ -375,10 +375,11 @@ template <int N, int NBMAX, int PASS, int GWIDE = 4, bool GAPS = false>
 CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, int mode, int now,
                               const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)], const v2f (&qd)[cable_pairs(N)],
                               const float4* cab, const float4 (&held4)[(N + 3) / 4], const float* wrot, const float4 (*ptab)[kGenPidFloats / 4],
-                              uint32_t need, uint32_t qslot0, float* qrows, float (&force)[N], float (&newpos)[N], GenDbg& dbg) {
+                              uint32_t need, uint32_t qslot0, float* qrows, float (&force)[N], float (&newpos)[N], GenDbg& dbg, float* park = nullptr) {
   constexpr int NV = gen_nv(NBMAX);
   constexpr int NBP = gen_nbp(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
+  static_assert(PASS != 2, "the second pass is the fit lanes' (gen_controller, tier 1)");
   const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16;
   const int nhead = kc.nm0, nbuf = kc.nbuf0;
   const int q4 = nhead >> 2, qc = nhead & 3;
@@ -492,7 +493,14 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
           o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
           RB.store4_if(live && !first, sa + q4, va, o);
         }
-        if constexpr (PASS == 1) qrows[waits ? 64u + qslot : 192u + lane] = error;  // (no branch: a lane without an item writes its dump word)
+        if constexpr (PASS == 1) {
+          // what the item's fit lane needs to finish this Pid::update (no branch: a lane without an item writes its dump word)
+          qrows[waits ? 64u + qslot : 192u + lane] = error;
+          float* const pk = waits ? park + qslot : qrows + 192u + lane;
+          const uint32_t ps = waits ? 64u : 0u;
+          pk[0 * ps] = dt, pk[1 * ps] = (g0[j].x * desired + p_term) + i_cl, pk[2 * ps] = (i_cl != i_term) ? i_cl * g2[j].w : fmaf(dt, error, prev_ierr);
+          pk[3 * ps] = prev_ierr, pk[4 * ps] = __uint_as_float(nmeta), pk[5 * ps] = __int_as_float(last2);
+        }
         const bool writes_h = (PASS == 0) ? live : ((PASS == 1) ? (live && !waits) : (live && waits));
         RB.store4_if(writes_h, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, (two && !first) ? __int_as_float(last2) : out));
       }
@@ -711,11 +719,16 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
 #pragma unroll
       for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
       float newpos[N];
+      // the hold-position slots are in registers now: their LDS rows park what an item's fit lane needs to finish the owner's
+      // Pid::update (six rows of 64 by item), the force it returns (row 6) and the `pid` topic's D term (row 7)
+      static_assert(LP >= 2, "eight rows of 64 floats in the hold-position slots");
+      float* const park = const_cast<float*>(reinterpret_cast<const float*>(hold_slots));
       const bool mine = lane < total;
       int t[NBMAX];
       uint32_t ol = 0u, ci = 0u, sp = 0u;
       int irun = 0, t_second = 0;
-      bool in_memory = false;
+      bool in_memory = false, owner_live = false;
+      uint32_t ocol = 0u;
       if (total != 0u) {  // (wave-uniform)
         const uint32_t it = qitems[mine ? lane : 0u];
         ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u;
@@ -726,9 +739,10 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
         t_second = ((it >> 15) & 1u) ? __float_as_int(oh.y) : __float_as_int(oh.w);
 #pragma unroll
         for (int j = 0; j < NBMAX; ++j) t[j] = 0;
+        const uint32_t ro = first_unit + ol;
+        owner_live = ro < units;
+        ocol = owner_live ? ro : (units - 1u);
         if (__builtin_amdgcn_ballot_w64(mine && in_memory) != 0ull) {  // (wave-uniform) a window whose stamps were written out: on their way
-          const uint32_t ro = first_unit + ol;
-          const uint32_t ocol = (ro < units) ? ro : (units - 1u);
           const uint32_t ob = ocol * 4u + (uint32_t)L.block_b(0, (int)ci) * RB.rs4 + (sp ? pid_b : 0u);
 #pragma unroll
           for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
@@ -737,9 +751,9 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
       if (any_gap) {  // (wave-uniform)
         gen_turn_rings<N, NBMAX>(kc, RB, L, lane, live, col, now, sel, cab);
-        gen_consecutive<N, NBMAX, 1, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
+        gen_consecutive<N, NBMAX, 1, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg, park);
       } else {
-        gen_consecutive<N, NBMAX, 1, 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
+        gen_consecutive<N, NBMAX, 1, 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg, park);
       }
       if (total != 0u) {  // (wave-uniform)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -770,14 +784,41 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           t_old = ((uint32_t)j == old) ? t[j] : t_old;
         }
         const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
-        qrows[mine ? 128u + lane : 192u + lane] = res;
+        {  // the rest of the owner's Pid::update (Pid.cpp:154-186) by the item's lane: D term, command, clamp, anti-windup, H
+          const uint32_t ix = mine ? lane : 0u;
+          const float dt_i = park[ix], pre = park[64u + ix], prev = park[192u + ix];
+          float ie = park[128u + ix];
+          const uint32_t nmeta = __float_as_uint(park[256u + ix]);
+          const float last2 = park[320u + ix];
+          const float4 ga = ptab[sp][0], gb = ptab[sp][1];
+          const float d_term = ga.w * res;
+          const float cmd = pre + d_term;
+          float out = __builtin_amdgcn_fmed3f(cmd, gb.w, gb.z);
+          const bool wind = out != cmd;
+          ie = wind ? prev : ie;
+          out = wind ? fmaf(dt_i * e_new, ga.z, out) : out;
+          const uint32_t oh = ocol * 16u + (sp ? pid_a : 0u) + (uint32_t)(L.block_a(0, (int)ci) + L.nv()) * RB.rs16;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the parked rows are read: rows 6 and 7 may be written)
+          __builtin_amdgcn_wave_barrier();
+          RB.store4_if(mine && owner_live, 0, oh, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, (nmeta & kGmTwo) ? last2 : out));
+          park[mine ? 384u + lane : 0u] = mine ? out : dt_i;  // (a lane without an item rewrites what item 0's row 0 holds)
+          park[mine ? 448u + lane : 0u] = mine ? d_term : dt_i;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (any_gap)
-          gen_consecutive<N, NBMAX, 2, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
-        else
-          gen_consecutive<N, NBMAX, 2, 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {  // the owners take their forces
+          const bool waits = ((need >> i) & 1u) != 0u;
+          const uint32_t qslot = slot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u));
+          const float f = park[384u + (waits ? qslot : 0u)];
+          force[i] = waits ? f : force[i];
+          if (i == 0) {
+            const float dd = park[448u + (waits ? qslot : 0u)];
+            dbg.d = waits ? dd : dbg.d;
+            dbg.dw = dbg.dw || waits;
+          }
+        }
       }
 #pragma unroll
       for (int g4 = 0; g4 < LP; ++g4)
