@@ -213,8 +213,11 @@ def test_role_split_general_kernel_is_bit_identical_to_the_one_wave_kernel(pkg, 
     joys = [(hold_commands(rng, B, cables, eps), rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32),
              (7.0 + rng.uniform(-0.5, 0.5, (B, cables))).astype(np.float32)) for _ in range(6)]
     out = []
-    for split in ("0", "1"):
+    # one-wave kernel | role-split kernel | the lean role-split kernel (batches beyond 32 768 robots use it: forced here; its
+    # controller wave inlines the first tier and leaves through gen_lean_cold_tail for the others; not with the optional physics)
+    for split, lean in (("0", "0"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("CDPR_GEN_SPLIT", split)
+        monkeypatch.setenv("CDPR_GEN_LEAN", lean)
         eng = pkg.Engine(cfg, 0)
         eng.set_platform_state(pose7=pose)
         eng.update(1)  # the first world step
@@ -236,9 +239,10 @@ def test_role_split_general_kernel_is_bit_identical_to_the_one_wave_kernel(pkg, 
             snaps.append(eng.platform_state() + eng.joint_states() + eng.fk_state() + eng.td_state() + ((eng.pid_debug(),) if variant == "pid_debug" else ()))
         out.append(snaps)
         eng.close()
-    for rnd, (a, b) in enumerate(zip(*out)):
-        for x, y in zip(a, b):
-            assert np.array_equal(x, y), f"round {rnd}"
+    for other, name in ((out[1], "role-split"), (out[2], "lean role-split")):
+        for rnd, (a, b) in enumerate(zip(out[0], other)):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), f"{name} kernel, round {rnd}"
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
