@@ -58,6 +58,7 @@ struct cdpr_engine {
   bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
   bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
   bool gen_split = false;   // general path: one-step launches use the role-split kernel (FK + TD, n >= 6, windows <= 11, <= 2 workgroups per CU)
+  bool gen_hot = false;     // general path: robots in the deep steady state keep mLastTime / mIerr in hot rows instead of their H slots (GenHot; CDPR_GEN_HOT=0: off)
   bool gen_lean = false;    // general path, larger batches: one-step launches use the lean role-split kernel (two waves per SIMD, the rare
                             // controller paths by call: cdpr_general_split.hpp)
   bool persist = false;     // one-step launches use the persistent one-wave kernel: one wave per SIMD walks over blocks of 64
@@ -661,6 +662,7 @@ GenCtl general_ctl(const cdpr_engine* h) {
   g.pcas_max = std::max(h->gpid[0].pcas, h->gpid[1].pcas);
   g.dcas_max = std::max(h->gpid[0].dcas, h->gpid[1].dcas);
   g.nbuf0 = h->gpid[0].nbuf, g.nbuf1 = h->gpid[1].nbuf;
+  g.hot = h->gen_hot ? 1 : 0;
   {
     const GenPid &p0 = h->gpid[0], &p1 = h->gpid[1];
     const bool same_window = p0.nbuf == p1.nbuf && p0.degree == p1.degree;
@@ -984,8 +986,15 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     return CDPR_OK;
   };
   bool reset_pid = false;
+  auto flush_hot = [&]() {  // the general path's hot rows back into the H slots (cdpr_gen_flush_hot_kernel) before a Pid's records are reset
+    if (!h->d_rec || !h->gen_hot) return;
+    GenFlushArgs fa{};
+    fa.rec = h->d_rec, fa.rstride = h->stride, fa.batch = h->batch, fa.lay = h->glay, fa.nbuf = std::max(h->gpid[0].nbuf, 1);
+    hipLaunchKernelGGL(cdpr_gen_flush_hot_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, fa);
+  };
   auto reset_block = [&](int which) -> hipError_t {  // Pid::reset of one Pid of every cable (general path): its slots, its rows
     const GenLayout& L = h->glay;
+    flush_hot();
     hipError_t e1 = hipMemsetAsync(h->d_rec + (size_t)L.block_a(which, 0) * h->stride * 4, 0, (size_t)L.pid_slots() * h->stride * 16, h->stream);
     if (e1 != hipSuccess || L.pid_rows() == 0) return e1;
     return hipMemsetAsync(h->d_rec + ((size_t)L.slots() * 4 + (size_t)L.block_b(which, 0)) * h->stride, 0, (size_t)L.pid_rows() * h->stride * 4, h->stream);
@@ -1024,6 +1033,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         HIP_TRY(h, hipGetLastError());
         return CDPR_OK;
       }
+      flush_hot();
       GenLatchArgs la{};
       la.mask = mask;
       la.mode = h->d_mode;
@@ -1610,6 +1620,11 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
         h->gen_lean = can && !h->phys && gl[0] == '1';
         if (h->gen_lean) h->gen_split = false;
       }
+      // hot rows: where the lean kernel steps the handle (beyond 32 768 robots: 176 B per robot-step less traffic at the same
+      // time per step; below, a workgroup per CU or less, the extra loads and the restore cost 0.5 us of a 9 us step);
+      // they take effect on handles whose configuration admits the consecutive-call branches (GenCtl::simple_ok)
+      h->gen_hot = h->gen_lean;
+      if (const char* gh = std::getenv("CDPR_GEN_HOT")) h->gen_hot = h->gen_lean && gh[0] != '0';  // (the role-split kernel carries no code for them)
     }
     const size_t rec_bytes = h->glay.bytes(h->stride);
     if (rec_bytes >= (1ull << 32)) {  // the record buffer is addressed with 32-bit offsets (one buffer resource)

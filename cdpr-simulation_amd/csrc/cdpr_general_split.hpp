@@ -120,6 +120,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_gen_split_kernel(const StepArgs a
     sel[i] = (mode == 2 && fabsf(target[i]) > g.eps) ? 1 : 0;
     asm volatile("" : "+v"(sel[i]));
   }
+  // (no hot rows here - GenHot: the engine keeps them to the handles the lean kernel steps)
   if (run_ctl) {
     float keep = (s.px + s.qy) + (s.vy + s.wz);
 #pragma unroll
@@ -573,6 +574,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   const float pv = g.ptab[min(lane, 2u * kGenPidFloats - 1u)];
   const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p2 = load_slot(a.state, st, 2, off),
                p3 = load_slot(a.state, st, 3, off);
+  const bool hot_on = g.hot != 0 && g.simple_ok != 0;
+  uint32_t hot_step1 = 0u, hot_mask = 0u;  // the robot's hot-row word (GenHot)
+  if (hot_on) hot_step1 = RB.loadc(0, col * 4u), hot_mask = RB.loadc(1, col * 4u);
   const int mode = g.mode_arr ? (int)g.mode_arr[rr] : g.mode;
   float target[N];
   lean_load_targets<N>(g, rr, mode, target);
@@ -602,6 +606,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
     sel[i] = (mode == 2 && fabsf(target[i]) > g.eps) ? 1 : 0;
     asm volatile("" : "+v"(sel[i]));
   }
+  GenHot hot{false, false, false, 0u, 0};  // hot rows (GenHot): this kernel starts and keeps them
+  float hot_ierr[N];
+  bool hot_skip = false;
   {
     float keep = (s.px + s.qy) + (s.vy + s.wz);
 #pragma unroll
@@ -609,7 +616,8 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
     bool holds = false;  // some cable of this lane is in the hold branch (JFC.cpp:78-82)
 #pragma unroll
     for (int i = 0; i < N; ++i) holds = holds || (mode == 2 && sel[i] == 0);
-    gen_stage_records<N, NBMAX>(RB, L, col, sel, &sm.stage[0][0][0], &sm.hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull);
+    hot = gen_hot_begin<N>(hot_on, RB, col, hot_step1, hot_mask, sel, mode, now, hot_ierr, hot_skip);
+    gen_stage_records<N, NBMAX>(RB, L, col, sel, &sm.stage[0][0][0], &sm.hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull, hot_skip);
   }
 
   // ---- IK on the state at t_k; the structure matrix stays alive for the world step (the inlined controller branch leaves room)
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
 #ifdef CDPR_STAMPS
   cc.stamps = nullptr;
 #endif
+  gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, hot_ierr, sel, &sm.stage[0][0][0]);
   bool simple, fast, gaps;
   gen_consecutive_test<N, NBMAX>(cc, &sm.stage[0][0][0], lane, mode, now, simple, fast, gaps);
   // Two `if`s in sequence on the same wave-uniform decision, the second through a scalar the compiler cannot see through.  As ONE
@@ -648,8 +657,8 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   // inlined branch nothing is live any more but the tail's own arguments.
   uint32_t cold = (__builtin_amdgcn_ballot_w64(!simple) != 0ull) ? 1u : 0u;
   if (cold == 0u) {  // every cable on a uniform or a filling window: the first branch of gen_controller, inline
-    gen_steady<N, NBMAX, CDPR_LEAN_GROUP>(cc, RB, L, lane, live, col, mode, now, target, sel, q, qd, &sm.stage[0][0][0], &sm.hold_slots[0][0], &sm.wrot[0][0][0], sm.ptab,
-                                         force, dbg);
+    gen_steady<N, NBMAX, CDPR_LEAN_GROUP, true>(cc, RB, L, lane, live, col, mode, now, target, sel, q, qd, &sm.stage[0][0][0], &sm.hold_slots[0][0], &sm.wrot[0][0][0],
+                                               sm.ptab, force, dbg, hot);
     lean_controller_epilogue<N, false>(a, sm, geo, lane, r, live, s, q, qd, jac, force, dbg);
   }
   cold = __builtin_amdgcn_readfirstlane(cold);
@@ -657,6 +666,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   if (cold != 0u) {  // the other paths finish this wave's work in a function of their own and end the program there
     // (this wave is late already and decides when the launch ends: it wins the SIMD's issue arbitration from here on)
     __builtin_amdgcn_s_setprio(3);
+    // (the tail's tiers write every H slot they touch: a robot that goes there with a valid word - its H slots restored in LDS
+    //  above - has it cleared here; the tail itself runs with the hot rows off)
+    if (hot.on) RB.storec_if(live && hot.has, 0, col * 4u, 0u);
     const uint64_t kaddr = (uint64_t)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
     // q, qd and the structure matrix travel through the lane's private memory (a stack object of this kernel that only this
     // block touches): the tail reads q and qd on entry and the matrix between the two barriers (rebuilding it there:

@@ -74,7 +74,10 @@ struct GenLayout {
   __host__ __device__ int rows() const { return 2 * pid_rows(); }                // region B
   __host__ __device__ int r_pfilt() const { return nb; }
   __host__ __device__ int r_dfilt() const { return nb + 4 * ncas; }
-  __host__ __device__ size_t bytes(size_t rstride) const { return ((size_t)slots() * 16 + (size_t)rows() * 4) * rstride; }
+  // region C, "hot rows" (dword rows, round 5): row 0 a world step + 1 (0: none), row 1 a Pid mask, rows 2 .. 2 + n - 1 mIerr
+  // of the cables' Pids of that mask - what a robot in the deep steady state rewrites instead of its H slots (gen_hot_*)
+  __host__ __device__ int hot_rows() const { return 2 + n; }
+  __host__ __device__ size_t bytes(size_t rstride) const { return ((size_t)slots() * 16 + (size_t)(rows() + hot_rows()) * 4) * rstride; }
 };
 
 constexpr uint32_t kGmWasLast = 1u, kGmCountShift = 1u, kGmHeadShift = 7u, kGmRunShift = 13u, kGmField = 63u;
@@ -109,6 +112,7 @@ struct GenCtl {
                          // next to the step's own constants (measured: 2 400 v_readlane / v_writelane per robot-step)
   int pcas_max, dcas_max;  // deepest P-input / D-input cascade of the two Pids
   int nbuf0, nbuf1;        // window lengths of the position / velocity Pid (the ring slot of a sample is its stamp mod nbuf)
+  int hot;                 // hot rows in use (the engine: simple_ok handles; CDPR_GEN_HOT=0 turns them off)
   int simple_ok;           // the steady-state branch may be taken: both Pids have the same window length and degree (one ring
                            // head and one weight row serve every cable), no cascades, a command clamp and iMin <= iMax
   // ROLLOUT: every trajectory works on a private copy of its robot's records (column = trajectory index in `rec`)
@@ -140,6 +144,7 @@ struct GenBuf {
   uint32_t rs16;   // bytes per slot row (region A)
   uint32_t rs4;    // bytes per dword row (region B)
   uint32_t base_b; // byte offset of region B
+  uint32_t base_c; // byte offset of region C (hot rows)
   // region A: float4 slots; voff = the lane's column * 16 (+ the selected Pid's offset)
   CDPR_DEV float4 load4(int slot, uint32_t voff) const {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -168,6 +173,11 @@ struct GenBuf {
   CDPR_DEV void storei_if(bool on, int row, uint32_t voff, int v) const {
     __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, rsrc, on ? voff : 0xFFFFFFFFu, base_b + (uint32_t)row * rs4, 0);
   }
+  // region C: hot rows; voff = the lane's column * 4
+  CDPR_DEV uint32_t loadc(int row, uint32_t voff) const { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, base_c + (uint32_t)row * rs4, 0); }
+  CDPR_DEV void storec_if(bool on, int row, uint32_t voff, uint32_t v) const {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, on ? voff : 0xFFFFFFFFu, base_c + (uint32_t)row * rs4, 0);
+  }
 };
 CDPR_DEV GenBuf gen_buffer(float* rec, uint32_t rstride, uint32_t rec_bytes, const GenLayout& L) {
   GenBuf b;
@@ -175,6 +185,7 @@ CDPR_DEV GenBuf gen_buffer(float* rec, uint32_t rstride, uint32_t rec_bytes, con
   b.rs16 = rstride * 16u;
   b.rs4 = rstride * 4u;
   b.base_b = (uint32_t)L.slots() * b.rs16;
+  b.base_c = b.base_b + (uint32_t)L.rows() * b.rs4;
   return b;
 }
 
@@ -358,6 +369,77 @@ struct GenDbg {
   float p, i, d, des;
   bool pi, dw;
 };
+// Hot rows (region C; round 5).  A robot whose cables all sit in the deep steady state - window full, `run` saturated, no
+// second run - changes only mLastTime and mIerr of its H slots from step to step.  Such a robot stops writing (and reading)
+// the eight H slots: it keeps one word "step s + 1 | Pid mask" and the integrals in dword rows (40 B read and 40 B written
+// per step against 256).  While the word is valid the H slots of the mask's Pids are STALE in memory; every kernel restores
+// them in LDS behind the DMA (gen_hot_restore), and a robot that leaves the state writes them back that very step.
+struct GenHot {
+  bool on;        // the handle uses hot rows
+  bool has;       // this robot's word is valid: the H slots of the Pids of `mask` are stale in memory
+  bool fresh;     // ... and those Pids were called one world step ago and are this step's Pids
+  uint32_t mask;  // bit i: the Pid (0 position, 1 velocity) that served cable i at that step
+  int step;       // that step
+};
+template <int N>
+CDPR_DEV GenHot gen_hot_state(bool on, uint32_t step1, uint32_t mask, const int (&sel)[N], int mode, int now) {
+  GenHot h;
+  h.on = on, h.has = on && step1 != 0u, h.step = (int)step1 - 1, h.mask = mask;
+  uint32_t sm = 0u;
+#pragma unroll
+  for (int i = 0; i < N; ++i) sm |= (uint32_t)sel[i] << i;
+  h.fresh = h.has && h.step == now - 1 && mask == sm && mode != 0;
+  return h;
+}
+// In front of the DMA of a step's record slots: the robot's word -> its hot state; the integrals on their way (ordinary
+// loads: first read behind the wait for the DMA); `skip_h`: every lane of the wave fresh - no H slot is loaded.
+// (step1, mask: the robot's word - rows 0 and 1 - loaded by the caller with its first loads: read here, they would be a round
+//  trip to memory between the Joy that selects the Pids and the DMA of their slots: + 0.9 us per step at 16 384 robots)
+template <int N>
+CDPR_DEV GenHot gen_hot_begin(bool on, const GenBuf& RB, uint32_t col, uint32_t step1, uint32_t mask, const int (&sel)[N], int mode, int now, float (&ierr)[N],
+                              bool& skip_h) {
+  const GenHot hot = gen_hot_state<N>(on, step1, mask, sel, mode, now);
+  skip_h = on && __builtin_amdgcn_ballot_w64(!hot.fresh) == 0ull;
+#pragma unroll
+  for (int i = 0; i < N; ++i) ierr[i] = 0.f;
+  if (__builtin_amdgcn_ballot_w64(hot.has) != 0ull) {  // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < N; ++i) ierr[i] = __uint_as_float(RB.loadc(2 + i, col * 4u));
+  }
+  return hot;
+}
+// Behind the DMA of a step's record slots: the staged H slots of the robots with a valid word, restored from it (every
+// lane fresh: the H slots were not loaded at all, gen_stage_records); a robot that is NOT fresh leaves the state - its
+// eight H slots go back to memory as they stand and its word is cleared.
+template <int N, int NBMAX>
+CDPR_DEV void gen_hot_restore(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, const GenHot hot,
+                              const float (&ierr)[N], const int (&sel)[N], float4* cab) {
+  constexpr int NV = gen_nv(NBMAX);
+  constexpr int kCab = (NV + 1) * 64;
+  if (__builtin_amdgcn_ballot_w64(hot.has) == 0ull) return;  // (wave-uniform)
+  const int nbuf = kc.nbuf0;
+  const int hd = hot.step - (hot.step / nbuf) * nbuf;  // the ring slot of a sample is its stamp mod nbuf
+  const uint32_t meta = kGmWasLast | ((uint32_t)nbuf << kGmCountShift) | ((uint32_t)hd << kGmHeadShift) | (kGmField << kGmRunShift);
+  const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16;
+  const bool all_fresh = __builtin_amdgcn_ballot_w64(!hot.fresh) == 0ull;
+  const bool leaves = hot.has && !hot.fresh;
+  const bool any_leaves = __builtin_amdgcn_ballot_w64(leaves) != 0ull;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float4 canon = make_float4(__uint_as_float(meta), __int_as_float(hot.step), ierr[i], 0.f);
+    const bool mine = hot.has && ((hot.mask >> i) & 1u) == (uint32_t)sel[i];  // the staged H slot is this Pid's
+    float4* const hs = cab + i * kCab + NV * 64 + lane;
+    if (all_fresh) {
+      *hs = canon;
+    } else {
+      const float4 rd = *hs;  // (component by component: a select of two float4 objects goes through scratch memory)
+      *hs = make_float4(mine ? canon.x : rd.x, mine ? canon.y : rd.y, mine ? canon.z : rd.z, mine ? canon.w : rd.w);
+    }
+    if (any_leaves) RB.store4_if(live && leaves, L.block_a(0, i) + L.nv(), col * 16u + (((hot.mask >> i) & 1u) ? pid_a : 0u), canon);
+  }
+  if (any_leaves) RB.storec_if(live && leaves, 0, col * 4u, 0u);
+}
+
 // Pid::update of every cable of a wave whose calls are all CONSECUTIVE (each Pid called one world step ago, mWasLastTime
 // set, no cascades, command clamp, iMin <= iMax, one window length for both Pids): ONE ring head for the whole wave (now
 // mod nbuf, a scalar), one row of weights, static LDS addresses; the table weighs the head slot with 0 and the new sample
@@ -375,7 +457,8 @@ template <int N, int NBMAX, int PASS, int GWIDE = 4, bool GAPS = false>
 CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, int mode, int now,
                               const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)], const v2f (&qd)[cable_pairs(N)],
                               const float4* cab, const float4 (&held4)[(N + 3) / 4], const float* wrot, const float4 (*ptab)[kGenPidFloats / 4],
-                              uint32_t need, uint32_t qslot0, float* qrows, float (&force)[N], float (&newpos)[N], GenDbg& dbg, float* park = nullptr) {
+                              uint32_t need, uint32_t qslot0, float* qrows, float (&force)[N], float (&newpos)[N], GenDbg& dbg, float* park = nullptr,
+                              bool sat = false) {
   constexpr int NV = gen_nv(NBMAX);
   constexpr int NBP = gen_nbp(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
@@ -501,7 +584,9 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
           pk[0 * ps] = dt, pk[1 * ps] = (g0[j].x * desired + p_term) + i_cl, pk[2 * ps] = (i_cl != i_term) ? i_cl * g2[j].w : fmaf(dt, error, prev_ierr);
           pk[3 * ps] = prev_ierr, pk[4 * ps] = __uint_as_float(nmeta), pk[5 * ps] = __int_as_float(last2);
         }
-        const bool writes_h = (PASS == 0) ? live : ((PASS == 1) ? (live && !waits) : (live && waits));
+        // (PASS 0, `sat`: the robot keeps its steady state in the hot rows - mIerr there, no H slot written: GenHot)
+        if constexpr (PASS == 0) RB.storec_if(live && sat, 2 + i, col * 4u, __float_as_uint(ie));
+        const bool writes_h = (PASS == 0) ? (live && !sat) : ((PASS == 1) ? (live && !waits) : (live && waits));
         RB.store4_if(writes_h, sa + L.nv(), va, make_float4(__uint_as_float(nmeta), __int_as_float(now), ie, (two && !first) ? __int_as_float(last2) : out));
       }
     }
@@ -597,18 +682,40 @@ CDPR_DEV void gen_turn_rings(const GenCtlConst kc, const GenBuf& RB, const GenLa
 
 // gen_controller's first branch: every cable of the wave on a uniform or a filling window (gen_consecutive<0>), then
 // mLastPosition back.
-template <int N, int NBMAX, int GWIDE>
+template <int N, int NBMAX, int GWIDE, bool HOT = false>
 CDPR_DEV void gen_steady(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, int mode, int now, const float (&target)[N],
                          const int (&sel)[N], const v2f (&q)[cable_pairs(N)], const v2f (&qd)[cable_pairs(N)], const float4* cab, const float4* hold_slots,
-                         const float* wrot, const float4 (*ptab)[kGenPidFloats / 4], float (&force)[N], GenDbg& dbg) {
+                         const float* wrot, const float4 (*ptab)[kGenPidFloats / 4], float (&force)[N], GenDbg& dbg, const GenHot hot = GenHot{false, false, false, 0u, 0}) {
   constexpr int LP = (N + 3) / 4;
+  constexpr int NV = gen_nv(NBMAX);
+  constexpr int kCab = (NV + 1) * 64;
   float4 held4[LP];
 #pragma unroll
   for (int g4 = 0; g4 < LP; ++g4) held4[g4] = hold_slots[g4 * 64 + lane];
   float newpos[N];
+  // HOT: a robot whose cables are all in the deep steady state AFTER this step (window full, run saturated, one run) keeps
+  // mLastTime and mIerr in its hot rows from now on (or goes on doing so) instead of writing eight H slots
+  bool sat = false;
+  if (HOT && hot.on) {
+    int bad = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t meta = __float_as_uint(reinterpret_cast<const float*>(cab)[(i * kCab + NV * 64 + lane) * 4]);
+      const int count = (int)((meta >> kGmCountShift) & kGmField), run = (int)((meta >> kGmRunShift) & kGmField);
+      bad |= (count - kc.nbuf0) | (run - ((int)kGmField - 1)) | ((meta & kGmTwo) ? -1 : 0);
+    }
+    sat = bad >= 0;
+  }
   GEN_CTL_STAMP(1);
-  gen_consecutive<N, NBMAX, 0, GWIDE>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, 0u, 0u, nullptr, force, newpos, dbg);
+  gen_consecutive<N, NBMAX, 0, GWIDE>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, 0u, 0u, nullptr, force, newpos, dbg, nullptr, sat);
   GEN_CTL_STAMP(3);
+  if (hot.on) {  // (wave-uniform) the word: valid from this step on, or cleared where a robot with one does not qualify (H slots written above)
+    uint32_t sm = 0u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) sm |= (uint32_t)sel[i] << i;
+    RB.storec_if(live && (sat || hot.has), 0, col * 4u, sat ? (uint32_t)(now + 1) : 0u);
+    RB.storec_if(live && sat && !(hot.fresh && hot.mask == sm), 1, col * 4u, sm);
+  }
 #pragma unroll
   for (int g4 = 0; g4 < LP; ++g4)
     RB.store4_if(live, g4, col * 16u, make_float4(newpos[4 * g4], (4 * g4 + 1 < N) ? newpos[4 * g4 + 1] : 0.f, (4 * g4 + 2 < N) ? newpos[4 * g4 + 2] : 0.f,
@@ -618,11 +725,12 @@ CDPR_DEV void gen_steady(const GenCtlConst kc, const GenBuf& RB, const GenLayout
 #ifndef CDPR_LEAN_GROUP
 #define CDPR_LEAN_GROUP 2  // cables per group in the branch the lean role-split kernel inlines (register pressure: 32 registers per cable of a group)
 #endif
-template <int N, int NBMAX, bool STEADY_ONLY = false, bool TIER1 = true>
+template <int N, int NBMAX, bool STEADY_ONLY = false, bool TIER1 = true, bool HOT = false>
 CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, uint32_t first_unit,
                              uint32_t units, int mode, int now, const float (&target)[N], const int (&sel)[N], const v2f (&q)[cable_pairs(N)],
                              const v2f (&qd)[cable_pairs(N)], float4* cab, const float4* hold_slots, const float* wrot,
-                             const float4 (*ptab)[kGenPidFloats / 4], uint32_t* q_count, float (&force)[N], GenDbg& dbg) {
+                             const float4 (*ptab)[kGenPidFloats / 4], uint32_t* q_count, float (&force)[N], GenDbg& dbg,
+                             const GenHot hot = GenHot{false, false, false, 0u, 0}) {
   constexpr int NV = gen_nv(NBMAX);
   constexpr int NBP = gen_nbp(NBMAX);
   constexpr int kCab = (NV + 1) * 64;    // float4 elements between the slot sets of consecutive cables
@@ -657,9 +765,12 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
 #else
   if (__builtin_amdgcn_ballot_w64(!simple) == 0ull) {  // (wave-uniform)
 #endif
-    gen_steady<N, NBMAX, STEADY_ONLY ? CDPR_LEAN_GROUP : 4>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, hold_slots, wrot, ptab, force, dbg);
+    gen_steady<N, NBMAX, STEADY_ONLY ? CDPR_LEAN_GROUP : 4, HOT>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, hold_slots, wrot, ptab, force, dbg, hot);
     return true;
   }
+  // (the other tiers write every H slot they touch: a robot that comes here with a valid word - restored in LDS by
+  //  gen_hot_restore - has it cleared)
+  if (hot.on) RB.storec_if(live && hot.has, 0, col * 4u, 0u);
   // ---- tier 1: every Pid called with mWasLastTime set; some windows carry a gap (the nbuf - 1 steps after a switch between
   //      the two Pids: the fit), some Pids are called for the first time after one (their rings are turned first,
   //      gen_turn_rings).  The queue is built FIRST, from the staged H slots alone, so that the stamps a fit needs - the only
@@ -1088,7 +1199,8 @@ CDPR_DEV float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstl
 // hold-position slots.  `keep`: a value every ordinary load issued so far feeds (hipcc drains every outstanding VMEM
 // operation at the first use of an ordinary load's result while an LDS-DMA is pending).
 template <int N, int NBMAX>
-CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t col, const int (&sel)[N], float4* cab, float4* hold_slots, float keep, bool need_hold) {
+CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t col, const int (&sel)[N], float4* cab, float4* hold_slots, float keep, bool need_hold,
+                                bool skip_h = false) {  // skip_h (wave-uniform): every lane's H slots come from its hot rows (gen_hot_restore)
   constexpr int NV = gen_nv(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
   constexpr int LP = (N + 3) / 4;
@@ -1104,7 +1216,7 @@ CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t co
     const int sa = L.block_a(0, i);
 #pragma unroll
     for (int s4 = 0; s4 < NV; ++s4) RB.slot_to_lds(sa + min(s4, L.nv() - 1), va, cab + i * kCab + s4 * 64);  // (slots past nv: a copy, weight 0)
-    RB.slot_to_lds(sa + L.nv(), va, cab + i * kCab + NV * 64);
+    if (!skip_h) RB.slot_to_lds(sa + L.nv(), va, cab + i * kCab + NV * 64);
   }
 }
 
@@ -1206,6 +1318,9 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       const float v = (reset_vel && row >= vb0 && row < vb1) ? 0.f : srcb[(size_t)row * g.src_rstride + rr];
       if (live) dstb[(size_t)row * rs + col] = v;
     }
+    for (int row = L.rows(); row < L.rows() + L.hot_rows(); ++row) {  // the hot rows (GenHot) travel with the records they stand for
+      if (live) dstb[(size_t)row * rs + col] = srcb[(size_t)row * g.src_rstride + rr];
+    }
     mode = 2;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1247,6 +1362,9 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     // (opaque per step: in a launch of several steps every slot offset is loop-invariant, and hoisted out of the step loop
     //  they overflow the scalar register file into v_writelane / v_readlane pairs)
     if (!SINGLE) asm volatile("" : "+s"(RB.rs16), "+s"(RB.rs4));
+    const bool hot_on = g.hot != 0 && g.simple_ok != 0;
+    uint32_t hot_step1 = 0u, hot_mask = 0u;  // the robot's hot-row word (GenHot), on its way under the selection below
+    if (hot_on) hot_step1 = RB.loadc(0, col * 4u), hot_mask = RB.loadc(1, col * 4u);
     // ---- which Pid serves each cable this step (JFC.cpp:67-89), and its slots on their way to LDS
     int sel[N];  // 0 position Pid, 1 velocity Pid (Force mode: 0, unused)
 #pragma unroll
@@ -1257,6 +1375,9 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       asm volatile("" : "+v"(sel[i]));  // (also keeps the selection a 0 / 1 register: as eight lane masks it crowds the scalar file)
     }
     const bool run_ctl = !first_world;
+    GenHot hot{false, false, false, 0u, 0};  // hot rows (GenHot): this kernel restores and clears them, it does not start them
+    float hot_ierr[N];
+    bool hot_skip = false;
 #ifdef CDPR_STAMPS_PRO
     { float k2 = 0.f;
 #pragma unroll
@@ -1271,7 +1392,8 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       bool holds = false;  // some cable of this lane is in the hold branch (JFC.cpp:78-82)
 #pragma unroll
       for (int i = 0; i < N; ++i) holds = holds || (mode == 2 && sel[i] == 0);
-      gen_stage_records<N, NBMAX>(RB, L, col, sel, &stage[0][0][0], &hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull);
+      hot = gen_hot_begin<N>(hot_on, RB, col, hot_step1, hot_mask, sel, mode, now, hot_ierr, hot_skip);
+      gen_stage_records<N, NBMAX>(RB, L, col, sel, &stage[0][0][0], &hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull, hot_skip);
     }
     GEN_PHASE_STAMP(1);
 
@@ -1354,8 +1476,9 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
 #ifdef CDPR_STAMPS
       cc.stamps = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
 #endif
+      gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, hot_ierr, sel, &stage[0][0][0]);
       gen_controller<N, NBMAX, false, false>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &stage[0][0][0], &hold_slots[0][0],
-                               &wrot[0][0][0], ptab, q_count, force, dbg);
+                               &wrot[0][0][0], ptab, q_count, force, dbg, hot);
     }
     CDPR_STAMP(5);
     v2f f[NP];
@@ -1495,6 +1618,32 @@ struct GenLatchArgs {
   GenLayout lay;
   int new_mode;
 };
+
+// The hot rows (GenHot) written back: every robot with a valid word gets the H slots of its word's Pids as they stand and
+// its word cleared.  Runs in front of anything that resets a Pid's records from outside the step kernels (a mode change),
+// so that those see - and zero - plain records.
+struct GenFlushArgs {
+  float* rec;
+  uint32_t rstride, batch;
+  GenLayout lay;
+  int nbuf;
+};
+static __global__ __launch_bounds__(256) void cdpr_gen_flush_hot_kernel(const GenFlushArgs a) {
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= a.batch) return;
+  uint32_t* const c = reinterpret_cast<uint32_t*>(a.rec) + ((size_t)a.lay.slots() * 4 + (size_t)a.lay.rows()) * a.rstride + r;
+  const uint32_t step1 = c[0];
+  if (step1 == 0u) return;
+  const uint32_t mask = c[a.rstride];
+  const int step = (int)step1 - 1;
+  const uint32_t meta = kGmWasLast | ((uint32_t)a.nbuf << kGmCountShift) | ((uint32_t)(step % a.nbuf) << kGmHeadShift) | (kGmField << kGmRunShift);
+  float4* const slots = reinterpret_cast<float4*>(a.rec);
+  for (int i = 0; i < a.lay.n; ++i) {
+    const float ierr = __uint_as_float(c[(size_t)(2 + i) * a.rstride]);
+    slots[(size_t)(a.lay.block_a((int)((mask >> i) & 1u), i) + a.lay.nv()) * a.rstride + r] = make_float4(__uint_as_float(meta), __int_as_float(step), ierr, 0.f);
+  }
+  c[0] = 0u;
+}
 
 static __global__ __launch_bounds__(256) void cdpr_gen_latch_kernel(const GenLatchArgs a) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
