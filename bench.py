@@ -55,7 +55,7 @@ CONFIGS = {2: dict(batch=4096, cables=4), 3: dict(batch=65536, cables=8)}
 SCHED_CHUNK = 1000  # world steps per launch on the scheduled path (small batches)
 FUSED_WARM, FUSED_LAUNCHES = 3, 30  # the fused leg's own schedule: untimed / minimum timed launches of 10 steps each
 ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
-GENERAL_SHAPE = (65536, 0.001, 60, 300)  # general-path leg (the contract's size since round 5): robots, velocityEpsilon, untimed steps (past the window fill), timed steps
+GENERAL_SHAPE = (65536, 0.001, 120, 400)  # general-path leg (the contract's size since round 5): robots, velocityEpsilon, untimed steps (past the window fill AND the 63 consecutive calls after which a robot keeps its steady state in the hot rows), timed steps
 FP64_SHAPES = ((65536, 300, 400), (1, 100, 300))  # (robots, warm-up steps, timed steps): the warm-up also brings the clock back up after the host-side replay of the leg before
 FP64_TOL = {"pose": 1e-10, "eff": 1e-7}         # fp64 kernels against the fp64 oracle (two double implementations; tests/test_gpu_fp64.py: 1e-13 / 1e-9 over short runs)
 LARGE_BATCH_SHAPE = (524288, 100, 200)           # HBM-streaming regime on ONE GPU: robots, untimed steps, timed steps
