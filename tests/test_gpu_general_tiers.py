@@ -59,3 +59,65 @@ def test_more_queued_cables_than_one_pass_of_the_queue(pkg, oracle, monkeypatch,
             eng.update(1)
         ora.update(k)
         compare(eng, ora, where=f"stretch {j}")
+
+
+@pytest.mark.parametrize("per_robot", [False, True])
+def test_hot_rows_survive_everything_that_touches_the_records(pkg, oracle, monkeypatch, per_robot):
+    """On the lean kernel's handles (forced here at a small batch) a robot that has sat in the deep steady state for 63 steps keeps
+    mLastTime / mIerr in its hot rows and its H slots go stale in memory.  Everything that reads or resets the records from
+    then on has to see through that: cables falling into the hold branch and coming back, MPC rollouts (private copies of
+    the records, the one-wave kernel), position and force Joys (a Pid reset: the rows are written back first), a masked
+    Joy on a per-robot handle, the trajectory record, a state write, a world reset - one history on the oracle."""
+    monkeypatch.setenv("CDPR_GEN_SPLIT", "0")
+    monkeypatch.setenv("CDPR_GEN_LEAN", "1")
+    B, n = 64 * 2 + 9, 8
+    rng = np.random.default_rng(31 + per_robot)
+    cfg = _cfg(pkg, B, perRobotCommands=per_robot)
+    eng, ora = pair(pkg, oracle, cfg, perturbed_poses(cfg.model, B, rng, 0.02, 0.05))
+    hi = rng.uniform(0.01, 0.03, (B, n)).astype(np.float32)
+    lo = hi.copy()
+    lo[2::7, 1::3] = 0.001  # some cables of some robots below epsilon
+
+    def run(k, where, how="one"):
+        if how == "one":
+            for _ in range(k):
+                eng.update(1)
+        elif how == "fused":
+            eng.update(k, 5)
+        else:
+            eng.update_record(k, 4)
+        ora.update(k)
+        compare(eng, ora, where=where)
+
+    def rollout(where):
+        cmds = rng.uniform(-0.03, 0.03, (B, 6, 3, n)).astype(np.float32)
+        ref = eng.raw_state()[0][:, :3].astype(np.float64) + np.array([0.0, 0.0, 0.01])
+        gc, oc = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref)
+        assert np.abs(gc - oc).max() <= 1e-9 + 2e-4 * np.abs(oc).max(), where
+
+    eng.set_velocity_command(hi), ora.set_velocity_command(hi)
+    run(90, "into the hot rows")
+    rollout("a rollout from records whose H slots are stale")
+    run(5, "after the rollout")
+    eng.set_velocity_command(lo), ora.set_velocity_command(lo)
+    run(30, "cables in the hold branch (their robots left the hot rows)")
+    eng.set_velocity_command(hi), ora.set_velocity_command(hi)
+    run(100, "back, and into the hot rows again", how="fused")
+    pos = rng.uniform(-0.004, 0.004, (B, n)).astype(np.float32)
+    kw = {"mask": np.arange(B) % 3 == 0} if per_robot else {}
+    eng.set_position_command(pos, **kw), ora.set_position_command(pos, **kw)
+    run(80, "position Joy (velocity Pid's rows written back, position Pid reset)")
+    rollout("a rollout in position mode")
+    frc = (7.0 + rng.uniform(-0.5, 0.5, (B, n))).astype(np.float32)
+    kw = {"mask": np.arange(B) % 3 == 1} if per_robot else {}
+    eng.set_force_command(frc, **kw), ora.set_force_command(frc, **kw)
+    run(12, "force Joy")
+    kw = {"mask": np.arange(B) % 2 == 0} if per_robot else {}
+    eng.set_velocity_command(hi, **kw), ora.set_velocity_command(hi, **kw)
+    run(75, "velocity again", how="record")
+    p = perturbed_poses(cfg.model, B, rng, 0.02, 0.05).astype(np.float32)
+    eng.set_platform_state(pose7=p), ora.set_platform_state(pose7=p.astype(np.float64))
+    run(70, "after a state write")
+    eng.reset(), ora.reset()
+    eng.set_velocity_command(lo), ora.set_velocity_command(lo)
+    run(20, "after a world reset")
