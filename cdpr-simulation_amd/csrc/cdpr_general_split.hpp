@@ -169,6 +169,7 @@ __global__ __launch_bounds__(128, 1) void cdpr_gen_split_kernel(const StepArgs a
     GenCtlConst cc;
     cc.pcas_max = g.pcas_max, cc.dcas_max = g.dcas_max, cc.dt = g.dt, cc.inv_dt = a.inv_dt;
     cc.nm0 = now % max(g.nbuf0, 1), cc.nm1 = now % max(g.nbuf1, 1), cc.nbuf0 = g.nbuf0, cc.simple_ok = g.simple_ok != 0;
+  cc.force_rows = nullptr;
 #ifdef CDPR_STAMPS
     cc.stamps = nullptr;
 #endif
@@ -510,6 +511,7 @@ CDPR_LEAN_TAIL_ATTR void gen_lean_cold_tail(lean_f4 s0, lean_f4 s1, lean_f4 s2, 
   GenCtlConst cc;
   cc.pcas_max = g.pcas_max, cc.dcas_max = g.dcas_max, cc.dt = g.dt, cc.inv_dt = a.inv_dt;
   cc.nm0 = now % max(g.nbuf0, 1), cc.nm1 = now % max(g.nbuf1, 1), cc.nbuf0 = g.nbuf0, cc.simple_ok = g.simple_ok != 0;
+  cc.force_rows = nullptr;
 #ifdef CDPR_STAMPS
 #ifdef CDPR_STAMPS_COLD
   cc.stamps = a.stamps ? a.stamps + ((size_t)gridDim.x + blockIdx.x) * 8 : nullptr;
@@ -607,7 +609,6 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
     asm volatile("" : "+v"(sel[i]));
   }
   GenHot hot{false, false, false, 0u, 0};  // hot rows (GenHot): this kernel starts and keeps them
-  float hot_ierr[N];
   bool hot_skip = false;
   {
     float keep = (s.px + s.qy) + (s.vy + s.wz);
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
     bool holds = false;  // some cable of this lane is in the hold branch (JFC.cpp:78-82)
 #pragma unroll
     for (int i = 0; i < N; ++i) holds = holds || (mode == 2 && sel[i] == 0);
-    hot = gen_hot_begin<N>(hot_on, RB, col, hot_step1, hot_mask, sel, mode, now, hot_ierr, hot_skip);
+    hot = gen_hot_begin<N>(hot_on, hot_step1, hot_mask, sel, mode, now, hot_skip);
     gen_stage_records<N, NBMAX>(RB, L, col, sel, &sm.stage[0][0][0], &sm.hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull, hot_skip);
   }
 
@@ -644,21 +645,25 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   GenCtlConst cc;
   cc.pcas_max = g.pcas_max, cc.dcas_max = g.dcas_max, cc.dt = g.dt, cc.inv_dt = a.inv_dt;
   cc.nm0 = now % max(g.nbuf0, 1), cc.nm1 = now % max(g.nbuf1, 1), cc.nbuf0 = g.nbuf0, cc.simple_ok = g.simple_ok != 0;
+  cc.force_rows = nullptr;
 #ifdef CDPR_STAMPS
   cc.stamps = nullptr;
 #endif
-  gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, hot_ierr, sel, &sm.stage[0][0][0]);
-  bool simple, fast, gaps;
-  gen_consecutive_test<N, NBMAX>(cc, &sm.stage[0][0][0], lane, mode, now, simple, fast, gaps);
+  gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, sel, &sm.stage[0][0][0]);
+  // tier 0 and - for waves without a gap call - tier 1 of the general controller inline (gen_controller<STEADY_ONLY>); what it
+  // does not serve goes to the tail.
   // Two `if`s in sequence on the same wave-uniform decision, the second through a scalar the compiler cannot see through.  As ONE
-  // if / else LLVM's structurizer puts the call block FIRST and lets it flow into the block in front of the inlined branch:
-  // everything that branch and the epilogue read is then live across the call, the call block saves it (33 stores, 60
-  // v_writelane) and the tail's entry - s_waitcnt vmcnt(0) by the calling convention - waits for those stores.  Behind the
-  // inlined branch nothing is live any more but the tail's own arguments.
-  uint32_t cold = (__builtin_amdgcn_ballot_w64(!simple) != 0ull) ? 1u : 0u;
-  if (cold == 0u) {  // every cable on a uniform or a filling window: the first branch of gen_controller, inline
-    gen_steady<N, NBMAX, CDPR_LEAN_GROUP, true>(cc, RB, L, lane, live, col, mode, now, target, sel, q, qd, &sm.stage[0][0][0], &sm.hold_slots[0][0], &sm.wrot[0][0][0],
-                                               sm.ptab, force, dbg, hot);
+  // if / else LLVM's structurizer puts the call block FIRST and lets it flow into the block in front of the epilogue:
+  // everything the epilogue reads is then live across the call, the call block saves it (33 stores, 60 v_writelane) and the
+  // tail's entry - s_waitcnt vmcnt(0) by the calling convention - waits for those stores.  Behind the epilogue nothing is
+  // live any more but the tail's own arguments.
+  cc.force_rows = &sm.tgt[0][0].x;  // (the Joy targets parked there are the tail's: it is entered only where nothing was written)
+  const bool served = gen_controller<N, NBMAX, true, true, true>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &sm.stage[0][0][0],
+                                                                 &sm.hold_slots[0][0], &sm.wrot[0][0][0], sm.ptab, sm.q_count, force, dbg, hot);
+  uint32_t cold = served ? 0u : 1u;
+  if (cold == 0u) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) force[i] = (&sm.tgt[0][0].x)[i * 64 + lane];
     lean_controller_epilogue<N, false>(a, sm, geo, lane, r, live, s, q, qd, jac, force, dbg);
   }
   cold = __builtin_amdgcn_readfirstlane(cold);

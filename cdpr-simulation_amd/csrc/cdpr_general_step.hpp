@@ -174,6 +174,9 @@ struct GenBuf {
     __builtin_amdgcn_raw_buffer_store_b32((unsigned)v, rsrc, on ? voff : 0xFFFFFFFFu, base_b + (uint32_t)row * rs4, 0);
   }
   // region C: hot rows; voff = the lane's column * 4
+  CDPR_DEV void rowc_to_lds(int row, uint32_t voff, void* dst_row) const {  // lane l's dword lands at dst_row + 4 l
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)dst_row, 4, voff, base_c + (uint32_t)row * rs4, 0, 0);
+  }
   CDPR_DEV uint32_t loadc(int row, uint32_t voff) const { return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, base_c + (uint32_t)row * rs4, 0); }
   CDPR_DEV void storec_if(bool on, int row, uint32_t voff, uint32_t v) const {
     __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, on ? voff : 0xFFFFFFFFu, base_c + (uint32_t)row * rs4, 0);
@@ -252,6 +255,18 @@ CDPR_DEV double gen_fit(const float (&y)[NBMAX], const int (&t)[NBMAX], int nb, 
     }
   }
   return deriv * inv_h;
+}
+
+// gen_fit as a CALL, for the kernel that must fit two waves per SIMD (cdpr_gen_lean_kernel inlines tier 1 for waves without
+// a gap call): inlined, the fit's registers come on top of everything the controller wave keeps for its epilogue and the
+// allocator spills on the first branch's path (20 registers, `force` among them: stores in the Pid loop, loads and a wait
+// in front of the hand-off).  As a function with 26 scalar arguments the pressure stays where the call is.
+__device__ __attribute__((noinline)) float gen_fit11_call(float y0, float y1, float y2, float y3, float y4, float y5, float y6, float y7, float y8, float y9, float y10,
+                                                          int t0, int t1, int t2, int t3, int t4, int t5, int t6, int t7, int t8, int t9, int t10, int nb, int degree,
+                                                          int t_new, int t_old, float dt) {
+  const float y[11] = {y0, y1, y2, y3, y4, y5, y6, y7, y8, y9, y10};
+  const int t[11] = {t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10};
+  return (float)(gen_fit<11>(y, t, nb, degree, t_new, t_old) / (double)dt);
 }
 
 // Pid::CascadeFilter::update (Pid.cpp:38-44) over BiQuad::process (Filter.h:152-165), states in the record rows of this lane.
@@ -334,6 +349,8 @@ struct GenCtlConst {
   int nm0, nm1;  // this step's ring slot in the position / velocity Pid's window: now mod nbuf
   int nbuf0;     // the position Pid's window length
   bool simple_ok;  // the handle's configuration admits the steady-state branch (GenCtl::simple_ok)
+  float* force_rows;  // nullptr, or LDS rows of 64 floats (cable i: row i) that take the per-cable forces of the consecutive-call
+                      // branches instead of the caller's array (the lean role-split kernel: eight registers less across the controller)
 #ifdef CDPR_STAMPS
   unsigned long long* stamps;  // this wave's eight stamps (diagnostic build)
 #endif
@@ -394,26 +411,22 @@ CDPR_DEV GenHot gen_hot_state(bool on, uint32_t step1, uint32_t mask, const int 
 // In front of the DMA of a step's record slots: the robot's word -> its hot state; the integrals on their way (ordinary
 // loads: first read behind the wait for the DMA); `skip_h`: every lane of the wave fresh - no H slot is loaded.
 // (step1, mask: the robot's word - rows 0 and 1 - loaded by the caller with its first loads: read here, they would be a round
-//  trip to memory between the Joy that selects the Pids and the DMA of their slots: + 0.9 us per step at 16 384 robots)
+//  trip to memory between the Joy that selects the Pids and the DMA of their slots: + 0.9 us per step at 16 384 robots.  The
+//  integrals: where every lane of the wave is fresh, their dword rows ride the DMA into the H slots' staging rows, which
+//  stay empty then (gen_stage_records); kept in registers from here to gen_hot_restore they were spilled, with a wait for
+//  them in front of the spill)
 template <int N>
-CDPR_DEV GenHot gen_hot_begin(bool on, const GenBuf& RB, uint32_t col, uint32_t step1, uint32_t mask, const int (&sel)[N], int mode, int now, float (&ierr)[N],
-                              bool& skip_h) {
+CDPR_DEV GenHot gen_hot_begin(bool on, uint32_t step1, uint32_t mask, const int (&sel)[N], int mode, int now, bool& skip_h) {
   const GenHot hot = gen_hot_state<N>(on, step1, mask, sel, mode, now);
   skip_h = on && __builtin_amdgcn_ballot_w64(!hot.fresh) == 0ull;
-#pragma unroll
-  for (int i = 0; i < N; ++i) ierr[i] = 0.f;
-  if (__builtin_amdgcn_ballot_w64(hot.has) != 0ull) {  // (wave-uniform)
-#pragma unroll
-    for (int i = 0; i < N; ++i) ierr[i] = __uint_as_float(RB.loadc(2 + i, col * 4u));
-  }
   return hot;
 }
 // Behind the DMA of a step's record slots: the staged H slots of the robots with a valid word, restored from it (every
 // lane fresh: the H slots were not loaded at all, gen_stage_records); a robot that is NOT fresh leaves the state - its
 // eight H slots go back to memory as they stand and its word is cleared.
 template <int N, int NBMAX>
-CDPR_DEV void gen_hot_restore(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, const GenHot hot,
-                              const float (&ierr)[N], const int (&sel)[N], float4* cab) {
+CDPR_DEV void gen_hot_restore(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, const GenHot hot, const int (&sel)[N],
+                              float4* cab) {
   constexpr int NV = gen_nv(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
   if (__builtin_amdgcn_ballot_w64(hot.has) == 0ull) return;  // (wave-uniform)
@@ -422,22 +435,31 @@ CDPR_DEV void gen_hot_restore(const GenCtlConst kc, const GenBuf& RB, const GenL
   const uint32_t meta = kGmWasLast | ((uint32_t)nbuf << kGmCountShift) | ((uint32_t)hd << kGmHeadShift) | (kGmField << kGmRunShift);
   const uint32_t pid_a = (uint32_t)L.pid_slots() * RB.rs16;
   const bool all_fresh = __builtin_amdgcn_ballot_w64(!hot.fresh) == 0ull;
+  float ierr[N];
+  if (all_fresh) {  // (wave-uniform) the integrals came with the DMA: a dword row at the head of every cable's (empty) H staging row
+#pragma unroll
+    for (int i = 0; i < N; ++i) ierr[i] = reinterpret_cast<const float*>(cab + i * kCab + NV * 64)[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (every lane has read its words before a lane's H slot is written over them)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < N; ++i) cab[i * kCab + NV * 64 + lane] = make_float4(__uint_as_float(meta), __int_as_float(hot.step), ierr[i], 0.f);
+    return;
+  }
+  // a wave with robots that are not fresh (rare): the integrals from memory, the staged H slots patched where they are this Pid's;
+  // a robot that is not fresh leaves the state: H slots back to memory, word cleared
+#pragma unroll
+  for (int i = 0; i < N; ++i) ierr[i] = __uint_as_float(RB.loadc(2 + i, col * 4u));
   const bool leaves = hot.has && !hot.fresh;
-  const bool any_leaves = __builtin_amdgcn_ballot_w64(leaves) != 0ull;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const float4 canon = make_float4(__uint_as_float(meta), __int_as_float(hot.step), ierr[i], 0.f);
     const bool mine = hot.has && ((hot.mask >> i) & 1u) == (uint32_t)sel[i];  // the staged H slot is this Pid's
     float4* const hs = cab + i * kCab + NV * 64 + lane;
-    if (all_fresh) {
-      *hs = canon;
-    } else {
-      const float4 rd = *hs;  // (component by component: a select of two float4 objects goes through scratch memory)
-      *hs = make_float4(mine ? canon.x : rd.x, mine ? canon.y : rd.y, mine ? canon.z : rd.z, mine ? canon.w : rd.w);
-    }
-    if (any_leaves) RB.store4_if(live && leaves, L.block_a(0, i) + L.nv(), col * 16u + (((hot.mask >> i) & 1u) ? pid_a : 0u), canon);
+    const float4 rd = *hs;  // (component by component: a select of two float4 objects goes through scratch memory)
+    *hs = make_float4(mine ? canon.x : rd.x, mine ? canon.y : rd.y, mine ? canon.z : rd.z, mine ? canon.w : rd.w);
+    RB.store4_if(live && leaves, L.block_a(0, i) + L.nv(), col * 16u + (((hot.mask >> i) & 1u) ? pid_a : 0u), canon);
   }
-  if (any_leaves) RB.storec_if(live && leaves, 0, col * 4u, 0u);
+  RB.storec_if(live && leaves, 0, col * 4u, 0u);
 }
 
 // Pid::update of every cable of a wave whose calls are all CONSECUTIVE (each Pid called one world step ago, mWasLastTime
@@ -568,9 +590,12 @@ CDPR_DEV void gen_consecutive(const GenCtlConst kc, const GenBuf& RB, const GenL
           ie = first ? prev_ierr : ie;
           out = first ? __builtin_amdgcn_fmed3f(0.f, g1[j].w, g1[j].z) : out;
         }
-        if constexpr (PASS == 0) force[i] = out;
-        if constexpr (PASS == 1) force[i] = (waits || first) ? 0.f : out;
-        if constexpr (PASS == 2) force[i] = waits ? out : force[i];
+        if (kc.force_rows) {  // (known where the kernel builds kc: one of the two forms is compiled)
+          kc.force_rows[i * 64 + lane] = (PASS == 0) ? out : ((waits || first) ? 0.f : out);
+        } else {
+          if constexpr (PASS == 0) force[i] = out;
+          if constexpr (PASS == 1) force[i] = (waits || first) ? 0.f : out;
+        }
         if constexpr (PASS != 2) {
           float4 o = vs[j];
           o.x = (qc == 0) ? error : o.x, o.y = (qc == 1) ? error : o.y, o.z = (qc == 2) ? error : o.z, o.w = (qc == 3) ? error : o.w;
@@ -779,7 +804,10 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
   //      over them alone (gen_consecutive<2>).  One pass of the queue (<= 64 items per wave); a wave with more, or with a
   //      lane that does not qualify, takes the general loop below (the lean role-split kernel: in its cold tail).
   //      `q_count` is followed by four rows of 64 words: items, new errors, results, dump words.
-  if constexpr (STEADY_ONLY) return false;  // (inlined with tier 1 the lean kernel spills 332 registers, on the first branch's path too)
+#ifndef CDPR_LEAN_TIER1
+#define CDPR_LEAN_TIER1 1  // the lean kernel inlines tier 1 for waves WITHOUT a gap call (fits behind consecutive calls); 0: the first branch only
+#endif
+  if constexpr (STEADY_ONLY && !CDPR_LEAN_TIER1) return false;  // (inlined with all of tier 1 the lean kernel spilled 332 registers, on the first branch's path too)
   if constexpr (TIER1)
   if (kc.simple_ok && __builtin_amdgcn_ballot_w64(!fast) == 0ull) {  // (wave-uniform)
     GEN_COLD_STAMP(0, __builtin_amdgcn_s_memrealtime());
@@ -787,6 +815,9 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     float* const qrows = reinterpret_cast<float*>(q_count + 4);
     const int nbuf = kc.nbuf0, nhead = kc.nm0;
     const bool any_gap = __builtin_amdgcn_ballot_w64(gaps) != 0ull;
+    if constexpr (STEADY_ONLY) {  // (the gap calls - one step in ten of a switching workload - go to the tail with their ring turns)
+      if (any_gap) return false;
+    }
     uint32_t need = 0u;
     uint32_t word[N];  // the items' upper bits: gap flag (bit 15) and the run of consecutive calls ending at the new sample
 #pragma unroll
@@ -840,7 +871,9 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       int irun = 0, t_second = 0;
       bool in_memory = false, owner_live = false;
       uint32_t ocol = 0u;
-      if (total != 0u) {  // (wave-uniform)
+      // (the item and - for a window that was written out - its stamps: fetched in front of the first pass, so that the loads
+      //  fly under it; STEADY_ONLY, the kernel at 256 registers: behind it - a dozen registers less across the pass)
+      auto fetch_item = [&]() {
         const uint32_t it = qitems[mine ? lane : 0u];
         ol = it & 63u, ci = (it >> 6) & 7u, sp = (it >> 9) & 1u;
         in_memory = ((it >> 14) & 1u) != 0u;
@@ -858,18 +891,21 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
 #pragma unroll
           for (int j = 0; j < NBMAX; ++j) t[j] = RB.loadi(min(j, L.nb - 1), ob);
         }
-      }
+      };
+      if (!STEADY_ONLY && total != 0u) fetch_item();  // (wave-uniform)
       GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
-      if (any_gap) {  // (wave-uniform)
+      if (!STEADY_ONLY && any_gap) {  // (wave-uniform)
         gen_turn_rings<N, NBMAX>(kc, RB, L, lane, live, col, now, sel, cab);
         gen_consecutive<N, NBMAX, 1, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg, park);
       } else {
-        gen_consecutive<N, NBMAX, 1, 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg, park);
+        gen_consecutive<N, NBMAX, 1, STEADY_ONLY ? CDPR_LEAN_GROUP : 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos,
+                                                                               dbg, park);
       }
       if (total != 0u) {  // (wave-uniform)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (STEADY_ONLY) fetch_item();
         GEN_COLD_STAMP(2, __builtin_amdgcn_s_memrealtime());
         const float e_new = qrows[64u + (mine ? lane : 0u)];
         float y[NBMAX];
@@ -894,7 +930,12 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           t[j] = (j >= nbuf) ? now : ((age <= irun) ? now - age : (in_memory ? t[j] : t_second - (age - irun - 1)));
           t_old = ((uint32_t)j == old) ? t[j] : t_old;
         }
-        const float res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
+        float res;
+        if constexpr (STEADY_ONLY && NBMAX == 11)
+          res = gen_fit11_call(y[0], y[1], y[2], y[3], y[4], y[5], y[6], y[7], y[8], y[9], y[10], t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], t[10], nbuf, degree,
+                               now, t_old, kc.dt);
+        else
+          res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
         {  // the rest of the owner's Pid::update (Pid.cpp:154-186) by the item's lane: D term, command, clamp, anti-windup, H
           const uint32_t ix = mine ? lane : 0u;
           const float dt_i = park[ix], pre = park[64u + ix], prev = park[192u + ix];
@@ -923,7 +964,10 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
           const bool waits = ((need >> i) & 1u) != 0u;
           const uint32_t qslot = slot0 + (uint32_t)__builtin_popcount(need & ((1u << i) - 1u));
           const float f = park[384u + (waits ? qslot : 0u)];
-          force[i] = waits ? f : force[i];
+          if (kc.force_rows)
+            *(waits ? kc.force_rows + i * 64 + lane : qrows + 192u + lane) = f;  // (no branch: a lane that does not wait writes its dump word)
+          else
+            force[i] = waits ? f : force[i];
           if (i == 0) {
             const float dd = park[448u + (waits ? qslot : 0u)];
             dbg.d = waits ? dd : dbg.d;
@@ -939,6 +983,7 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       return true;
     }
   }
+  if constexpr (STEADY_ONLY) return false;
   GEN_COLD_STAMP(0, __builtin_amdgcn_s_memrealtime());
 
   float4 held4[LP];
@@ -1216,7 +1261,10 @@ CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t co
     const int sa = L.block_a(0, i);
 #pragma unroll
     for (int s4 = 0; s4 < NV; ++s4) RB.slot_to_lds(sa + min(s4, L.nv() - 1), va, cab + i * kCab + s4 * 64);  // (slots past nv: a copy, weight 0)
-    if (!skip_h) RB.slot_to_lds(sa + L.nv(), va, cab + i * kCab + NV * 64);
+    if (!skip_h)
+      RB.slot_to_lds(sa + L.nv(), va, cab + i * kCab + NV * 64);
+    else
+      RB.rowc_to_lds(2 + i, col * 4u, cab + i * kCab + NV * 64);  // (the cable's integral, a dword per lane: gen_hot_restore)
   }
 }
 
@@ -1376,7 +1424,6 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
     }
     const bool run_ctl = !first_world;
     GenHot hot{false, false, false, 0u, 0};  // hot rows (GenHot): this kernel restores and clears them, it does not start them
-    float hot_ierr[N];
     bool hot_skip = false;
 #ifdef CDPR_STAMPS_PRO
     { float k2 = 0.f;
@@ -1392,7 +1439,7 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       bool holds = false;  // some cable of this lane is in the hold branch (JFC.cpp:78-82)
 #pragma unroll
       for (int i = 0; i < N; ++i) holds = holds || (mode == 2 && sel[i] == 0);
-      hot = gen_hot_begin<N>(hot_on, RB, col, hot_step1, hot_mask, sel, mode, now, hot_ierr, hot_skip);
+      hot = gen_hot_begin<N>(hot_on, hot_step1, hot_mask, sel, mode, now, hot_skip);
       gen_stage_records<N, NBMAX>(RB, L, col, sel, &stage[0][0][0], &hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull, hot_skip);
     }
     GEN_PHASE_STAMP(1);
@@ -1473,10 +1520,11 @@ __global__ __launch_bounds__(64, 1) void cdpr_gen_step_kernel(const StepArgs a, 
       GenCtlConst cc;
       cc.pcas_max = g.pcas_max, cc.dcas_max = g.dcas_max, cc.dt = g.dt, cc.inv_dt = a.inv_dt;
       cc.nm0 = nm0, cc.nm1 = nm1, cc.nbuf0 = g.nbuf0, cc.simple_ok = g.simple_ok != 0;
+      cc.force_rows = nullptr;
 #ifdef CDPR_STAMPS
       cc.stamps = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
 #endif
-      gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, hot_ierr, sel, &stage[0][0][0]);
+      gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, sel, &stage[0][0][0]);
       gen_controller<N, NBMAX, false, false>(cc, RB, L, lane, live, col, blockIdx.x * 64u, units, mode, now, target, sel, q, qd, &stage[0][0][0], &hold_slots[0][0],
                                &wrot[0][0][0], ptab, q_count, force, dbg, hot);
     }
