@@ -815,7 +815,11 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     float* const qrows = reinterpret_cast<float*>(q_count + 4);
     const int nbuf = kc.nbuf0, nhead = kc.nm0;
     const bool any_gap = __builtin_amdgcn_ballot_w64(gaps) != 0ull;
-    if constexpr (STEADY_ONLY) {  // (the gap calls - one step in ten of a switching workload - go to the tail with their ring turns)
+#ifndef CDPR_LEAN_GAPS
+#define CDPR_LEAN_GAPS 0  // 1: the gap calls inline as well - measured and not kept: 44 spilled registers (in that branch), the steady
+                          // step 16.0 -> 16.8 us at 65 536 x 8, the switching workload the same 22.8 us
+#endif
+    if constexpr (STEADY_ONLY && !CDPR_LEAN_GAPS) {  // (the gap calls - one step in ten of a switching workload - go to the tail with their ring turns)
       if (any_gap) return false;
     }
     uint32_t need = 0u;
@@ -894,7 +898,7 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       };
       if (!STEADY_ONLY && total != 0u) fetch_item();  // (wave-uniform)
       GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
-      if (!STEADY_ONLY && any_gap) {  // (wave-uniform)
+      if ((!STEADY_ONLY || CDPR_LEAN_GAPS) && any_gap) {  // (wave-uniform)
         gen_turn_rings<N, NBMAX>(kc, RB, L, lane, live, col, now, sel, cab);
         gen_consecutive<N, NBMAX, 1, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg, park);
       } else {
