@@ -647,7 +647,11 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   cc.nm0 = now % max(g.nbuf0, 1), cc.nm1 = now % max(g.nbuf1, 1), cc.nbuf0 = g.nbuf0, cc.simple_ok = g.simple_ok != 0;
   cc.force_rows = nullptr;
 #ifdef CDPR_STAMPS
+#ifdef CDPR_STAMPS_COLD
+  cc.stamps = a.stamps ? a.stamps + ((size_t)gridDim.x + blockIdx.x) * 8 : nullptr;  // (tier 1 inline: the same stamps as in the tail)
+#else
   cc.stamps = nullptr;
+#endif
 #endif
   gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, sel, &sm.stage[0][0][0]);
   // tier 0 and - for waves without a gap call - tier 1 of the general controller inline (gen_controller<STEADY_ONLY>); what it
