@@ -817,10 +817,26 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
     const bool any_gap = __builtin_amdgcn_ballot_w64(gaps) != 0ull;
 #ifndef CDPR_LEAN_GAPS
 #define CDPR_LEAN_GAPS 0  // 1: the gap calls inline as well - measured and not kept: 44 spilled registers (in that branch), the steady
-                          // step 16.0 -> 16.8 us at 65 536 x 8, the switching workload the same 22.8 us
+                          // step 16.0 -> 16.8 us at 65 536 x 8, the switching workload the same 22.8 us.  2: inline unless a ring has
+                          // to turn (no spill) - the same 23.0 us: the few waves that turn rings AND fit decide the refresh step
 #endif
-    if constexpr (STEADY_ONLY && !CDPR_LEAN_GAPS) {  // (the gap calls - one step in ten of a switching workload - go to the tail with their ring turns)
+    if constexpr (STEADY_ONLY && CDPR_LEAN_GAPS == 0) {  // (the gap calls - one step in ten of a switching workload - go to the tail with their ring turns)
       if (any_gap) return false;
+    }
+    if constexpr (STEADY_ONLY && CDPR_LEAN_GAPS == 2) {  // gap calls inline unless some lane's ring has to turn (few waves of a refresh step)
+      if (any_gap) {
+        bool turns = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const float2 ml = *reinterpret_cast<const float2*>(&cab[i * kCab + NV * 64 + lane]);
+          const uint32_t meta = __float_as_uint(ml.x);
+          const int count = (int)((meta >> kGmCountShift) & kGmField), head = (int)((meta >> kGmHeadShift) & kGmField);
+          int shift = nhead - 1 - head;
+          shift += (shift < 0) ? nbuf : 0;
+          turns = turns || (count > 0 && (now - __float_as_int(ml.y)) != 1 && shift != 0);
+        }
+        if (__builtin_amdgcn_ballot_w64(turns) != 0ull) return false;
+      }
     }
     uint32_t need = 0u;
     uint32_t word[N];  // the items' upper bits: gap flag (bit 15) and the run of consecutive calls ending at the new sample
@@ -899,8 +915,9 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
       if (!STEADY_ONLY && total != 0u) fetch_item();  // (wave-uniform)
       GEN_COLD_STAMP(1, __builtin_amdgcn_s_memrealtime());
       if ((!STEADY_ONLY || CDPR_LEAN_GAPS) && any_gap) {  // (wave-uniform)
-        gen_turn_rings<N, NBMAX>(kc, RB, L, lane, live, col, now, sel, cab);
-        gen_consecutive<N, NBMAX, 1, 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos, dbg, park);
+        if constexpr (!(STEADY_ONLY && CDPR_LEAN_GAPS == 2)) gen_turn_rings<N, NBMAX>(kc, RB, L, lane, live, col, now, sel, cab);
+        gen_consecutive<N, NBMAX, 1, STEADY_ONLY ? CDPR_LEAN_GROUP : 4, true>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos,
+                                                                              dbg, park);
       } else {
         gen_consecutive<N, NBMAX, 1, STEADY_ONLY ? CDPR_LEAN_GROUP : 4, false>(kc, RB, L, lane, live, col, mode, now, target, sel, q, qd, cab, held4, wrot, ptab, need, slot0, qrows, force, newpos,
                                                                                dbg, park);
