@@ -18,8 +18,12 @@ BASE_FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall
 UNITS = ["k_step", "k_pr", "k_onestep", "k_pair", "k_cable", "k_f64", "k_gen_one", "k_gen_split", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32"]
 
 
+NOVC_UNITS = {"k_step", "k_gen_one", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32"}  # (the Makefile's: built without VectorCombine)
+
+
 def remarks(unit, flags):
-    cmd = ["/opt/rocm/bin/hipcc", *flags.split(), "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", unit + ".hip"]
+    extra = ["-mllvm", "-disable-vector-combine"] if unit in NOVC_UNITS else []
+    cmd = ["/opt/rocm/bin/hipcc", *flags.split(), *extra, "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", unit + ".hip"]
     return subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
 
 
