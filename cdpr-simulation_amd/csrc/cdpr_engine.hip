@@ -144,6 +144,7 @@ struct cdpr_engine {
   uint64_t roll_pending = 0;     // trajectories of the launched, not yet fetched rollout
   // cdpr_config_t.precision = 64: the step in double (cdpr_step_kernel_f64.hpp); its own state, observables, tables
   bool fp64 = false;
+  bool hold64 = false;   // ... with the position-hold branch live (velocity_epsilon >= 0): both Pids of every cable in rows behind the state (HOLD kernels)
   double* d_state64 = nullptr;
   double* d_obs64 = nullptr;
   double* d_geom64 = nullptr;    // [n][7]
@@ -466,10 +467,13 @@ std::vector<float4> home_state(const cdpr_engine* h) {
   return s;
 }
 
+// rows of an fp64 handle's state: platform, FK estimate, one Pid's rows per cable - and, hold branch live, both Pids' records
+static size_t state64_rows(const cdpr_engine* h) { return (size_t)f64_state_rows((int)h->n) + (h->hold64 ? (size_t)f64_hold_rows((int)h->n) : 0); }
+
 // fp64 handles: home state (platform at home, FK seed at home, controller rows zero), observables before the first publish
 int upload_home64(cdpr_engine* h) {
   const size_t st = h->stride;
-  std::vector<double> s((size_t)f64_state_rows((int)h->n) * st, 0.0), o((size_t)f64_obs_rows((int)h->n) * st, 0.0);
+  std::vector<double> s(state64_rows(h) * st, 0.0), o((size_t)f64_obs_rows((int)h->n) * st, 0.0);
   for (uint32_t r = 0; r < h->stride; ++r)
     for (int c = 0; c < 7; ++c) {
       s[(size_t)c * st + r] = h->cfg.home_pose[c];
@@ -807,7 +811,7 @@ void fill_pid64(const cdpr_pid_params_t& p, double dt, F64Args& k) {
 // precision = 64: the same host logic (commands are latched by run_steps before this is reached), the fp64 kernel
 int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, double* record = nullptr) {
   const uint32_t n = h->n;
-  if (reset_pid) {  // Pid::reset (Pid.cpp:100-115): zero every controller row
+  if (reset_pid && !h->hold64) {  // Pid::reset (Pid.cpp:100-115): zero every controller row (hold branch live: the latch reset that Pid's own rows)
     h->pid_calls = 0;
     HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)11 * n * h->stride * sizeof(double), h->stream));
   }
@@ -826,6 +830,24 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
     a.alt_imax = p.imax, a.alt_imin = p.imin, a.alt_cmax = p.cmax, a.alt_cmin = p.cmin, a.alt_clamp_cmd = p.clamp_cmd;
     a.meta = h->d_mode;
   }
+  if (h->hold64) {  // both Pids alive: the velocity Pid in the primary fields, the position Pid in alt_*
+    F64Args v = h->base64, p = h->base64;
+    fill_pid64(h->cfg.velocity_pid, h->cfg.dt, v);
+    fill_pid64(h->cfg.position_pid, h->cfg.dt, p);
+    a.kf = v.kf, a.kp = v.kp, a.ki = v.ki, a.kd = v.kd, a.imax = v.imax, a.imin = v.imin, a.cmax = v.cmax, a.cmin = v.cmin, a.nbuf = v.nbuf, a.clamp_cmd = v.clamp_cmd;
+    a.alt_kf = p.kf, a.alt_kp = p.kp, a.alt_ki = p.ki, a.alt_kd = p.kd, a.alt_imax = p.imax, a.alt_imin = p.imin, a.alt_cmax = p.cmax, a.alt_cmin = p.cmin;
+    a.alt_clamp_cmd = p.clamp_cmd, a.alt_nbuf = p.nbuf;
+    a.degree = (int)h->cfg.velocity_pid.d_degree, a.alt_degree = (int)h->cfg.position_pid.d_degree;
+    a.hold_eps = h->cfg.velocity_epsilon;
+    a.hold_mode = frc ? 0 : (vel ? 2 : 1);
+    const cdpr_pid_params_t* pids[2] = {&h->cfg.position_pid, &h->cfg.velocity_pid};
+    for (int t = 0; t < 2; ++t) {  // uniform-grid weights by age of the sample (derivative_weights: oldest first)
+      double w[CDPR_MAX_D_BUFFER];
+      const uint32_t nb = pids[t]->d_buffer_length;
+      if (derivative_weights(nb, pids[t]->d_degree, w) == CDPR_OK)
+        for (uint32_t age = 0; age < nb && age <= (uint32_t)kWin; ++age) a.hold_w[t][age] = w[nb - 1 - age];
+    }
+  }
   const size_t image64 = (size_t)f64_obs_rows((int)n) * h->stride;  // doubles per observable image
   a.obs_step_stride = record ? image64 : 0;
   // the rings in LDS (64 KiB per wave at n = 8: two waves per CU) while the batch leaves CUs to spare
@@ -833,12 +855,13 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
   const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
-  F64Kernel kern = pr ? pick_f64_pr_kernel(n, ring_lds) : pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
+  F64Kernel kern = h->hold64 ? pick_f64_hold_kernel(n)
+                             : pr ? pick_f64_pr_kernel(n, ring_lds) : pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
   const bool sp_lean = sp_env >= 0 ? sp_env == 2 : h->batch > 16384u;
-  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr) ? pick_f64_split_kernel(n, sp_lean) : nullptr;  // (per-robot handles: the one-wave kernel)
+  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr && !h->hold64) ? pick_f64_split_kernel(n, sp_lean) : nullptr;  // (per-robot handles, the hold branch: the one-wave kernel)
   // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
   // (14.4 against 20.8 us per step at one robot x 8, same bits): a fused update then runs as one-step launches
   if (split_kern && !sp_lean) per_launch = 1;
@@ -852,6 +875,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
     if (record) a.obs = record + (size_t)done * image64;
     a.pid_calls = sat_pid_calls(h->pid_calls);
     a.ring_slot = ring_slot_of(h->step);
+    a.step0 = (int)h->step;
     a.publish_mask = 0;
     for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
       const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
@@ -999,6 +1023,13 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     if (e1 != hipSuccess || L.pid_rows() == 0) return e1;
     return hipMemsetAsync(h->d_rec + ((size_t)L.slots() * 4 + (size_t)L.block_b(which, 0)) * h->stride, 0, (size_t)L.pid_rows() * h->stride * 4, h->stream);
   };
+  auto reset_block64 = [&](int which) -> hipError_t {  // precision = 64 with the hold branch: Pid::reset of one Pid of every cable (its rows behind the state)
+    for (uint32_t i = 0; i < h->n; ++i) {
+      hipError_t e1 = hipMemsetAsync(h->d_state64 + (size_t)f64_hold_row((int)h->n, (int)i, which) * h->stride, 0, (size_t)kHoldPidRows * h->stride * sizeof(double), h->stream);
+      if (e1 != hipSuccess) return e1;
+    }
+    return hipSuccess;
+  };
   if (h->per_robot) {
     // every robot has its own mode: commands (masked or not) are latched on the device, robot by robot
     auto latch = [&](float* pending, float* latched, const uint8_t* mask, int which, int new_mode) -> int {
@@ -1090,6 +1121,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     h->have_vel = true;
     reset_pid = (h->mode != kModeVelocity);  // JFC.cpp:113-115
     if (h->general && reset_pid) HIP_TRY(h, reset_block(1));
+    if (h->hold64 && reset_pid) HIP_TRY(h, reset_block64(1));
     h->mode = kModeVelocity;
   }
   if (h->pos_pending) {
@@ -1105,6 +1137,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     h->have_pos = true;
     reset_pid = (h->mode != kModePosition);  // JFC.cpp:101-103 (fast path: the single record now belongs to the position Pid)
     if (h->general && reset_pid) HIP_TRY(h, reset_block(0));
+    if (h->hold64 && reset_pid) HIP_TRY(h, reset_block64(0));
     h->mode = kModePosition;
   }
   if (h->frc_pending) {  // setForce (JFC.h:92-95): mode Force, no Pid is reset.  [NEW] ordering: after the two Joy topics
@@ -1397,7 +1430,12 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     g_create_error = "internal: per-robot handle routed to the register-resident path with windows it cannot hold";
     return CDPR_ERR_UNSUPPORTED;
   }
-  if (cfg->precision == 64 && (general || phys_cfg)) {
+  // precision = 64 with the hold branch as the ONLY thing the register-resident path cannot represent: the HOLD instantiations of the
+  // fp64 kernel (uniform-mode handles; round 5)
+  cdpr_config_t no_hold = *cfg;
+  no_hold.velocity_epsilon = -1.0;
+  const bool hold64 = cfg->precision == 64 && !(cfg->velocity_epsilon < 0.0) && fast_path_obstacle(no_hold).empty() && cfg->per_robot_commands == 0 && !phys_cfg;
+  if (cfg->precision == 64 && (general || phys_cfg) && !hold64) {
     g_create_error = "precision = 64 covers the register-resident path only (no lumped legs, travel_stop, hold branch, cascades, long windows, "
                      "cmd_limit 0, or per-robot modes with two different derivative windows): " +
                      (general ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
@@ -1429,8 +1467,9 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->fk = (cfg->stages & CDPR_STAGE_FK) != 0;
   h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
-  h->general = general;
+  h->general = general && !hold64;  // (precision = 64 with the hold branch: the fp64 kernel's HOLD instantiations, not the fp32 general path)
   h->fp64 = cfg->precision == 64;
+  h->hold64 = hold64;
   h->per_robot = cfg->per_robot_commands != 0;
   h->phys = phys_cfg;
   {
@@ -1531,7 +1570,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   const size_t slot_bytes = (size_t)h->stride * sizeof(float4);
   if (h->fp64) {
     const size_t row = (size_t)h->stride * sizeof(double);
-    if ((e = hipMalloc(&h->d_state64, row * f64_state_rows((int)h->n))) != hipSuccess) return fail("hipMalloc(state64)", e);
+    if ((e = hipMalloc(&h->d_state64, row * state64_rows(h))) != hipSuccess) return fail("hipMalloc(state64)", e);
     if ((e = hipMalloc(&h->d_obs64, row * f64_obs_rows((int)h->n))) != hipSuccess) return fail("hipMalloc(obs64)", e);
     std::vector<double> g((size_t)h->n * 7), wt((size_t)2 * kWin * (kWin + 2), 0.0);
     for (uint32_t i = 0; i < h->n; ++i) {

@@ -203,8 +203,8 @@ CDPR_DEV GenBuf gen_buffer(float* rec, uint32_t rstride, uint32_t rec_bytes, con
 // samples per degree, which yields sum p^2, sum y p and the next sum x p^2 together; one division per degree (1 / sum p^2
 // serves c_k, then alpha and beta of the next degree).  ~40 registers instead of ~110: the fit runs inside the kernels'
 // inlined controller branch; ~260 fp64 instructions at 11 samples, degree 2 (the array form: ~500, three divisions per degree).
-template <int NBMAX>
-CDPR_DEV double gen_fit(const float (&y)[NBMAX], const int (&t)[NBMAX], int nb, int degree, int t_new, int t_old) {
+template <int NBMAX, typename Y = float>
+CDPR_DEV double gen_fit(const Y (&y)[NBMAX], const int (&t)[NBMAX], int nb, int degree, int t_new, int t_old) {
   double h = (double)(t_new - t_old) / (double)(nb - 1);
   if (!(h > 0.0)) h = 1.0;
   const double inv_h = 1.0 / h;

@@ -59,6 +59,7 @@ GenKernel pick_gen_split11(uint32_t n);  // k_gen_split.hip: one step per launch
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean);  // lean: nothing cached in LDS (four workgroups per CU)
 //  // one step per launch, two waves per 64 robots split by role (FK + TD, n >= 6)
 F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds);  // per-robot handles (mode, call count and Pid per lane)
+F64Kernel pick_f64_hold_kernel(uint32_t n);                 // velocityEpsilon >= 0: the position-hold branch live (both Pids of every cable)
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache);  // ring_lds: the derivative rings staged in LDS (small batches); jcache: and the structure-matrix rows (one workgroup per CU)
 
 }  // namespace cdpr

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "cdpr_step_kernel.hpp"
+#include "cdpr_general_step.hpp"  // gen_fit: the least-squares derivative on real stamps (the HOLD instantiations)
 
 // Every multiply-add of this file is an explicit fma(), as in the fp32 kernels (the build runs with -ffp-contract=off so
 // that all instantiations - here: the one-wave kernel in its LDS variants, its multi-step launches and the role-split
@@ -63,9 +64,24 @@ struct F64Args {
   uint8_t* meta;
   double alt_kf, alt_kp, alt_ki, alt_kd, alt_imax, alt_imin, alt_cmax, alt_cmin;
   int alt_clamp_cmd;
+  // HOLD instantiations (round 5: the position-hold branch of JointForceCalculator::update, JFC.cpp:72-82, in double): mode of the
+  // handle, velocityEpsilon, the two Pids' windows (the VELOCITY Pid in the primary fields, the POSITION Pid in alt_*)
+  int hold_mode;  // 0 Force, 1 Position, 2 Velocity
+  int step0;      // world step of the launch's first step (the Pids' stamps)
+  double hold_eps;
+  int degree, alt_nbuf, alt_degree;
+  double hold_w[2][kWin + 1];  // [position | velocity] Pid: the uniform-grid derivative weights by AGE of the sample (0: newest), in steps
 };
 
 __host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
+// HOLD handles keep BOTH Pids of every cable behind those rows: per cable mLastPosition (JFC.h:45), then per Pid (0 position,
+// 1 velocity) mWasLastTime | mLastTime (world step) | mIerr | samples in the window | ring head | the window's values |
+// the window's stamps (world steps, exact in a double)
+constexpr int kHoldWin = kWin + 1;
+constexpr int kHoldPidRows = 5 + 2 * kHoldWin;
+constexpr int kHoldCableRows = 1 + 2 * kHoldPidRows;
+__host__ __device__ constexpr int f64_hold_row(int n, int cable, int pid) { return f64_state_rows(n) + cable * kHoldCableRows + 1 + pid * kHoldPidRows; }
+__host__ __device__ constexpr int f64_hold_rows(int n) { return n * kHoldCableRows; }
 __host__ __device__ constexpr int f64_obs_rows(int n) { return 16 + 3 * n; }
 
 // 1 / sqrt(x) to double precision: v_rsq_f64 (about 26 good bits) + two Newton steps, y <- y + y e / 2 with e = 1 - x y^2
@@ -230,6 +246,85 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 // with a run-time index: the structure matrix is never held as a whole, every stage rebuilds the rows it needs and
 // accumulates J^T J / J^T v on the fly.  (Fully unrolled, with both structure matrices in registers, the double
 // version of this kernel needed 512 registers and 2 KiB of scratch per lane.)
+// Pid::update (Pid.cpp:122-191) with Pid::derive (Pid.cpp:193-217) on a Pid's own rows, in double, for the HOLD instantiations: a
+// Pid is called whenever its branch of JointForceCalculator::update runs, so its window holds samples taken at any steps;
+// a full window's derivative is the least-squares fit on the real stamps (gen_fit: orthogonal polynomials, any gap
+// pattern; on a uniform window it is the closed form of the other instantiations to rounding).  R: the Pid's first row
+// of this robot, rows `st` doubles apart.  No biquad cascades, a command clamp (cdpr_create refuses the rest).
+__device__ __forceinline__ double hold_pid64(double* R, size_t st, double desired, double actual, int now, double dt, double kf, double kp, double ki,
+                                             double kd, double imax, double imin, double cmax, double cmin, int nbuf, int degree, const double* w_age,
+                                             bool& ran, double& p_out, double& i_out, double& d_out) {
+  ran = false;
+  if (R[0] == 0.0) {  // Pid.cpp:123-126: the first call since reset returns 0
+    R[0] = 1.0;
+    R[1 * st] = (double)now;
+    return 0.0;
+  }
+  const int last = (int)R[1 * st];
+  const double dts = (double)(now - last) * dt;
+  const double error = desired - actual;
+  const double p_term = kp * error;
+  const double prev_ierr = R[2 * st];
+  double ie = fma(dts, error, prev_ierr);
+  double i_term = ki * ie;
+  const double i_raw = i_term;
+  if (i_term > imax) {  // Pid.cpp:143-152
+    i_term = imax;
+    ie = i_term / ki;
+  } else if (i_term < imin) {
+    i_term = imin;
+    ie = i_term / ki;
+  }
+  // Pid::derive: push the sample (dt > 0 always: a Pid is called at most once per world step)
+  // (row 3: samples in the window | the length of the run of consecutive world steps the newest samples form, << 8, saturating)
+  const int word = (int)R[3 * st];
+  int count = word & 255, run = word >> 8, head = (int)R[4 * st];
+  head = (count == 0) ? 0 : ((head + 1 >= nbuf) ? 0 : head + 1);
+  count = min(count + 1, nbuf);
+  run = (now == last + 1) ? min(run + 1, 255) : 1;
+  double derived = 0.0;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
+  if (run >= nbuf) {
+    // the whole window is one step apart (the steady case: this Pid has been called every step for nbuf steps): the fit is the
+    // fixed end-point filter of the plain instantiations, weights looked up by the sample's age (the ring head is per cable)
+    double acc = w_age[0] * error;
+#pragma unroll
+    for (int j = 0; j < kHoldWin; ++j)
+      if (j < nbuf) {
+        int age = head - j;
+        age = age < 0 ? age + nbuf : age;
+        const double yj = R[(size_t)(5 + j) * st];
+        acc = (j == head) ? acc : fma(w_age[age], yj, acc);
+      }
+    derived = acc / dt;
+  } else if (count >= nbuf) {
+    double y[kHoldWin];
+    int t[kHoldWin];
+    int t_old = now;
+#pragma unroll
+    for (int j = 0; j < kHoldWin; ++j) {
+      y[j] = (j == head) ? error : R[(size_t)(5 + j) * st];
+      t[j] = (j == head) ? now : (int)R[(size_t)(5 + kHoldWin + j) * st];
+      t_old = (j < nbuf) ? min(t_old, t[j]) : t_old;
+    }
+    derived = gen_fit<kHoldWin, double>(y, t, nbuf, degree, now, t_old) / dt;
+  }
+  R[(size_t)(5 + head) * st] = error;
+  R[(size_t)(5 + kHoldWin + head) * st] = (double)now;
+  const double d_term = kd * derived;
+  const double cmd = fma(kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
+  double out = fmax(fmin(cmd, cmax), cmin);                       // Pid.cpp:175-177 (cmdMin < cmdMax here)
+  if (out != cmd) {                                                // Pid.cpp:181-184
+    ie = prev_ierr;
+    out = fma(dts * error, ki, out);
+  }
+  R[1 * st] = (double)now;
+  R[2 * st] = ie;
+  R[3 * st] = (double)(count | run << 8);
+  R[4 * st] = (double)head;
+  ran = true, p_out = p_term, i_out = i_raw, d_out = d_term;
+  return out;
+}
+
 // RING_LDS: the derivative rings of a lane's cables are loaded once, in one batch, into LDS columns (40 KiB per wave at
 // n = 8) and written back at the end: the FIR then costs no memory round trip per cable and step (small batches: the step
 // is one latency chain).  Otherwise they stay in HBM / L2 (large batches: four waves per CU need the LDS).
@@ -237,8 +332,11 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 // needed again - the rows at the true pose (IK stage) for the world step, the rows at the estimate (the Newton stage's
 // closing evaluation) for both passes of the tension distribution - instead of being recomputed: 48 row evaluations per
 // step instead of 72 at n = 8 (a row is ~60 fp64 instructions, a reload 6 LDS reads).  Same values, same bits.
-template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false>
+// HOLD: the position-hold branch live (velocityEpsilon >= 0): both Pids of every cable in the rows behind the state (f64_hold_row),
+// selected per cable and step as JointForceCalculator::update does (JFC.cpp:67-89); uniform-mode handles, rings in memory.
+template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, bool HOLD = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
+  static_assert(!HOLD || (!RING_LDS && !JCACHE && !PR), "the hold branch: the plain instantiation");
   // cables per pass of the loops over the cables.  One lane's step is a dependent chain (rotate the anchor, length,
   // reciprocal square root, row, accumulate): with a single wave per SIMD a dependent fp64 instruction waits ~8 cycles for
   // its predecessor, and only several cables in flight fill those slots.  The role-split kernel
@@ -259,8 +357,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   //  a round trip more: one robot 14.4 -> 14.7 us)
   constexpr bool kGeomLds = !RING_LDS;
   __shared__ double c_geom_lds[kGeomLds ? N * 7 : 1];
+  __shared__ double c_hold_w[HOLD ? 2 : 1][kHoldWin];
   if (kGeomLds) {
     if (lane < N * 7) c_geom_lds[lane] = a.geom[lane];
+    if (HOLD && lane < 2 * kHoldWin) c_hold_w[HOLD ? lane / kHoldWin : 0][lane % kHoldWin] = a.hold_w[lane / kHoldWin][lane % kHoldWin];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -302,7 +402,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     const bool full = calls >= a.nbuf;
     const int ring_slot = (a.ring_slot + step) % kWin;
     const double* wt = a.wtab + ring_slot * (kWin + 2);
-    double dbg_p = 0.0, dbg_i = 0.0, dbg_d = 0.0;
+    double dbg_p = 0.0, dbg_i = 0.0, dbg_d = 0.0, dbg_des = 0.0;
+    bool dbg_ran = false;  // (HOLD: cable 0's Pid really ran this step)
     // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
     {
       const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
@@ -320,7 +421,30 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           for (int c = 0; c < 6; ++c) c_jt[JCACHE ? i : 0][JCACHE ? c : 0][lane] = j[c];
         }
         double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
-        if (run_pid) {
+        if constexpr (HOLD) {  // JFC.cpp:59-96 with both Pids alive
+          double* const LP = S + (size_t)(f64_state_rows(N) + i * kHoldCableRows) * st;  // mLastPosition
+          if (!first_world) {
+            const double target = c_des[i][lane];
+            const bool vel_branch = a.hold_mode == 2 && fabs(target) > a.hold_eps;  // JFC.cpp:72
+            const bool pos_branch = a.hold_mode == 1 || (a.hold_mode == 2 && !vel_branch);
+            const bool hold = a.hold_mode == 2 && !vel_branch;
+            const double held = LP[0];
+            if (!hold) LP[0] = q;  // JFC.cpp:68,75,87
+            bool ran = false;
+            double tp = 0.0, ti = 0.0, td = 0.0;
+            if (vel_branch)
+              force = hold_pid64(S + (size_t)f64_hold_row(N, i, 1) * st, st, target, qd, (int)(a.step0 + step), a.dt, a.kf, a.kp, a.ki, a.kd, a.imax, a.imin, a.cmax, a.cmin,
+                                 a.nbuf, a.degree, c_hold_w[HOLD ? 1 : 0], ran, tp, ti, td);
+            else if (pos_branch)
+              force = hold_pid64(S + (size_t)f64_hold_row(N, i, 0) * st, st, hold ? held : target, q, (int)(a.step0 + step), a.dt, a.alt_kf, a.alt_kp, a.alt_ki, a.alt_kd,
+                                 a.alt_imax, a.alt_imin, a.alt_cmax, a.alt_cmin, a.alt_nbuf, a.alt_degree, c_hold_w[0], ran, tp, ti, td);
+            if (i == 0 && ran) {
+              dbg_p = tp, dbg_i = ti, dbg_d = td;
+              dbg_ran = true;
+              dbg_des = vel_branch ? target : (hold ? held : target);
+            }
+          }
+        } else if (run_pid) {
           const double desired = c_des[i][lane];
           const double error = desired - (actual_is_vel ? qd : q);
           double acc = wt[kWin] * error;
@@ -473,11 +597,11 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     }
     if (a.dbg) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
       double* d = a.dbg + (size_t)r * 9;
-      if (run_pid) {
+      if (HOLD ? dbg_ran : run_pid) {
         d[0] = dbg_p;
         d[1] = dbg_i;
         d[2] = dbg_d;
-        d[3] = c_des[0][lane];
+        d[3] = HOLD ? dbg_des : c_des[0][lane];
       }
       d[4] = c_f[0][lane];
     }

@@ -264,11 +264,65 @@ def test_fp64_facade_runs_n_steps_as_one_launch_chain(pkg, oracle):
         assert np.array_equal(m0.effort, m1.effort) and np.array_equal(m0.position, m1.position)
 
 
+@pytest.mark.parametrize("cables,stages,B", [(8, 3, 130), (4, 0, 70), (8, 3, 5000)])
+def test_fp64_hold_branch(pkg, oracle, cables, stages, B):
+    """velocityEpsilon >= 0 in the reference's own precision (round 5: the HOLD instantiations of the fp64 kernel): both Pids of
+    every cable alive, cables drifting into the hold branch and back (their windows sampled at non-uniform times: the
+    derivative is a least-squares fit on the real stamps in double), then Position mode (the position Pid reset), Force
+    mode, Velocity again (the velocity Pid reset), fused launches and the trajectory record in between, the `pid` topic -
+    against the fp64 oracle.  The fit here runs on orthogonal polynomials, the oracle's on normal equations in centred
+    time: two double formulations of an ill-conditioned step (a window with a gap), hence the effort tolerance."""
+    from test_gpu_general_matrix import hold_commands
+
+    eps = 0.004
+    rng = np.random.default_rng(640 + cables)
+    model = pkg.eight_cable_model() if cables == 8 else pkg.cube_model()
+    cfg = pkg.Config(model=model, batch=B, stages=stages | pkg._abi.STAGE_PID_DEBUG, velocityEpsilon=eps, precision=64)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05).astype(np.float64))
+    tol = dict(TOL64, eff=2e-7, twist=1e-10, qd=1e-10, pose=1e-12, q=1e-12)
+    eng.update(3), ora.update(3)
+    for j in range(7):
+        cmd = hold_commands(rng, B, cables, eps)
+        eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+        k = [9, 14, 3, 25, 12, 6, 31][j]
+        if j % 3 == 1:
+            eng.update(k, 5)
+        elif j % 3 == 2:
+            eng.update_record(k, 4)
+        else:
+            for _ in range(k):
+                eng.update(1)
+        ora.update(k)
+        compare64(eng, ora, f"hold round {j}", tol)
+        assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 1e-6, f"pid topic, round {j}"
+    p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+    eng.set_position_command(p), ora.set_position_command(p)
+    eng.update(40), ora.update(40)
+    compare64(eng, ora, "position mode", tol)
+    f = (7.0 + rng.uniform(-0.5, 0.5, (B, cables))).astype(np.float32)
+    eng.set_force_command(f), ora.set_force_command(f)
+    eng.update(7), ora.update(7)
+    compare64(eng, ora, "force mode", tol)
+    cmd = hold_commands(rng, B, cables, eps)
+    eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+    eng.update(33, 11), ora.update(33)
+    compare64(eng, ora, "velocity mode again", tol)
+    eng.reset(), ora.reset()
+    eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+    eng.update(20), ora.update(20)
+    compare64(eng, ora, "after a world reset", tol)
+
+
 def test_fp64_refuses_what_it_does_not_cover(pkg):
-    for kw in (dict(velocityEpsilon=0.01), dict(perRobotCommands=True, velocityEpsilon=0.01)):
+    for kw in (dict(perRobotCommands=True, velocityEpsilon=0.01),):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(pkg.Config(batch=4, precision=64, **kw), 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+    cascaded = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)
+    cascaded.velocityController.pFilter.cascade = 1
+    with pytest.raises(pkg.CdprError) as ei:
+        pkg.Engine(cascaded, 0)
+    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
     lumped = pkg.cube_model()
     lumped.passive_damping = 0.01
     with pytest.raises(pkg.CdprError):
