@@ -56,6 +56,7 @@ SCHED_CHUNK = 1000  # world steps per launch on the scheduled path (small batche
 FUSED_WARM, FUSED_LAUNCHES = 3, 30  # the fused leg's own schedule: untimed / minimum timed launches of 10 steps each
 ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
 GENERAL_SHAPE = (65536, 0.001, 120, 400)  # general-path leg (the contract's size since round 5): robots, velocityEpsilon, untimed steps (past the window fill AND the 63 consecutive calls after which a robot keeps its steady state in the hot rows), timed steps
+FP64_HOLD_SHAPES = ((65536, 0.001, 200, 300), (1, 0.001, 100, 300))  # ... with the position-hold branch live (robots, velocityEpsilon, warm-up, timed steps)
 FP64_SHAPES = ((65536, 300, 400), (1, 100, 300))  # (robots, warm-up steps, timed steps): the warm-up also brings the clock back up after the host-side replay of the leg before
 FP64_TOL = {"pose": 1e-10, "eff": 1e-7}         # fp64 kernels against the fp64 oracle (two double implementations; tests/test_gpu_fp64.py: 1e-13 / 1e-9 over short runs)
 LARGE_BATCH_SHAPE = (524288, 100, 200)           # HBM-streaming regime on ONE GPU: robots, untimed steps, timed steps
@@ -774,9 +775,11 @@ def main():
         #     the contract's size and one robot, kernel time by HIP events, 64 robots replayed on the fp64 oracle
         if n == 8 and args.config == 3:
             fp64_legs = []
-            for Bf, warm_f, steps_f in FP64_SHAPES:
+            hold_legs = []
+            for Bf, eps_f, warm_f, steps_f in tuple((b, None, w, k) for b, w, k in FP64_SHAPES) + FP64_HOLD_SHAPES:
                 Bf = min(Bf, args.batch)  # (--batch below the contract's size: the leg follows)
-                ef = pkg.Engine(pkg.Config(batch=Bf, precision=64, **cfg_kwargs), device=device)
+                cfg_kwargs_f = cfg_kwargs if eps_f is None else dict(cfg_kwargs, velocityEpsilon=eps_f)
+                ef = pkg.Engine(pkg.Config(batch=Bf, precision=64, **cfg_kwargs_f), device=device)
                 ef.set_platform_state(pose7=pose[:Bf])
                 d_cmd_f = ef.device_upload(command(0)[:Bf])
                 ef.bind_velocity_command_device(d_cmd_f, Bf * n)
@@ -791,7 +794,7 @@ def main():
                     import oracle
 
                     fs = slice(max(0, Bf - 64), Bf)
-                    osim = oracle.OracleSim(pkg.Config(batch=fs.stop - fs.start, **cfg_kwargs).to_struct(), oracle.DERIV_EXACT)
+                    osim = oracle.OracleSim(pkg.Config(batch=fs.stop - fs.start, **cfg_kwargs_f).to_struct(), oracle.DERIV_EXACT)
                     osim.set_platform_state(pose7=pose[fs].astype(np.float64))
                     osim.set_velocity_command(command(0)[fs])
                     osim.update(warm_f + steps_f)
@@ -804,7 +807,8 @@ def main():
                 ef.device_free(d_cmd_f)
                 ef.close()
                 kus_f = msf * 1e3 / max(nlf, 1)
-                fp64_legs.append({"robots": Bf, "kernel_us": kus_f, "value_per_gpu": Bf / (kus_f * 1e-6), "steps_timed": steps_f, "parity_check": fpar})
+                (fp64_legs if eps_f is None else hold_legs).append({"robots": Bf, "kernel_us": kus_f, "value_per_gpu": Bf / (kus_f * 1e-6), "steps_timed": steps_f,
+                                                                     "velocity_epsilon": eps_f, "parity_check": fpar})
             secondary["fp64"] = {
                 "workload": f"precision = 64 (the reference's own arithmetic): {n}-cable robots, every stage, one launch per step, one held Joy",
                 "dtype": "f64",
@@ -813,7 +817,9 @@ def main():
                 "value_per_gpu": fp64_legs[0]["value_per_gpu"],
                 "kernel_us": fp64_legs[0]["kernel_us"],
                 "kernel_us_one_robot": fp64_legs[-1]["kernel_us"],
-                "parity_check": {"ok": all((l["parity_check"] or {"ok": True})["ok"] for l in fp64_legs)} if not args.no_parity_check else None,
+                # the position-hold branch live (velocityEpsilon >= 0: both Pids of every cable, windows on real stamps) in double
+                "hold_branch": {"legs": hold_legs, "kernel_us": hold_legs[0]["kernel_us"], "kernel_us_one_robot": hold_legs[-1]["kernel_us"]},
+                "parity_check": {"ok": all((l["parity_check"] or {"ok": True})["ok"] for l in fp64_legs + hold_legs)} if not args.no_parity_check else None,
             }
 
         # (e) the HBM-streaming regime: 524 288 x 8 on ONE GPU (a 65 536-robot handle's ~40 MB of state and observables stay in

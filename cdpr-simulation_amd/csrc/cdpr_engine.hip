@@ -861,7 +861,8 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
   const bool sp_lean = sp_env >= 0 ? sp_env == 2 : h->batch > 16384u;
-  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr && !h->hold64) ? pick_f64_split_kernel(n, sp_lean) : nullptr;  // (per-robot handles, the hold branch: the one-wave kernel)
+  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr) ? (h->hold64 ? pick_f64_split_hold_kernel(n, sp_lean) : pick_f64_split_kernel(n, sp_lean))
+                                                               : nullptr;  // (per-robot handles: the one-wave kernel)
   // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
   // (14.4 against 20.8 us per step at one robot x 8, same bits): a fused update then runs as one-step launches
   if (split_kern && !sp_lean) per_launch = 1;

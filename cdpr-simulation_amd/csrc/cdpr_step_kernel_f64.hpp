@@ -75,10 +75,11 @@ struct F64Args {
 
 __host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
 // HOLD handles keep BOTH Pids of every cable behind those rows: per cable mLastPosition (JFC.h:45), then per Pid (0 position,
-// 1 velocity) mWasLastTime | mLastTime (world step) | mIerr | samples in the window | ring head | the window's values |
-// the window's stamps (world steps, exact in a double)
+// 1 velocity) one packed word (bits 0-31 mLastTime as a world step | 32-35 ring head | 36-39 samples in the window | 40-47 length
+// of the newest run of consecutive steps, saturating | 48 mWasLastTime; the bits of a double, moved, never computed with) |
+// mIerr | the window's values | the window's stamps (world steps, exact in a double)
 constexpr int kHoldWin = kWin + 1;
-constexpr int kHoldPidRows = 5 + 2 * kHoldWin;
+constexpr int kHoldPidRows = 2 + 2 * kHoldWin;
 constexpr int kHoldCableRows = 1 + 2 * kHoldPidRows;
 __host__ __device__ constexpr int f64_hold_row(int n, int cable, int pid) { return f64_state_rows(n) + cable * kHoldCableRows + 1 + pid * kHoldPidRows; }
 __host__ __device__ constexpr int f64_hold_rows(int n) { return n * kHoldCableRows; }
@@ -249,80 +250,99 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 // Pid::update (Pid.cpp:122-191) with Pid::derive (Pid.cpp:193-217) on a Pid's own rows, in double, for the HOLD instantiations: a
 // Pid is called whenever its branch of JointForceCalculator::update runs, so its window holds samples taken at any steps;
 // a full window's derivative is the least-squares fit on the real stamps (gen_fit: orthogonal polynomials, any gap
-// pattern; on a uniform window it is the closed form of the other instantiations to rounding).  R: the Pid's first row
-// of this robot, rows `st` doubles apart.  No biquad cascades, a command clamp (cdpr_create refuses the rest).
-__device__ __forceinline__ double hold_pid64(double* R, size_t st, double desired, double actual, int now, double dt, double kf, double kp, double ki,
-                                             double kd, double imax, double imin, double cmax, double cmin, int nbuf, int degree, const double* w_age,
-                                             bool& ran, double& p_out, double& i_out, double& d_out) {
-  ran = false;
-  if (R[0] == 0.0) {  // Pid.cpp:123-126: the first call since reset returns 0
-    R[0] = 1.0;
-    R[1 * st] = (double)now;
-    return 0.0;
-  }
-  const int last = (int)R[1 * st];
+// pattern); a window whose samples are one step apart (the packed word keeps the length of the newest run of consecutive
+// steps) goes through the fixed end-point filter of the other instantiations, weights looked up by the sample's age.
+// R: the Pid's first row of this robot, rows `st` doubles apart.  No biquad cascades, a command clamp (cdpr_create refuses
+// the rest).  A lane's step is one latency chain, so the shape matters more than the count: HoldRows64 is loaded - fourteen
+// independent loads, no branch between them - BEFORE the cable's IK, whose arithmetic then hides the round trip;
+// hold_finish64 is straight-line up to the stores (the first call since a reset by selects); only the non-uniform window
+// branches, to reload with the stamps.
+struct HoldPid64 {
+  double kf, kp, ki, kd, imax, imin, cmax, cmin;
+  int nbuf, degree;
+};
+struct HoldRows64 {
+  unsigned long long word;
+  double ierr, held;
+  double y[kHoldWin];
+};
+
+__device__ __forceinline__ HoldRows64 hold_load64(const double* R, const double* LP, size_t st) {
+  HoldRows64 h;
+  h.word = (unsigned long long)__double_as_longlong(R[0]);
+  h.ierr = R[st];
+  h.held = LP[0];
+#pragma unroll
+  for (int j = 0; j < kHoldWin; ++j) h.y[j] = R[(size_t)(2 + j) * st];  // (rows beyond nbuf exist and stay zero)
+  return h;
+}
+
+__device__ __forceinline__ double hold_finish64(double* R, size_t st, const HoldRows64& h, const double* w_age, double desired, double actual, int now, double dt,
+                                                const HoldPid64& g, bool& ran, double& p_out, double& i_out, double& d_out, bool live = true) {
+  const int last = (int)(uint32_t)h.word, head_old = (int)(h.word >> 32) & 15, count_old = (int)(h.word >> 36) & 15, run_old = (int)(h.word >> 40) & 255;
+  const bool was = ((h.word >> 48) & 1ull) != 0ull;  // Pid.cpp:123-126: the first call since reset returns 0 (and pushes no sample)
   const double dts = (double)(now - last) * dt;
   const double error = desired - actual;
-  const double p_term = kp * error;
-  const double prev_ierr = R[2 * st];
-  double ie = fma(dts, error, prev_ierr);
-  double i_term = ki * ie;
+  const double p_term = g.kp * error;
+  double ie = fma(dts, error, h.ierr);
+  double i_term = g.ki * ie;
   const double i_raw = i_term;
-  if (i_term > imax) {  // Pid.cpp:143-152
-    i_term = imax;
-    ie = i_term / ki;
-  } else if (i_term < imin) {
-    i_term = imin;
-    ie = i_term / ki;
+  if (i_term > g.imax) {  // Pid.cpp:143-152
+    i_term = g.imax;
+    ie = i_term / g.ki;
+  } else if (i_term < g.imin) {
+    i_term = g.imin;
+    ie = i_term / g.ki;
   }
   // Pid::derive: push the sample (dt > 0 always: a Pid is called at most once per world step)
-  // (row 3: samples in the window | the length of the run of consecutive world steps the newest samples form, << 8, saturating)
-  const int word = (int)R[3 * st];
-  int count = word & 255, run = word >> 8, head = (int)R[4 * st];
-  head = (count == 0) ? 0 : ((head + 1 >= nbuf) ? 0 : head + 1);
-  count = min(count + 1, nbuf);
-  run = (now == last + 1) ? min(run + 1, 255) : 1;
-  double derived = 0.0;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
-  if (run >= nbuf) {
-    // the whole window is one step apart (the steady case: this Pid has been called every step for nbuf steps): the fit is the
-    // fixed end-point filter of the plain instantiations, weights looked up by the sample's age (the ring head is per cable)
-    double acc = w_age[0] * error;
+  const int head = (count_old == 0) ? 0 : ((head_old + 1 >= g.nbuf) ? 0 : head_old + 1);
+  const int count = min(count_old + 1, g.nbuf);
+  const int run = (now == last + 1) ? min(run_old + 1, 255) : 1;
+  double acc = w_age[0] * error;
 #pragma unroll
-    for (int j = 0; j < kHoldWin; ++j)
-      if (j < nbuf) {
-        int age = head - j;
-        age = age < 0 ? age + nbuf : age;
-        const double yj = R[(size_t)(5 + j) * st];
-        acc = (j == head) ? acc : fma(w_age[age], yj, acc);
-      }
-    derived = acc / dt;
-  } else if (count >= nbuf) {
+  for (int j = 0; j < kHoldWin; ++j) {
+    int age = head - j;
+    age = age < 0 ? age + g.nbuf : age;
+    const double w = w_age[min(max(age, 0), kHoldWin - 1)];
+    acc = (j < g.nbuf && j != head) ? fma(w, h.y[j], acc) : acc;
+  }
+  double derived = (run >= g.nbuf) ? acc / dt : 0.0;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
+  if (was && run < g.nbuf && count >= g.nbuf) {     // a full window with a gap in it: the fit on the real stamps
     double y[kHoldWin];
     int t[kHoldWin];
     int t_old = now;
+    double stamp[kHoldWin];
 #pragma unroll
     for (int j = 0; j < kHoldWin; ++j) {
-      y[j] = (j == head) ? error : R[(size_t)(5 + j) * st];
-      t[j] = (j == head) ? now : (int)R[(size_t)(5 + kHoldWin + j) * st];
-      t_old = (j < nbuf) ? min(t_old, t[j]) : t_old;
+      stamp[j] = R[(size_t)(2 + kHoldWin + j) * st];
+      asm volatile("" : "+v"(stamp[j]));  // (all eleven in flight at once: otherwise each is sunk into its own `j != head` branch, a round trip each)
     }
-    derived = gen_fit<kHoldWin, double>(y, t, nbuf, degree, now, t_old) / dt;
+#pragma unroll
+    for (int j = 0; j < kHoldWin; ++j) {
+      y[j] = (j == head) ? error : h.y[j];
+      t[j] = (j == head) ? now : (int)stamp[j];
+      t_old = (j < g.nbuf) ? min(t_old, t[j]) : t_old;
+    }
+    derived = gen_fit<kHoldWin, double>(y, t, g.nbuf, g.degree, now, t_old) / dt;
   }
-  R[(size_t)(5 + head) * st] = error;
-  R[(size_t)(5 + kHoldWin + head) * st] = (double)now;
-  const double d_term = kd * derived;
-  const double cmd = fma(kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
-  double out = fmax(fmin(cmd, cmax), cmin);                       // Pid.cpp:175-177 (cmdMin < cmdMax here)
-  if (out != cmd) {                                                // Pid.cpp:181-184
-    ie = prev_ierr;
-    out = fma(dts * error, ki, out);
+  const double d_term = g.kd * derived;
+  const double cmd = fma(g.kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
+  double out = fmax(fmin(cmd, g.cmax), g.cmin);                     // Pid.cpp:175-177 (cmdMin < cmdMax here)
+  if (out != cmd) {                                                  // Pid.cpp:181-184
+    ie = h.ierr;
+    out = fma(dts * error, g.ki, out);
   }
-  R[1 * st] = (double)now;
-  R[2 * st] = ie;
-  R[3 * st] = (double)(count | run << 8);
-  R[4 * st] = (double)head;
-  ran = true, p_out = p_term, i_out = i_raw, d_out = d_term;
-  return out;
+  const unsigned long long word = was ? ((unsigned long long)(uint32_t)now | (unsigned long long)head << 32 | (unsigned long long)count << 36 |
+                                         (unsigned long long)run << 40 | 1ull << 48)
+                                      : ((h.word & ~0xffffffffull) | (unsigned long long)(uint32_t)now | 1ull << 48);
+  if (live) R[0] = __longlong_as_double((long long)word);
+  if (was && live) {
+    R[st] = ie;
+    R[(size_t)(2 + head) * st] = error;
+    R[(size_t)(2 + kHoldWin + head) * st] = (double)now;
+  }
+  ran = was, p_out = p_term, i_out = i_raw, d_out = d_term;
+  return was ? out : 0.0;
 }
 
 // RING_LDS: the derivative rings of a lane's cables are loaded once, in one batch, into LDS columns (40 KiB per wave at
@@ -409,6 +429,12 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
 #pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
+        // (HOLD: the rows of the Pid this cable calls in this step - known from the command alone - before the IK)
+        double* const LP = S + (size_t)(f64_state_rows(N) + (HOLD ? i : 0) * kHoldCableRows) * st;  // mLastPosition
+        const bool vel_branch = HOLD && a.hold_mode == 2 && fabs(c_des[i][lane]) > a.hold_eps;  // JFC.cpp:72
+        double* const HR = S + (size_t)(f64_hold_row(N, HOLD ? i : 0, 0) + (vel_branch ? kHoldPidRows : 0)) * st;
+        HoldRows64 hrows;
+        if constexpr (HOLD) hrows = hold_load64(HR, LP, st);
         double L, j[6];
         ik_row64(c_geom + i * 7, R, p, L, j);
         const double q = c_geom[i * 7 + 6] - L;
@@ -422,26 +448,26 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         }
         double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
         if constexpr (HOLD) {  // JFC.cpp:59-96 with both Pids alive
-          double* const LP = S + (size_t)(f64_state_rows(N) + i * kHoldCableRows) * st;  // mLastPosition
           if (!first_world) {
             const double target = c_des[i][lane];
-            const bool vel_branch = a.hold_mode == 2 && fabs(target) > a.hold_eps;  // JFC.cpp:72
             const bool pos_branch = a.hold_mode == 1 || (a.hold_mode == 2 && !vel_branch);
             const bool hold = a.hold_mode == 2 && !vel_branch;
-            const double held = LP[0];
             if (!hold) LP[0] = q;  // JFC.cpp:68,75,87
-            bool ran = false;
-            double tp = 0.0, ti = 0.0, td = 0.0;
-            if (vel_branch)
-              force = hold_pid64(S + (size_t)f64_hold_row(N, i, 1) * st, st, target, qd, (int)(a.step0 + step), a.dt, a.kf, a.kp, a.ki, a.kd, a.imax, a.imin, a.cmax, a.cmin,
-                                 a.nbuf, a.degree, c_hold_w[HOLD ? 1 : 0], ran, tp, ti, td);
-            else if (pos_branch)
-              force = hold_pid64(S + (size_t)f64_hold_row(N, i, 0) * st, st, hold ? held : target, q, (int)(a.step0 + step), a.dt, a.alt_kf, a.alt_kp, a.alt_ki, a.alt_kd,
-                                 a.alt_imax, a.alt_imin, a.alt_cmax, a.alt_cmin, a.alt_nbuf, a.alt_degree, c_hold_w[0], ran, tp, ti, td);
-            if (i == 0 && ran) {
-              dbg_p = tp, dbg_i = ti, dbg_d = td;
-              dbg_ran = true;
-              dbg_des = vel_branch ? target : (hold ? held : target);
+            if (vel_branch || pos_branch) {
+              HoldPid64 g;
+              g.kf = vel_branch ? a.kf : a.alt_kf, g.kp = vel_branch ? a.kp : a.alt_kp, g.ki = vel_branch ? a.ki : a.alt_ki, g.kd = vel_branch ? a.kd : a.alt_kd;
+              g.imax = vel_branch ? a.imax : a.alt_imax, g.imin = vel_branch ? a.imin : a.alt_imin;
+              g.cmax = vel_branch ? a.cmax : a.alt_cmax, g.cmin = vel_branch ? a.cmin : a.alt_cmin;
+              g.nbuf = vel_branch ? a.nbuf : a.alt_nbuf, g.degree = vel_branch ? a.degree : a.alt_degree;
+              const double desired = vel_branch ? target : (hold ? hrows.held : target);
+              bool ran = false;
+              double tp = 0.0, ti = 0.0, td = 0.0;
+              force = hold_finish64(HR, st, hrows, c_hold_w[HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, ran, tp, ti, td);
+              if (i == 0 && ran) {
+                dbg_p = tp, dbg_i = ti, dbg_d = td;
+                dbg_ran = true;
+                dbg_des = desired;
+              }
             }
           }
         } else if (run_pid) {
@@ -737,7 +763,9 @@ static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF
 // workgroup on one SIMD) - the rings are read from HBM / L2 inside the PID loop and the structure-matrix rows are rebuilt
 // where they are needed again, as in the one-wave kernel's large-batch variant; what the split buys there is the other
 // wave's arithmetic under this wave's memory round trips.
-template <int N, bool LEAN = false>
+// HOLD: the position-hold branch live, as in cdpr_step_kernel_f64<.., HOLD> (the controller wave is the lighter of the two:
+// the selected Pid's round trip and its arithmetic run under the estimator wave's Newton stage).
+template <int N, bool LEAN = false, bool HOLD = false>
 __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const F64Args a) {
   __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
   __shared__ double c_win[LEAN ? 1 : N][LEAN ? 1 : kWin][64];
@@ -756,6 +784,13 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   const double* const c_geom = LEAN ? c_geom_lds : a.geom;
+  __shared__ double c_hold_w[HOLD ? 2 : 1][2][kHoldWin];  // (a copy per wave: each reads what it wrote)
+  if (HOLD) {
+    if (lane < 2 * kHoldWin) c_hold_w[HOLD ? wave : 0][lane / kHoldWin][lane % kHoldWin] = a.hold_w[lane / kHoldWin][lane % kHoldWin];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   const bool live = r < a.batch;  // (no early return: both waves meet at two barriers; tail lanes shadow the last robot)
   const size_t st = a.stride;
   double* const S = a.state + (live ? r : a.batch - 1u);
@@ -913,12 +948,19 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
   const bool full = calls >= a.nbuf;
   const int ring_slot = a.ring_slot % kWin;
   const double* wt = a.wtab + ring_slot * (kWin + 2);
-  double dbg_p = 0.0, dbg_i = 0.0, dbg_d = 0.0;
+  double dbg_p = 0.0, dbg_i = 0.0, dbg_d = 0.0, dbg_des = 0.0;
+  bool dbg_ran = false;  // (HOLD: cable 0's Pid really ran this step)
   // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
   {
     const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
 #pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
+      // (HOLD: the rows of the Pid this cable calls in this step - known from the command alone - before the IK)
+      double* const LP = S + (size_t)(f64_state_rows(N) + (HOLD ? i : 0) * kHoldCableRows) * st;  // mLastPosition
+      const bool vel_branch = HOLD && a.hold_mode == 2 && fabs(c_des[i][lane]) > a.hold_eps;  // JFC.cpp:72
+      double* const HR = S + (size_t)(f64_hold_row(N, HOLD ? i : 0, 0) + (vel_branch ? kHoldPidRows : 0)) * st;
+      HoldRows64 hrows;
+      if constexpr (HOLD) hrows = hold_load64(HR, LP, st);
       double L, j[6];
       ik_row64(c_geom + i * 7, R, p, L, j);
       const double q = c_geom[i * 7 + 6] - L;
@@ -930,7 +972,30 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
         for (int c = 0; c < 6; ++c) c_jt[LEAN ? 0 : i][LEAN ? 0 : c][lane] = j[c];
       }
       double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
-      if (run_pid) {
+      if constexpr (HOLD) {  // JFC.cpp:59-96 with both Pids alive
+        if (!first_world) {
+          const double target = c_des[i][lane];
+          const bool pos_branch = a.hold_mode == 1 || (a.hold_mode == 2 && !vel_branch);
+          const bool hold = a.hold_mode == 2 && !vel_branch;
+          if (!hold && live) LP[0] = q;  // JFC.cpp:68,75,87
+          if (vel_branch || pos_branch) {
+            HoldPid64 g;
+            g.kf = vel_branch ? a.kf : a.alt_kf, g.kp = vel_branch ? a.kp : a.alt_kp, g.ki = vel_branch ? a.ki : a.alt_ki, g.kd = vel_branch ? a.kd : a.alt_kd;
+            g.imax = vel_branch ? a.imax : a.alt_imax, g.imin = vel_branch ? a.imin : a.alt_imin;
+            g.cmax = vel_branch ? a.cmax : a.alt_cmax, g.cmin = vel_branch ? a.cmin : a.alt_cmin;
+            g.nbuf = vel_branch ? a.nbuf : a.alt_nbuf, g.degree = vel_branch ? a.degree : a.alt_degree;
+            const double desired = vel_branch ? target : (hold ? hrows.held : target);
+            bool ran = false;
+            double tp = 0.0, ti = 0.0, td = 0.0;
+            force = hold_finish64(HR, st, hrows, c_hold_w[HOLD ? wave : 0][HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, a.step0, a.dt, g, ran, tp, ti, td, live);
+            if (i == 0 && ran) {
+              dbg_p = tp, dbg_i = ti, dbg_d = td;
+              dbg_ran = true;
+              dbg_des = desired;
+            }
+          }
+        }
+      } else if (run_pid) {
         const double desired = c_des[i][lane];
         const double error = desired - (actual_is_vel ? qd : q);
         double acc = wt[kWin] * error;
@@ -992,11 +1057,11 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
   }
   if (a.dbg && live) {  // `pid` topic, cable 0 only (PLG.cpp:223-227; Pid.cpp:139-142,158-168)
     double* d = a.dbg + (size_t)r * 9;
-    if (run_pid) {
+    if (HOLD ? dbg_ran : run_pid) {
       d[0] = dbg_p;
       d[1] = dbg_i;
       d[2] = dbg_d;
-      d[3] = c_des[0][lane];
+      d[3] = HOLD ? dbg_des : c_des[0][lane];
     }
     d[4] = c_f[0][lane];
   }

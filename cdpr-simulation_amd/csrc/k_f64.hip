@@ -12,6 +12,22 @@ template <int N> F64Kernel f64_hold_n() { return cdpr_step_kernel_f64<N, false, 
 F64Kernel pick_f64_hold_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_hold_n); }  // the position-hold branch live (both Pids of every cable)
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }
 F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds) { CDPR_PICK_CABLES(f64_pr_n, ring_lds); }  // per-robot modes (PR)
+F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean) {  // ... with the position-hold branch live
+  if (lean) {
+    switch (n) {
+      case 6: return cdpr_split_kernel_f64<6, true, true>;
+      case 7: return cdpr_split_kernel_f64<7, true, true>;
+      case 8: return cdpr_split_kernel_f64<8, true, true>;
+    }
+    return nullptr;
+  }
+  switch (n) {
+    case 6: return cdpr_split_kernel_f64<6, false, true>;
+    case 7: return cdpr_split_kernel_f64<7, false, true>;
+    case 8: return cdpr_split_kernel_f64<8, false, true>;
+  }
+  return nullptr;
+}
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean) {
   if (lean) {
     switch (n) {

@@ -118,8 +118,11 @@ typedef struct cdpr_config {
                                        reference's own precision (Pid.h, Gazebo/ODE compute in double): one plain fp64 kernel for
                                        handles on the register-resident path (IK, Pid, FK, TD, limits, observables, world step; any steps
                                        per launch; trajectory records, command schedules and per_robot_commands since ABI 5), meant for
-                                       one robot / small batches; read it out with the *_f64 getters.  Not with the general controller
-                                       path, the lumped legs, travel_stop or rollouts (cdpr_create / the call return CDPR_ERR_UNSUPPORTED) */
+                                       one robot / small batches; read it out with the *_f64 getters.  velocity_epsilon >= 0 (the position-hold
+                                       branch, JFC.cpp:72-82: both Pids of every cable alive, derivative windows on real stamps) is served in
+                                       double too on uniform-mode handles (round 5).  Not with biquad cascades, cmd_limit = 0 or windows beyond
+                                       11 (the rest of the general controller path), per_robot_commands together with the hold branch, the lumped
+                                       legs, travel_stop or rollouts (cdpr_create / the call return CDPR_ERR_UNSUPPORTED) */
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */

@@ -264,19 +264,27 @@ def test_fp64_facade_runs_n_steps_as_one_launch_chain(pkg, oracle):
         assert np.array_equal(m0.effort, m1.effort) and np.array_equal(m0.position, m1.position)
 
 
-@pytest.mark.parametrize("cables,stages,B", [(8, 3, 130), (4, 0, 70), (8, 3, 5000)])
-def test_fp64_hold_branch(pkg, oracle, cables, stages, B):
+@pytest.mark.parametrize("cables,stages,B,split", [(8, 3, 130, None), (4, 0, 70, None), (8, 3, 5000, "0"), (8, 3, 17000, None), (6, 3, 100, "2")])
+def test_fp64_hold_branch(pkg, oracle, monkeypatch, cables, stages, B, split):
     """velocityEpsilon >= 0 in the reference's own precision (round 5: the HOLD instantiations of the fp64 kernel): both Pids of
     every cable alive, cables drifting into the hold branch and back (their windows sampled at non-uniform times: the
     derivative is a least-squares fit on the real stamps in double), then Position mode (the position Pid reset), Force
     mode, Velocity again (the velocity Pid reset), fused launches and the trajectory record in between, the `pid` topic -
     against the fp64 oracle.  The fit here runs on orthogonal polynomials, the oracle's on normal equations in centred
-    time: two double formulations of an ill-conditioned step (a window with a gap), hence the effort tolerance."""
+    time: two double formulations of an ill-conditioned step (a window with a gap), hence the effort tolerance.
+    Kernels: FK + TD handles take the role-split kernel's HOLD instantiations (its LDS build to 16 384 robots, its lean build
+    beyond; CDPR_F64_SPLIT forces one or, "0", the one-wave kernel); the others the one-wave kernel's."""
     from test_gpu_general_matrix import hold_commands
+
+    if split is not None:
+        monkeypatch.setenv("CDPR_F64_SPLIT", split)
 
     eps = 0.004
     rng = np.random.default_rng(640 + cables)
-    model = pkg.eight_cable_model() if cables == 8 else pkg.cube_model()
+    from dataclasses import replace
+
+    full = pkg.eight_cable_model()
+    model = pkg.cube_model() if cables == 4 else replace(full, frame_anchors=full.frame_anchors[:cables], platform_anchors=full.platform_anchors[:cables])
     cfg = pkg.Config(model=model, batch=B, stages=stages | pkg._abi.STAGE_PID_DEBUG, velocityEpsilon=eps, precision=64)
     eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05).astype(np.float64))
     tol = dict(TOL64, eff=2e-7, twist=1e-10, qd=1e-10, pose=1e-12, q=1e-12)
