@@ -144,6 +144,7 @@ struct cdpr_engine {
   uint64_t roll_pending = 0;     // trajectories of the launched, not yet fetched rollout
   // cdpr_config_t.precision = 64: the step in double (cdpr_step_kernel_f64.hpp); its own state, observables, tables
   bool fp64 = false;
+  bool tstop64 = false;  // ... with the joint stop modelled (travel_stop > 0; TSTOP kernels)
   bool hold64 = false;   // ... with the position-hold branch live (velocity_epsilon >= 0): both Pids of every cable in rows behind the state (HOLD kernels)
   double* d_state64 = nullptr;
   double* d_obs64 = nullptr;
@@ -855,13 +856,15 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
   const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
+  a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
   F64Kernel kern = h->hold64 ? pick_f64_hold_kernel(n)
+                   : h->tstop64 ? pick_f64_tstop_kernel(n)
                              : pr ? pick_f64_pr_kernel(n, ring_lds) : pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
   const bool sp_lean = sp_env >= 0 ? sp_env == 2 : h->batch > 16384u;
-  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr) ? (h->hold64 ? pick_f64_split_hold_kernel(n, sp_lean) : pick_f64_split_kernel(n, sp_lean))
+  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr && !h->tstop64) ? (h->hold64 ? pick_f64_split_hold_kernel(n, sp_lean) : pick_f64_split_kernel(n, sp_lean))
                                                                : nullptr;  // (per-robot handles: the one-wave kernel)
   // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
   // (14.4 against 20.8 us per step at one robot x 8, same bits): a fused update then runs as one-step launches
@@ -1436,8 +1439,11 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   cdpr_config_t no_hold = *cfg;
   no_hold.velocity_epsilon = -1.0;
   const bool hold64 = cfg->precision == 64 && !(cfg->velocity_epsilon < 0.0) && fast_path_obstacle(no_hold).empty() && cfg->per_robot_commands == 0 && !phys_cfg;
-  if (cfg->precision == 64 && (general || phys_cfg) && !hold64) {
-    g_create_error = "precision = 64 covers the register-resident path only (no lumped legs, travel_stop, hold branch, cascades, long windows, "
+  // ... and with the joint stop as the only optional physics: the TSTOP instantiations (uniform-mode handles without the hold branch)
+  const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
+  const bool tstop64 = cfg->precision == 64 && cfg->travel_stop != 0 && !lumped_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;
+  if (cfg->precision == 64 && (general || phys_cfg) && !hold64 && !tstop64) {
+    g_create_error = "precision = 64 covers the register-resident path, the hold branch and the joint stop on uniform-mode handles (no lumped legs, cascades, long windows, "
                      "cmd_limit 0, or per-robot modes with two different derivative windows): " +
                      (general ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
                               : std::string("optional physics"));
@@ -1471,6 +1477,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->general = general && !hold64;  // (precision = 64 with the hold branch: the fp64 kernel's HOLD instantiations, not the fp32 general path)
   h->fp64 = cfg->precision == 64;
   h->hold64 = hold64;
+  h->tstop64 = tstop64;
   h->per_robot = cfg->per_robot_commands != 0;
   h->phys = phys_cfg;
   {

@@ -71,6 +71,7 @@ struct F64Args {
   double hold_eps;
   int degree, alt_nbuf, alt_degree;
   double hold_w[2][kWin + 1];  // [position | velocity] Pid: the uniform-grid derivative weights by AGE of the sample (0: newest), in steps
+  int travel_stop;             // TSTOP instantiations: sweeps of the joint stop (cdpr_config_t.travel_stop), 0 = flag only
 };
 
 __host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
@@ -354,9 +355,15 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
 // step instead of 72 at n = 8 (a row is ~60 fp64 instructions, a reload 6 LDS reads).  Same values, same bits.
 // HOLD: the position-hold branch live (velocityEpsilon >= 0): both Pids of every cable in the rows behind the state (f64_hold_row),
 // selected per cable and step as JointForceCalculator::update does (JFC.cpp:67-89); uniform-mode handles, rings in memory.
-template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, bool HOLD = false>
+// TSTOP: the joint stop itself (cdpr_config_t.travel_stop > 0, [EXT] Gazebo/ODE -> reduced; apply_travel_stop of the fp32 kernels,
+// oracle/cdpr_oracle.c world_step): between the velocity and the pose half of the world step a joint at or beyond a limit that
+// still moves outward takes the impulse that stops it, cables in index order, travel_stop sweeps; the rows of the structure
+// matrix at t_k wait in private LDS columns.
+template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, bool HOLD = false, bool TSTOP = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   static_assert(!HOLD || (!RING_LDS && !JCACHE && !PR), "the hold branch: the plain instantiation");
+  static_assert(!TSTOP || (!RING_LDS && !JCACHE && !PR && !HOLD), "the joint stop: the plain instantiation");
+  __shared__ double c_js[TSTOP ? N : 1][TSTOP ? 6 : 1][64];
   // cables per pass of the loops over the cables.  One lane's step is a dependent chain (rotate the anchor, length,
   // reciprocal square root, row, accumulate): with a single wave per SIMD a dependent fp64 instruction waits ~8 cycles for
   // its predecessor, and only several cables in flight fill those slots.  The role-split kernel
@@ -665,6 +672,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         } else {
           ik_row64(c_geom + i * 7, R, p, L, j);
         }
+        if (TSTOP) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) c_js[TSTOP ? i : 0][TSTOP ? c : 0][lane] = j[c];
+        }
         double t = fma(-a.damping, c_qd[i][lane], c_f[i][lane]);
         if (a.unilateral) t = fmax(t, 0.0);
 #pragma unroll
@@ -686,6 +697,35 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       om[0] = fma(a.dt, fma(R.r02, ab[2], fma(R.r01, ab[1], R.r00 * ab[0])), om[0]);
       om[1] = fma(a.dt, fma(R.r12, ab[2], fma(R.r11, ab[1], R.r10 * ab[0])), om[1]);
       om[2] = fma(a.dt, fma(R.r22, ab[2], fma(R.r21, ab[1], R.r20 * ab[0])), om[2]);
+      if constexpr (TSTOP) {
+        for (int sweep = 0; sweep < a.travel_stop; ++sweep) {
+#pragma clang loop unroll(disable)
+          for (int i = 0; i < N; ++i) {
+            double j[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) j[c] = c_js[TSTOP ? i : 0][TSTOP ? c : 0][lane];
+            const double qi = c_q[i][lane];
+            const double qdn = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
+            const bool hit = (qi >= a.travel_hi && qdn > 0.0) || (qi <= a.travel_lo && qdn < 0.0);
+            // Iw^-1 (rb x u) = R Ib^-1 R^T (rb x u)
+            const double sb[3] = {fma(R.r20, j[5], fma(R.r10, j[4], R.r00 * j[3])), fma(R.r21, j[5], fma(R.r11, j[4], R.r01 * j[3])),
+                                  fma(R.r22, j[5], fma(R.r12, j[4], R.r02 * j[3]))};
+            const double cb[3] = {fma(a.ibinv[4], sb[2], fma(a.ibinv[3], sb[1], a.ibinv[0] * sb[0])), fma(a.ibinv[5], sb[2], fma(a.ibinv[1], sb[1], a.ibinv[3] * sb[0])),
+                                  fma(a.ibinv[2], sb[2], fma(a.ibinv[5], sb[1], a.ibinv[4] * sb[0]))};
+            const double aw[3] = {fma(R.r02, cb[2], fma(R.r01, cb[1], R.r00 * cb[0])), fma(R.r12, cb[2], fma(R.r11, cb[1], R.r10 * cb[0])),
+                                  fma(R.r22, cb[2], fma(R.r21, cb[1], R.r20 * cb[0]))};
+            const double d = fma(j[5], aw[2], fma(j[4], aw[1], fma(j[3], aw[0], fma(j[2], j[2], fma(j[1], j[1], j[0] * j[0])) * a.inv_mass)));
+            const double lam = hit ? qdn / d : 0.0;
+            const double lm = lam * a.inv_mass;
+            v[0] = fma(lm, j[0], v[0]);
+            v[1] = fma(lm, j[1], v[1]);
+            v[2] = fma(lm, j[2], v[2]);
+            om[0] = fma(lam, aw[0], om[0]);
+            om[1] = fma(lam, aw[1], om[1]);
+            om[2] = fma(lam, aw[2], om[2]);
+          }
+        }
+      }
       p[0] = fma(a.dt, v[0], p[0]);
       p[1] = fma(a.dt, v[1], p[1]);
       p[2] = fma(a.dt, v[2], p[2]);
@@ -772,7 +812,10 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
   __shared__ double c_jt[LEAN ? 1 : N][LEAN ? 1 : 6][64];  // rows at the true pose (controller wave: IK stage -> world step)
   __shared__ double c_je[LEAN ? 1 : N][LEAN ? 1 : 6][64];  // rows at the FK estimate (estimator wave: closing evaluation -> tension distribution)
   __shared__ double x_est[3][64];    // estimator -> controller: residual, iterations, infeasible flag
-  constexpr int kU = LEAN ? (N < 4 ? N : 4) : N;  // cables per pass of the loops over the cables (see cdpr_step_kernel_f64); LEAN at
+#ifndef CDPR_F64_HOLD_KU
+#define CDPR_F64_HOLD_KU N
+#endif
+  constexpr int kU = LEAN ? (N < 4 ? N : 4) : (HOLD ? (N < CDPR_F64_HOLD_KU ? N : CDPR_F64_HOLD_KU) : N);  // cables per pass of the loops over the cables (see cdpr_step_kernel_f64); LEAN at
                                                   // 65 536 x 8: 31.8 us with 2, 29.4 with 4, 44.9 with 8 (356 B of scratch)
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const uint32_t r = blockIdx.x * 64u + lane;

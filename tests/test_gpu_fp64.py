@@ -321,10 +321,47 @@ def test_fp64_hold_branch(pkg, oracle, monkeypatch, cables, stages, B, split):
     compare64(eng, ora, "after a world reset", tol)
 
 
+@pytest.mark.parametrize("cables,stages,B", [(8, 3, 150), (4, 0, 70)])
+def test_fp64_travel_stop(pkg, oracle, cables, stages, B):
+    """The inelastic joint stop (cdpr_config_t.travel_stop sweeps) in double: the TSTOP instantiations of the one-wave kernel
+    (round 5).  Both sides compute in double, so - unlike the fp32 test (test_gpu_parity.py::test_travel_stop_against_the_oracle) -
+    the thresholds fall on the same step and the comparison stays tight through the contacts; one-step and fused launches, the
+    limit flags, the joints resting on their stops."""
+    rng = np.random.default_rng(77 + cables)
+    model = pkg.eight_cable_model() if cables == 8 else pkg.cube_model()
+    lim = 0.004
+    model.travel_lower, model.travel_upper, model.travel_stop = -lim, lim, 4
+    cfg = pkg.Config(model=model, batch=B, stages=stages, precision=64)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.002, 0.01).astype(np.float64))
+    jac = oracle.ik(cfg.to_struct(), model.home_pose())[3]
+    tw = np.concatenate([rng.uniform(-0.05, 0.05, (B, 3)), rng.uniform(-0.2, 0.2, (B, 3))], axis=1)
+    cmd = (-(jac @ tw.T).T).astype(np.float32)
+    eng.update(10), ora.update(10)
+    eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+    tol = dict(TOL64, pose=1e-11, q=1e-11, twist=1e-9, qd=1e-9, eff=1e-6)
+    for k in range(10):
+        if k % 2:
+            eng.update(30, 10)
+        else:
+            eng.update(30)
+        ora.update(30)
+        compare64(eng, ora, f"{30 * (k + 1)} steps", tol)
+    q = eng.observables_f64()[0]
+    assert np.abs(q).max() < lim + 1.5e-4 and (np.abs(q) > lim - 1e-5).any()
+    assert (eng.limit_state() != 0).mean() > 0.3
+    assert np.array_equal(eng.limit_state(), ora.limit_state())
+
+
 def test_fp64_refuses_what_it_does_not_cover(pkg):
     for kw in (dict(perRobotCommands=True, velocityEpsilon=0.01),):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(pkg.Config(batch=4, precision=64, **kw), 0)
+        assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+    lumped = pkg.eight_cable_model()
+    lumped.travel_lower, lumped.travel_upper, lumped.travel_stop, lumped.leg_inertia = -0.01, 0.01, 2, 0.004
+    for cfg in (pkg.Config(model=lumped, batch=4, precision=64), ):
+        with pytest.raises(pkg.CdprError) as ei:
+            pkg.Engine(cfg, 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
     cascaded = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)
     cascaded.velocityController.pFilter.cascade = 1
