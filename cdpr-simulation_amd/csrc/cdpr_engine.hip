@@ -1424,31 +1424,35 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   // (hold branch, cascades, long windows, cmdLimit 0), and per-robot modes combined with the lumped-leg physics or with
   // two Pids that fit different derivative windows, take the general controller path
   const bool pr_windows_differ = cfg->velocity_pid.d_buffer_length != cfg->position_pid.d_buffer_length || cfg->velocity_pid.d_degree != cfg->position_pid.d_degree;
-  const bool general = !fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && (phys_cfg || pr_windows_differ));
+  const bool general_cfg = !fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && (phys_cfg || pr_windows_differ));
   // The per-robot kernels of the register-resident path do not clear a reset Pid's derivative ring (the latch zeroes only
   // the integral rows) and a velocity rollout keeps stale position-Pid errors in it: that is correct only while
   // full = calls >= nbuf hides every stale slot, i.e. nbuf <= kWin + 1 and one window shared by both Pids.  Both follow
   // from the routing above; checked here so that a change to the routing cannot silently break the kernels' invariant.
-  if (!general && cfg->per_robot_commands != 0 &&
+  if (!general_cfg && cfg->per_robot_commands != 0 &&
       (pr_windows_differ || cfg->velocity_pid.d_buffer_length > (uint32_t)kWin + 1 || cfg->position_pid.d_buffer_length > (uint32_t)kWin + 1)) {
     g_create_error = "internal: per-robot handle routed to the register-resident path with windows it cannot hold";
     return CDPR_ERR_UNSUPPORTED;
   }
   // precision = 64 with the hold branch as the ONLY thing the register-resident path cannot represent: the HOLD instantiations of the
   // fp64 kernel (uniform-mode handles; round 5)
+  // (cmd_limit = 0 stays out: without the clamp the reference's Pid returns its stale mCmd member plus the anti-windup increment,
+  //  Pid.cpp:175-184 - a per-Pid state only the general path's records hold)
   cdpr_config_t no_hold = *cfg;
   no_hold.velocity_epsilon = -1.0;
-  const bool hold64 = cfg->precision == 64 && !(cfg->velocity_epsilon < 0.0) && fast_path_obstacle(no_hold).empty() && cfg->per_robot_commands == 0 && !phys_cfg;
+  const bool clean64 = cfg->precision == 64 && fast_path_obstacle(no_hold).empty();  // no cascades, windows to 11, a command clamp
+  const bool hold64 = clean64 && !(cfg->velocity_epsilon < 0.0) && cfg->per_robot_commands == 0 && !phys_cfg;
   // ... and with the joint stop as the only optional physics: the TSTOP instantiations (uniform-mode handles without the hold branch)
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
-  const bool tstop64 = cfg->precision == 64 && cfg->travel_stop != 0 && !lumped_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;
-  if (cfg->precision == 64 && (general || phys_cfg) && !hold64 && !tstop64) {
-    g_create_error = "precision = 64 covers the register-resident path, the hold branch and the joint stop on uniform-mode handles (no lumped legs, cascades, long windows, "
-                     "cmd_limit 0, or per-robot modes with two different derivative windows): " +
-                     (general ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
+  const bool tstop64 = clean64 && cfg->travel_stop != 0 && !lumped_cfg && cfg->velocity_epsilon < 0.0 && cfg->per_robot_commands == 0;
+  if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64) {
+    g_create_error = "precision = 64 covers the register-resident path, the hold branch and the joint stop on uniform-mode handles (no lumped legs, cascades, long windows, cmd_limit 0, "
+                     "or per-robot modes with two different derivative windows, the hold branch or the joint stop): " +
+                     (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
                               : std::string("optional physics"));
     return CDPR_ERR_UNSUPPORTED;
   }
+  const bool general = general_cfg && cfg->precision != 64;  // (a precision = 64 handle that got here runs on the fp64 kernels' own instantiations)
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -1474,7 +1478,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->fk = (cfg->stages & CDPR_STAGE_FK) != 0;
   h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
   h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
-  h->general = general && !hold64;  // (precision = 64 with the hold branch: the fp64 kernel's HOLD instantiations, not the fp32 general path)
+  h->general = general;  // (precision = 64 with the hold branch: the fp64 kernel's HOLD instantiations, not the fp32 general path)
   h->fp64 = cfg->precision == 64;
   h->hold64 = hold64;
   h->tstop64 = tstop64;

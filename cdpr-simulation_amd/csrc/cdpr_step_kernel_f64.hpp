@@ -328,7 +328,8 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
   }
   const double d_term = g.kd * derived;
   const double cmd = fma(g.kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
-  double out = fmax(fmin(cmd, g.cmax), g.cmin);                     // Pid.cpp:175-177 (cmdMin < cmdMax here)
+  double out = fmax(fmin(cmd, g.cmax), g.cmin);                     // Pid.cpp:175-177 (cmdMin < cmdMax here: with cmd_limit = 0 the reference keeps a
+                                                                     // stale mCmd, Pid.cpp:175-184, a state only the general path's records hold)
   if (out != cmd) {                                                  // Pid.cpp:181-184
     ie = h.ierr;
     out = fma(dts * error, g.ki, out);

@@ -363,6 +363,11 @@ def test_fp64_refuses_what_it_does_not_cover(pkg):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(cfg, 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+    unclamped = pkg.Config(batch=4, precision=64)  # (without the clamp Pid::update returns its stale mCmd: a state of the general path's records only)
+    unclamped.velocityController.cmdLimit = 0.0
+    with pytest.raises(pkg.CdprError) as ei:
+        pkg.Engine(unclamped, 0)
+    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
     cascaded = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)
     cascaded.velocityController.pFilter.cascade = 1
     with pytest.raises(pkg.CdprError) as ei:
