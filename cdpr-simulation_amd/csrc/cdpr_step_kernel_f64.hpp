@@ -405,7 +405,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   // the integrals and the commands (and, RING_LDS, the derivative rings) in one batch of loads
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
+    if (!HOLD) c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
     c_des[i][lane] = (double)a.cmd[(size_t)r * N + i];
     if (RING_LDS) {
 #pragma unroll
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   }
 #pragma clang loop unroll_count(kCableUnroll)
   for (int i = 0; i < N; ++i) {
-    S[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
+    if (!HOLD) S[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];  // (HOLD: the integrals live in the Pids' own rows)
     if (RING_LDS) {
 #pragma unroll
       for (int k = 0; k < kWin; ++k) S[(size_t)(20 + 11 * i + k) * st] = c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane];
@@ -979,9 +979,9 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
   const uint32_t rc = live ? r : a.batch - 1u;
 #pragma clang loop unroll_count(kU)
   for (int i = 0; i < N; ++i) {
-    c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
+    if (!HOLD) c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
     c_des[i][lane] = (double)a.cmd[(size_t)rc * N + i];
-    if (!LEAN) {
+    if (!LEAN && !HOLD) {  // (HOLD: the windows live in the Pids' own rows)
 #pragma unroll
       for (int k = 0; k < kWin; ++k) c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane] = S[(size_t)(20 + 11 * i + k) * st];
     }
@@ -1191,8 +1191,8 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     for (int c = 0; c < 4; ++c) W[(size_t)(3 + c) * st] = q4[c];
 #pragma clang loop unroll_count(kU)
     for (int i = 0; i < N; ++i) {
-      W[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];
-      if (!LEAN) {
+      if (!HOLD) W[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];  // (HOLD: the integrals live in the Pids' own rows)
+      if (!LEAN && !HOLD) {
 #pragma unroll
         for (int k = 0; k < kWin; ++k) W[(size_t)(20 + 11 * i + k) * st] = c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane];
       }
