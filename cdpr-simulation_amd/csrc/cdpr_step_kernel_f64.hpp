@@ -356,8 +356,8 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
 // step instead of 72 at n = 8 (a row is ~60 fp64 instructions, a reload 6 LDS reads).  Same values, same bits.
 // HOLD: the position-hold branch live (velocityEpsilon >= 0): both Pids of every cable in the rows behind the state (f64_hold_row),
 // selected per cable and step as JointForceCalculator::update does (JFC.cpp:67-89); uniform-mode handles, rings in memory.
-// TSTOP: the joint stop itself (cdpr_config_t.travel_stop > 0, [EXT] Gazebo/ODE -> reduced; apply_travel_stop of the fp32 kernels,
-// oracle/cdpr_oracle.c world_step): between the velocity and the pose half of the world step a joint at or beyond a limit that
+// TSTOP: the joint stop itself (cdpr_config_t.travel_stop > 0, [EXT] Gazebo/ODE -> reduced; apply_travel_stop of the fp32 kernels):
+// between the velocity and the pose half of the world step a joint at or beyond a limit that
 // still moves outward takes the impulse that stops it, cables in index order, travel_stop sweeps; the rows of the structure
 // matrix at t_k wait in private LDS columns.
 template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, bool HOLD = false, bool TSTOP = false>
