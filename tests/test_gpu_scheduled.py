@@ -161,12 +161,20 @@ def test_per_robot_handles_take_a_mask_per_batch(pkg, oracle, kind, general):
     run_both(pkg, oracle, cfg, pose, kind, sched, refresh, T, masks=masks, before=before)
 
 
-def test_fp64_handles_take_schedules(pkg, oracle):
+@pytest.mark.parametrize("variant", ["plain", "hold", "stop"])
+def test_fp64_handles_take_schedules(pkg, oracle, variant):
+    """... the HOLD (velocityEpsilon >= 0: some cables of every batch at or below epsilon) and TSTOP (joint stop) instantiations too."""
     B, n, refresh, T = 70, 8, 10, 64
     rng = np.random.default_rng(10)
-    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, precision=64)
+    model = pkg.eight_cable_model()
+    if variant == "stop":
+        model.travel_lower, model.travel_upper, model.travel_stop = -0.004, 0.004, 3
+    cfg = pkg.Config(model=model, batch=B, stages=3, precision=64, velocityEpsilon=0.004 if variant == "hold" else -0.001)
     pose = perturbed_poses(cfg.model, B, rng, 0.02, 0.05)
     sched = rng.uniform(-0.03, 0.03, ((T + refresh - 1) // refresh, B, n)).astype(np.float32)
+    if variant == "hold":
+        low = rng.random(sched.shape) < 0.3
+        sched[low] = (rng.uniform(-1.0, 1.0, int(low.sum())) * 0.004).astype(np.float32)
     run_both(pkg, oracle, cfg, pose, "velocity", sched, refresh, T, record=False, f64=True)
 
 
