@@ -857,7 +857,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
   a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
-  F64Kernel kern = h->hold64 ? pick_f64_hold_kernel(n)
+  F64Kernel kern = h->hold64 ? (pr ? pick_f64_hold_pr_kernel(n) : pick_f64_hold_kernel(n))
                    : h->tstop64 ? pick_f64_tstop_kernel(n)
                              : pr ? pick_f64_pr_kernel(n, ring_lds) : pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
@@ -1048,6 +1048,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         lf.batch = h->batch;
         lf.n = h->n;
         lf.new_mode = (new_mode == kModeVelocity) ? kMetaVelocity : (new_mode == kModePosition) ? kMetaPosition : kMetaForce;
+        lf.hold = h->hold64 ? 1u : 0u;
         hipLaunchKernelGGL(cdpr_latch_f64_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, lf);
         HIP_TRY(h, hipGetLastError());
         return CDPR_OK;
@@ -1441,7 +1442,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   cdpr_config_t no_hold = *cfg;
   no_hold.velocity_epsilon = -1.0;
   const bool clean64 = cfg->precision == 64 && fast_path_obstacle(no_hold).empty();  // no cascades, windows to 11, a command clamp
-  const bool hold64 = clean64 && !(cfg->velocity_epsilon < 0.0) && cfg->per_robot_commands == 0 && !phys_cfg;
+  const bool hold64 = clean64 && !(cfg->velocity_epsilon < 0.0) && !phys_cfg;  // (per-robot modes too: each Pid has its own rows and window)
   // ... and with the joint stop as the only optional physics: the TSTOP instantiations (uniform-mode handles without the hold branch)
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
   const bool tstop64 = clean64 && cfg->travel_stop != 0 && !lumped_cfg && cfg->velocity_epsilon < 0.0 && cfg->per_robot_commands == 0;

@@ -57,6 +57,7 @@ GenKernel pick_gen_lean11(uint32_t n);   // k_gen_split.hip: the same for larger
 GenKernel pick_gen_split11(uint32_t n);  // k_gen_split.hip: one step per launch, two waves per 64 robots split by role (FK + TD, n >= 6, windows <= 11)
 // k_f64.hip: precision = 64
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean);  // lean: nothing cached in LDS (four workgroups per CU)
+F64Kernel pick_f64_hold_pr_kernel(uint32_t n);  // HOLD on per-robot handles
 F64Kernel pick_f64_tstop_kernel(uint32_t n);  // TSTOP instantiations (the joint stop in double)
 F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean);  // ... HOLD instantiations (the position-hold branch in double)
 //  // one step per launch, two waves per 64 robots split by role (FK + TD, n >= 6)

@@ -362,7 +362,7 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
 // matrix at t_k wait in private LDS columns.
 template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, bool HOLD = false, bool TSTOP = false>
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
-  static_assert(!HOLD || (!RING_LDS && !JCACHE && !PR), "the hold branch: the plain instantiation");
+  static_assert(!HOLD || (!RING_LDS && !JCACHE), "the hold branch: the plain instantiation (uniform modes, or PR: the mode per lane)");
   static_assert(!TSTOP || (!RING_LDS && !JCACHE && !PR && !HOLD), "the joint stop: the plain instantiation");
   __shared__ double c_js[TSTOP ? N : 1][TSTOP ? 6 : 1][64];
   // cables per pass of the loops over the cables.  One lane's step is a dependent chain (rotate the anchor, length,
@@ -439,7 +439,9 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       for (int i = 0; i < N; ++i) {
         // (HOLD: the rows of the Pid this cable calls in this step - known from the command alone - before the IK)
         double* const LP = S + (size_t)(f64_state_rows(N) + (HOLD ? i : 0) * kHoldCableRows) * st;  // mLastPosition
-        const bool vel_branch = HOLD && a.hold_mode == 2 && fabs(c_des[i][lane]) > a.hold_eps;  // JFC.cpp:72
+        // (PR: this robot's own mode - the meta byte's kMetaForce / kMetaPosition / kMetaVelocity are 0 / 1 / 2 as hold_mode's)
+        const int hmode = PR ? (int)(meta & kMetaModeMask) : a.hold_mode;
+        const bool vel_branch = HOLD && hmode == 2 && fabs(c_des[i][lane]) > a.hold_eps;  // JFC.cpp:72
         double* const HR = S + (size_t)(f64_hold_row(N, HOLD ? i : 0, 0) + (vel_branch ? kHoldPidRows : 0)) * st;
         HoldRows64 hrows;
         if constexpr (HOLD) hrows = hold_load64(HR, LP, st);
@@ -458,8 +460,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         if constexpr (HOLD) {  // JFC.cpp:59-96 with both Pids alive
           if (!first_world) {
             const double target = c_des[i][lane];
-            const bool pos_branch = a.hold_mode == 1 || (a.hold_mode == 2 && !vel_branch);
-            const bool hold = a.hold_mode == 2 && !vel_branch;
+            const bool pos_branch = hmode == 1 || (hmode == 2 && !vel_branch);
+            const bool hold = hmode == 2 && !vel_branch;
             if (!hold) LP[0] = q;  // JFC.cpp:68,75,87
             if (vel_branch || pos_branch) {
               HoldPid64 g;
@@ -778,6 +780,7 @@ struct LatchF64Args {
   size_t stride;
   uint32_t batch, n;
   uint32_t new_mode;     // kMetaForce / kMetaPosition / kMetaVelocity
+  uint32_t hold;         // HOLD handles: both Pids of every cable live in their own rows (f64_hold_row); entering a mode clears THAT Pid's
 };
 static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF64Args a) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
@@ -788,7 +791,13 @@ static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF
   if (a.new_mode == kMetaForce) {
     m = (m & ~kMetaModeMask) | kMetaForce;
   } else if ((m & kMetaModeMask) != a.new_mode) {
-    for (uint32_t i = 0; i < a.n; ++i) a.state[(size_t)(20 + 11 * i + 10) * a.stride + r] = 0.0;
+    if (a.hold) {  // Pid::reset of the Pid of the mode entered (JFC.cpp:101-103,113-115), every cable: word, integral, window, stamps
+      const int pid = (a.new_mode == kMetaVelocity) ? 1 : 0;
+      for (uint32_t i = 0; i < a.n; ++i)
+        for (int row = 0; row < kHoldPidRows; ++row) a.state[(size_t)(f64_hold_row((int)a.n, (int)i, pid) + row) * a.stride + r] = 0.0;
+    } else {
+      for (uint32_t i = 0; i < a.n; ++i) a.state[(size_t)(20 + 11 * i + 10) * a.stride + r] = 0.0;
+    }
     m = a.new_mode;  // call count 0
   }
   a.meta[r] = (uint8_t)m;

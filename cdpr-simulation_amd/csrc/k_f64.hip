@@ -8,8 +8,10 @@ template <int N> F64Kernel f64_n(bool ring_lds, bool jcache) {
   return ring_lds ? cdpr_step_kernel_f64<N, true> : cdpr_step_kernel_f64<N, false>;
 }
 template <int N> F64Kernel f64_hold_n() { return cdpr_step_kernel_f64<N, false, false, false, true>; }
+template <int N> F64Kernel f64_hold_pr_n() { return cdpr_step_kernel_f64<N, false, false, true, true>; }
 template <int N> F64Kernel f64_tstop_n() { return cdpr_step_kernel_f64<N, false, false, false, false, true>; }
 }  // namespace
+F64Kernel pick_f64_hold_pr_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_hold_pr_n); }  // ... on per-robot handles (the mode per lane)
 F64Kernel pick_f64_tstop_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_tstop_n); }  // the joint stop modelled (travel_stop > 0)
 F64Kernel pick_f64_hold_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_hold_n); }  // the position-hold branch live (both Pids of every cable)
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }

@@ -193,6 +193,58 @@ def test_fp64_per_robot_modes(pkg, oracle, cables, stages, B):
     compare64(eng, ora, "unmasked Joy at the end")
 
 
+@pytest.mark.parametrize("cables,stages,B", [(8, 3, 200), (4, 0, 90)])
+def test_fp64_per_robot_modes_with_the_hold_branch(pkg, oracle, cables, stages, B):
+    """per_robot_commands AND velocityEpsilon >= 0 in double (round 5: the PR + HOLD instantiation of the one-wave kernel, the mode
+    per lane; the latch clears the rows of the Pid a robot's mode change enters): velocity Joys with cables at or below epsilon,
+    position and setForce commands reaching subsets, a group going Velocity -> Position -> Velocity (both resets) while the
+    others keep their Pids, fused launches and a trajectory record, a world reset - against the fp64 oracle."""
+    from test_gpu_general_matrix import hold_commands
+
+    eps = 0.004
+    rng = np.random.default_rng(184 + cables)
+    model = pkg.eight_cable_model() if cables == 8 else pkg.cube_model()
+    cfg = pkg.Config(model=model, batch=B, stages=stages | pkg._abi.STAGE_PID_DEBUG, precision=64, perRobotCommands=True, velocityEpsilon=eps)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05).astype(np.float64))
+    tol = dict(TOL64, eff=2e-7, twist=1e-10, qd=1e-10, pose=1e-12, q=1e-12)
+    eng.update(9), ora.update(9)
+    compare64(eng, ora, "position mode from Load", tol)
+    grp = np.arange(B) % 4
+    steps = iter([13, 1, 24, 7, 30, 12, 19, 26, 5])
+    for rnd in range(2):
+        v = hold_commands(rng, B, cables, eps)
+        f = ((7.0 if cables == 8 else 3.97) + rng.uniform(-0.5, 0.5, (B, cables))).astype(np.float32)
+        p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+        for e in (eng, ora):
+            e.set_velocity_command(v, mask=(grp <= 1).astype(np.uint8))       # groups 0, 1 -> Velocity (some of their cables hold)
+            e.set_force_command(f, mask=(grp == 2).astype(np.uint8))          # group 2 -> Force; group 3 stays in Position mode
+        k = next(steps)
+        eng.update(k, 1), ora.update(k)
+        compare64(eng, ora, f"round {rnd}: velocity + force subsets", tol)
+        v2 = hold_commands(rng, B, cables, eps)
+        for e in (eng, ora):
+            e.set_velocity_command(v2, mask=(grp == 0).astype(np.uint8))      # a new Joy in the same mode: no reset, cables change branch
+            e.set_position_command(p, mask=(grp == 1).astype(np.uint8))       # group 1 back to Position: that Pid is reset
+        k = next(steps)
+        if rnd:
+            eng.update_record(k, 5)
+        else:
+            eng.update(k, 5)
+        ora.update(k)
+        compare64(eng, ora, f"round {rnd}: position subset (fused launches)", tol)
+        assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 1e-6, f"pid topic, round {rnd}"
+        for e in (eng, ora):
+            e.set_velocity_command(v[::-1].copy(), mask=(grp >= 1).astype(np.uint8))  # Position / Force / Position -> Velocity: the velocity Pid reset
+        k = next(steps)
+        eng.update(k, 1), ora.update(k)
+        compare64(eng, ora, f"round {rnd}: entering Velocity mode", tol)
+    eng.reset(), ora.reset()
+    v = hold_commands(rng, B, cables, eps)
+    eng.set_velocity_command(v), ora.set_velocity_command(v)
+    eng.update(25, 3), ora.update(25)
+    compare64(eng, ora, "unmasked Joy after a world reset", tol)
+
+
 @pytest.mark.parametrize("per_robot", [False, True])
 def test_fp64_trajectory_record_and_schedule(pkg, oracle, per_robot):
     """cdpr_update_record on precision = 64 handles (round 5): every step's observables kept, in double, equal to what step-
@@ -353,10 +405,11 @@ def test_fp64_travel_stop(pkg, oracle, cables, stages, B):
 
 
 def test_fp64_refuses_what_it_does_not_cover(pkg):
-    for kw in (dict(perRobotCommands=True, velocityEpsilon=0.01),):
-        with pytest.raises(pkg.CdprError) as ei:
-            pkg.Engine(pkg.Config(batch=4, precision=64, **kw), 0)
-        assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+    stop_pr = pkg.eight_cable_model()
+    stop_pr.travel_lower, stop_pr.travel_upper, stop_pr.travel_stop = -0.01, 0.01, 2
+    with pytest.raises(pkg.CdprError) as ei:  # (the joint stop on per-robot handles: fp32 only)
+        pkg.Engine(pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), 0)
+    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
     lumped = pkg.eight_cable_model()
     lumped.travel_lower, lumped.travel_upper, lumped.travel_stop, lumped.leg_inertia = -0.01, 0.01, 2, 0.004
     for cfg in (pkg.Config(model=lumped, batch=4, precision=64), ):
