@@ -842,6 +842,24 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
     a.hold_eps = h->cfg.velocity_epsilon;
     a.hold_mode = frc ? 0 : (vel ? 2 : 1);
     const cdpr_pid_params_t* pids[2] = {&h->cfg.position_pid, &h->cfg.velocity_pid};
+    a.any_cas = a.max_cas = 0;
+    a.any_noclamp = (!v.clamp_cmd || !p.clamp_cmd) ? 1 : 0;
+    for (int t = 0; t < 2; ++t) {  // BiQuad::SetFc(fc, fs = 1.0, q), Filter.h:130-140, in double
+      const cdpr_filter_params_t* fl[2] = {&pids[t]->p_filter, &pids[t]->d_filter};
+      double* co[2] = {a.pcoef[t], a.dcoef[t]};
+      for (int f = 0; f < 2; ++f) {
+        for (int c = 0; c < 5; ++c) co[f][c] = 0.0;
+        if (!fl[f]->cascade) continue;
+        const double k = std::tan(M_PI * fl[f]->rel_cutoff / 1.0);
+        const double den = k * k + k / fl[f]->quality + 1.0;
+        co[f][0] = k * k / den, co[f][1] = 2.0 * co[f][0], co[f][2] = co[f][0];
+        co[f][3] = 2.0 * (k * k - 1.0) / den, co[f][4] = (k * k - k / fl[f]->quality + 1.0) / den;
+      }
+      a.pcas[t] = (int)std::min<uint32_t>(pids[t]->p_filter.cascade, (uint32_t)kHoldMaxCas);
+      a.dcas[t] = (int)std::min<uint32_t>(pids[t]->d_filter.cascade, (uint32_t)kHoldMaxCas);
+      a.max_cas = std::max(a.max_cas, std::max(a.pcas[t], a.dcas[t]));
+    }
+    a.any_cas = a.max_cas > 0 ? 1 : 0;
     for (int t = 0; t < 2; ++t) {  // uniform-grid weights by age of the sample (derivative_weights: oldest first)
       double w[CDPR_MAX_D_BUFFER];
       const uint32_t nb = pids[t]->d_buffer_length;
@@ -1437,18 +1455,19 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   }
   // precision = 64 with the hold branch as the ONLY thing the register-resident path cannot represent: the HOLD instantiations of the
   // fp64 kernel (uniform-mode handles; round 5)
-  // (cmd_limit = 0 stays out: without the clamp the reference's Pid returns its stale mCmd member plus the anti-windup increment,
-  //  Pid.cpp:175-184 - a per-Pid state only the general path's records hold)
-  cdpr_config_t no_hold = *cfg;
-  no_hold.velocity_epsilon = -1.0;
-  const bool clean64 = cfg->precision == 64 && fast_path_obstacle(no_hold).empty();  // no cascades, windows to 11, a command clamp
-  const bool hold64 = clean64 && !(cfg->velocity_epsilon < 0.0) && !phys_cfg;  // (per-robot modes too: each Pid has its own rows and window)
+  // The HOLD instantiations are the fp64 kernels' whole Pid::update: besides the hold branch they carry the biquad cascades and
+  // cmd_limit = 0 (the Pid then returns its stale mCmd member plus the anti-windup increment, Pid.cpp:175-184: a row of its own).
+  // What stays out: derivative windows beyond 11 samples.
+  const bool windows_fit = cfg->velocity_pid.d_buffer_length <= (uint32_t)kWin + 1 && cfg->position_pid.d_buffer_length <= (uint32_t)kWin + 1;
+  const bool clean64 = cfg->precision == 64 && windows_fit;
+  const bool hold64 = clean64 && !phys_cfg && (!fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && pr_windows_differ));  // (per-robot modes too:
+                                                                                                    // each Pid has its own rows and its own window)
   // ... and with the joint stop as the only optional physics: the TSTOP instantiations (uniform-mode handles without the hold branch)
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
-  const bool tstop64 = clean64 && cfg->travel_stop != 0 && !lumped_cfg && cfg->velocity_epsilon < 0.0 && cfg->per_robot_commands == 0;
+  const bool tstop64 = clean64 && cfg->travel_stop != 0 && !lumped_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;
   if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64) {
-    g_create_error = "precision = 64 covers the register-resident path, the hold branch and the joint stop on uniform-mode handles (no lumped legs, cascades, long windows, cmd_limit 0, "
-                     "or per-robot modes with two different derivative windows, the hold branch or the joint stop): " +
+    g_create_error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) with windows to 11 samples and the joint stop "
+                     "on uniform-mode handles without those (no lumped legs): " +
                      (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
                               : std::string("optional physics"));
     return CDPR_ERR_UNSUPPORTED;

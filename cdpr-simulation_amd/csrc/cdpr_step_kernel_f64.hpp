@@ -72,15 +72,24 @@ struct F64Args {
   int degree, alt_nbuf, alt_degree;
   double hold_w[2][kWin + 1];  // [position | velocity] Pid: the uniform-grid derivative weights by AGE of the sample (0: newest), in steps
   int travel_stop;             // TSTOP instantiations: sweeps of the joint stop (cdpr_config_t.travel_stop), 0 = flag only
+  // HOLD instantiations, the rest of Pid::update (round 5): the biquad cascades on the P and the D input (Pid.cpp:27-44 over
+  // Filter.h:130-165; coefficients a0 a1 a2 b1 b2 of BiQuad::SetFc(relCutoff, 1, quality)) and cmd_limit = 0 (no clamp: the Pid
+  // returns its stale mCmd member, Pid.cpp:175-184); [0] the POSITION Pid, [1] the VELOCITY Pid
+  int any_cas, any_noclamp, max_cas;
+  int pcas[2], dcas[2];
+  double pcoef[2][5], dcoef[2][5];
 };
 
 __host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
 // HOLD handles keep BOTH Pids of every cable behind those rows: per cable mLastPosition (JFC.h:45), then per Pid (0 position,
 // 1 velocity) one packed word (bits 0-31 mLastTime as a world step | 32-35 ring head | 36-39 samples in the window | 40-47 length
 // of the newest run of consecutive steps, saturating | 48 mWasLastTime; the bits of a double, moved, never computed with) |
-// mIerr | the window's values | the window's stamps (world steps, exact in a double)
+// mIerr | the window's values | the window's stamps (world steps, exact in a double) | mCmd | the biquads' states
 constexpr int kHoldWin = kWin + 1;
-constexpr int kHoldPidRows = 2 + 2 * kHoldWin;
+constexpr int kHoldMaxCas = 4;                              // CDPR_MAX_CASCADE
+constexpr int kHoldCmdRow = 2 + 2 * kHoldWin;               // mCmd (read only where cmd_limit = 0 leaves it stale)
+constexpr int kHoldCasRow = kHoldCmdRow + 1;                // x1 x2 y1 y2 of the P filter's stages, then of the D filter's (Filter.h:152-165)
+constexpr int kHoldPidRows = kHoldCasRow + 8 * kHoldMaxCas;
 constexpr int kHoldCableRows = 1 + 2 * kHoldPidRows;
 __host__ __device__ constexpr int f64_hold_row(int n, int cable, int pid) { return f64_state_rows(n) + cable * kHoldCableRows + 1 + pid * kHoldPidRows; }
 __host__ __device__ constexpr int f64_hold_rows(int n) { return n * kHoldCableRows; }
@@ -261,7 +270,30 @@ __device__ __forceinline__ void chol_solve64(double (&m)[6][6], double (&g)[6]) 
 struct HoldPid64 {
   double kf, kp, ki, kd, imax, imin, cmax, cmin;
   int nbuf, degree;
+  bool clamp;             // cmdMax > cmdMin
+  int pcas, dcas;         // stages of the two cascades
 };
+
+// Pid::CascadeFilter::update (Pid.cpp:38-44): `stages` identical biquads in series (direct form I, Filter.h:152-165), states in the
+// Pid's own rows.  A runtime loop, a round trip per stage: handles with cascades only (g.any_cas), and nothing of it in the
+// registers of the others.
+__device__ __forceinline__ double hold_cascade64(double* F, size_t st, int stages, int max_stages, const double* c, double x, bool writes) {
+#pragma clang loop unroll(disable)
+  for (int s = 0; s < max_stages; ++s) {
+    double* const B = F + (size_t)(4 * s) * st;
+    const double x1 = B[0], x2 = B[st], y1 = B[2 * st], y2 = B[3 * st];
+    const double y0 = c[0] * x + c[1] * x1 + c[2] * x2 - c[3] * y1 - c[4] * y2;
+    const bool on = s < stages;
+    if (on && writes) {
+      B[0] = x;
+      B[st] = x1;
+      B[2 * st] = y0;
+      B[3 * st] = y1;
+    }
+    x = on ? y0 : x;
+  }
+  return x;
+}
 struct HoldRows64 {
   unsigned long long word;
   double ierr, held;
@@ -279,12 +311,18 @@ __device__ __forceinline__ HoldRows64 hold_load64(const double* R, const double*
 }
 
 __device__ __forceinline__ double hold_finish64(double* R, size_t st, const HoldRows64& h, const double* w_age, double desired, double actual, int now, double dt,
-                                                const HoldPid64& g, bool& ran, double& p_out, double& i_out, double& d_out, bool live = true) {
+                                                const HoldPid64& g, const F64Args& a, bool velocity_pid, bool& ran, double& p_out, double& i_out, double& d_out,
+                                                bool live = true) {
+  // (the coefficients stay where they are - the argument block - behind a per-lane choice of the Pid)
+  const double* const pc = velocity_pid ? a.pcoef[1] : a.pcoef[0];
+  const double* const dc = velocity_pid ? a.dcoef[1] : a.dcoef[0];
   const int last = (int)(uint32_t)h.word, head_old = (int)(h.word >> 32) & 15, count_old = (int)(h.word >> 36) & 15, run_old = (int)(h.word >> 40) & 255;
   const bool was = ((h.word >> 48) & 1ull) != 0ull;  // Pid.cpp:123-126: the first call since reset returns 0 (and pushes no sample)
   const double dts = (double)(now - last) * dt;
   const double error = desired - actual;
-  const double p_term = g.kp * error;
+  double perr = error;
+  if (a.any_cas) perr = hold_cascade64(R + (size_t)kHoldCasRow * st, st, g.pcas, a.max_cas, pc, error, was && live);  // Pid.cpp:131
+  const double p_term = g.kp * perr;
   double ie = fma(dts, error, h.ierr);
   double i_term = g.ki * ie;
   const double i_raw = i_term;
@@ -326,10 +364,12 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
     }
     derived = gen_fit<kHoldWin, double>(y, t, g.nbuf, g.degree, now, t_old) / dt;
   }
+  if (a.any_cas) derived = hold_cascade64(R + (size_t)(kHoldCasRow + 4 * kHoldMaxCas) * st, st, g.dcas, a.max_cas, dc, derived, was && live);  // Pid.cpp:157
   const double d_term = g.kd * derived;
   const double cmd = fma(g.kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
-  double out = fmax(fmin(cmd, g.cmax), g.cmin);                     // Pid.cpp:175-177 (cmdMin < cmdMax here: with cmd_limit = 0 the reference keeps a
-                                                                     // stale mCmd, Pid.cpp:175-184, a state only the general path's records hold)
+  double stale = 0.0;                                                // mCmd as the last call left it: what the Pid returns without a clamp
+  if (a.any_noclamp) stale = R[(size_t)kHoldCmdRow * st];
+  double out = g.clamp ? fmax(fmin(cmd, g.cmax), g.cmin) : stale;   // Pid.cpp:175-177
   if (out != cmd) {                                                  // Pid.cpp:181-184
     ie = h.ierr;
     out = fma(dts * error, g.ki, out);
@@ -338,6 +378,7 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
                                          (unsigned long long)run << 40 | 1ull << 48)
                                       : ((h.word & ~0xffffffffull) | (unsigned long long)(uint32_t)now | 1ull << 48);
   if (live) R[0] = __longlong_as_double((long long)word);
+  if (a.any_noclamp && live) R[(size_t)kHoldCmdRow * st] = was ? out : 0.0;  // (the first call since a reset: mCmd = 0, Pid.cpp:125)
   if (was && live) {
     R[st] = ie;
     R[(size_t)(2 + head) * st] = error;
@@ -469,10 +510,12 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
               g.imax = vel_branch ? a.imax : a.alt_imax, g.imin = vel_branch ? a.imin : a.alt_imin;
               g.cmax = vel_branch ? a.cmax : a.alt_cmax, g.cmin = vel_branch ? a.cmin : a.alt_cmin;
               g.nbuf = vel_branch ? a.nbuf : a.alt_nbuf, g.degree = vel_branch ? a.degree : a.alt_degree;
+              g.clamp = (vel_branch ? a.clamp_cmd : a.alt_clamp_cmd) != 0;
+              g.pcas = vel_branch ? a.pcas[1] : a.pcas[0], g.dcas = vel_branch ? a.dcas[1] : a.dcas[0];  // (selects: a dynamic index copies the arrays to scratch)
               const double desired = vel_branch ? target : (hold ? hrows.held : target);
               bool ran = false;
               double tp = 0.0, ti = 0.0, td = 0.0;
-              force = hold_finish64(HR, st, hrows, c_hold_w[HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, ran, tp, ti, td);
+              force = hold_finish64(HR, st, hrows, c_hold_w[HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, a, vel_branch, ran, tp, ti, td);
               if (i == 0 && ran) {
                 dbg_p = tp, dbg_i = ti, dbg_d = td;
                 dbg_ran = true;
@@ -1037,10 +1080,12 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
             g.imax = vel_branch ? a.imax : a.alt_imax, g.imin = vel_branch ? a.imin : a.alt_imin;
             g.cmax = vel_branch ? a.cmax : a.alt_cmax, g.cmin = vel_branch ? a.cmin : a.alt_cmin;
             g.nbuf = vel_branch ? a.nbuf : a.alt_nbuf, g.degree = vel_branch ? a.degree : a.alt_degree;
+              g.clamp = (vel_branch ? a.clamp_cmd : a.alt_clamp_cmd) != 0;
+              g.pcas = vel_branch ? a.pcas[1] : a.pcas[0], g.dcas = vel_branch ? a.dcas[1] : a.dcas[0];  // (selects: a dynamic index copies the arrays to scratch)
             const double desired = vel_branch ? target : (hold ? hrows.held : target);
             bool ran = false;
             double tp = 0.0, ti = 0.0, td = 0.0;
-            force = hold_finish64(HR, st, hrows, c_hold_w[HOLD ? wave : 0][HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, a.step0, a.dt, g, ran, tp, ti, td, live);
+            force = hold_finish64(HR, st, hrows, c_hold_w[HOLD ? wave : 0][HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, a.step0, a.dt, g, a, vel_branch, ran, tp, ti, td, live);
             if (i == 0 && ran) {
               dbg_p = tp, dbg_i = ti, dbg_d = td;
               dbg_ran = true;

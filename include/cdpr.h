@@ -120,10 +120,11 @@ typedef struct cdpr_config {
                                        per launch; trajectory records, command schedules and per_robot_commands since ABI 5), meant for
                                        one robot / small batches; read it out with the *_f64 getters.  velocity_epsilon >= 0 (the position-hold
                                        branch, JFC.cpp:72-82: both Pids of every cable alive, derivative windows on real stamps) is served in
-                                       double too (round 5; with per_robot_commands as well), and so is travel_stop > 0 (the joint stop) on
-                                       uniform-mode handles without the hold branch.  Not with biquad cascades, cmd_limit = 0 or windows beyond
-                                       11 (the rest of the general controller path), per_robot_commands together with the joint stop, the
-                                       lumped legs or rollouts (cdpr_create / the call return CDPR_ERR_UNSUPPORTED) */
+                                       double too (round 5), with the rest of Pid::update - biquad cascades, cmd_limit = 0 - and with
+                                       per_robot_commands (two different derivative windows included); travel_stop > 0 (the joint stop) on
+                                       uniform-mode handles without any of those.  Not with derivative windows beyond 11 samples, the joint
+                                       stop together with per_robot_commands or the hold branch, the lumped legs or rollouts (cdpr_create /
+                                       the call return CDPR_ERR_UNSUPPORTED) */
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */

@@ -404,42 +404,69 @@ def test_fp64_travel_stop(pkg, oracle, cables, stages, B):
     assert np.array_equal(eng.limit_state(), ora.limit_state())
 
 
+@pytest.mark.parametrize("variant", ["cascades", "cascades_hold", "noclamp", "noclamp_hold", "per_robot_all"])
+def test_fp64_rest_of_pid_update(pkg, oracle, variant):
+    """What else Pid::update holds, in double on the HOLD instantiations (round 5): the biquad cascades on the P and the D input
+    (Pid.cpp:27-44; different depths on the two Pids), cmdLimit = 0 (Pid.cpp:175-184: without the clamp the Pid returns its stale
+    mCmd member plus the anti-windup increment and restores the integral - the oracle follows the reference there), with and
+    without the hold branch, and all of it together on a per-robot handle whose two Pids also fit different windows."""
+    from test_gpu_general_matrix import hold_commands
+
+    B, n = 150, 8
+    rng = np.random.default_rng(300 + len(variant))
+    model = pkg.eight_cable_model()
+    hold = variant.endswith("_hold") or variant == "per_robot_all"
+    eps = 0.004 if hold else -0.001
+    pr = variant == "per_robot_all"
+    cfg = pkg.Config(model=model, batch=B, stages=3 | pkg._abi.STAGE_PID_DEBUG, precision=64, velocityEpsilon=eps, perRobotCommands=pr)
+    vc, pc = cfg.velocityController, cfg.positionController
+    if variant.startswith("cascades") or pr:
+        for f, depth in ((vc.pFilter, 1), (vc.dFilter, 2), (pc.pFilter, 3), (pc.dFilter, 1)):
+            f.cascade, f.relCutoff, f.quality = depth, 0.05, 0.5
+        vc.pGain, vc.iGain, vc.dGain = 4.0, 40.0, 0.01  # (a gentle loop: the filters' lag with the shipped gains rings)
+    if variant.startswith("noclamp"):
+        vc.cmdLimit = 0.0
+    if pr:
+        pc.cmdLimit = 0.0
+        pc.dBufferLength, pc.dDegree = 7, 1
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.05).astype(np.float64))
+    tol = dict(TOL64, eff=2e-7, twist=1e-10, qd=1e-10, pose=1e-12, q=1e-12)
+    eng.update(3), ora.update(3)
+    grp = np.arange(B) % 3
+    for j in range(5):
+        cmd = hold_commands(rng, B, n, abs(eps) if hold else 0.002)
+        kw = dict(mask=(grp != j % 3).astype(np.uint8)) if pr else {}
+        eng.set_velocity_command(cmd, **kw), ora.set_velocity_command(cmd, **kw)
+        if pr and j == 2:
+            p = rng.uniform(-0.004, 0.004, (B, n)).astype(np.float32)
+            eng.set_position_command(p, mask=(grp == 0).astype(np.uint8)), ora.set_position_command(p, mask=(grp == 0).astype(np.uint8))
+        k = [14, 9, 25, 3, 17][j]
+        eng.update(k, 1 if j % 2 else 5), ora.update(k)
+        compare64(eng, ora, f"{variant}, round {j}", tol)
+        assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 1e-6, f"{variant}: pid topic, round {j}"
+    p = rng.uniform(-0.004, 0.004, (B, n)).astype(np.float32)
+    eng.set_position_command(p), ora.set_position_command(p)
+    eng.update(30), ora.update(30)
+    compare64(eng, ora, f"{variant}, position mode", tol)
+    eng.reset(), ora.reset()
+    cmd = hold_commands(rng, B, n, abs(eps) if hold else 0.002)
+    eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+    eng.update(20, 4), ora.update(20)
+    compare64(eng, ora, f"{variant}, after a world reset", tol)
+
+
 def test_fp64_refuses_what_it_does_not_cover(pkg):
-    stop_pr = pkg.eight_cable_model()
-    stop_pr.travel_lower, stop_pr.travel_upper, stop_pr.travel_stop = -0.01, 0.01, 2
-    with pytest.raises(pkg.CdprError) as ei:  # (the joint stop on per-robot handles: fp32 only)
-        pkg.Engine(pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), 0)
-    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
     lumped = pkg.eight_cable_model()
     lumped.travel_lower, lumped.travel_upper, lumped.travel_stop, lumped.leg_inertia = -0.01, 0.01, 2, 0.004
-    for cfg in (pkg.Config(model=lumped, batch=4, precision=64), ):
+    stop_pr = pkg.eight_cable_model()
+    stop_pr.travel_lower, stop_pr.travel_upper, stop_pr.travel_stop = -0.01, 0.01, 2
+    long_window = pkg.Config(batch=4, precision=64)
+    long_window.velocityController.dBufferLength = 16
+    stop_hold = pkg.Config(model=stop_pr, batch=4, precision=64, velocityEpsilon=0.01)
+    for cfg in (pkg.Config(model=lumped, batch=4, precision=64), pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), long_window, stop_hold):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(cfg, 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
-    unclamped = pkg.Config(batch=4, precision=64)  # (without the clamp Pid::update returns its stale mCmd: a state of the general path's records only)
-    unclamped.velocityController.cmdLimit = 0.0
-    with pytest.raises(pkg.CdprError) as ei:
-        pkg.Engine(unclamped, 0)
-    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
-    cascaded = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)
-    cascaded.velocityController.pFilter.cascade = 1
-    with pytest.raises(pkg.CdprError) as ei:
-        pkg.Engine(cascaded, 0)
-    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
-    lumped = pkg.cube_model()
-    lumped.passive_damping = 0.01
-    with pytest.raises(pkg.CdprError):
-        pkg.Engine(pkg.Config(model=lumped, batch=4, precision=64), 0)
-    eng = pkg.Engine(pkg.Config(model=pkg.eight_cable_model(), batch=4, stages=3, precision=64), 0)
-    with pytest.raises(pkg.CdprError) as ei:
-        eng.rollout_velocity(np.zeros((4, 3, 2, 8), np.float32), np.zeros((4, 3), np.float32))
-    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
-    plain = pkg.Engine(pkg.Config(batch=2), 0)
-    with pytest.raises(pkg.CdprError) as ei:
-        plain.observables_f64()
-    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
-    with pytest.raises(ValueError):
-        pkg.Config(batch=1, precision=16).to_struct()
 
 
 def test_zz_report_measured_agreement():
