@@ -875,14 +875,15 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
   a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
-  F64Kernel kern = h->hold64 ? (pr ? pick_f64_hold_pr_kernel(n) : pick_f64_hold_kernel(n))
+  const bool hold_full = h->hold64 && (a.any_cas || a.any_noclamp);  // the HOLD = 2 instantiations: cascades, cmd_limit 0
+  F64Kernel kern = h->hold64 ? (pr ? pick_f64_hold_pr_kernel(n, hold_full) : pick_f64_hold_kernel(n, hold_full))
                    : h->tstop64 ? pick_f64_tstop_kernel(n)
                              : pr ? pick_f64_pr_kernel(n, ring_lds) : pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
   const bool sp_lean = sp_env >= 0 ? sp_env == 2 : h->batch > 16384u;
-  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr && !h->tstop64) ? (h->hold64 ? pick_f64_split_hold_kernel(n, sp_lean) : pick_f64_split_kernel(n, sp_lean))
+  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr && !h->tstop64) ? (h->hold64 ? pick_f64_split_hold_kernel(n, sp_lean, hold_full) : pick_f64_split_kernel(n, sp_lean))
                                                                : nullptr;  // (per-robot handles: the one-wave kernel)
   // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
   // (14.4 against 20.8 us per step at one robot x 8, same bits): a fused update then runs as one-step launches

@@ -57,12 +57,12 @@ GenKernel pick_gen_lean11(uint32_t n);   // k_gen_split.hip: the same for larger
 GenKernel pick_gen_split11(uint32_t n);  // k_gen_split.hip: one step per launch, two waves per 64 robots split by role (FK + TD, n >= 6, windows <= 11)
 // k_f64.hip: precision = 64
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean);  // lean: nothing cached in LDS (four workgroups per CU)
-F64Kernel pick_f64_hold_pr_kernel(uint32_t n);  // HOLD on per-robot handles
+F64Kernel pick_f64_hold_pr_kernel(uint32_t n, bool full);  // HOLD on per-robot handles
 F64Kernel pick_f64_tstop_kernel(uint32_t n);  // TSTOP instantiations (the joint stop in double)
-F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean);  // ... HOLD instantiations (the position-hold branch in double)
+F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean, bool full);  // ... HOLD instantiations (the position-hold branch in double)
 //  // one step per launch, two waves per 64 robots split by role (FK + TD, n >= 6)
 F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds);  // per-robot handles (mode, call count and Pid per lane)
-F64Kernel pick_f64_hold_kernel(uint32_t n);                 // velocityEpsilon >= 0: the position-hold branch live (both Pids of every cable)
+F64Kernel pick_f64_hold_kernel(uint32_t n, bool full);  // full: + biquad cascades, cmd_limit 0                 // velocityEpsilon >= 0: the position-hold branch live (both Pids of every cable)
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache);  // ring_lds: the derivative rings staged in LDS (small batches); jcache: and the structure-matrix rows (one workgroup per CU)
 
 }  // namespace cdpr

@@ -310,6 +310,9 @@ __device__ __forceinline__ HoldRows64 hold_load64(const double* R, const double*
   return h;
 }
 
+// FULL: the handle has a biquad cascade or a Pid without the command clamp (the HOLD = 2 instantiations); otherwise none of that
+// is compiled in (its uniform branches cost the others 1.3 us per step).
+template <bool FULL>
 __device__ __forceinline__ double hold_finish64(double* R, size_t st, const HoldRows64& h, const double* w_age, double desired, double actual, int now, double dt,
                                                 const HoldPid64& g, const F64Args& a, bool velocity_pid, bool& ran, double& p_out, double& i_out, double& d_out,
                                                 bool live = true) {
@@ -321,7 +324,7 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
   const double dts = (double)(now - last) * dt;
   const double error = desired - actual;
   double perr = error;
-  if (a.any_cas) perr = hold_cascade64(R + (size_t)kHoldCasRow * st, st, g.pcas, a.max_cas, pc, error, was && live);  // Pid.cpp:131
+  if (FULL && a.any_cas) perr = hold_cascade64(R + (size_t)kHoldCasRow * st, st, g.pcas, a.max_cas, pc, error, was && live);  // Pid.cpp:131
   const double p_term = g.kp * perr;
   double ie = fma(dts, error, h.ierr);
   double i_term = g.ki * ie;
@@ -364,12 +367,12 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
     }
     derived = gen_fit<kHoldWin, double>(y, t, g.nbuf, g.degree, now, t_old) / dt;
   }
-  if (a.any_cas) derived = hold_cascade64(R + (size_t)(kHoldCasRow + 4 * kHoldMaxCas) * st, st, g.dcas, a.max_cas, dc, derived, was && live);  // Pid.cpp:157
+  if (FULL && a.any_cas) derived = hold_cascade64(R + (size_t)(kHoldCasRow + 4 * kHoldMaxCas) * st, st, g.dcas, a.max_cas, dc, derived, was && live);  // Pid.cpp:157
   const double d_term = g.kd * derived;
   const double cmd = fma(g.kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
   double stale = 0.0;                                                // mCmd as the last call left it: what the Pid returns without a clamp
-  if (a.any_noclamp) stale = R[(size_t)kHoldCmdRow * st];
-  double out = g.clamp ? fmax(fmin(cmd, g.cmax), g.cmin) : stale;   // Pid.cpp:175-177
+  if (FULL && a.any_noclamp) stale = R[(size_t)kHoldCmdRow * st];
+  double out = (!FULL || g.clamp) ? fmax(fmin(cmd, g.cmax), g.cmin) : stale;  // Pid.cpp:175-177
   if (out != cmd) {                                                  // Pid.cpp:181-184
     ie = h.ierr;
     out = fma(dts * error, g.ki, out);
@@ -378,7 +381,7 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
                                          (unsigned long long)run << 40 | 1ull << 48)
                                       : ((h.word & ~0xffffffffull) | (unsigned long long)(uint32_t)now | 1ull << 48);
   if (live) R[0] = __longlong_as_double((long long)word);
-  if (a.any_noclamp && live) R[(size_t)kHoldCmdRow * st] = was ? out : 0.0;  // (the first call since a reset: mCmd = 0, Pid.cpp:125)
+  if (FULL && a.any_noclamp && live) R[(size_t)kHoldCmdRow * st] = was ? out : 0.0;  // (the first call since a reset: mCmd = 0, Pid.cpp:125)
   if (was && live) {
     R[st] = ie;
     R[(size_t)(2 + head) * st] = error;
@@ -401,7 +404,7 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
 // between the velocity and the pose half of the world step a joint at or beyond a limit that
 // still moves outward takes the impulse that stops it, cables in index order, travel_stop sweeps; the rows of the structure
 // matrix at t_k wait in private LDS columns.
-template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, bool HOLD = false, bool TSTOP = false>
+template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, int HOLD = 0, bool TSTOP = false>  // HOLD: 0 | 1 | 2 (+ cascades, cmd_limit 0)
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   static_assert(!HOLD || (!RING_LDS && !JCACHE), "the hold branch: the plain instantiation (uniform modes, or PR: the mode per lane)");
   static_assert(!TSTOP || (!RING_LDS && !JCACHE && !PR && !HOLD), "the joint stop: the plain instantiation");
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
               const double desired = vel_branch ? target : (hold ? hrows.held : target);
               bool ran = false;
               double tp = 0.0, ti = 0.0, td = 0.0;
-              force = hold_finish64(HR, st, hrows, c_hold_w[HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, a, vel_branch, ran, tp, ti, td);
+              force = hold_finish64<HOLD == 2>(HR, st, hrows, c_hold_w[HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, a, vel_branch, ran, tp, ti, td);
               if (i == 0 && ran) {
                 dbg_p = tp, dbg_i = ti, dbg_d = td;
                 dbg_ran = true;
@@ -858,7 +861,7 @@ static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF
 // wave's arithmetic under this wave's memory round trips.
 // HOLD: the position-hold branch live, as in cdpr_step_kernel_f64<.., HOLD> (the controller wave is the lighter of the two:
 // the selected Pid's round trip and its arithmetic run under the estimator wave's Newton stage).
-template <int N, bool LEAN = false, bool HOLD = false>
+template <int N, bool LEAN = false, int HOLD = 0>  // HOLD: 0 | 1 | 2 (+ cascades, cmd_limit 0)
 __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const F64Args a) {
   __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
   __shared__ double c_win[LEAN ? 1 : N][LEAN ? 1 : kWin][64];
@@ -1085,7 +1088,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
             const double desired = vel_branch ? target : (hold ? hrows.held : target);
             bool ran = false;
             double tp = 0.0, ti = 0.0, td = 0.0;
-            force = hold_finish64(HR, st, hrows, c_hold_w[HOLD ? wave : 0][HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, a.step0, a.dt, g, a, vel_branch, ran, tp, ti, td, live);
+            force = hold_finish64<HOLD == 2>(HR, st, hrows, c_hold_w[HOLD ? wave : 0][HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, a.step0, a.dt, g, a, vel_branch, ran, tp, ti, td, live);
             if (i == 0 && ran) {
               dbg_p = tp, dbg_i = ti, dbg_d = td;
               dbg_ran = true;

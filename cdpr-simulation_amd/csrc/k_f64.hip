@@ -7,31 +7,32 @@ template <int N> F64Kernel f64_n(bool ring_lds, bool jcache) {
   if (jcache) return cdpr_step_kernel_f64<N, true, true>;  // (112 KiB of LDS per wave at n = 8: one workgroup per CU)
   return ring_lds ? cdpr_step_kernel_f64<N, true> : cdpr_step_kernel_f64<N, false>;
 }
-template <int N> F64Kernel f64_hold_n() { return cdpr_step_kernel_f64<N, false, false, false, true>; }
-template <int N> F64Kernel f64_hold_pr_n() { return cdpr_step_kernel_f64<N, false, false, true, true>; }
-template <int N> F64Kernel f64_tstop_n() { return cdpr_step_kernel_f64<N, false, false, false, false, true>; }
+template <int N> F64Kernel f64_hold_n(bool full) { return full ? cdpr_step_kernel_f64<N, false, false, false, 2> : cdpr_step_kernel_f64<N, false, false, false, 1>; }
+template <int N> F64Kernel f64_hold_pr_n(bool full) { return full ? cdpr_step_kernel_f64<N, false, false, true, 2> : cdpr_step_kernel_f64<N, false, false, true, 1>; }
+template <int N> F64Kernel f64_tstop_n() { return cdpr_step_kernel_f64<N, false, false, false, 0, true>; }
 }  // namespace
-F64Kernel pick_f64_hold_pr_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_hold_pr_n); }  // ... on per-robot handles (the mode per lane)
+F64Kernel pick_f64_hold_pr_kernel(uint32_t n, bool full) { CDPR_PICK_CABLES(f64_hold_pr_n, full); }  // ... on per-robot handles (the mode per lane)
 F64Kernel pick_f64_tstop_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_tstop_n); }  // the joint stop modelled (travel_stop > 0)
-F64Kernel pick_f64_hold_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_hold_n); }  // the position-hold branch live (both Pids of every cable)
+F64Kernel pick_f64_hold_kernel(uint32_t n, bool full) { CDPR_PICK_CABLES(f64_hold_n, full); }  // the position-hold branch live (both Pids of every cable)
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }
 F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds) { CDPR_PICK_CABLES(f64_pr_n, ring_lds); }  // per-robot modes (PR)
-F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean) {  // ... with the position-hold branch live
+template <int H> F64Kernel f64_split_hold(uint32_t n, bool lean) {
   if (lean) {
     switch (n) {
-      case 6: return cdpr_split_kernel_f64<6, true, true>;
-      case 7: return cdpr_split_kernel_f64<7, true, true>;
-      case 8: return cdpr_split_kernel_f64<8, true, true>;
+      case 6: return cdpr_split_kernel_f64<6, true, H>;
+      case 7: return cdpr_split_kernel_f64<7, true, H>;
+      case 8: return cdpr_split_kernel_f64<8, true, H>;
     }
     return nullptr;
   }
   switch (n) {
-    case 6: return cdpr_split_kernel_f64<6, false, true>;
-    case 7: return cdpr_split_kernel_f64<7, false, true>;
-    case 8: return cdpr_split_kernel_f64<8, false, true>;
+    case 6: return cdpr_split_kernel_f64<6, false, H>;
+    case 7: return cdpr_split_kernel_f64<7, false, H>;
+    case 8: return cdpr_split_kernel_f64<8, false, H>;
   }
   return nullptr;
 }
+F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean, bool full) { return full ? f64_split_hold<2>(n, lean) : f64_split_hold<1>(n, lean); }  // ... with the hold branch live
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean) {
   if (lean) {
     switch (n) {
