@@ -13,8 +13,9 @@ resident in HBM before the timed region starts.  `--config 2` selects config 2 i
 Multi-GPU (config 4: 524 288 robots = 8 x 65 536; weak scaling, no collective on the data
 path): `python bench.py --gpus N` starts N rank processes itself, one per GPU, BEFORE it
 touches the GPU (the parent never does); under `torch.distributed.run` (WORLD_SIZE set)
-it is one of those ranks.  torch.distributed is only the rendezvous: barrier and max of
-the elapsed time over ranks.
+it is one of those ranks.  The rendezvous (barrier, max of the elapsed time over ranks) is a
+plain socket + a shared-memory spin barrier (cdpr_simulation_amd/sharding.py): no torch, no RCCL;
+CDPR_BENCH_BACKEND=nccl|gloo opts into a torch.distributed process group instead.
 
 One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per launch
 (4*(39+28n) = 1052 B per state-step at n = 8) / the average launch duration
@@ -427,13 +428,14 @@ def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` with no launcher around it: start N rank processes (one per GPU) and wait.  Runs
     before this process has loaded the HIP library or torch, so the parent never touches the GPU; rank 0's stdout is
     the parent's, so the one JSON line comes out unchanged."""
-    with socket.socket() as s:
+    with socket.socket() as s, socket.socket() as s2:  # two free ports: MASTER_PORT, and the TCP store of the nccl / gloo opt-in
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+        s2.bind(("127.0.0.1", 0))
+        port, store_port = s.getsockname()[1], s2.getsockname()[1]
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CDPR_STORE_PORT=str(store_port), CDPR_RDV_PORT=str(store_port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -481,8 +483,9 @@ def main():
     placement = host_placement(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))),
                                sysfs=os.environ.get("CDPR_BENCH_SYSFS", "/sys"))
 
-    # torch.distributed (RCCL) only provides the rendezvous: barrier + max over ranks. No data-path collective.
-    ctx = RankContext.from_env(backend=os.environ.get("CDPR_BENCH_BACKEND", "nccl"))
+    # the rendezvous: barrier + max over ranks + a few gathered words, no data-path collective.  Default: a plain socket
+    # between the ranks (no torch, no RCCL: north_star); CDPR_BENCH_BACKEND=nccl|gloo opts into a torch process group
+    ctx = RankContext.from_env(backend=os.environ.get("CDPR_BENCH_BACKEND", "socket"))
     rank, local_rank, world = ctx.rank, ctx.local_rank, ctx.world
     n = args.cables
     refresh = 10
@@ -565,7 +568,7 @@ def main():
 
     def barrier():
         eng.synchronize()  # hipStreamSynchronize on the engine's stream (all of this process's GPU work)
-        ctx.barrier()      # torch.cuda.synchronize() + dist.barrier() when N > 1
+        ctx.barrier()      # every rank here (socket rendezvous; + torch.cuda.synchronize() on the nccl opt-in) when N > 1
 
     def edge():
         """Edge of a timed region: this rank's GPU work done, then every rank here.  The cross-rank part is a shared-memory
@@ -918,7 +921,7 @@ def main():
                                 else "one launch per world step" if args.steps_per_launch == 1 else f"{args.steps_per_launch} steps per launch"),
                 "mapping": eng.mapping,
                 "state_finite": finite,
-                "rendezvous": ctx.backend_name(),  # "none" (one rank), "nccl" (= RCCL) or "gloo": barrier + max only, no data-path collective
+                "rendezvous": ctx.backend_name(),  # "none" (one rank), "socket" (default), or the opt-ins "nccl" (= RCCL) / "gloo": barrier + max only, no data-path collective
                 "rendezvous_fallback": ctx.fallback,  # why the rendezvous is not on RCCL, if it is not (cdpr_simulation_amd/sharding.py)
             },
             "roofline": {

@@ -57,11 +57,25 @@ def test_config_switch_selects_the_baseline_shapes():
     assert (a.batch, a.cables) == (128, 4)
 
 
-def _run_bench(extra, timeout=300, backend="gloo"):
+def _block_torch(env, tmp_path):
+    """PYTHONPATH entry whose `torch` package raises on import: a process that touches torch dies."""
+    d = tmp_path / "no_torch" / "torch"
+    d.mkdir(parents=True, exist_ok=True)
+    (d / "__init__.py").write_text("raise ImportError('torch is blocked in this test: the default rendezvous must not need it')\n")
+    env["PYTHONPATH"] = str(tmp_path / "no_torch") + os.pathsep + env.get("PYTHONPATH", "")
+    return env
+
+
+def _run_bench(extra, timeout=300, backend=None, no_torch_dir=None):
     import json
     import subprocess
 
-    env = dict(os.environ, CDPR_BENCH_BACKEND=backend, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("CDPR_BENCH_BACKEND", None)
+    if backend is not None:
+        env["CDPR_BENCH_BACKEND"] = backend
+    if no_torch_dir is not None:
+        _block_torch(env, no_torch_dir)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
@@ -71,18 +85,31 @@ def _run_bench(extra, timeout=300, backend="gloo"):
     return json.loads(lines[0])                                     # (gloo / RCCL notices go to stderr)
 
 
-def test_bench_gpus_2_spawns_its_own_ranks():
-    """`python bench.py --gpus 2` with no launcher around it must itself become two ranks (gloo rendezvous on a
-    CPU-only box; --dry-run skips the GPU work, everything else is the real path) and report n_gpus = 2."""
-    out = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"])
+def test_bench_gpus_2_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must itself become two ranks (--dry-run skips the GPU work,
+    everything else is the real path) and report n_gpus = 2 - over the default rendezvous, a plain socket, with `import
+    torch` made to fail in every rank (north_star: "no PyTorch needed ... no RCCL required")."""
+    out = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"], no_torch_dir=tmp_path)
     assert out["n_gpus"] == 2 and out["dry_run"] is True and out["steps"] == 20 and out["scaling"] == "weak"
     assert out["metric"].startswith("CDPR sim-steps/sec")
+    assert out["rendezvous"] == "socket" and out["rendezvous_fallback"] is None
+
+
+def test_bench_gpus_8_dry_run_over_the_socket_rendezvous(tmp_path):
+    out = _run_bench(["--gpus", "8", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--dry-run"], timeout=600, no_torch_dir=tmp_path)
+    assert out["n_gpus"] == 8 and out["rendezvous"] == "socket"
+    assert [r["rank"] for r in out["per_rank"]] == list(range(8))
+
+
+def test_bench_gpus_2_over_gloo_opt_in():
+    out = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"], backend="gloo")
+    assert out["n_gpus"] == 2 and out["rendezvous"] == "gloo"
 
 
 def test_bench_gpus_8_dry_run_pins_and_reports_every_rank():
     """The driver's N = 8 launch, rank plumbing only: eight ranks, disjoint core sets (when the box has at least eight
     CPUs), one JSON line carrying every rank's own figure."""
-    # (the driver's own backend request, "nccl" = RCCL: on this GPU-less box the pre-flight must end on gloo)
+    # (the "nccl" = RCCL opt-in: on this GPU-less box the pre-flight must end on gloo)
     out = _run_bench(["--gpus", "8", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--dry-run"], timeout=600, backend="nccl")
     assert out["n_gpus"] == 8 and out["dry_run"] is True
     assert [r["rank"] for r in out["per_rank"]] == list(range(8))

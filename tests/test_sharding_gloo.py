@@ -1,4 +1,5 @@
-"""The N > 1 path on CPU: world_size-2 `gloo` processes, robots sharded by contiguous blocks with no data-path
+"""The N > 1 path on CPU: world_size-2 processes (the `gloo` opt-in under torch.distributed.run, and the default socket
+rendezvous with torch blocked), robots sharded by contiguous blocks with no data-path
 collective; only the rendezvous (barrier, max over ranks of the elapsed time) is distributed.
 Each rank advances its shard with the CPU oracle (test infrastructure) and the union must equal the unsharded run."""
 import os
@@ -14,12 +15,14 @@ WORKER = r"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
-import torch.distributed as dist
 import cdpr_simulation_amd as pkg
 from cdpr_simulation_amd.sharding import RankContext, shard_range
 import oracle
 
-ctx = RankContext.from_env(backend="gloo")
+ctx = RankContext.from_env(backend=os.environ.get("TEST_BACKEND", "gloo"))
+assert ctx.backend_name() == os.environ.get("TEST_BACKEND", "gloo")
+if os.environ.get("TEST_BACKEND") == "socket":
+    assert "torch" not in sys.modules
 total = 10
 lo, hi = shard_range(ctx.rank, ctx.world, total)
 rng = np.random.default_rng(42)
@@ -47,14 +50,35 @@ ctx.close()
 """
 
 
-def test_two_rank_sharding_matches_unsharded(tmp_path, pkg, oracle):
+def _spawn_two_ranks_without_torch(script, tmp_path, port, extra_env=None):
+    """Two rank processes with the launcher's environment (what bench.py's own spawn_ranks and torch.distributed.run export)
+    and a PYTHONPATH entry that makes `import torch` raise."""
+    blocker = tmp_path / "no_torch" / "torch"
+    blocker.mkdir(parents=True, exist_ok=True)
+    (blocker / "__init__.py").write_text("raise ImportError('torch is blocked in this test')\n")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, OMP_NUM_THREADS="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TEST_BACKEND="socket", **(extra_env or {}))
+        env["PYTHONPATH"] = str(tmp_path / "no_torch") + os.pathsep + env.get("PYTHONPATH", "")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+
+
+@pytest.mark.parametrize("rendezvous", ["gloo", "socket", "socket-tcp"])
+def test_two_rank_sharding_matches_unsharded(tmp_path, pkg, oracle, rendezvous):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", str(script)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
+    if rendezvous == "gloo":
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29517", str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    else:  # the default rendezvous (VERDICT r05 next 5): torch blocked in both ranks; Unix socket, or TCP as across nodes
+        _spawn_two_ranks_without_torch(script, tmp_path, 29531 if rendezvous == "socket" else 29533,
+                                       {"CDPR_RDV_TCP": "1"} if rendezvous == "socket-tcp" else None)
     total = 10
     rng = np.random.default_rng(42)
     pose = np.tile(pkg.cube_model().home_pose(), (total, 1))
@@ -79,7 +103,7 @@ import os, sys, time
 sys.path.insert(0, {root!r})
 from cdpr_simulation_amd.sharding import RankContext
 
-ctx = RankContext.from_env(backend="gloo")
+ctx = RankContext.from_env(backend=os.environ.get("TEST_BACKEND", "gloo"))
 t0 = time.perf_counter()
 if ctx.rank == 1:
     time.sleep(0.3)
@@ -89,16 +113,20 @@ ctx.close()
 """
 
 
-def test_spin_barrier_is_taken_by_all_ranks_or_none(tmp_path):
-    """If the shared-memory barrier cannot be set up on ONE rank, every rank must fall back to the process group's barrier
+@pytest.mark.parametrize("rendezvous", ["gloo", "socket"])
+def test_spin_barrier_is_taken_by_all_ranks_or_none(tmp_path, rendezvous):
+    """If the shared-memory barrier cannot be set up on ONE rank, every rank must fall back to the group's barrier
     (a rank alone in either barrier would hang the job): rank 1's set-up is made to fail, both ranks still rendezvous."""
     script = tmp_path / "worker.py"
     script.write_text(FALLBACK_WORKER.format(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, OMP_NUM_THREADS="1", CDPR_TEST_SPIN_FAIL_RANK="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29519", str(script)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
+    if rendezvous == "gloo":
+        env = dict(os.environ, OMP_NUM_THREADS="1", CDPR_TEST_SPIN_FAIL_RANK="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29519", str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    else:
+        _spawn_two_ranks_without_torch(script, tmp_path, 29519, {"CDPR_TEST_SPIN_FAIL_RANK": "1"})
     w0, spin0 = eval((tmp_path / "fb0.txt").read_text())
     w1, spin1 = eval((tmp_path / "fb1.txt").read_text())
     assert not spin0 and not spin1 and w0 >= 0.29  # nobody spins, and the fallback barrier still holds rank 0 back
@@ -147,3 +175,16 @@ def test_shard_range_covers_everything(pkg):
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_socket_rendezvous_names_the_rank_that_never_came(tmp_path):
+    """A rank that dies before the rendezvous must not leave rank 0 waiting for ever: SocketGroup's accept loop times out
+    and says which ranks are missing."""
+    from cdpr_simulation_amd.sharding import SocketGroup
+
+    os.environ["MASTER_PORT"] = "29541"
+    try:
+        with pytest.raises(RuntimeError, match=r"ranks \[1\] did not connect"):
+            SocketGroup(0, 2, 2, timeout_s=0.5)
+    finally:
+        os.environ.pop("MASTER_PORT", None)
