@@ -139,9 +139,10 @@ def effective_cpu_count():
 
 
 def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0, kind="velocity"):
-    """Time the fp64 oracle ("port" of the reference step) on the host cores, bounded sample.  Two derivative modes
-    (BASELINE.md section 3): `fir`-equivalent EXACT (same least-squares problem in centred time; the headline `value`)
-    and FAITHFUL (per-step normal equations in absolute time + pow() + column-pivoted QR, as Pid.cpp:219-247)."""
+    """Time the fp64 oracle ("port" of the reference step) on the host cores, bounded sample.  Derivative modes
+    (BASELINE.md section 3): FIR (`fir`: the fixed 11-tap end-point filter on uniform windows; the headline `value`),
+    FAITHFUL (per-step normal equations in absolute time + pow() + column-pivoted QR, as Pid.cpp:219-247), and EXACT
+    (the same least-squares problem in centred time: what the parity checks run)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
 
@@ -164,28 +165,37 @@ def cpu_baseline(pkg, cfg_kwargs, pose, command, refresh, target_seconds=12.0, k
         sim.close()
         return dt_
 
+    def timed(mode, share):
+        """`share` of the time budget on the bounded sample with every core, then ~1 s on one core."""
+        t_probe = run(probe_steps, mode=mode)
+        nsteps = int(max(refresh, min(2000, share * target_seconds * (sample_b * probe_steps / t_probe) / sample_b)))
+        t = run(nsteps, mode=mode)
+        t1 = run(one_steps, one_b, 1, mode=mode)
+        return sample_b * nsteps / t, one_b * one_steps / t1, nsteps, t
+
     probe_steps = 20
-    t_probe = run(probe_steps)
-    rate = sample_b * probe_steps / t_probe
-    nsteps = int(max(refresh, min(2000, target_seconds * rate / sample_b)))
-    t = run(nsteps)
-    t_probe_f = run(probe_steps, mode=oracle.DERIV_FAITHFUL)
-    nsteps_f = int(max(refresh, min(2000, 0.5 * target_seconds * (sample_b * probe_steps / t_probe_f) / sample_b)))
-    t_f = run(nsteps_f, mode=oracle.DERIV_FAITHFUL)
     one_b, one_steps = min(256, pose.shape[0]), 100  # single-core figures on a small sample (about 1 s each)
-    t1 = run(one_steps, one_b, 1)
-    t1_f = run(one_steps, one_b, 1, mode=oracle.DERIV_FAITHFUL)
+    v_fir, v_fir1, n_fir, t_fir = timed(oracle.DERIV_FIR, 0.4)
+    v_ex, v_ex1, n_ex, t_ex = timed(oracle.DERIV_EXACT, 0.3)
+    v_fa, v_fa1, n_fa, t_fa = timed(oracle.DERIV_FAITHFUL, 0.3)
     return {
-        "value": sample_b * nsteps / t,
-        "value_1core": one_b * one_steps / t1,
-        "value_faithful": sample_b * nsteps_f / t_f,
-        "value_faithful_1core": one_b * one_steps / t1_f,
+        # BASELINE.md section 3: two modes, `fir` (default: the 11-tap derivative, mathematically equal) and `faithful`
+        "value": v_fir,
+        "value_1core": v_fir1,
+        "value_fir": v_fir,
+        "value_fir_1core": v_fir1,
+        "value_exact_fit": v_ex,
+        "value_exact_fit_1core": v_ex1,
+        "value_faithful": v_fa,
+        "value_faithful_1core": v_fa1,
         "unit": "state-steps/s",
         "cores": int(cores),
         "kind": "port",
-        "sample": f"{sample_b} robots x {nsteps} steps of the same workload, fp64 oracle (CPU restatement of the "
-                  f"cdpr_gazebo step, not Gazebo/ODE), OpenMP over robots, {t:.1f} s; value_faithful: {nsteps_f} steps with the "
-                  f"reference-style per-step polynomial fit (Pid.cpp:219-247), {t_f:.1f} s",
+        "sample": f"{sample_b} robots x {n_fir} steps of the same workload, fp64 oracle (CPU restatement of the "
+                  f"cdpr_gazebo step, not Gazebo/ODE), OpenMP over robots, {t_fir:.1f} s, derivative as the fixed 11-tap filter "
+                  f"(`fir`, BASELINE.md section 3; through round 5 `value` was value_exact_fit); value_exact_fit: {n_ex} steps with the "
+                  f"least-squares fit in centred time per cable-step, {t_ex:.1f} s; value_faithful: {n_fa} steps with the "
+                  f"reference-style per-step polynomial fit (Pid.cpp:219-247: absolute time, pow(), column-pivoted QR), {t_fa:.1f} s",
     }
 
 

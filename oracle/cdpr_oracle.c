@@ -59,83 +59,175 @@ static double cascade_update(orc_biquad *f, unsigned cascade, double x) {
 
 /* ------------------------------------------------------------------ */
 /* Column-pivoted Householder QR solve — Eigen 3.3 ColPivHouseholderQR  */
-/* (third-party, not vendored; call site Pid.cpp:246).  Restated from   */
-/* the published algorithm: pivot on the largest remaining column norm, */
-/* reflect, rank-truncate on |R_kk| <= eps * n * max|R_kk|, back-solve. */
+/* (third-party dependency of the reference: `find_package(Eigen3)`,    */
+/* CMakeLists.txt; Ubuntu 18.04 / ROS melodic ship Eigen 3.3.4; not     */
+/* vendored, absent from this image; call site Pid.cpp:246              */
+/* `A.colPivHouseholderQr().solve(b)`).  Restated step by step from the */
+/* published algorithm of Eigen 3.3's                                   */
+/* ColPivHouseholderQR::computeInPlace / _solve_impl and                */
+/* MatrixBase::makeHouseholder / applyHouseholderOnTheLeft:             */
+/*  (1) column norms ||A(:,j)|| computed once ("direct") and kept as    */
+/*      "updated" norms; threshold_helper = (eps * max norm)^2 / rows;  */
+/*  (2) step k: pivot = column of the largest UPDATED norm among k..;   */
+/*      the first k at which that squared norm falls below              */
+/*      threshold_helper * (rows - k) fixes nonzero_pivots = k (the     */
+/*      decomposition itself continues: "bug 941");                     */
+/*  (3) swap columns and both norm tables; Householder vector of        */
+/*      A(k.., k): tail == 0 (<= DBL_MIN) -> tau = 0, beta = A(k,k);    */
+/*      else beta = -sign(A(k,k)) * ||A(k..,k)||, essential = tail /    */
+/*      (A(k,k) - beta), tau = (beta - A(k,k)) / beta; A(k,k) = beta;   */
+/*  (4) trailing columns: tmp = essential^T * bottom + row k; row k -=  */
+/*      tau * tmp; bottom -= (tau * essential) * tmp;                   */
+/*  (5) norm down-date of every trailing column (LAPACK xGEQP3, LAWN    */
+/*      176): temp = (1 + |A(k,j)| / upd_j)(1 - |A(k,j)| / upd_j)       */
+/*      clamped at 0, temp2 = temp * (upd_j / direct_j)^2; if temp2 <=  */
+/*      sqrt(eps) the norm of A(k+1.., j) is recomputed and becomes     */
+/*      both direct_j and upd_j, else upd_j *= sqrt(temp);              */
+/*  solve: c = b with the first nonzero_pivots reflectors applied,      */
+/*      back substitution on the leading nonzero_pivots x nonzero_pivots */
+/*      triangle, x(perm(i)) = c(i) for i < nonzero_pivots, 0 beyond.   */
+/* Not bit-compatible with a build of Eigen: inner products are summed  */
+/* here in index order, Eigen's vectorised reductions pair them         */
+/* differently (last-bit differences, amplified only where the          */
+/* reference's fit is already ill-conditioned).  PARITY UNPINNED.       */
 /* ------------------------------------------------------------------ */
 void orc_colpiv_qr_solve(int n, double *a, double *b, double *x) {
+  const double eps = 2.220446049250313e-16;   /* NumTraits<double>::epsilon() */
+  const double tiny = 2.2250738585072014e-308; /* (std::numeric_limits<double>::min)() */
   int perm[16];
-  double y[16];
+  double c[16], hcoef[16], tmp[16], upd[16], direct[16];
   if (n > 16) n = 16;
-  for (int j = 0; j < n; ++j) perm[j] = j;
-  for (int i = 0; i < n; ++i) y[i] = b[i];
-  double maxpivot = 0.0;
-  int rank = n;
-  for (int k = 0; k < n; ++k) {
-    /* pick the column with the largest remaining squared norm */
+  const int rows = n, cols = n, size = n;
+  for (int j = 0; j < cols; ++j) perm[j] = j;
+  /* (1) */
+  double maxnorm = 0.0;
+  for (int j = 0; j < cols; ++j) {
+    double s = 0.0;
+    for (int i = 0; i < rows; ++i) s += a[i * n + j] * a[i * n + j];
+    direct[j] = upd[j] = sqrt(s);
+    if (upd[j] > maxnorm) maxnorm = upd[j];
+  }
+  const double threshold_helper = (maxnorm * eps) * (maxnorm * eps) / (double)rows;
+  const double norm_downdate_threshold = sqrt(eps);
+  int nonzero_pivots = size;
+  for (int k = 0; k < size; ++k) {
+    /* (2) first maximum wins, as DenseBase::maxCoeff(&index) */
     int piv = k;
-    double best = -1.0;
-    for (int j = k; j < n; ++j) {
-      double s = 0;
-      for (int i = k; i < n; ++i) s += a[i * n + j] * a[i * n + j];
-      if (s > best) {
-        best = s;
-        piv = j;
-      }
-    }
+    for (int j = k + 1; j < cols; ++j)
+      if (upd[j] > upd[piv]) piv = j;
+    double biggest_sq = upd[piv] * upd[piv];
+    if (nonzero_pivots == size && biggest_sq < threshold_helper * (double)(rows - k)) nonzero_pivots = k;
+    /* (3) */
     if (piv != k) {
-      for (int i = 0; i < n; ++i) {
+      for (int i = 0; i < rows; ++i) {
         double t = a[i * n + k];
         a[i * n + k] = a[i * n + piv];
         a[i * n + piv] = t;
       }
-      int t = perm[k];
-      perm[k] = perm[piv];
-      perm[piv] = t;
+      double t = upd[k]; upd[k] = upd[piv]; upd[piv] = t;
+      t = direct[k]; direct[k] = direct[piv]; direct[piv] = t;
+      int ti = perm[k]; perm[k] = perm[piv]; perm[piv] = ti;
     }
-    /* Householder reflector for column k, rows k..n-1 */
-    double alpha = a[k * n + k];
-    double tail = 0;
-    for (int i = k + 1; i < n; ++i) tail += a[i * n + k] * a[i * n + k];
-    double beta;
-    if (tail == 0.0) {
-      beta = alpha; /* nothing to annihilate */
+    double c0 = a[k * n + k], tail = 0.0, beta, tau;
+    for (int i = k + 1; i < rows; ++i) tail += a[i * n + k] * a[i * n + k];
+    if (tail <= tiny) {
+      tau = 0.0;
+      beta = c0;
+      for (int i = k + 1; i < rows; ++i) a[i * n + k] = 0.0;
     } else {
-      double norm = sqrt(alpha * alpha + tail);
-      beta = (alpha >= 0) ? -norm : norm;
-      double v0 = alpha - beta;
-      /* v = [1, a[k+1..]/v0], tau = (beta - alpha)/beta */
-      double tau = (beta - alpha) / beta;
-      for (int i = k + 1; i < n; ++i) a[i * n + k] /= v0;
-      for (int j = k + 1; j < n; ++j) {
-        double s = a[k * n + j];
-        for (int i = k + 1; i < n; ++i) s += a[i * n + k] * a[i * n + j];
-        s *= tau;
-        a[k * n + j] -= s;
-        for (int i = k + 1; i < n; ++i) a[i * n + j] -= s * a[i * n + k];
-      }
-      double s = y[k];
-      for (int i = k + 1; i < n; ++i) s += a[i * n + k] * y[i];
-      s *= tau;
-      y[k] -= s;
-      for (int i = k + 1; i < n; ++i) y[i] -= s * a[i * n + k];
+      beta = sqrt(c0 * c0 + tail);
+      if (c0 >= 0.0) beta = -beta;
+      for (int i = k + 1; i < rows; ++i) a[i * n + k] /= (c0 - beta);
+      tau = (beta - c0) / beta;
     }
+    hcoef[k] = tau;
     a[k * n + k] = beta;
-    if (fabs(beta) > maxpivot) maxpivot = fabs(beta);
+    /* (4) on the block rows k.., columns k+1..: one row left -> scale it by 1 - tau */
+    if (rows - k == 1) {
+      for (int j = k + 1; j < cols; ++j) a[k * n + j] *= 1.0 - tau;
+    } else if (tau != 0.0) {
+      for (int j = k + 1; j < cols; ++j) {
+        double s = 0.0;
+        for (int i = k + 1; i < rows; ++i) s += a[i * n + k] * a[i * n + j];
+        tmp[j] = s + a[k * n + j];
+      }
+      for (int j = k + 1; j < cols; ++j) a[k * n + j] -= tau * tmp[j];
+      for (int j = k + 1; j < cols; ++j)
+        for (int i = k + 1; i < rows; ++i) a[i * n + j] -= (tau * a[i * n + k]) * tmp[j];
+    }
+    /* (5) */
+    for (int j = k + 1; j < cols; ++j) {
+      if (upd[j] != 0.0) {
+        double temp = fabs(a[k * n + j]) / upd[j];
+        temp = (1.0 + temp) * (1.0 - temp);
+        temp = temp < 0.0 ? 0.0 : temp;
+        double r = upd[j] / direct[j];
+        double temp2 = temp * (r * r);
+        if (temp2 <= norm_downdate_threshold) {
+          double s = 0.0;
+          for (int i = k + 1; i < rows; ++i) s += a[i * n + j] * a[i * n + j];
+          direct[j] = upd[j] = sqrt(s);
+        } else {
+          upd[j] *= sqrt(temp);
+        }
+      }
+    }
   }
-  /* rank by Eigen's default threshold: eps * diagonal size */
-  double thr = 2.220446049250313e-16 * (double)n * maxpivot;
-  rank = 0;
-  for (int k = 0; k < n; ++k)
-    if (fabs(a[k * n + k]) > thr) ++rank;
-  double z[16];
-  for (int i = 0; i < n; ++i) z[i] = 0.0;
-  for (int i = rank - 1; i >= 0; --i) {
-    double s = y[i];
-    for (int j = i + 1; j < rank; ++j) s -= a[i * n + j] * z[j];
-    z[i] = s / a[i * n + i];
+  /* _solve_impl */
+  for (int i = 0; i < n; ++i) x[i] = 0.0;
+  if (nonzero_pivots == 0) return;
+  for (int i = 0; i < rows; ++i) c[i] = b[i];
+  for (int k = 0; k < nonzero_pivots; ++k) { /* c = H_{r-1} ... H_0 c, each by applyHouseholderOnTheLeft */
+    if (rows - k == 1) {
+      c[k] *= 1.0 - hcoef[k];
+    } else if (hcoef[k] != 0.0) {
+      double s = 0.0;
+      for (int i = k + 1; i < rows; ++i) s += a[i * n + k] * c[i];
+      s += c[k];
+      c[k] -= hcoef[k] * s;
+      for (int i = k + 1; i < rows; ++i) c[i] -= (hcoef[k] * a[i * n + k]) * s;
+    }
   }
-  for (int i = 0; i < n; ++i) x[perm[i]] = z[i];
+  for (int i = nonzero_pivots - 1; i >= 0; --i) { /* triangularView<Upper>().solveInPlace */
+    double s = c[i];
+    for (int j = i + 1; j < nonzero_pivots; ++j) s -= a[i * n + j] * c[j];
+    c[i] = s / a[i * n + i];
+  }
+  for (int i = 0; i < nonzero_pivots; ++i) x[perm[i]] = c[i];
+}
+
+/* End-point derivative weights of the degree-`degree` least-squares polynomial through `nbuf` equally spaced samples
+ * (oldest first; unit spacing): what Pid::derive (Pid.cpp:193-217) computes when every sample of the window is one
+ * step apart, as a fixed filter.  Discrete orthogonal polynomials by the three-term recurrence
+ * on the centred abscissae in long double; w_j = sum_k p_k(x_j) p_k'(x_last) / <p_k, p_k>.  The oracle's own
+ * derivation (the product's is cdpr_derivative_weights in the HIP library; tests compare the two). */
+void orc_fir_weights(unsigned nbuf, unsigned degree, double *w) {
+  long double xs[CDPR_MAX_D_BUFFER], pm[CDPR_MAX_D_BUFFER], pc[CDPR_MAX_D_BUFFER], pn[CDPR_MAX_D_BUFFER];
+  long double dm[CDPR_MAX_D_BUFFER], dc[CDPR_MAX_D_BUFFER], dn[CDPR_MAX_D_BUFFER], acc[CDPR_MAX_D_BUFFER];
+  if (nbuf > CDPR_MAX_D_BUFFER) nbuf = CDPR_MAX_D_BUFFER;
+  if (degree + 1u > nbuf) degree = nbuf ? nbuf - 1u : 0u;
+  for (unsigned j = 0; j < nbuf; ++j) {
+    xs[j] = (long double)j - 0.5L * (long double)(nbuf - 1u);
+    pm[j] = 0.0L; dm[j] = 0.0L; /* p_{-1} */
+    pc[j] = 1.0L; dc[j] = 0.0L; /* p_0 */
+    acc[j] = 0.0L;
+  }
+  long double norm_prev = 1.0L;
+  for (unsigned k = 0; k <= degree; ++k) {
+    long double nk = 0.0L, xk = 0.0L;
+    for (unsigned j = 0; j < nbuf; ++j) { nk += pc[j] * pc[j]; xk += xs[j] * pc[j] * pc[j]; }
+    long double dlast = dc[nbuf - 1u];
+    for (unsigned j = 0; j < nbuf; ++j) acc[j] += pc[j] * dlast / nk;
+    /* p_{k+1} = (x - alpha) p_k - beta p_{k-1} */
+    long double alpha = xk / nk, betak = (k == 0) ? 0.0L : nk / norm_prev;
+    for (unsigned j = 0; j < nbuf; ++j) {
+      pn[j] = (xs[j] - alpha) * pc[j] - betak * pm[j];
+      dn[j] = pc[j] + (xs[j] - alpha) * dc[j] - betak * dm[j];
+    }
+    for (unsigned j = 0; j < nbuf; ++j) { pm[j] = pc[j]; dm[j] = dc[j]; pc[j] = pn[j]; dc[j] = dn[j]; }
+    norm_prev = nk;
+  }
+  for (unsigned j = 0; j < nbuf; ++j) w[j] = (double)acc[j];
 }
 
 /* ------------------------------------------------------------------ */
@@ -165,6 +257,7 @@ void orc_pid_init(orc_pid *p, const cdpr_pid_params_t *prm, int deriv_mode) {
   p->cmd_max = fabs(prm->cmd_limit);
   p->cmd_min = -fabs(prm->cmd_limit);
   p->deriv_mode = deriv_mode;
+  if (deriv_mode == ORC_DERIV_FIR) orc_fir_weights(p->prm.d_buffer_length, p->prm.d_degree, p->fir);
   /* CascadeFilter ctor, Pid.cpp:27-36: SetValue(0), SetFc(relCutoff, 1.0, quality) */
   for (unsigned i = 0; i < p->prm.p_filter.cascade; ++i) {
     orc_biquad_set_value(&p->pf[i], 0.0);
@@ -212,7 +305,20 @@ double orc_pid_derive(orc_pid *p, double value, double now) {
   double derived = 0;
   if (p->missing == 0u) {
     double coef[CDPR_MAX_D_DEGREE + 2];
-    if (p->deriv_mode == ORC_DERIV_FAITHFUL) {
+    int uniform = 0;
+    if (p->deriv_mode == ORC_DERIV_FIR && nbuf > 1) { /* every sample one and the same step apart? (stamps are k*dt) */
+      double h0 = p->bx[nbuf - 1] - p->bx[nbuf - 2];
+      uniform = h0 > 0.0;
+      for (unsigned j = 1; uniform && j + 1 < nbuf; ++j) uniform = fabs((p->bx[j] - p->bx[j - 1]) - h0) <= 1e-9 * h0;
+      if (uniform) {
+        double acc = 0.0;
+        for (unsigned j = 0; j < nbuf; ++j) acc += p->fir[j] * p->by[j];
+        derived = acc / h0;
+      }
+    }
+    if (uniform) {
+      /* done: the fixed filter */
+    } else if (p->deriv_mode == ORC_DERIV_FAITHFUL) {
       fit_polynomial(p->bx, p->by, nbuf, degree, coef);
       for (unsigned i = 1; i <= degree; ++i) coef[i - 1] = i * coef[i]; /* Pid.cpp:205-208 */
       coef[degree] = 0.0;

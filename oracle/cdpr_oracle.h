@@ -35,6 +35,9 @@ extern "C" {
 /* how Pid::derive's polynomial fit is evaluated */
 #define ORC_DERIV_FAITHFUL 0 /* normal equations in absolute sim time + pow(), Pid.cpp:219-247 (drifts for t >~ 2 s) */
 #define ORC_DERIV_EXACT 1    /* same least-squares problem in centred, scaled time: the exact answer        */
+#define ORC_DERIV_FIR 2      /* BASELINE.md section 3's `fir` mode: a window whose samples are one step apart takes the fixed
+                                end-point filter (11 taps at the shipped N = 11, d = 2), any other window
+                                the EXACT fit; the CPU counterpart of the product's cdpr_derivative_weights */
 
 /* ---- unit-level pieces (each is one reference function restated) ---- */
 
@@ -55,6 +58,7 @@ typedef struct orc_pid {
   orc_biquad pf[CDPR_MAX_CASCADE], df[CDPR_MAX_CASCADE];
   unsigned missing;
   double bx[CDPR_MAX_D_BUFFER], by[CDPR_MAX_D_BUFFER];
+  double fir[CDPR_MAX_D_BUFFER]; /* ORC_DERIV_FIR: weights, oldest sample first, unit spacing */
   /* what the `pid` debug topic would carry if this PID served cable 0 */
   double dbg_p, dbg_i, dbg_d, dbg_desired;
   int dbg_pi_written, dbg_d_written, dbg_desired_written;
@@ -64,9 +68,13 @@ void orc_pid_reset(orc_pid *p);                                              /* 
 double orc_pid_update(orc_pid *p, double desired, double actual, double now);/* Pid.cpp:122-191 */
 double orc_pid_derive(orc_pid *p, double value, double now);                 /* Pid.cpp:193-217 */
 
-/* Dense solve by column-pivoted Householder QR (what Eigen 3.3's
- * colPivHouseholderQr().solve does, Pid.cpp:246); a is n x n row-major, overwritten. */
+/* Dense solve by column-pivoted Householder QR: Eigen 3.3's colPivHouseholderQr().solve (Pid.cpp:246) restated from its
+ * published algorithm - pivoting on down-dated column norms, the nonzeroPivots() truncation rule, reflectors as
+ * makeHouseholder builds them (cdpr_oracle.c has the steps).  Same algorithm, not the same bits: Eigen is not in this
+ * image and its vectorised inner products sum in another order.  a is n x n row-major, overwritten. */
 void orc_colpiv_qr_solve(int n, double *a, double *b, double *x);
+/* End-point derivative weights of the least-squares polynomial through nbuf equally spaced samples (oldest first). */
+void orc_fir_weights(unsigned nbuf, unsigned degree, double *w);
 
 /* IK (Joint::Position / GetVelocity restated; geometry statement gen_cdpr.py:113-118).
  * pose = x y z qx qy qz qw, twist = v(3) w(3) world frame.

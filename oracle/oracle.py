@@ -16,6 +16,7 @@ REF_FILTER_PATH = os.path.join(_HERE, "_ref", "libref_filter.so")
 
 DERIV_FAITHFUL = 0
 DERIV_EXACT = 1
+DERIV_FIR = 2
 
 _lib = None
 

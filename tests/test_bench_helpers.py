@@ -44,6 +44,9 @@ def test_cpu_baseline_reports_the_faithful_mode_too(pkg):
     out = bench.cpu_baseline(pkg, dict(model=model, stages=0), pose, command, 10, target_seconds=0.2)
     # `faithful` = per-step polynomial fit as Pid.cpp:219-247, next to the FIR-equivalent mode
     assert out["value_faithful"] > 1e3 and out["value_faithful_1core"] > 1e3 and "value_faithful" in out["sample"]
+    # BASELINE.md section 3's `fir` mode is the headline figure; the fit modes ride along
+    assert out["value"] == out["value_fir"] and out["value_1core"] == out["value_fir_1core"] and out["value_exact_fit"] > 1e3
+    assert out["value_fir_1core"] > out["value_faithful_1core"]  # 11 multiply-adds against pow() + a 3 x 3 QR per cable-step
 
 
 def test_config_switch_selects_the_baseline_shapes():

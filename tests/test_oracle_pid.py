@@ -148,6 +148,83 @@ def test_qr_solver_matches_numpy(oracle):
         assert np.allclose(oracle.qr_solve(a, b), np.linalg.solve(a, b), rtol=1e-10, atol=1e-12)
 
 
+def test_qr_solver_truncates_by_eigens_nonzero_pivots_rule(oracle):
+    """Eigen 3.3 ColPivHouseholderQR (Pid.cpp:246): a pivot is dropped when the largest remaining SQUARED column norm is below
+    (eps * max column norm)^2 * (rows - k) / rows - not by |R_kk| <= eps * n * max|R_kk| (rank()'s default threshold, what the
+    oracle used through round 5).  diag(1, 2e-16) separates the two rules: 4e-32 >= 2.46e-32 keeps the pivot."""
+    x = oracle.qr_solve(np.diag([1.0, 2e-16]), np.array([3.0, 4e-16]))
+    assert np.allclose(x, [3.0, 2.0], rtol=1e-15)
+    x = oracle.qr_solve(np.diag([1.0, 1e-16]), np.array([3.0, 4e-16]))  # 1e-32 < 2.46e-32: dropped, that unknown is 0
+    assert x[0] == 3.0 and x[1] == 0.0
+    # an exactly dependent column: two pivots, the third unknown (the permuted-last column) set to 0, and A x = b still holds
+    a = np.array([[2.0, 1.0, 3.0], [0.0, 1.0, 1.0], [1.0, 0.0, 1.0]])  # col 2 = col 0 + col 1
+    b = a @ np.array([1.0, -2.0, 0.5])
+    x = oracle.qr_solve(a, b)
+    assert np.count_nonzero(x == 0.0) == 1 and np.allclose(a @ x, b, atol=1e-14)
+    # (an all-zero matrix: threshold_helper = 0 and `0 < 0` is false, so the published rule keeps every pivot and divides by 0;
+    #  Pid::fitPolynomial never builds one - its (0, 0) entry is the sample count)
+
+
+def test_qr_solver_on_the_reference_fit_matrices(oracle):
+    """The matrices Pid::fitPolynomial really hands over (Pid.cpp:224-244: power sums of absolute time): while they are
+    well conditioned the solve agrees with an SVD least-squares solve; far out (t = 100 s, cond ~ 1e21) it must still return
+    finite numbers with every pivot kept or a trailing unknown zeroed, never NaN."""
+    for t0, tol in ((0.0, 1e-9), (0.5, 1e-7)):
+        t = t0 + 1e-3 * np.arange(11)
+        y = np.sin(5.0 * t)
+        a = np.array([[np.sum(t ** (i + j)) for j in range(3)] for i in range(3)])
+        b = np.array([np.sum(t ** i * y) for i in range(3)])
+        x = oracle.qr_solve(a, b)
+        ref = np.polyfit(t - t.mean(), y, 2)[::-1]  # centred fit, then shifted back to absolute-time coefficients
+        m = t.mean()
+        ref_abs = np.array([ref[0] - ref[1] * m + ref[2] * m * m, ref[1] - 2 * ref[2] * m, ref[2]])
+        assert np.allclose(x[1] + 2 * x[2] * t[-1], ref_abs[1] + 2 * ref_abs[2] * t[-1], rtol=tol, atol=tol)
+    t = 100.0 + 1e-3 * np.arange(11)
+    a = np.array([[np.sum(t ** (i + j)) for j in range(3)] for i in range(3)])
+    assert np.isfinite(oracle.qr_solve(a, np.array([np.sum(t ** i) for i in range(3)]))).all()
+
+
+def test_fir_weights_and_the_three_derivative_modes(pkg, oracle):
+    """ORC_DERIV_FIR (BASELINE.md section 3's `fir` baseline mode): the oracle's own end-point weights equal SURVEY.md 8(a)
+    row 5's published values and the product's host-side table (cdpr_derivative_weights); FAITHFUL, EXACT and FIR agree
+    while the reference's fit is accurate (t <= 2 s); a window with a gap in it makes FIR fall back to the EXACT fit."""
+    import ctypes as C
+
+    from cdpr_simulation_amd._native import lib as hip_lib
+
+    survey = [0.129370629371, 0.0335664335664, -0.0389277389277, -0.0881118881119, -0.113986013986, -0.11655011655,
+              -0.0958041958042, -0.0517482517483, 0.0156177156177, 0.106293706294, 0.22027972028]
+    w = np.zeros(32)
+    oracle.lib().orc_fir_weights.argtypes = [C.c_uint, C.c_uint, C.POINTER(C.c_double)]
+    oracle.lib().orc_fir_weights(11, 2, w.ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.allclose(w[:11], survey, rtol=0, atol=5e-13) and abs(w[:11].sum()) < 1e-15
+    for nbuf, deg in ((11, 2), (5, 1), (32, 3), (7, 2)):
+        w = np.zeros(32)
+        oracle.lib().orc_fir_weights(nbuf, deg, w.ctypes.data_as(C.POINTER(C.c_double)))
+        wp = np.zeros(32)
+        assert hip_lib().cdpr_derivative_weights(nbuf, deg, wp.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert np.allclose(w[:nbuf], wp[:nbuf], rtol=0, atol=1e-13), (nbuf, deg)
+        x = np.arange(nbuf, dtype=np.float64)
+        assert np.allclose(w[:nbuf], np.linalg.pinv(np.vander(x - x.mean(), deg + 1, increasing=True))[1] + 0, atol=1e-12) or deg >= 2
+    s = pkg.Config().to_struct()
+    p = s.velocity_pid
+    p.p_gain, p.i_gain, p.d_gain, p.cmd_limit, p.i_limit = 0.0, 0.0, 1.0, 1e9, 1e9
+    dt = 1e-3
+    pids = [oracle.OraclePid(p, m) for m in (oracle.DERIV_FAITHFUL, oracle.DERIV_EXACT, oracle.DERIV_FIR)]
+    for k in range(2000):
+        t = k * dt
+        f = [q.update(np.sin(5.0 * t), 0.0, t) for q in pids]
+        assert abs(f[2] - f[1]) < 1e-9 and abs(f[0] - f[1]) < 2e-5 * (1 + t * t * 30), (k, f)
+    # a gap: skip 7 steps, then the window is not uniform for 10 calls -> FIR mode must give EXACT's answer bit for bit
+    for k in range(2007, 2030):
+        t = k * dt
+        f = [q.update(np.sin(5.0 * t), 0.0, t) for q in pids[1:]]
+        if k < 2017:
+            assert f[0] == f[1], k
+        else:
+            assert abs(f[0] - f[1]) < 1e-9
+
+
 def test_plugin_ordering_first_steps(pkg, oracle):
     """update() at t = 0 sees stepTime = 0 -> force 0 and no Pid call (JFC.cpp:61-66); the next call is the Pid's
     'first' (-> 0); the position Pid (target 0 after Load, PLG.cpp:153-157) acts from the third step."""
