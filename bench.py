@@ -392,6 +392,170 @@ def device_identity(local_rank, rendezvous_backend):
     return info
 
 
+def leg_bound(kind):
+    """`roofline.bound` per leg (not one constant for every workload).  The roof every leg is priced
+    against stays HBM (the contract's roofline); `bound` names what the launch is really limited by."""
+    return {
+        # >= one wave on every SIMD, each carrying one robot's serial chain of dependent vector instructions: neither HBM
+        # nor the vector pipes are saturated (profiles/*_bench_pmc_summary.json), the chain's issue rate sets the time
+        "chain": "valu-issue",
+        # measured traffic at >= 75 % of what a plain copy kernel reaches: the HBM-streaming regime
+        "stream": "hbm",
+        # fewer waves than SIMDs (4 096 x 4 as lane pairs: 128 waves on 1 024 SIMDs): one wave's instruction latency, most
+        # of the chip idle
+        "underfilled": "latency (under-filled chip)",
+        # one robot with the host in the loop: launch + completion + read-back round trip per world step
+        "host": "host round trip",
+    }[kind]
+
+
+def leg_config2(pkg, device, rank, placement, no_parity):
+    """BASELINE.json configs[1]: 4 096 parallel 4-cable robots, IK + PID + dynamics, fp32, one GPU - sinevelocitytest-style
+    commands (every robot its own sine, a Joy batch every 10 world steps: sinevelocitytest.cpp:34-49 publishes at 100 Hz
+    against the 1 ms world step), observables every step (PLG.cpp:236-242).  Both launch forms, each with HIP-event kernel
+    time and a replay of the first and last 64 robots on the fp64 oracle:
+      scheduled        cdpr_update_scheduled, 1 000 world steps per launch, Joy batches read from HBM inside the kernel
+      launch_per_step  one launch per world step (hipGraph replays of 10), the Joy batch copied device to device"""
+    Bc, n, refresh = CONFIGS[2]["batch"], CONFIGS[2]["cables"], 10
+    warm_s, steps_s = SCHED_CHUNK, 2 * SCHED_CHUNK
+    warm_l, steps_l = 200, 1000
+    total = max(warm_s + steps_s, warm_l + steps_l)
+    model, pose, command, n_cmd = make_workload(pkg, Bc, n, 1234 + rank, total, refresh)
+    cfg_kwargs = dict(model=model, stages=0)
+    count = Bc * n
+    bytes_step = 4 * (39 + 28 * n)
+    try:
+        ttab = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        ttab = {}
+    threads = max(1, min(4, int(placement["cpus_effective"])))
+    out = {"workload": f"config2: {Bc} x {n}-cable robots, IK + PID + dynamics, f32, observables every step, per-robot sine "
+                       f"jointVelocities refreshed every {refresh} steps from HBM", "unit": "state-steps/s", "dtype": "f32"}
+
+    def roof(us_per_step, traffic_per_step, steps_per_launch):
+        ach = bytes_step * Bc / (us_per_step * 1e-6) / 1e9
+        return {"bound": leg_bound("underfilled"), "roof": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None if traffic_per_step is None else traffic_per_step * steps_per_launch,  # HBM bytes per LAUNCH (rocprofv3 PMC)
+                "traffic_frac": None if traffic_per_step is None else traffic_per_step / (us_per_step * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "bytes_per_state_step": bytes_step, "waves": Bc * 2 // 64, "simds": 1024}
+
+    # ---- scheduled form
+    eng = pkg.Engine(pkg.Config(batch=Bc, **cfg_kwargs), device=device)
+    eng.set_platform_state(pose7=pose)
+    d_all = eng.device_upload(np.stack([command(j) for j in range(n_cmd)]))
+    eng.update_scheduled(warm_s, refresh, d_all)
+    eng.synchronize()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps_s:
+        eng.update_scheduled(SCHED_CHUNK, refresh, d_all + ((warm_s + done) // refresh) * count * 4)
+        done += SCHED_CHUNK
+    ms, nl = eng.profile_end()
+    wall = time.perf_counter() - t0
+    mapping = eng.mapping
+    got = eng.platform_state() + eng.joint_states()
+    par = None if no_parity else parity_check(pkg, cfg_kwargs, pose, command, refresh, warm_s + steps_s, got, parity_slices(Bc), threads=threads)
+    eng.device_free(d_all)
+    eng.close()
+    us_step = ms * 1e3 / steps_s
+    t_s = ttab.get(f"n{n}_b{Bc}_sched{SCHED_CHUNK}")
+    out["scheduled"] = {"launch_form": f"cdpr_update_scheduled: one launch per {SCHED_CHUNK} world steps", "steps_timed": steps_s, "launches": int(nl),
+                        "kernel_us_per_step": us_step, "value_per_gpu": Bc / (us_step * 1e-6), "value_wall": Bc * steps_s / wall, "mapping": mapping,
+                        "roofline": roof(us_step, None if t_s is None else t_s / SCHED_CHUNK, SCHED_CHUNK), "parity_check": par}
+
+    # ---- one launch per world step
+    eng = pkg.Engine(pkg.Config(batch=Bc, **cfg_kwargs), device=device)
+    eng.set_platform_state(pose7=pose)
+    sched = [eng.device_upload(command(j)) for j in range((warm_l + steps_l) // refresh)]
+
+    def advance(first, nsteps):
+        for s_ in range(first, first + nsteps, refresh):
+            eng.set_velocity_command_device(sched[s_ // refresh], count)
+            eng.update(refresh)
+
+    advance(0, warm_l)
+    eng.synchronize()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    advance(warm_l, steps_l)
+    ms, nl = eng.profile_end()
+    wall = time.perf_counter() - t0
+    got = eng.platform_state() + eng.joint_states()
+    par_l = None if no_parity else parity_check(pkg, cfg_kwargs, pose, command, refresh, warm_l + steps_l, got, parity_slices(Bc), threads=threads)
+    for p_ in sched:
+        eng.device_free(p_)
+    eng.close()
+    us_launch = ms * 1e3 / max(nl, 1)
+    us_step_l = ms * 1e3 / steps_l  # (events bracket the whole region: the gaps between launches are in it)
+    out["launch_per_step"] = {"launch_form": "cdpr_update: one launch per world step (hipGraph replays of 10), Joy batch copied device to device every 10 steps",
+                              "steps_timed": steps_l, "launches": int(nl), "kernel_us": us_launch, "us_per_step_on_stream": us_step_l,
+                              "value_per_gpu": Bc / (us_step_l * 1e-6), "value_wall": Bc * steps_l / wall,
+                              "roofline": roof(us_step_l, ttab.get(f"n{n}_b{Bc}_spl1"), 1), "parity_check": par_l}
+    out["value_per_gpu"] = out["scheduled"]["value_per_gpu"]
+    out["kernel_us_per_step"] = us_step
+    out["roofline"] = out["scheduled"]["roofline"]
+    out["parity_check"] = None if no_parity else {"ok": bool(par["ok"] and par_l["ok"])}
+    return out
+
+
+def leg_config1(pkg, device, no_parity):
+    """BASELINE.json configs[0]: ONE 4-cable robot under the sinevelocitytest publisher (sinevelocitytest.cpp:6-10,34-49: 100 Hz,
+    amp 0.05 m/s, 0.1 Hz, the same value on every axis), 1 ms world step, the host in the loop as the reference's plugin
+    is (PLG.cpp:202-246): every world step = latch the pending Joy (every 10th step), one launch, read the step's JointState +
+    PlatformState back through cdpr_get_observables.  Wall-clock microseconds per world step in f32 and in the reference's
+    own arithmetic (precision = 64); the whole trajectory is compared with the fp64 oracle stepping beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    warm, steps, refresh = 200, 2000, 10
+    out = {"workload": "config1: one 4-cable robot, sinevelocitytest publisher (100 Hz), 1 ms step, host in the loop: per world step "
+                       "one launch + cdpr_get_observables", "unit": "us per world step", "steps_timed": steps}
+    ok = True
+    for prec in (32, 64):
+        cfg = pkg.Config(model=pkg.cube_model(), batch=1, precision=prec)
+        eng = pkg.Engine(cfg, device=device)
+        gen = pkg.stimulus.sine_velocity(4)
+        joys = [next(gen) for _ in range((warm + steps) // refresh)]
+        read = eng.observables_f64 if prec == 64 else eng.observables
+        traj = np.empty((warm + steps, 7 + 4))
+        t0 = 0.0
+        for k in range(warm + steps):
+            if k == warm:
+                eng.synchronize()
+                t0 = time.perf_counter()
+            if k % refresh == 0:
+                eng.set_velocity_command(joys[k // refresh])
+            eng.update(1)
+            q, qd, e, p, t = read()
+            traj[k, :7], traj[k, 7:] = p[0], e[0]
+        wall = time.perf_counter() - t0
+        mapping = eng.mapping
+        eng.close()
+        leg = {"us_per_step": wall / steps * 1e6, "steps_per_s": steps / wall, "real_time_factor": 1e-3 / (wall / steps), "mapping": mapping}
+        if not no_parity:
+            import oracle
+
+            osim = oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+            dp = de = 0.0
+            for k in range(warm + steps):
+                if k % refresh == 0:
+                    osim.set_velocity_command(joys[k // refresh])
+                osim.update(1)
+                dp = max(dp, float(np.abs(osim.platform_state()[0][0] - traj[k, :7]).max()))
+                de = max(de, float(np.abs(osim.joint_states()[2][0] - traj[k, 7:]).max()))
+            osim.close()
+            tol = FP64_TOL if prec == 64 else {"pose": PARITY_TOL["pose"], "eff": PARITY_TOL["eff"]}
+            leg["parity_check"] = {"steps": warm + steps, "compared": "pose and effort of every published step", "max_abs_pose": dp, "max_abs_effort": de,
+                                   "tolerance": tol, "ok": bool(np.isfinite(traj).all() and dp <= tol["pose"] and de <= tol["eff"])}
+            ok = ok and leg["parity_check"]["ok"]
+        out["f32" if prec == 32 else "f64"] = leg
+    out["us_per_step"] = out["f32"]["us_per_step"]
+    out["roofline"] = {"bound": leg_bound("host"), "roof": "hbm", "achieved": 4 * (39 + 28 * 4) / (out["f32"]["us_per_step"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": 4 * (39 + 28 * 4) / (out["f32"]["us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "note": "one robot is 604 B per step: the figure that matters is us_per_step against the reference's real-time budget of 1 000 us"}
+    out["parity_check"] = None if no_parity else {"ok": bool(ok)}
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -779,6 +943,8 @@ def main():
                 "value_per_gpu": Bg / (kus * 1e-6),
                 "unit": "state-steps/s",
                 "steps_timed": steps_g,
+                "bound": leg_bound("chain"),
+                "frac": 4 * (39 + 28 * n) * Bg / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS,  # algorithmic bytes per launch / kernel time / 8 TB/s
                 "traffic": gen_traffic,
                 "traffic_frac": (gen_traffic / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if gen_traffic else None,
                 "parity_check": gen_parity,
@@ -794,7 +960,17 @@ def main():
                 cfg_kwargs_f = cfg_kwargs if eps_f is None else dict(cfg_kwargs, velocityEpsilon=eps_f)
                 ef = pkg.Engine(pkg.Config(batch=Bf, precision=64, **cfg_kwargs_f), device=device)
                 ef.set_platform_state(pose7=pose[:Bf])
-                d_cmd_f = ef.device_upload(command(0)[:Bf])
+                cmd_f = command(0)[:Bf].copy()
+                held_share = None
+                if eps_f is not None:
+                    # hold legs: every third CABLE (not whole robots) commanded 0 <= velocityEpsilon, so that the hold
+                    # branch runs - and the two Pids of a robot diverge per cable - at every size including the one-robot leg,
+                    # and the parity slice holds held cables
+                    held = (np.arange(Bf * n).reshape(Bf, n) % 3) == 0
+                    cmd_f[held] = 0.0
+                    cmd_f[~held & (np.abs(cmd_f) <= eps_f)] = 0.02  # (the others clearly above epsilon: on the velocity Pid)
+                    held_share = float(held.mean())
+                d_cmd_f = ef.device_upload(cmd_f)
                 ef.bind_velocity_command_device(d_cmd_f, Bf * n)
                 ef.update(warm_f)
                 ef.synchronize()
@@ -809,7 +985,7 @@ def main():
                     fs = slice(max(0, Bf - 64), Bf)
                     osim = oracle.OracleSim(pkg.Config(batch=fs.stop - fs.start, **cfg_kwargs_f).to_struct(), oracle.DERIV_EXACT)
                     osim.set_platform_state(pose7=pose[fs].astype(np.float64))
-                    osim.set_velocity_command(command(0)[fs])
+                    osim.set_velocity_command(cmd_f[fs])
                     osim.update(warm_f + steps_f)
                     g64 = ef.observables_f64()
                     dp = float(np.abs(g64[3][fs] - osim.platform_state()[0]).max())
@@ -821,16 +997,19 @@ def main():
                 ef.close()
                 kus_f = msf * 1e3 / max(nlf, 1)
                 (fp64_legs if eps_f is None else hold_legs).append({"robots": Bf, "kernel_us": kus_f, "value_per_gpu": Bf / (kus_f * 1e-6), "steps_timed": steps_f,
-                                                                     "velocity_epsilon": eps_f, "parity_check": fpar})
+                                                                     "velocity_epsilon": eps_f, "held_cable_share": held_share, "parity_check": fpar})
             secondary["fp64"] = {
                 "workload": f"precision = 64 (the reference's own arithmetic): {n}-cable robots, every stage, one launch per step, one held Joy",
                 "dtype": "f64",
                 "unit": "state-steps/s",
+                "bound": leg_bound("chain"),
+                "frac": 4 * (39 + 28 * n) * fp64_legs[0]["robots"] / (fp64_legs[0]["kernel_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,  # the contract's (f32) bytes; in doubles twice that
                 "legs": fp64_legs,
                 "value_per_gpu": fp64_legs[0]["value_per_gpu"],
                 "kernel_us": fp64_legs[0]["kernel_us"],
                 "kernel_us_one_robot": fp64_legs[-1]["kernel_us"],
-                # the position-hold branch live (velocityEpsilon >= 0: both Pids of every cable, windows on real stamps) in double
+                # the position-hold branch live (velocityEpsilon >= 0; a third of the cables commanded 0 and held by their position
+                # Pid, the others on their velocity Pid: held_cable_share) in double
                 "hold_branch": {"legs": hold_legs, "kernel_us": hold_legs[0]["kernel_us"], "kernel_us_one_robot": hold_legs[-1]["kernel_us"]},
                 "parity_check": {"ok": all((l["parity_check"] or {"ok": True})["ok"] for l in fp64_legs + hold_legs)} if not args.no_parity_check else None,
             }
@@ -872,12 +1051,19 @@ def main():
                 "value_wall": Bl * steps_l / wall_l,
                 "unit": "state-steps/s",
                 "steps_timed": steps_l,
+                "bound": leg_bound("stream"),
                 "frac": bytes_l / (kus_l * 1e-6) / 1e9 / HBM_PEAK_GBS,  # algorithmic bytes per launch / kernel time / 8 TB/s
                 "traffic": t_l,                                           # HBM bytes per launch (rocprofv3 PMC of this round's layout)
                 "traffic_frac": (t_l / (kus_l * 1e-6) / 1e9 / HBM_PEAK_GBS) if t_l else None,
                 "traffic_frac_of_copy_rate": (t_l / (kus_l * 1e-6) / 1e9 / HBM_COPY_GBS) if t_l else None,
                 "parity_check": lpar,
             }
+
+        # (f) / (g) the other BASELINE configs that run on one GPU: config 2 in both launch forms, config 1
+        #     with the host in the loop; each with its own roofline object and parity check
+        if args.config == 3 and world == 1:
+            secondary["config2"] = leg_config2(pkg, device, rank, placement, args.no_parity_check)
+            secondary["config1"] = leg_config1(pkg, device, args.no_parity_check)
 
     if rank == 0:
         bytes_step = eng.bytes_per_state_step()
@@ -937,7 +1123,7 @@ def main():
             "roofline": {
                 # what limits the launch, and the tighter of the two roofs it is priced against (frozen in round 4: these
                 # keys keep their meaning from here on)
-                "bound": "valu-issue",
+                "bound": leg_bound("underfilled" if args.batch * (2 if eng.mapping == "lane-pair" else 1) < 65536 else "stream" if args.batch > 131072 else "chain"),
                 "roof": "hbm",
                 "frac_definition": "achieved / peak with achieved = algorithmic bytes per launch (SURVEY.md 8(d): 4*(39+28n) B per "
                                    "state-step x robots x steps of one launch) / the step kernel's average launch duration by HIP events "
@@ -992,7 +1178,9 @@ def main():
     failed = [name for name, chk in (("step", parity), ("rollout", (secondary.get("rollout") or {}).get("parity_check")),
                                      ("general_path", (secondary.get("general_path") or {}).get("parity_check")),
                                      ("fp64", (secondary.get("fp64") or {}).get("parity_check")),
-                                     ("large_batch", (secondary.get("large_batch") or {}).get("parity_check"))) if chk and not chk.get("ok_all_ranks", chk["ok"])]
+                                     ("large_batch", (secondary.get("large_batch") or {}).get("parity_check")),
+                                     ("config2", (secondary.get("config2") or {}).get("parity_check")),
+                                     ("config1", (secondary.get("config1") or {}).get("parity_check"))) if chk and not chk.get("ok_all_ranks", chk["ok"])]
     if failed:
         print(f"bench.py: parity check against the oracle FAILED for: {', '.join(failed)}", file=sys.stderr)
         sys.exit(3)
