@@ -96,6 +96,7 @@ struct cdpr_engine {
   };
   std::vector<GraphEntry> graphs;
   bool use_graphs = true;
+  bool pair_stream = true;  // cdpr_pair_stream_kernel serves the steady several-steps launches of lane-pair handles (CDPR_PAIR_STREAM=0: never; A/B and tests)
   float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
   float* d_pos[2] = {nullptr, nullptr};
   float* d_frc[2] = {nullptr, nullptr};  // force commands (cdpr_set_force_command; JFC.h:92-95)
@@ -747,6 +748,14 @@ StepKernel select_step_kernel(const cdpr_engine* h, int k) {
                                                  : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_step_kernel(true, h->n, h->fk, h->td)))
                                     : pick_step_kernel(false, h->n, h->fk, h->td));
 }
+// May a launch of k > 1 world steps with the arguments `a` (flags, pid_calls, pointers set) run on cdpr_pair_stream_kernel?
+// That kernel has no branch for anything but the steady state of a plain handle (cdpr_step_kernel_pair.hpp): every
+// condition below is one the general several-steps kernel tests per step instead.  CDPR_PAIR_STREAM=0: never (A/B).
+bool pair_stream_ok(const cdpr_engine* h, const StepArgs& a, int k) {
+  return h->pair_stream && h->lane_pair && !h->per_robot && !h->phys && !h->lane_cable && !h->fk && !h->td && (h->n == 4 || h->n == 8) && k > 1 &&
+         h->step != 0 && h->mode != kModeForce && a.pid_calls >= a.nbuf && h->cfg.publish_period == 0.0 && !a.dbg && !a.travel_on &&
+         !(a.vel_limit > 0.f) && !a.unilateral && a.effort >= 0.f && a.clamp_cmd && !h->sched_ready;
+}
 uint32_t step_block_threads(const cdpr_engine* h, int k) {
   // the role-split kernel runs two waves (estimator, controller) per 64 robots
   return (k == 1 && h->split && !h->phys && !h->lane_pair && !h->lowreg && !h->persist) ? 128u : 64u;
@@ -1234,6 +1243,17 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     const int kk = h->sched_refresh ? std::max(k, 2) : k;
     StepKernel kern = select_step_kernel(h, kk);
     const dim3 block(step_block_threads(h, kk));
+    const bool stream = pair_stream_ok(h, a, kk);  // steady state of a plain lane-pair handle: the branch-free several-steps kernel
+    auto weights_for = [&](StepArgs& x) {          // ... which reads the weights by AGE from the row of ring position 0
+      const int slot = x.ring_slot;
+      if (stream) x.ring_slot = 0;
+      set_weight_row(h, x);
+      x.ring_slot = slot;
+    };
+    if (stream) {
+      kern = pick_pair_stream_kernel(h->n, h->mode == kModeVelocity);
+      weights_for(a);
+    }
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
@@ -1259,7 +1279,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
           for (int j = 0; j < kGraphChunk; ++j) {
             StepArgs aj = a;  // each node carries its own ring position
             aj.ring_slot = (a.ring_slot + j * k) % kWin;
-            set_weight_row(h, aj);
+            weights_for(aj);
             hipLaunchKernelGGL(kern, grid, block, 0, h->stream, aj);
             launched = launched && (hipGetLastError() == hipSuccess);
           }
@@ -1589,6 +1609,8 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   {
     const char* ng = std::getenv("CDPR_NO_GRAPH");
     h->use_graphs = !(ng && ng[0] == '1');
+    const char* ps = std::getenv("CDPR_PAIR_STREAM");
+    h->pair_stream = !(ps && ps[0] == '0');
   }
 
   auto fail = [&](const char* what, hipError_t code) {

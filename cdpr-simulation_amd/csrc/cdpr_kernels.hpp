@@ -50,6 +50,7 @@ StepKernel pick_split_kernel(uint32_t n);
 StepKernel pick_pr_split_kernel(uint32_t n);
 // k_pair.hip / k_cable.hip: the other two wavefront mappings
 StepKernel pick_pair_kernel(bool single, uint32_t n, bool fk, bool td);
+StepKernel pick_pair_stream_kernel(uint32_t n, bool vel);  // several steps per launch in the steady state (no FK / TD): see pair_stream_ok
 StepKernel pick_cable_kernel(uint32_t n, bool fk, bool td);
 // k_gen.hip: the general controller path (cdpr_general_step.hpp); long_window: derivative windows of 12 .. 32 samples
 GenKernel pick_gen_kernel(uint32_t n, bool fk, bool td, bool rollout, bool long_window, bool single);

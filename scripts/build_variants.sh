@@ -21,7 +21,8 @@ flags_of() {
     # diagnosis only (not in the test's list): hypotheses about the expect variant's deviation
     expect_nsa)   echo "-DCDPR_EXPECT_STEADY -fno-strict-aliasing" ;;
     expect_fence) echo "-DCDPR_EXPECT_STEADY -DCDPR_HYP_STEP_FENCE" ;;
-    descbuf)      echo "-DCDPR_DESC_PER_BUFFER" ;;                  # round 2's experiment: one buffer descriptor per buffer in store_slot
+    descbuf)      echo "-DCDPR_DESC_PER_BUFFER" ;;
+    noslp)        echo "-fno-slp-vectorize" ;;                      # round 6 A/B: every unit without LLVM's SLP vectorizer (the shipped build: k_pair only)                  # round 2's experiment: one buffer descriptor per buffer in store_slot
     *) echo "unknown variant $1" >&2; exit 2 ;;
   esac
 }

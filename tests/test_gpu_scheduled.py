@@ -272,3 +272,68 @@ def test_bad_arguments(pkg):
     assert lib().cdpr_update_scheduled_kind(eng._h, 3, 20, 10, C.c_void_p(d), None, None, None, 0) == pkg._abi.ERR_INVALID
     assert lib().cdpr_update_scheduled_kind(eng._h, 0, 20, 0, C.c_void_p(d), None, None, None, 0) == pkg._abi.ERR_INVALID
     eng.close()
+
+
+@pytest.mark.parametrize("n_cables,kind", [(4, "velocity"), (4, "position"), (8, "velocity"), (8, "position")])
+def test_steady_state_stream_kernel_is_bit_identical(pkg, oracle, monkeypatch, n_cables, kind):
+    """cdpr_pair_stream_kernel (round 6: the steady-state several-steps launch of lane-pair handles: ten step copies with the
+    ring position as a compile-time constant, one observable descriptor per step, the next Joy batch fetched a period
+    ahead) against (a) the general several-steps kernel it replaces (CDPR_PAIR_STREAM=0), (b) one launch per world step,
+    bit for bit - every recorded step's observables, the state, the derivative windows as later steps see them - and
+    against the fp64 oracle.  The launch starts at an arbitrary ring position (step 37), runs a schedule whose length is
+    not a multiple of the refresh period or of the ring's ten, and is followed by plain updates."""
+    monkeypatch.setenv("CDPR_MAPPING", "2")  # the lane-pair mapping whatever AUTO would take for this batch
+    B, refresh, T = 301, 7, 83
+    rng = np.random.default_rng(60 + n_cables)
+    model = pkg.eight_cable_model() if n_cables == 8 else pkg.cube_model()
+    cfg = pkg.Config(model=model, batch=B, stages=0)
+    pose = perturbed_poses(cfg.model, B, rng).astype(np.float32)
+    nb = (T + refresh - 1) // refresh
+    amp = 0.03 if kind == "velocity" else 0.003
+    sched = rng.uniform(-amp, amp, (nb, B, n_cables)).astype(np.float32)
+    first = rng.uniform(-amp, amp, (B, n_cables)).astype(np.float32)
+
+    def run(stream, per_step):
+        monkeypatch.setenv("CDPR_PAIR_STREAM", "1" if stream else "0")
+        e = pkg.Engine(cfg, 0)
+        assert e.mapping == "lane-pair"
+        e.set_platform_state(pose7=pose)
+        getattr(e, SETTER[kind])(first)
+        e.update(37)  # past the window fill, at ring position (37 + 8) % 10
+        image = e.observable_image_bytes()
+        d_rec = e.device_alloc(image * T)
+        if per_step:
+            recs = []
+            for j in range(nb):
+                getattr(e, SETTER[kind])(sched[j])
+                k = min(refresh, T - j * refresh)
+                for _ in range(k):
+                    e.update(1)
+                    recs.append(np.concatenate([x.ravel() for x in e.observables()]))
+            rec = np.array(recs)
+        else:
+            d_s = e.device_upload(sched)
+            e.update_scheduled(T, refresh, d_s, d_rec, image * T, kind=kind)
+            raw = e.device_download(d_rec, (T, image), dtype=np.uint8)
+            rec = np.array([np.concatenate([x.ravel() for x in e.decode_observables(raw[j])]) for j in range(T)])
+            e.device_free(d_s)
+        e.device_free(d_rec)
+        e.update(13, 13)  # a fused launch from wherever the ring stands now (stream kernel again where it is on)
+        e.update(3)
+        return e, rec
+
+    a, rec_a = run(True, False)
+    b, rec_b = run(False, False)
+    c, rec_c = run(False, True)
+    assert np.array_equal(rec_a, rec_b) and np.array_equal(rec_a, rec_c), "every step's observables"
+    assert_same(a, b, "stream kernel against the general several-steps kernel")
+    assert_same(a, c, "stream kernel against one launch per world step")
+    ora = oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+    ora.set_platform_state(pose7=pose.astype(np.float64))
+    getattr(ora, SETTER[kind])(first)
+    ora.update(37)
+    for j in range(nb):
+        getattr(ora, SETTER[kind])(sched[j])
+        ora.update(min(refresh, T - j * refresh))
+    ora.update(16)
+    compare(a, ora, tol=TOL, where=f"stream kernel, {kind} schedule")
