@@ -2100,18 +2100,30 @@ static int scheduled_update(cdpr_engine* h, uint32_t kind, int nsteps, int refre
     done += k;
     ++j;
   }
-  if (j < nbatches) {
+  while (j < nbatches) {
     // ---- the rest in one launch: batch j is latched as any command of its kind is (entering the mode resets its Pid,
-    //      JFC.cpp:101-103,113-115), the later ones are read by the kernel
+    //      JFC.cpp:101-103,113-115), the later ones are read by the kernel.  Lane-pair handles whose derivative windows are not
+    //      full yet (world step 0, a mode just entered) take the batches that fill them in a launch of their own: from there on
+    //      the launch qualifies for the steady-state kernel (pair_stream_ok), which has no branch for a filling window.
     stage_batch(j);
     h->sched_refresh = refresh_steps;
     h->sched_ready = d_ready ? d_ready + j : nullptr;
-    const int rest = nsteps - done;
+    int rest = nsteps - done;
+    if (h->lane_pair && h->pair_stream && !h->fk && !h->td && kind != CDPR_COMMAND_FORCE) {
+      const int new_mode = (kind == CDPR_COMMAND_VELOCITY) ? kModeVelocity : kModePosition;
+      const int nbuf = (kind == CDPR_COMMAND_VELOCITY) ? h->pid_vel.nbuf : h->pid_pos.nbuf;
+      const int calls = (h->mode == new_mode) ? h->pid_calls : 0;  // (entering the mode resets the Pid)
+      const int fill = (calls >= nbuf ? 0 : nbuf - calls) + (h->step == 0 ? 1 : 0);
+      const int pre = ((fill + refresh_steps - 1) / refresh_steps) * refresh_steps;  // whole batches
+      if (pre > 0 && pre < rest) rest = pre;
+    }
     const int rc = run_steps(h, rest, rest, record ? record + (size_t)done * image : nullptr);
     h->sched_refresh = 0;
     h->sched_ready = nullptr;
     if (rc != CDPR_OK) return rc;
-    ext[kind][0] = d_commands + (size_t)(nbatches - 1) * batch_floats;  // the batch that stays latched
+    done += rest;
+    j += (rest + refresh_steps - 1) / refresh_steps;
+    if (j >= nbatches) ext[kind][0] = d_commands + (size_t)(nbatches - 1) * batch_floats;  // the batch that stays latched
   }
   return CDPR_OK;
 }
