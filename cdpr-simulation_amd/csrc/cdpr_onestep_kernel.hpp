@@ -542,8 +542,10 @@ template <int N, int XS, int ES>
 CDPR_DEV void split_estimator_wave(const StepArgs& a, float* geo, float gval, uint32_t lane, bool live, size_t st, uint32_t off, uint32_t woff,
                                    const float4& p0, const float4& p1, const float4& p3, const v2f* x_force, v2f* x_tension, float* x_est) {
   constexpr int NP = cable_pairs(N);
-#if CDPR_SPLIT_PRIO == 1
+#if CDPR_SPLIT_PRIO == 1 || CDPR_SPLIT_PRIO == 4
   __builtin_amdgcn_s_setprio(3);  // the estimator is the critical path: it wins the SIMD's issue arbitration
+#elif CDPR_SPLIT_PRIO == 3 || CDPR_SPLIT_PRIO == 5
+  __builtin_amdgcn_s_setprio(2);
 #endif
   const float4 p4 = load_slot(a.state, st, 4, off);
   if (lane < NP * kGeomFloatsPerPair) geo[lane] = gval;
@@ -682,8 +684,8 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     return;
   }
   // ---------------------------------------------------------------------------------------------------- controller wave
-#if CDPR_SPLIT_PRIO == 2
-  __builtin_amdgcn_s_setprio(3);
+#if CDPR_SPLIT_PRIO == 2 || CDPR_SPLIT_PRIO == 5
+  __builtin_amdgcn_s_setprio(3);  // (5: from its first instruction to the force hand-off)
 #endif
 #if CDPR_CTL_LOAD_DELAY > 0
   __builtin_amdgcn_s_sleep(CDPR_CTL_LOAD_DELAY);  // the estimator waves' two rows go first through the memory system
@@ -790,6 +792,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
     for (int k = 0; k < NP; ++k) actual[k] = actual_is_vel ? qd[k] : q[k];
     const int ring_slot = a.ring_slot;
     const bool is_force = PR && (meta & kMetaModeMask) == kMetaForce;
+#if CDPR_SPLIT_PRIO == 3 || CDPR_SPLIT_PRIO == 4
+    __builtin_amdgcn_s_setprio(3);  // (experiment) the forces are what the estimator wave will wait for
+#endif
     pid_pairs<NP, PR>(a, calls, actual_is_vel, desired, actual, win, ierr, f, e_new, dbg_p, dbg_i, dbg_d, is_force);
     dbg_wrote = (!PR || calls != 0) && !is_force;
     if (live) {
@@ -812,6 +817,9 @@ __global__ __launch_bounds__(128, 2) void cdpr_split_kernel(const StepArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the forces are in LDS (vector memory operations stay in flight)
   CDPR_CTL_STAMP(4);
+#if CDPR_SPLIT_PRIO >= 3
+  __builtin_amdgcn_s_setprio(0);
+#endif
   __builtin_amdgcn_s_barrier();        // #1
   __builtin_amdgcn_s_barrier();        // #2: the estimator wave has finished the tension distribution
   CDPR_CTL_STAMP(5);
