@@ -71,7 +71,14 @@ def main():
     unit = sys.argv[1] if len(sys.argv) > 1 else "k_step"
     pat = sys.argv[2] if len(sys.argv) > 2 else "cdpr_step_kernelILi8ELb1ELb1ELb0ELb1ELb0ELb0ELb0"  # the rollout kernel, n = 8, FK + TD
     asm = f"/tmp/region_{unit}.s"
-    r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS.split(), "-o", asm, unit + ".hip"], cwd=CSRC, capture_output=True, text=True)
+    # the unit's own flags (csrc/Makefile: NOVC_UNITS, NOSLP_UNITS), so that the budget is that of the shipped code
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    extra = []
+    for var, flags in (("NOVC_UNITS", ["-mllvm", "-disable-vector-combine"]), ("NOSLP_UNITS", ["-fno-slp-vectorize"])):
+        m = re.search(rf"^{var} := (.*)$", mk, re.M)
+        if m and unit in m.group(1).split():
+            extra += flags
+    r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS.split(), *extra, "-o", asm, unit + ".hip"], cwd=CSRC, capture_output=True, text=True)
     if r.returncode != 0:
         sys.exit(r.stderr[-2000:])
     text = open(asm).read().split("\n")
