@@ -5,7 +5,7 @@ loader and the function prototypes are in `_native.py`.
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_CABLES = 8
 MAX_D_BUFFER = 32
 MAX_D_DEGREE = 4
@@ -24,6 +24,7 @@ STAGE_FK = 0x1
 STAGE_TD = 0x2
 STAGE_PID_DEBUG = 0x4
 
+PLAN_FIRST_WORLD_STEP, PLAN_SCHEDULED, PLAN_ROLLOUT, PLAN_NOT_STEADY = 1, 2, 4, 8  # cdpr_plan_kernel flags
 MAP_AUTO = 0
 MAP_LANE_PER_ROBOT = 1
 MAP_LANE_PAIR = 2

@@ -19,7 +19,7 @@ EXPORTS = [
     "cdpr_set_velocity_command", "cdpr_set_position_command", "cdpr_set_velocity_command_device",
     "cdpr_set_position_command_device", "cdpr_bind_velocity_command_device", "cdpr_bind_position_command_device",
     "cdpr_set_velocity_command_masked", "cdpr_set_position_command_masked", "cdpr_set_force_command", "cdpr_set_force_command_device",
-    "cdpr_bind_force_command_device", "cdpr_set_force_command_masked", "cdpr_update", "cdpr_update_fused", "cdpr_observable_image_bytes", "cdpr_update_record", "cdpr_update_scheduled", "cdpr_update_scheduled_kind", "cdpr_decode_observables", "cdpr_decode_observables_f64", "cdpr_synchronize", "cdpr_mapping", "cdpr_step_count",
+    "cdpr_bind_force_command_device", "cdpr_set_force_command_masked", "cdpr_update", "cdpr_update_fused", "cdpr_observable_image_bytes", "cdpr_update_record", "cdpr_update_scheduled", "cdpr_update_scheduled_kind", "cdpr_decode_observables", "cdpr_decode_observables_f64", "cdpr_synchronize", "cdpr_mapping", "cdpr_plan_kernel", "cdpr_kernel_name", "cdpr_step_count",
     "cdpr_get_joint_states", "cdpr_get_platform_state", "cdpr_get_observables", "cdpr_get_pid_debug", "cdpr_get_fk_state", "cdpr_get_td_state", "cdpr_get_limit_state", "cdpr_get_observables_f64", "cdpr_get_raw_state_f64", "cdpr_set_platform_state_f64",
     "cdpr_get_raw_state", "cdpr_rollout_velocity", "cdpr_rollout_velocity_launch", "cdpr_rollout_velocity_fetch",
     "cdpr_rollout_velocity_device", "cdpr_device_malloc", "cdpr_device_free", "cdpr_device_upload", "cdpr_device_download",
@@ -79,6 +79,8 @@ def lib():
     L.cdpr_synchronize.argtypes = [H]
     L.cdpr_mapping.argtypes = [H]
     L.cdpr_mapping.restype = C.c_uint32
+    L.cdpr_plan_kernel.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.cdpr_kernel_name.argtypes = [H, C.c_char_p, C.c_size_t]
     L.cdpr_step_count.argtypes = [H]
     L.cdpr_step_count.restype = C.c_uint64
     L.cdpr_get_joint_states.argtypes = [H, fp, fp, fp]

@@ -19,6 +19,7 @@
 
 #include "../../include/cdpr.h"
 #include "cdpr_kernels.hpp"
+#include "cdpr_select.hpp"
 #include "cdpr_latch.hpp"
 #include "cdpr_solvers.hpp"
 
@@ -95,6 +96,9 @@ struct cdpr_engine {
     hipGraphExec_t exec;
   };
   std::vector<GraphEntry> graphs;
+  PlannedKernel last_kernel;  // what the last step launch ran on (cdpr_kernel_name)
+  KernelPlan plan;          // the routing cdpr_create took for this configuration (cdpr_select.hpp)
+  int cus = 256;
   bool use_graphs = true;
   bool pair_stream = true;  // cdpr_pair_stream_kernel serves the steady several-steps launches of lane-pair handles (CDPR_PAIR_STREAM=0: never; A/B and tests)
   float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
@@ -153,6 +157,7 @@ struct cdpr_engine {
   double* d_wtab64 = nullptr;    // [velocity | position] x [10][12]
   double* d_dbg64 = nullptr;
   void* d_unpack64 = nullptr;    // read-out scratch of the fp64 getters (bytes)
+  void* h_pub64 = nullptr;       // mapped pinned image the fp64 getters of small batches are gathered into (2 MiB)
   size_t unpack64_cap = 0;
   F64Args base64{};
   float* d_unpack = nullptr;     // read-out scratch (cdpr_get_*): robot-major copy of the requested fields, grow-only
@@ -212,68 +217,7 @@ int derivative_weights(uint32_t n, uint32_t degree, double* w) {
   return CDPR_OK;
 }
 
-bool mat3_inverse_sym(const double in[6], double out[6]) {
-  const double m[9] = {in[0], in[3], in[4], in[3], in[1], in[5], in[4], in[5], in[2]};
-  const double c0 = m[4] * m[8] - m[5] * m[7], c1 = m[5] * m[6] - m[3] * m[8], c2 = m[3] * m[7] - m[4] * m[6];
-  const double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
-  if (!(std::fabs(det) > 0.0)) return false;
-  out[0] = c0 / det;
-  out[1] = (m[0] * m[8] - m[2] * m[6]) / det;
-  out[2] = (m[0] * m[4] - m[1] * m[3]) / det;
-  out[3] = c1 / det;
-  out[4] = c2 / det;
-  out[5] = (m[1] * m[6] - m[0] * m[7]) / det;
-  return true;
-}
-
-// Returns "" when the configuration is acceptable, else the reason.
-std::string validate(const cdpr_config_t& c) {
-  char buf[256];
-  if (c.abi_version != CDPR_ABI_VERSION) return "abi_version mismatch";
-  if (c.n_cables < 1 || c.n_cables > CDPR_MAX_CABLES) {
-    snprintf(buf, sizeof buf, "invalid joint count %u (PLG.cpp:167-168; engine takes 1..%u)", c.n_cables, CDPR_MAX_CABLES);
-    return buf;
-  }
-  if (c.batch < 1 || c.batch > (1ull << 27)) return "batch out of range (1 .. 2^27 robots per handle)";
-  if (!(c.dt > 0.0)) return "dt must be > 0";
-  if (!(c.mass > 0.0)) return "mass must be > 0";
-  if (c.passive_damping < 0.0 || c.leg_inertia < 0.0 || c.cable_axial_mass < 0.0 || c.anchor_point_mass < 0.0 || c.anchor_inertia < 0.0)
-    return "lumped-leg terms (passive_damping, leg_inertia, cable_axial_mass, anchor_point_mass, anchor_inertia) must be >= 0";
-  double inv[6];
-  if (!mat3_inverse_sym(c.inertia, inv)) return "inertia is singular";
-  for (uint32_t i = 0; i < c.n_cables; ++i)
-    if (!(c.cable_ref_length[i] > 0.0)) return "cable_ref_length must be > 0";
-  const cdpr_pid_params_t* pids[2] = {&c.velocity_pid, &c.position_pid};
-  for (auto* p : pids) {
-    if (p->d_buffer_length < 2 || p->d_buffer_length > CDPR_MAX_D_BUFFER) return "d_buffer_length out of range";
-    if (p->d_degree < 1 || p->d_degree > CDPR_MAX_D_DEGREE || p->d_degree >= p->d_buffer_length) return "d_degree out of range";
-    if (p->p_filter.cascade > CDPR_MAX_CASCADE || p->d_filter.cascade > CDPR_MAX_CASCADE) return "filter cascade out of range";
-  }
-  if (c.precision != 0 && c.precision != 32 && c.precision != 64) return "precision must be 32 (or 0) or 64";
-  if (c.travel_lower > c.travel_upper) return "travel_lower must not exceed travel_upper";
-  if (c.travel_stop && !(c.travel_lower < c.travel_upper)) return "travel_stop needs travel limits (travel_lower < travel_upper)";
-  if (c.travel_stop > 64) return "travel_stop (sweeps of the joint stop) must be <= 64";
-  if ((c.stages & (CDPR_STAGE_FK | CDPR_STAGE_TD)) && c.n_cables < 6) return "FK / tension distribution need >= 6 cables";
-  if ((c.stages & CDPR_STAGE_FK) && (c.fk_max_iterations < 1 || c.fk_max_iterations > 64)) return "fk_max_iterations out of range";
-  if ((c.stages & CDPR_STAGE_TD) && !(c.td_f_max > c.td_f_min)) return "td_f_max must exceed td_f_min";
-  if (c.mapping > CDPR_MAP_LANE_PER_CABLE) return "unknown mapping";
-  if (c.mapping == CDPR_MAP_LANE_PAIR && c.n_cables != 4 && c.n_cables != 8) return "the lane-pair mapping needs 4 or 8 cables";
-  return "";
-}
-
-// What the register-resident fast path cannot represent (it keeps ONE Pid record per
-// cable: the active mode's): the position-hold branch (JFC.cpp:78-82) keeps both PIDs
-// alive in Velocity mode, filters add state, long windows do not fit the record.
-std::string fast_path_obstacle(const cdpr_config_t& c) {
-  if (!(c.velocity_epsilon < 0.0)) return "velocity_epsilon >= 0 (position-hold branch live)";
-  const cdpr_pid_params_t* pids[2] = {&c.velocity_pid, &c.position_pid};
-  for (auto* p : pids) {
-    if (p->p_filter.cascade || p->d_filter.cascade) return "biquad cascades enabled";
-    if (p->d_buffer_length > kWin + 1) return "derivative window longer than 11 samples";
-    if (!(std::fabs(p->cmd_limit) > 0.0)) return "cmd_limit == 0 (command clamp disabled, Pid.cpp:175)";
-  }
-  return "";
-}
+// (mat3_inverse_sym, validate_config, fast_path_obstacle: cdpr_select.hpp - pure functions, shared with cdpr_plan_kernel)
 
 void fill_pid(const cdpr_pid_params_t& p, double dt, StepArgs& k, float* wtab_host) {
   k.kf = (float)p.forward_gain;
@@ -541,6 +485,7 @@ void free_all(cdpr_engine* h) {
     if (p64) (void)hipFree(p64);
   if (h->h_fault) (void)hipHostFree(h->h_fault);
   if (h->h_pub) (void)hipHostFree(h->h_pub);
+  if (h->h_pub64) (void)hipHostFree(h->h_pub64);
   if (h->h_pub_done) (void)hipHostFree(h->h_pub_done);
   if (h->d_pub_arrivals) (void)hipFree(h->d_pub_arrivals);
   if (h->d_roll_ref) (void)hipFree(h->d_roll_ref);
@@ -649,6 +594,50 @@ inline void set_weight_row(const cdpr_engine* h, StepArgs& a) {
   memcpy(a.wrow, &h->wtab_host[(h->per_robot || h->mode == kModeVelocity) ? 0 : 1][slot * (kWin + 2)], sizeof a.wrow);
 }
 
+// The kernel a launch uses: the routing is planned_kernel's (cdpr_select.hpp: a pure function of the handle's plan and the
+// launch's shape, the same one cdpr_plan_kernel answers from without a GPU); here its answer becomes a function pointer.
+LaunchShape launch_shape(const cdpr_engine* h, int k, bool steady = false) {
+  LaunchShape s;
+  s.steps = k;
+  s.first_world = h->step == 0;
+  s.scheduled = h->sched_refresh != 0;
+  s.steady = steady;
+  return s;
+}
+StepKernel step_kernel_of(const cdpr_engine* h, const PlannedKernel& pk) {
+  const uint32_t n = h->n;
+  switch (pk.id) {
+    case KernelId::StepSingle: return pick_step_kernel(true, n, h->fk, h->td);
+    case KernelId::StepMulti: return pick_step_kernel(false, n, h->fk, h->td);
+    case KernelId::Lowreg: return pick_lowreg_kernel(n, h->td);
+    case KernelId::OnestepPersist: return pick_onestep_persist_kernel(n, h->fk, h->td);
+    case KernelId::Split: return pick_split_kernel(n);
+    case KernelId::Onestep: return pick_onestep_kernel(n, h->fk, h->td);
+    case KernelId::PhysStep: return pick_phys_kernel(n, h->fk, h->td, kPhysStep);
+    case KernelId::Rollout: return pick_rollout_kernel(n, h->fk, h->td);
+    case KernelId::PhysRollout: return pick_phys_kernel(n, h->fk, h->td, kPhysRollout);
+    case KernelId::PrSingle: return pick_pr_kernel(true, false, false, n, h->fk, h->td);
+    case KernelId::PrLowreg: return pick_pr_kernel(true, false, true, n, h->fk, h->td);
+    case KernelId::PrSplit: return pick_pr_split_kernel(n);
+    case KernelId::PrMulti: return pick_pr_kernel(false, false, false, n, h->fk, h->td);
+    case KernelId::PrRollout: return pick_pr_kernel(false, true, false, n, h->fk, h->td);
+    case KernelId::PairSingle: return pick_pair_kernel(true, n, h->fk, h->td);
+    case KernelId::PairMulti: return pick_pair_kernel(false, n, h->fk, h->td);
+    case KernelId::PairStream: return pick_pair_stream_kernel(n, h->mode == kModeVelocity);
+    case KernelId::Cable: return pick_cable_kernel(n, h->fk, h->td);
+    default: return nullptr;  // (general path and precision = 64: their own launch functions)
+  }
+}
+StepKernel select_step_kernel(const cdpr_engine* h, int k, bool steady = false) { return step_kernel_of(h, planned_kernel(h->plan, launch_shape(h, k, steady))); }
+// May a launch of k > 1 world steps with the arguments `a` (flags, pid_calls, pointers set) run on cdpr_pair_stream_kernel?
+// That kernel has no branch for anything but the steady state of a plain handle (cdpr_step_kernel_pair.hpp): every
+// condition below is one the general several-steps kernel tests per step instead (LaunchShape::steady).  CDPR_PAIR_STREAM=0: never (A/B).
+bool pair_stream_steady(const cdpr_engine* h, const StepArgs& a) {
+  return h->step != 0 && h->mode != kModeForce && a.pid_calls >= a.nbuf && h->cfg.publish_period == 0.0 && !a.dbg && !a.travel_on &&
+         !(a.vel_limit > 0.f) && !a.unilateral && a.effort >= 0.f && a.clamp_cmd && !h->sched_ready;
+}
+uint32_t step_block_threads(const cdpr_engine* h, int k) { return planned_kernel(h->plan, launch_shape(h, k)).block; }
+
 // The controller half of a general-path launch: records, latched commands, gains.
 GenCtl general_ctl(const cdpr_engine* h) {
   GenCtl g{};
@@ -705,11 +694,12 @@ int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
-    // one step per launch on FK + TD handles up to two workgroups per CU: the role-split form (cdpr_general_split.hpp)
-    const bool gsplit = h->gen_split && k == 1;
-    // ... and beyond: the lean role-split kernel (two waves per SIMD; the rare controller paths by call)
-    const bool glean = h->gen_lean && k == 1 && h->step != 0;  // (world step 0 runs no controller: the one-wave kernel's case)
-    GenKernel kern = gsplit ? pick_gen_split11(h->n) : glean ? pick_gen_lean11(h->n) : pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11, k == 1);
+    // one step per launch on FK + TD handles up to two workgroups per CU: the role-split form (cdpr_general_split.hpp), beyond: the
+    // lean role-split kernel (two waves per SIMD; the rare controller paths by call) - planned_kernel, cdpr_select.hpp
+    const PlannedKernel pk = planned_kernel(h->plan, launch_shape(h, k));
+    const bool gsplit = pk.id == KernelId::GenSplit, glean = pk.id == KernelId::GenLean;
+    GenKernel kern = gsplit ? pick_gen_split11(h->n) : glean ? pick_gen_lean11(h->n) : pick_gen_kernel(h->n, h->fk, h->td, false, h->glay.nb > 11, pk.id == KernelId::GenOne);
+    h->last_kernel = pk;
     a.nsteps = k;
     a.flags = (h->step == 0) ? kFlagFirstWorldStep : 0u;
     g.now_step = (int)h->step;
@@ -731,34 +721,6 @@ int run_steps_general(cdpr_engine* h, int nsteps, int per_launch, float4* record
   if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
     HIP_TRY(h, hipMemcpyAsync(h->d_obs, record + (size_t)(nsteps - 1) * image, image * sizeof(float4), hipMemcpyDeviceToDevice, h->stream));
   return CDPR_OK;
-}
-
-// The kernel a fast-path launch of k world steps uses on this handle, and its workgroup size.
-StepKernel select_step_kernel(const cdpr_engine* h, int k) {
-  if (h->per_robot)
-    return (k == 1) ? (h->lowreg ? pick_pr_kernel(true, false, true, h->n, h->fk, h->td)
-                                 : h->split ? pick_pr_split_kernel(h->n) : pick_pr_kernel(true, false, false, h->n, h->fk, h->td))
-                    : pick_pr_kernel(false, false, false, h->n, h->fk, h->td);
-  if (h->lane_cable) return pick_cable_kernel(h->n, h->fk, h->td);
-  return h->phys ? pick_phys_kernel(h->n, h->fk, h->td, kPhysStep)
-         : h->lane_pair ? pick_pair_kernel(k == 1, h->n, h->fk, h->td)
-                        : ((k == 1) ? (h->persist ? pick_onestep_persist_kernel(h->n, h->fk, h->td)
-                                                 : h->lowreg ? pick_lowreg_kernel(h->n, h->td)
-                                                 : h->split ? pick_split_kernel(h->n)
-                                                 : (h->onestep_v2 ? pick_onestep_kernel(h->n, h->fk, h->td) : pick_step_kernel(true, h->n, h->fk, h->td)))
-                                    : pick_step_kernel(false, h->n, h->fk, h->td));
-}
-// May a launch of k > 1 world steps with the arguments `a` (flags, pid_calls, pointers set) run on cdpr_pair_stream_kernel?
-// That kernel has no branch for anything but the steady state of a plain handle (cdpr_step_kernel_pair.hpp): every
-// condition below is one the general several-steps kernel tests per step instead.  CDPR_PAIR_STREAM=0: never (A/B).
-bool pair_stream_ok(const cdpr_engine* h, const StepArgs& a, int k) {
-  return h->pair_stream && h->lane_pair && !h->per_robot && !h->phys && !h->lane_cable && !h->fk && !h->td && (h->n == 4 || h->n == 8) && k > 1 &&
-         h->step != 0 && h->mode != kModeForce && a.pid_calls >= a.nbuf && h->cfg.publish_period == 0.0 && !a.dbg && !a.travel_on &&
-         !(a.vel_limit > 0.f) && !a.unilateral && a.effort >= 0.f && a.clamp_cmd && !h->sched_ready;
-}
-uint32_t step_block_threads(const cdpr_engine* h, int k) {
-  // the role-split kernel runs two waves (estimator, controller) per 64 robots
-  return (k == 1 && h->split && !h->phys && !h->lane_pair && !h->lowreg && !h->persist) ? 128u : 64u;
 }
 
 // cdpr_create pays the cold costs of the handle's one-step kernel (the runtime loads a kernel's code object and sets up
@@ -882,21 +844,35 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   const int ring_env = [] { const char* v = std::getenv("CDPR_F64_RING_LDS"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
   const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
-  const bool ring_lds = ring_env >= 0 ? ring_env != 0 : h->batch <= 32768u;
   a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
-  const bool hold_full = h->hold64 && (a.any_cas || a.any_noclamp);  // the HOLD = 2 instantiations: cascades, cmd_limit 0
-  F64Kernel kern = h->hold64 ? (pr ? pick_f64_hold_pr_kernel(n, hold_full) : pick_f64_hold_kernel(n, hold_full))
-                   : h->tstop64 ? pick_f64_tstop_kernel(n)
-                             : pr ? pick_f64_pr_kernel(n, ring_lds) : pick_f64_kernel(n, ring_lds, ring_lds && (jc_env >= 0 ? jc_env != 0 : h->batch <= 16384u));
+  const bool hold_full = h->plan.hold_full;  // the HOLD = 2 instantiations: cascades, cmd_limit 0
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
-  const bool sp_lean = sp_env >= 0 ? sp_env == 2 : h->batch > 16384u;
-  F64Kernel split_kern = (a.fk && a.td && sp_env != 0 && !pr && !h->tstop64) ? (h->hold64 ? pick_f64_split_hold_kernel(n, sp_lean, hold_full) : pick_f64_split_kernel(n, sp_lean))
-                                                               : nullptr;  // (per-robot handles: the one-wave kernel)
+  // The routing itself: planned_kernel (cdpr_select.hpp) for a one-step and for a several-steps launch of this handle
+  LaunchShape s1 = launch_shape(h, 1), sk = launch_shape(h, 2);
+  s1.f64_ring_lds = sk.f64_ring_lds = ring_env, s1.f64_jcache = sk.f64_jcache = jc_env, s1.f64_split = sk.f64_split = sp_env;
+  const PlannedKernel pk1 = planned_kernel(h->plan, s1), pkk = planned_kernel(h->plan, sk);
+  auto f64_kernel_of = [&](const PlannedKernel& q) -> F64Kernel {
+    switch (q.id) {
+      case KernelId::F64Split: return pick_f64_split_kernel(n, q.f64_lean);
+      case KernelId::F64SplitHold: return pick_f64_split_hold_kernel(n, q.f64_lean, hold_full);
+      case KernelId::F64Hold: return pick_f64_hold_kernel(n, hold_full);
+      case KernelId::F64HoldPr: return pick_f64_hold_pr_kernel(n, hold_full);
+      case KernelId::F64Tstop: return pick_f64_tstop_kernel(n);
+      case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
+      default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);
+    }
+  };
+  const bool split1 = pk1.id == KernelId::F64Split || pk1.id == KernelId::F64SplitHold;
+  F64Kernel split_kern = split1 ? f64_kernel_of(pk1) : nullptr;  // (per-robot handles: the one-wave kernel)
   // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
   // (14.4 against 20.8 us per step at one robot x 8, same bits): a fused update then runs as one-step launches
-  if (split_kern && !sp_lean) per_launch = 1;
+  const bool fused_as_single = pkk.id == KernelId::F64Split || pkk.id == KernelId::F64SplitHold;
+  if (fused_as_single) per_launch = 1;
+  PlannedKernel one_wave = pkk;  // the one-wave kernel of this handle (what a several-steps launch runs, or would run)
+  if (fused_as_single) { LaunchShape so = sk; so.f64_split = 0; one_wave = planned_kernel(h->plan, so); }
+  F64Kernel kern = f64_kernel_of(one_wave);
   int done = 0;
   while (done < nsteps) {
     const int k = std::min(per_launch, nsteps - done);
@@ -916,10 +892,13 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
         a.publish_mask |= (1ull << j);
       }
     }
-    if (k == 1 && split_kern)
+    if (k == 1 && split_kern) {
       hipLaunchKernelGGL(split_kern, dim3((h->batch + 63u) / 64u), dim3(128), 0, h->stream, a);
-    else
+      h->last_kernel = pk1;
+    } else {
       hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
+      h->last_kernel = one_wave;
+    }
     HIP_TRY(h, hipGetLastError());
     ++h->launches;
     h->step += (uint64_t)k;
@@ -959,14 +938,61 @@ int fetch_rows64(cdpr_engine* h, const double* rows, uint32_t first_row, uint32_
 }
 
 // the five observable arrays of an fp64 handle (any may be null), double or rounded to float
+// The five observable arrays of a precision = 64 handle in ONE device round trip (round 6; five unpack launches, five copies and
+// five waits before: 88 us per world step for one robot with the host in the loop): one gather launch writes them - small
+// batches straight into a mapped pinned host image, larger ones into device scratch followed by one copy each - one wait.
 int fetch_observables64(cdpr_engine* h, void* position, void* velocity, void* effort, void* pose7, void* twist6, bool as_float) {
   const uint32_t n = h->n;
-  int rc = fetch_rows64(h, h->d_obs64, 16, n, position, as_float);
-  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 16 + n, n, velocity, as_float);
-  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 16 + 2 * n, n, effort, as_float);
-  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 0, 7, pose7, as_float);
-  if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 7, 6, twist6, as_float);
-  return rc;
+  void* dst[5] = {position, velocity, effort, pose7, twist6};
+  const uint32_t first[5] = {16u, 16u + n, 16u + 2u * n, 0u, 7u}, width[5] = {n, n, n, 7u, 6u};
+  Unpack64MultiArgs u{};
+  u.rows = h->d_obs64;
+  u.stride = h->stride;
+  u.batch = h->batch;
+  u.as_float = as_float ? 1 : 0;
+  void* want[5];
+  uint32_t cum = 0;
+  size_t off = 0;
+  for (int i = 0; i < 5; ++i) {
+    if (!dst[i]) continue;
+    const uint32_t k = u.nseg++;
+    u.first_row[k] = first[i], u.width[k] = width[i], u.cum[k] = cum, u.off[k] = (uint32_t)off;
+    want[k] = dst[i];
+    cum += width[i];
+    off += (size_t)h->batch * width[i];
+  }
+  if (u.nseg == 0) return CDPR_OK;
+  u.total_width = cum;
+  const size_t esz = as_float ? sizeof(float) : sizeof(double), bytes = off * esz;
+  if (off >= (1ull << 32)) {  // element offsets are 32-bit
+    int rc = CDPR_OK;
+    for (int i = 0; i < 5 && rc == CDPR_OK; ++i) rc = fetch_rows64(h, h->d_obs64, first[i], width[i], dst[i], as_float);
+    return rc;
+  }
+  const bool pinned = bytes <= (2u << 20);
+  if (pinned) {
+    if (!h->h_pub64) HIP_TRY(h, hipHostMalloc(&h->h_pub64, 2u << 20, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(h, hipHostGetDevicePointer(&u.out, h->h_pub64, 0));
+  } else {
+    if (h->unpack64_cap < bytes) {
+      HIP_TRY(h, wait_stream(h));
+      if (h->d_unpack64) (void)hipFree(h->d_unpack64);
+      h->d_unpack64 = nullptr;
+      h->unpack64_cap = 0;
+      HIP_TRY(h, hipMalloc(&h->d_unpack64, bytes));
+      h->unpack64_cap = bytes;
+    }
+    u.out = h->d_unpack64;
+  }
+  hipLaunchKernelGGL(cdpr_unpack64_multi_kernel, dim3((uint32_t)(((size_t)h->batch * cum + 255) / 256)), dim3(256), 0, h->stream, u);
+  HIP_TRY(h, hipGetLastError());
+  if (!pinned)
+    for (uint32_t k = 0; k < u.nseg; ++k)
+      HIP_TRY(h, hipMemcpyAsync(want[k], static_cast<const char*>(h->d_unpack64) + (size_t)u.off[k] * esz, (size_t)h->batch * u.width[k] * esz, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, wait_stream(h));
+  if (pinned)
+    for (uint32_t k = 0; k < u.nseg; ++k) memcpy(want[k], static_cast<const char*>(h->h_pub64) + (size_t)u.off[k] * esz, (size_t)h->batch * u.width[k] * esz);
+  return CDPR_OK;
 }
 
 int set_platform_state64(cdpr_engine* h, const double* pose7, const double* twist6) {
@@ -1241,19 +1267,18 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
     // a launch over a command schedule always runs on the several-steps kernel, even for one step: only that one reads the
     // schedule, its mailbox and kFlagPublishAll
     const int kk = h->sched_refresh ? std::max(k, 2) : k;
-    StepKernel kern = select_step_kernel(h, kk);
-    const dim3 block(step_block_threads(h, kk));
-    const bool stream = pair_stream_ok(h, a, kk);  // steady state of a plain lane-pair handle: the branch-free several-steps kernel
-    auto weights_for = [&](StepArgs& x) {          // ... which reads the weights by AGE from the row of ring position 0
+    const PlannedKernel pk = planned_kernel(h->plan, launch_shape(h, kk, pair_stream_steady(h, a)));
+    StepKernel kern = step_kernel_of(h, pk);
+    const dim3 block(pk.block);
+    const bool stream = pk.id == KernelId::PairStream;  // steady state of a plain lane-pair handle: the branch-free several-steps kernel
+    auto weights_for = [&](StepArgs& x) {                // ... which reads the weights by AGE from the row of ring position 0
       const int slot = x.ring_slot;
       if (stream) x.ring_slot = 0;
       set_weight_row(h, x);
       x.ring_slot = slot;
     };
-    if (stream) {
-      kern = pick_pair_stream_kernel(h->n, h->mode == kModeVelocity);
-      weights_for(a);
-    }
+    if (stream) weights_for(a);
+    h->last_kernel = pk;
 
     // Steady state (every step published, derivative window full, not t = 0): the next launches are
     // byte-identical, so replay them from a captured hipGraph instead of paying a host launch each.
@@ -1452,48 +1477,13 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     g_create_error = "null argument";
     return CDPR_ERR_INVALID;
   }
-  std::string why = validate(*cfg);
-  if (!why.empty()) {
-    g_create_error = why;
-    return CDPR_ERR_INVALID;
+  // the routing of this configuration (which kernel family, which mapping): cdpr_select.hpp, a pure function of the
+  // configuration shared with cdpr_plan_kernel; 256 CUs assumed until the device is known (re-planned below)
+  KernelPlan plan = plan_kernels(*cfg);
+  if (plan.rc != CDPR_OK) {
+    g_create_error = plan.error;
+    return plan.rc;
   }
-  // the PHYS instantiations carry the lumped legs and the joint stop
-  const bool phys_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 ||
-                        cfg->anchor_inertia != 0.0 || cfg->travel_stop != 0;
-  // per-robot commands run on the register-resident kernels too (PR instantiations); only what those cannot represent
-  // (hold branch, cascades, long windows, cmdLimit 0), and per-robot modes combined with the lumped-leg physics or with
-  // two Pids that fit different derivative windows, take the general controller path
-  const bool pr_windows_differ = cfg->velocity_pid.d_buffer_length != cfg->position_pid.d_buffer_length || cfg->velocity_pid.d_degree != cfg->position_pid.d_degree;
-  const bool general_cfg = !fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && (phys_cfg || pr_windows_differ));
-  // The per-robot kernels of the register-resident path do not clear a reset Pid's derivative ring (the latch zeroes only
-  // the integral rows) and a velocity rollout keeps stale position-Pid errors in it: that is correct only while
-  // full = calls >= nbuf hides every stale slot, i.e. nbuf <= kWin + 1 and one window shared by both Pids.  Both follow
-  // from the routing above; checked here so that a change to the routing cannot silently break the kernels' invariant.
-  if (!general_cfg && cfg->per_robot_commands != 0 &&
-      (pr_windows_differ || cfg->velocity_pid.d_buffer_length > (uint32_t)kWin + 1 || cfg->position_pid.d_buffer_length > (uint32_t)kWin + 1)) {
-    g_create_error = "internal: per-robot handle routed to the register-resident path with windows it cannot hold";
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  // precision = 64 with the hold branch as the ONLY thing the register-resident path cannot represent: the HOLD instantiations of the
-  // fp64 kernel (uniform-mode handles; round 5)
-  // The HOLD instantiations are the fp64 kernels' whole Pid::update: besides the hold branch they carry the biquad cascades and
-  // cmd_limit = 0 (the Pid then returns its stale mCmd member plus the anti-windup increment, Pid.cpp:175-184: a row of its own).
-  // What stays out: derivative windows beyond 11 samples.
-  const bool windows_fit = cfg->velocity_pid.d_buffer_length <= (uint32_t)kWin + 1 && cfg->position_pid.d_buffer_length <= (uint32_t)kWin + 1;
-  const bool clean64 = cfg->precision == 64 && windows_fit;
-  const bool hold64 = clean64 && !phys_cfg && (!fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && pr_windows_differ));  // (per-robot modes too:
-                                                                                                    // each Pid has its own rows and its own window)
-  // ... and with the joint stop as the only optional physics: the TSTOP instantiations (uniform-mode handles without the hold branch)
-  const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
-  const bool tstop64 = clean64 && cfg->travel_stop != 0 && !lumped_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;
-  if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64) {
-    g_create_error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) with windows to 11 samples and the joint stop "
-                     "on uniform-mode handles without those (no lumped legs): " +
-                     (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
-                              : std::string("optional physics"));
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  const bool general = general_cfg && cfg->precision != 64;  // (a precision = 64 handle that got here runs on the fp64 kernels' own instantiations)
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -1516,88 +1506,38 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   // alike; smaller batches are not padded (16 384: a pad costs 3-4 %).  CDPR_STRIDE_PAD=<columns> forces a pad (A/B).
   if (h->stride % 131072u == 0u) h->stride += 128u;
   if (const char* sp = std::getenv("CDPR_STRIDE_PAD")) h->stride = ((h->batch + 63u) & ~63u) + ((uint32_t)(std::max(0L, std::atol(sp)) + 63L) & ~63u);
-  h->fk = (cfg->stages & CDPR_STAGE_FK) != 0;
-  h->td = (cfg->stages & CDPR_STAGE_TD) != 0;
-  h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
-  h->general = general;  // (precision = 64 with the hold branch: the fp64 kernel's HOLD instantiations, not the fp32 general path)
-  h->fp64 = cfg->precision == 64;
-  h->hold64 = hold64;
-  h->tstop64 = tstop64;
-  h->per_robot = cfg->per_robot_commands != 0;
-  h->phys = phys_cfg;
   {
-    // Mapping: measured on MI355X (scripts/ab_bench.py), two lanes per robot win while the batch leaves SIMDs
-    // under-filled (16 384 x 8 cables: 9.0 vs 10.2 us/step; 4 096 x 4: 3.0 vs 3.4) and lose from 65 536 robots on
-    // (16.4 vs 15.7 us/step: the duplicated 6x6 solves cost more than the second wave per SIMD hides), so AUTO
-    // takes the pair mapping up to 32 768 robots at n = 8 (32 768: 9.5 vs 10.5 us/step; 49 152: 13.6 vs 11.2) and up
-    // to 65 536 at n = 4 (65 536: 4.9 vs 5.2; 131 072: 8.5 vs 8.1).  CDPR_MAPPING=1|2 overrides AUTO (for A/B runs).
-    const bool can_pair = !general && !h->phys && !h->per_robot && (cfg->n_cables == 4 || cfg->n_cables == 8);
-    uint32_t mapping = cfg->mapping;
-    if (mapping == CDPR_MAP_AUTO) {
-      const char* mv = std::getenv("CDPR_MAPPING");
-      if (mv && (mv[0] == '1' || mv[0] == '2' || mv[0] == '3')) mapping = (uint32_t)(mv[0] - '0');
-    }
-    // FK + TD handles: the role-split kernel (cdpr_split_kernel: two waves per 64 robots with different roles) beats both
-    // mappings up to one robot per hardware lane (profiles/r02o_split_kernel_batch_scan.txt, us/step pair or one-wave ->
-    // split: 4 096: 7.6 -> 7.2; 16 384: 8.4 -> 7.7; 32 768: 9.7 -> 9.1; 49 152: 10.8 -> 9.7; 65 536: 11.9 -> 10.9), so AUTO
-    // keeps those on the lane-per-robot mapping; above ~90 000 robots the low-register kernel takes over (below)
-    const bool split_case = !general && !h->phys && (cfg->stages & CDPR_STAGE_FK) && (cfg->stages & CDPR_STAGE_TD) && cfg->n_cables >= 6;
-    if (mapping == CDPR_MAP_AUTO)
-      mapping = (can_pair && !split_case && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
-    if (h->fp64) mapping = CDPR_MAP_LANE_PER_ROBOT;  // one plain kernel
-    // a mapping the CONFIGURATION asks for by name is served or refused; the CDPR_MAPPING environment override (A/B runs over
-    // whole test suites) keeps falling back to one lane per robot where the requested mapping does not exist
-    const bool can_cable = !general && !h->phys && !h->per_robot;
-    if (!h->fp64 && ((cfg->mapping == CDPR_MAP_LANE_PAIR && !can_pair) || (cfg->mapping == CDPR_MAP_LANE_PER_CABLE && !can_cable))) {
-      g_create_error = std::string(cfg->mapping == CDPR_MAP_LANE_PAIR ? "CDPR_MAP_LANE_PAIR" : "CDPR_MAP_LANE_PER_CABLE") +
-                       " is not available with the general controller path, the optional physics terms or per_robot_commands" +
-                       (cfg->mapping == CDPR_MAP_LANE_PAIR ? " (and needs 4 or 8 cables)" : "") + "; use CDPR_MAP_AUTO or CDPR_MAP_LANE_PER_ROBOT";
-      delete h;
-      return CDPR_ERR_UNSUPPORTED;
-    }
-    h->lane_pair = (mapping == CDPR_MAP_LANE_PAIR) && can_pair;
-    // one lane per cable: any cable count; not with the optional physics, per-robot modes or the general path (those
-    // handles silently keep the lane-per-robot mapping, as the lane-pair request does where it cannot be served)
-    h->lane_cable = (mapping == CDPR_MAP_LANE_PER_CABLE) && can_cable;
-    // more robots than hardware lanes (65 536): two co-resident waves per SIMD pay, if the kernel fits twice.
-    // Measured (scripts/ab_bench.py with CDPR_LOWREG=0|1, us/step without -> with): 65 536: 13.4 -> 13.8; 98 304: 26.0 -> 21.6;
-    // 131 072: 29.9 -> 27.0; 196 608: 41.2 -> 36.3; 524 288: 89.9 -> 79.0 (6.6e9 state-steps/s)
-    h->lowreg = !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6 && cfg->batch > 90112u;  // crossover measured: profiles/r03j_cliff_scan.txt
-    if (const char* lr = std::getenv("CDPR_LOWREG"))
-      h->lowreg = (lr[0] == '1') && !general && !h->phys && !h->lane_pair && !h->lane_cable && (cfg->stages & CDPR_STAGE_FK) && cfg->n_cables >= 6;
-    // Between one and a few robots per hardware lane a single launch is a bulk-synchronous load -> compute -> store in which
-    // the co-resident waves of a SIMD start together: their memory phases coincide and their compute phases coincide, so two
-    // waves per SIMD cost 2.1-2.7x one (rocprofv3 PMC at 65 536 / 98 304 / 131 072 / 196 608: the vector pipes are busy 45 % of
-    // the launch at one AND at two waves per SIMD, profiles/r04_cliff_analysis.txt).  Round 4 measured the two obvious
-    // mitigations and keeps neither as a default: the same step as back-to-back launches over blocks of <= 65 536 robots
-    // (CDPR_CHUNK=N; bit-identical, tested) is within +-4 % of the single launch at every size and 20-30 % slower from 262 144
-    // robots on, where a large launch de-phases by itself (waves start as slots free up) and streams at the copy rate; delaying
-    // the second wave slot's workgroups by 2-6 us (s_sleep) changes nothing.  What would: a persistent kernel that prefetches
-    // the next block's rows while it computes.
-    if (const char* ck = std::getenv("CDPR_CHUNK")) {  // A/B: 0 = never, N = blocks of at most N robots whatever the batch
-      const long v = std::atol(ck);
-      h->chunk = (v > 0 && !general && !h->fp64 && !h->lane_pair && !h->lane_cable) ? (uint32_t)((v + 63) & ~63L) : 0u;
-    }
-    if (h->chunk && h->chunk <= 90112u && !std::getenv("CDPR_LOWREG")) h->lowreg = false;  // every block runs in the role-split kernel's range
-    // the persistent one-wave kernel (cdpr_onestep_kernel<..., PERSIST>): uniform-mode handles on the lane-per-robot mapping
-    const bool can_persist = !general && !h->phys && !h->lane_pair && !h->lane_cable && cfg->per_robot_commands == 0 && cfg->precision != 64 && !h->chunk;
-    h->persist = false;
-    if (const char* ps = std::getenv("CDPR_PERSIST")) h->persist = (ps[0] == '1') && can_persist;
-    if (h->persist) {
-      h->lowreg = false;
-      int cus = 0;
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-      h->persist_grid = (uint32_t)cus * 4u;
-      if (const char* pg = std::getenv("CDPR_PERSIST_GRID")) h->persist_grid = (uint32_t)std::max(1L, std::atol(pg));
-    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    plan = plan_kernels(*cfg, cus);  // (the general path's role-split limit follows the device's CU count)
+    h->cus = cus;
   }
-  // second-generation one-step kernel: wins wherever there is a Newton stage to hide the controller rows under, and
-  // without one from ~32 768 robots on (65 536 x 8, no FK: 6.3 vs 7.0 us/step); small batches without FK are pure
-  // latency and the extra LDS round trip loses (4 096 x 4: 4.18 vs 3.99 us by rocprofv3)
-  h->onestep_v2 = h->fk || cfg->batch > 32768u;
-  if (const char* os = std::getenv("CDPR_ONESTEP")) h->onestep_v2 = (os[0] != '1');
-  h->split = (h->onestep_v2 || h->per_robot) && !general && !h->phys && !h->lane_pair && !h->lane_cable && !h->lowreg && !h->persist && h->fk && h->td && cfg->n_cables >= 6;
-  if (const char* sp = std::getenv("CDPR_SPLIT")) h->split = h->split && sp[0] != '0';
+  h->plan = plan;
+  const bool general = plan.general;
+  h->fk = plan.fk;
+  h->td = plan.td;
+  h->dbg = (cfg->stages & CDPR_STAGE_PID_DEBUG) != 0;
+  h->general = plan.general;  // (precision = 64 with the hold branch: the fp64 kernel's HOLD instantiations, not the fp32 general path)
+  h->fp64 = plan.fp64;
+  h->hold64 = plan.hold64;
+  h->tstop64 = plan.tstop64;
+  h->per_robot = plan.per_robot;
+  h->phys = plan.phys;
+  h->lane_pair = plan.lane_pair;
+  h->lane_cable = plan.lane_cable;
+  h->lowreg = plan.lowreg;
+  h->chunk = plan.chunk;
+  h->persist = plan.persist;
+  if (h->persist) {
+    h->persist_grid = (uint32_t)h->cus * 4u;
+    if (const char* pg = std::getenv("CDPR_PERSIST_GRID")) h->persist_grid = (uint32_t)std::max(1L, std::atol(pg));
+  }
+  h->onestep_v2 = plan.onestep_v2;
+  h->split = plan.split;
+  h->gen_split = plan.gen_split;
+  h->gen_lean = plan.gen_lean;
+  h->gen_hot = plan.gen_hot;
+  h->pair_stream = plan.pair_stream;
   h->n_state = general ? plat_slots(h->fk) : state_slots((int)h->n, h->fk);
   h->n_obs = obs_slots((int)h->n);
   memset(&h->base, 0, sizeof h->base);
@@ -1609,8 +1549,6 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   {
     const char* ng = std::getenv("CDPR_NO_GRAPH");
     h->use_graphs = !(ng && ng[0] == '1');
-    const char* ps = std::getenv("CDPR_PAIR_STREAM");
-    h->pair_stream = !(ps && ps[0] == '0');
   }
 
   auto fail = [&](const char* what, hipError_t code) {
@@ -1699,27 +1637,6 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     h->glay.nb = (int)std::max(cfg->velocity_pid.d_buffer_length, cfg->position_pid.d_buffer_length);
     h->glay.ncas = (int)std::max(std::max(cfg->velocity_pid.p_filter.cascade, cfg->velocity_pid.d_filter.cascade),
                                  std::max(cfg->position_pid.p_filter.cascade, cfg->position_pid.d_filter.cascade));
-    {
-      // role-split one-step kernel: compiled for one workgroup per pair of SIMDs (each wave may use the whole register
-      // file), so it serves batches up to two workgroups of 64 robots per CU; CDPR_GEN_SPLIT=0|1 overrides (A/B)
-      int cus = 0;
-      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-      const bool can = h->fk && h->td && h->n >= 6 && h->glay.nb <= 11;
-      h->gen_split = can && cfg->batch <= (uint32_t)cus * 128u;
-      if (const char* gs = std::getenv("CDPR_GEN_SPLIT")) h->gen_split = can && gs[0] == '1';
-      // beyond that: the lean role-split kernel (not with the optional physics: it carries none); CDPR_GEN_LEAN=0|1 overrides
-      // (A/B; 1 also below the role-split kernel's limit)
-      h->gen_lean = can && !h->phys && !h->gen_split;
-      if (const char* gl = std::getenv("CDPR_GEN_LEAN")) {
-        h->gen_lean = can && !h->phys && gl[0] == '1';
-        if (h->gen_lean) h->gen_split = false;
-      }
-      // hot rows: where the lean kernel steps the handle (beyond 32 768 robots: 176 B per robot-step less traffic at the same
-      // time per step; below, a workgroup per CU or less, the extra loads and the restore cost 0.5 us of a 9 us step);
-      // they take effect on handles whose configuration admits the consecutive-call branches (GenCtl::simple_ok)
-      h->gen_hot = h->gen_lean;
-      if (const char* gh = std::getenv("CDPR_GEN_HOT")) h->gen_hot = h->gen_lean && gh[0] != '0';  // (the role-split kernel carries no code for them)
-    }
     const size_t rec_bytes = h->glay.bytes(h->stride);
     if (rec_bytes >= (1ull << 32)) {  // the record buffer is addressed with 32-bit offsets (one buffer resource)
       g_create_error = "general controller path: the controller records of this batch pass 4 GiB; split the batch over several handles";
@@ -2083,6 +2000,29 @@ static int scheduled_update(cdpr_engine* h, uint32_t kind, int nsteps, int refre
     *pending[kind] = true;
     *masked[kind] = false;
   };
+  // Per-robot handles: a command of the SAME kind still pending at the call (cdpr_set_*_command[_masked] without an update since)
+  // would have to reach its robots before batch 0 reaches batch 0's - B independent plugins each keep the last message that
+  // reached THEM.  Staging batch 0 would overwrite it silently: refused, the caller latches it with cdpr_update first
+  // or leaves it out.  (Uniform handles: the later message of a kind replaces the earlier one, as in the plugin, PLG.cpp:67-83.)
+  if (h->per_robot && *pending[kind]) {
+    h->err = "cdpr_update_scheduled_kind: a command of the same kind is still pending on this per-robot handle; step it in with cdpr_update first";
+    return CDPR_ERR_INVALID;
+  }
+  // whatever way this function is left, nothing of the caller's schedule stays staged in the handle: an error return must not
+  // leave `pending` set on pointers the caller may free, nor the schedule fields set for the next plain cdpr_update
+  struct Unstage {
+    cdpr_engine* h; uint32_t kind; bool* pend; const float** ext; bool ok = false;
+    ~Unstage() {
+      h->sched_rows[kind] = nullptr;
+      h->sched_mask[kind] = nullptr;
+      h->sched_refresh = 0;
+      h->sched_ready = nullptr;
+      if (!ok) {  // an error in between: drop the batch that was staged but not latched
+        if (*pend && (h->per_robot || ext[1])) *pend = false;
+        ext[1] = nullptr;
+      }
+    }
+  } unstage{h, kind, pending[kind], ext[kind]};
   const bool in_launch = !(h->general || h->fp64 || h->per_robot || h->lane_cable) && h->cfg.publish_period == 0.0;
   bool others = false;
   for (uint32_t k = 0; k < 3; ++k) others = others || (k != kind && *pending[k]);
@@ -2125,6 +2065,7 @@ static int scheduled_update(cdpr_engine* h, uint32_t kind, int nsteps, int refre
     j += (rest + refresh_steps - 1) / refresh_steps;
     if (j >= nbatches) ext[kind][0] = d_commands + (size_t)(nbatches - 1) * batch_floats;  // the batch that stays latched
   }
+  unstage.ok = true;
   return CDPR_OK;
 }
 
@@ -2212,11 +2153,44 @@ static int check_fault(cdpr_engine* h) {
   return CDPR_OK;
 }
 
+// every path that hands results out ends here (include/cdpr.h: after a mailbox timeout cdpr_synchronize, the getters and
+// cdpr_device_download return CDPR_ERR_DEVICE until cdpr_reset - the fp64 read-outs and the FK / TD / limit / debug getters too)
+static int checked(cdpr_engine* h, int rc) { return rc != CDPR_OK ? rc : check_fault(h); }
+
 int cdpr_synchronize(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   HIP_TRY(h, wait_stream(h));
   return check_fault(h);
+}
+
+static int copy_name(const std::string& text, char* name, size_t len) {
+  if (!name || len == 0) return CDPR_ERR_INVALID;
+  const size_t k = std::min(text.size(), len - 1);
+  memcpy(name, text.data(), k);
+  name[k] = 0;
+  return CDPR_OK;
+}
+
+int cdpr_plan_kernel(const cdpr_config_t* cfg, int steps_per_launch, uint32_t flags, char* name, size_t len) {
+  if (!cfg || !name || len == 0 || steps_per_launch < 1) return CDPR_ERR_INVALID;
+  const KernelPlan plan = plan_kernels(*cfg);  // (no HIP call: works on a box without a GPU)
+  if (plan.rc != CDPR_OK) {
+    copy_name(plan.error, name, len);
+    return plan.rc;
+  }
+  LaunchShape s;
+  s.steps = steps_per_launch;
+  s.first_world = (flags & CDPR_PLAN_FIRST_WORLD_STEP) != 0u;
+  s.scheduled = (flags & CDPR_PLAN_SCHEDULED) != 0u;
+  s.rollout = (flags & CDPR_PLAN_ROLLOUT) != 0u;
+  s.steady = (flags & CDPR_PLAN_NOT_STEADY) == 0u;
+  return copy_name(planned_kernel_name(plan, planned_kernel(plan, s)), name, len);
+}
+
+int cdpr_kernel_name(cdpr_handle_t h, char* name, size_t len) {
+  if (!h) return CDPR_ERR_INVALID;
+  return copy_name(planned_kernel_name(h->plan, h->last_kernel), name, len);
 }
 
 uint32_t cdpr_mapping(cdpr_handle_t h) {
@@ -2228,7 +2202,7 @@ uint64_t cdpr_step_count(cdpr_handle_t h) { return h ? h->step : 0; }
 int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, float* effort) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  if (h->fp64) return fetch_observables64(h, position, velocity, effort, nullptr, nullptr, true);
+  if (h->fp64) return checked(h, fetch_observables64(h, position, velocity, effort, nullptr, nullptr, true));
   const int G = joint_groups((int)h->n);
   float* dst[3] = {position, velocity, effort};
   for (int f = 0; f < 3; ++f) {
@@ -2246,7 +2220,7 @@ int cdpr_get_joint_states(cdpr_handle_t h, float* position, float* velocity, flo
 int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, float* effort, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  if (h->fp64) return fetch_observables64(h, position, velocity, effort, pose7, twist6, true);
+  if (h->fp64) return checked(h, fetch_observables64(h, position, velocity, effort, pose7, twist6, true));
   const uint32_t n = h->n, width = 3u * n + 13u;
   const size_t count = (size_t)h->batch * width;
   // lazy set-up, every allocation guarded on its own pointer (a failure half way leaves nothing to leak or to skip next
@@ -2346,7 +2320,7 @@ int cdpr_get_observables(cdpr_handle_t h, float* position, float* velocity, floa
 int cdpr_get_platform_state(cdpr_handle_t h, float* pose7, float* twist6) {
   if (!h) return CDPR_ERR_INVALID;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  if (h->fp64) return fetch_observables64(h, nullptr, nullptr, nullptr, pose7, twist6, true);
+  if (h->fp64) return checked(h, fetch_observables64(h, nullptr, nullptr, nullptr, pose7, twist6, true));
   const int rc = fetch_platform(h, h->d_obs, pose7, twist6);
   return rc != CDPR_OK ? rc : check_fault(h);
 }
@@ -2356,7 +2330,7 @@ int cdpr_get_raw_state(cdpr_handle_t h, float* pose7, float* twist6) {
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   if (h->fp64) {
     int rc = fetch_rows64(h, h->d_state64, 0, 7, pose7, true);
-    return rc != CDPR_OK ? rc : fetch_rows64(h, h->d_state64, 7, 6, twist6, true);
+    return rc != CDPR_OK ? rc : checked(h, fetch_rows64(h, h->d_state64, 7, 6, twist6, true));
   }
   const int rc = fetch_platform(h, h->d_state, pose7, twist6);
   return rc != CDPR_OK ? rc : check_fault(h);
@@ -2372,7 +2346,7 @@ int cdpr_get_observables_f64(cdpr_handle_t h, double* position, double* velocity
   if (!h) return CDPR_ERR_INVALID;
   if (int rc = need_fp64(h, "cdpr_get_observables_f64")) return rc;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  return fetch_observables64(h, position, velocity, effort, pose7, twist6, false);
+  return checked(h, fetch_observables64(h, position, velocity, effort, pose7, twist6, false));
 }
 
 int cdpr_get_raw_state_f64(cdpr_handle_t h, double* pose7, double* twist6) {
@@ -2380,7 +2354,7 @@ int cdpr_get_raw_state_f64(cdpr_handle_t h, double* pose7, double* twist6) {
   if (int rc = need_fp64(h, "cdpr_get_raw_state_f64")) return rc;
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   int rc = fetch_rows64(h, h->d_state64, 0, 7, pose7, false);
-  return rc != CDPR_OK ? rc : fetch_rows64(h, h->d_state64, 7, 6, twist6, false);
+  return rc != CDPR_OK ? rc : checked(h, fetch_rows64(h, h->d_state64, 7, 6, twist6, false));
 }
 
 int cdpr_set_platform_state_f64(cdpr_handle_t h, const double* pose7, const double* twist6) {
@@ -2402,12 +2376,12 @@ int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
     HIP_TRY(h, hipMemcpyAsync(d.data(), h->d_dbg64, d.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, wait_stream(h));
     for (size_t i = 0; i < d.size(); ++i) axes9[i] = (float)d[i];
-    return CDPR_OK;
+    return check_fault(h);
   }
   HIP_TRY(h, hipMemcpyAsync(axes9, h->d_dbg, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(float), hipMemcpyDeviceToHost,
                             h->stream));
   HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
+  return check_fault(h);
 }
 
 // fp64 handles: one observable row of doubles as int32 per robot (iteration count, flags)
@@ -2430,14 +2404,14 @@ int cdpr_get_fk_state(cdpr_handle_t h, float* pose7, float* residual, int32_t* i
   if (h->fp64) {
     int rc = fetch_rows64(h, h->d_state64, 13, 7, pose7, true);
     if (rc == CDPR_OK) rc = fetch_rows64(h, h->d_obs64, 13, 1, residual, true);
-    return rc != CDPR_OK ? rc : fetch_int_row64(h, 14, iterations);
+    return rc != CDPR_OK ? rc : checked(h, fetch_int_row64(h, 14, iterations));
   }
   // estimate: state slot 3 yzw + slot 4 xyzw; residual / iteration count: observable slot 3 y, z
   int rc = fetch_fields(h, h->d_state, {{3, 1}, {3, 2}, {3, 3}, {4, 0}, {4, 1}, {4, 2}, {4, 3}}, pose7);
   if (rc != CDPR_OK) return rc;
   rc = fetch_fields(h, h->d_obs, {{3, 1}}, residual);
   if (rc != CDPR_OK) return rc;
-  return fetch_fields(h, h->d_obs, {{3, 2}}, iterations, 1u);
+  return checked(h, fetch_fields(h, h->d_obs, {{3, 2}}, iterations, 1u));
 }
 
 int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
@@ -2451,7 +2425,7 @@ int cdpr_get_td_state(cdpr_handle_t h, float* tension, int32_t* infeasible) {
   rc = h->fp64 ? fetch_int_row64(h, 15, infeasible) : fetch_fields(h, h->d_obs, {{3, 3}}, infeasible, 1u);
   if (rc == CDPR_OK && infeasible)
     for (uint32_t b = 0; b < h->batch; ++b) infeasible[b] &= 1;  // the travel-limit mask shares the component (pack_flags)
-  return rc;
+  return checked(h, rc);
 }
 
 int cdpr_get_limit_state(cdpr_handle_t h, uint32_t* cable_mask) {
@@ -2460,7 +2434,7 @@ int cdpr_get_limit_state(cdpr_handle_t h, uint32_t* cable_mask) {
   int rc = h->fp64 ? fetch_int_row64(h, 15, reinterpret_cast<int32_t*>(cable_mask)) : fetch_fields(h, h->d_obs, {{3, 3}}, cable_mask, 1u);
   if (rc == CDPR_OK)
     for (uint32_t b = 0; b < h->batch; ++b) cable_mask[b] >>= 1;  // bit 0 is the tension-distribution flag
-  return rc;
+  return checked(h, rc);
 }
 
 // Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in
@@ -2542,8 +2516,9 @@ static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float
   a.roll_cost = d_cost;
   a.roll_samples = (uint32_t)samples;
   const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  StepKernel kern = h->per_robot ? pick_pr_kernel(false, true, false, h->n, h->fk, h->td)
-                    : h->phys  ? pick_phys_kernel(h->n, h->fk, h->td, kPhysRollout) : pick_rollout_kernel(h->n, h->fk, h->td);
+  LaunchShape rs = launch_shape(h, horizon);
+  rs.rollout = true;
+  StepKernel kern = step_kernel_of(h, planned_kernel(h->plan, rs));
   hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
   ++h->launches;
@@ -2664,7 +2639,7 @@ int cdpr_device_download(cdpr_handle_t h, void* dst, const void* src, size_t byt
   if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
   HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
+  return check_fault(h);  // (a trajectory record of a schedule whose mailbox timed out is not the scheduled one)
 }
 
 int cdpr_profile_begin(cdpr_handle_t h) {

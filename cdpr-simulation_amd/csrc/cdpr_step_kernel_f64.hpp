@@ -1258,6 +1258,31 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
 }
 
 // Read-out of double rows into robot-major arrays (double or float), one thread per (robot, column)
+// Several row ranges of a double row buffer -> robot-major arrays in ONE launch (cdpr_get_observables_f64: position, velocity,
+// effort, pose, twist): segment s = rows [first_row[s], + width[s]) -> out + off[s] elements, [batch][width[s]].
+struct Unpack64MultiArgs {
+  const double* rows;
+  void* out;
+  uint32_t stride, batch, nseg, total_width;
+  uint32_t first_row[5], width[5], cum[5], off[5];  // cum: widths of the segments before s; off: element offset of segment s in `out`
+  int as_float;
+};
+static __global__ __launch_bounds__(256) void cdpr_unpack64_multi_kernel(const Unpack64MultiArgs a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= a.batch * a.total_width) return;
+  const uint32_t r = t / a.total_width, j = t - r * a.total_width;
+  uint32_t s = 0;
+#pragma unroll
+  for (uint32_t k = 1; k < 5; ++k) s = (k < a.nseg && j >= a.cum[k]) ? k : s;
+  const uint32_t jj = j - a.cum[s];
+  const double v = a.rows[(size_t)(a.first_row[s] + jj) * a.stride + r];
+  const size_t o = (size_t)a.off[s] + (size_t)r * a.width[s] + jj;
+  if (a.as_float)
+    static_cast<float*>(a.out)[o] = (float)v;
+  else
+    static_cast<double*>(a.out)[o] = v;
+}
+
 struct Unpack64Args {
   const double* rows;
   void* out;

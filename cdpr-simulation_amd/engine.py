@@ -30,6 +30,18 @@ def derivative_weights(n: int, degree: int) -> np.ndarray:
     return w
 
 
+def plan_kernel(config: Config, steps_per_launch: int = 1, flags: int = 0) -> str:
+    """The kernel CDPR_MAP_AUTO would run a launch of `steps_per_launch` world steps of this configuration on (cdpr_plan_kernel:
+    answered from the configuration alone, no GPU needed).  flags: _abi.PLAN_* bits.  Raises CdprError with the reason where
+    cdpr_create would refuse the configuration."""
+    buf = C.create_string_buffer(256)
+    s = config.to_struct()
+    rc = lib().cdpr_plan_kernel(C.byref(s), int(steps_per_launch), int(flags), buf, 256)
+    if rc != _abi.OK:
+        raise CdprError(rc, buf.value.decode())
+    return buf.value.decode()
+
+
 class Engine:
     """B independent robots advanced in lock step on one GPU."""
 
@@ -188,6 +200,13 @@ class Engine:
     @property
     def step_count(self) -> int:
         return int(lib().cdpr_step_count(self._h))
+
+    @property
+    def kernel_name(self) -> str:
+        """The kernel the last step launch of this handle ran on (cdpr_kernel_name)."""
+        buf = C.create_string_buffer(256)
+        self._check(lib().cdpr_kernel_name(self._h, buf, 256))
+        return buf.value.decode()
 
     @property
     def mapping(self) -> str:

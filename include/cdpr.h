@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define CDPR_ABI_VERSION 5u   /* 5 = 4 + cdpr_update_scheduled_kind, cdpr_device_pci_bus_id, cdpr_decode_observables_f64 (cdpr_config_t unchanged) */
+#define CDPR_ABI_VERSION 6u   /* 6 = 5 + cdpr_plan_kernel, cdpr_kernel_name (cdpr_config_t unchanged); 5 = 4 + cdpr_update_scheduled_kind, cdpr_device_pci_bus_id, cdpr_decode_observables_f64 */
 #define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
 #define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
 #define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
@@ -302,6 +302,23 @@ int cdpr_update_scheduled_kind(cdpr_handle_t h, uint32_t kind, int nsteps, int r
  * overrides, 0 = always block). */
 int cdpr_synchronize(cdpr_handle_t h);
 uint32_t cdpr_mapping(cdpr_handle_t h);              /* CDPR_MAP_* actually in use (what CDPR_MAP_AUTO resolved to) */
+/* Which kernel serves a launch - the routing CDPR_MAP_AUTO takes, answered WITHOUT a GPU from the configuration alone (a
+ * 256-CU part is assumed; the CDPR_* A/B environment overrides are honoured as cdpr_create honours them).  No counterpart
+ * in the reference (one robot, one code path: PLG.cpp:202-246); what it replaces is "run it and read the profiler".
+ *   steps_per_launch  world steps of the launch (1 = cdpr_update's launches)
+ *   flags             CDPR_PLAN_FIRST_WORLD_STEP: the launch starts at world step 0; CDPR_PLAN_SCHEDULED: cdpr_update_scheduled's
+ *                     in-launch form; CDPR_PLAN_ROLLOUT: cdpr_rollout_velocity*; CDPR_PLAN_NOT_STEADY: a derivative window still
+ *                     filling, Force mode, publish decimation, pid debug topic, travel flags, velocity limit, unilateral cables
+ *                     or a mailbox (launches of several steps on lane-pair handles then keep the general kernel)
+ * name receives the kernel's name with its template arguments as rocprofv3 prints the family (NUL-terminated, truncated to
+ * len).  Returns CDPR_OK, or the code cdpr_create would return for this configuration (name = the reason).
+ * cdpr_kernel_name: the same for the LAST step launch a handle made (what really ran). */
+#define CDPR_PLAN_FIRST_WORLD_STEP 1u
+#define CDPR_PLAN_SCHEDULED 2u
+#define CDPR_PLAN_ROLLOUT 4u
+#define CDPR_PLAN_NOT_STEADY 8u
+int cdpr_plan_kernel(const cdpr_config_t *cfg, int steps_per_launch, uint32_t flags, char *name, size_t len);
+int cdpr_kernel_name(cdpr_handle_t h, char *name, size_t len);
 uint64_t cdpr_step_count(cdpr_handle_t h);           /* world steps since create/reset; sim time = count * dt */
 
 /* Replaces publishJointStates (PLG.cpp:248-256): sensor_msgs/JointState

@@ -25,7 +25,8 @@ _cache = {}
 def digests(lib_name):
     if lib_name not in _cache:
         env = dict(os.environ, CDPR_LIB=lib_name)
-        for k in ("CDPR_MAPPING", "CDPR_SPLIT", "CDPR_ONESTEP", "CDPR_LOWREG", "CDPR_GEN_SPLIT", "CDPR_F64_SPLIT", "CDPR_PERSIST"):
+        for k in ("CDPR_MAPPING", "CDPR_SPLIT", "CDPR_ONESTEP", "CDPR_LOWREG", "CDPR_GEN_SPLIT", "CDPR_GEN_LEAN", "CDPR_GEN_HOT", "CDPR_F64_SPLIT", "CDPR_F64_RING_LDS",
+                  "CDPR_F64_JCACHE", "CDPR_PERSIST", "CDPR_PAIR_STREAM", "CDPR_CHUNK"):
             env.pop(k, None)  # the scenarios set what they need themselves
         r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "variant_digest.py")], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, f"{lib_name}: variant_digest.py failed\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"

@@ -463,3 +463,41 @@ def test_loaded_models_run_on_the_hip_path(pkg, oracle, monkeypatch):
             assert np.abs(g - o).max() <= TOL[name], name
         for name, g, o in zip(("q", "qd", "eff"), eng.joint_states(), ora.joint_states()):
             assert np.abs(g - o).max() <= TOL[name], name
+
+
+def test_the_kernel_a_handle_launches_is_the_planned_one(pkg, monkeypatch):
+    """cdpr_plan_kernel answers from the configuration alone (tests/test_kernel_selection.py pins its table on the CPU); the
+    engine routes every launch through the same function.  Here the two are compared on the GPU: after each launch form,
+    cdpr_kernel_name (what the handle really ran) equals the plan for that form - fast path (both mappings), per-robot,
+    general path (role-split, lean, one-wave at world step 0), precision = 64, scheduled and fused launches."""
+    for k in ("CDPR_MAPPING", "CDPR_LOWREG", "CDPR_GEN_SPLIT", "CDPR_GEN_LEAN", "CDPR_PAIR_STREAM", "CDPR_SPLIT", "CDPR_ONESTEP"):
+        monkeypatch.delenv(k, raising=False)
+    A = pkg._abi
+    m8 = pkg.eight_cable_model()
+    cases = [
+        dict(model=m8, batch=65536, stages=3),
+        dict(model=m8, batch=100000, stages=3),
+        dict(batch=4096),
+        dict(model=m8, batch=2048, stages=3, perRobotCommands=True),
+        dict(model=m8, batch=4096, stages=3, velocityEpsilon=0.001),
+        dict(model=m8, batch=40000, stages=3, velocityEpsilon=0.001),
+        dict(model=m8, batch=300, stages=3, precision=64),
+        dict(model=m8, batch=300, stages=0, precision=64),
+    ]
+    for kw in cases:
+        cfg = pkg.Config(**kw)
+        e = pkg.Engine(cfg, 0)
+        e.update(1)
+        assert e.kernel_name == pkg.plan_kernel(cfg, 1, A.PLAN_FIRST_WORLD_STEP), kw
+        e.update(14)
+        assert e.kernel_name == pkg.plan_kernel(cfg, 1), kw
+        e.update(20, 10)
+        assert e.kernel_name == pkg.plan_kernel(cfg, 10), kw
+        if not cfg.perRobotCommands:
+            d = e.device_upload(np.zeros((3, cfg.batch, cfg.n_cables), dtype=np.float32))
+            e.update_scheduled(30, 10, d)
+            in_launch = int(cfg.precision) != 64 and cfg.velocityEpsilon < 0  # (the other handles serve a schedule as a chain of update calls)
+            assert e.kernel_name == pkg.plan_kernel(cfg, 30 if in_launch else 10, A.PLAN_SCHEDULED if in_launch else 0), kw
+            e.synchronize()
+            e.device_free(d)
+        e.close()

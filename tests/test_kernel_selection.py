@@ -1,0 +1,128 @@
+"""What CDPR_MAP_AUTO picks, as a table: the routing rules of cdpr-simulation_amd/csrc/cdpr_select.hpp are
+pure functions of the configuration, exposed without a GPU through cdpr_plan_kernel (include/cdpr.h), and every cell of
+  cables {4, 6, 7, 8} x stages {none, FK, TD, FK + TD} x batch {1, 4 096, 32 768, 65 536, 131 072, 524 288}
+  x handle {uniform, per-robot, general (hold branch live), precision = 64} x steps per launch {1, 10}
+is pinned to the kernel name in tests/golden/kernel_selection.json (regenerate: python tests/test_kernel_selection.py --write,
+and review the diff: a changed cell is a changed routing decision).  The engine takes its kernels from the same function
+(cdpr_engine.hip: planned_kernel -> step_kernel_of), and tests/test_gpu_full_size.py checks on the GPU that the kernel a
+handle really launched (cdpr_kernel_name) is the planned one."""
+import ctypes as C
+import json
+import os
+import sys
+from dataclasses import replace
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "kernel_selection.json")
+OVERRIDES = ("CDPR_MAPPING", "CDPR_LOWREG", "CDPR_CHUNK", "CDPR_PERSIST", "CDPR_ONESTEP", "CDPR_SPLIT", "CDPR_PAIR_STREAM", "CDPR_GEN_SPLIT", "CDPR_GEN_LEAN",
+             "CDPR_GEN_HOT")
+CABLES, BATCHES = (4, 6, 7, 8), (1, 4096, 32768, 65536, 131072, 524288)
+STAGES = {"none": 0, "fk": 1, "td": 2, "fk+td": 3}
+HANDLES = ("uniform", "per_robot", "general", "fp64")
+FIRST, SCHEDULED, ROLLOUT, NOT_STEADY = 1, 2, 4, 8
+
+
+def model_of(pkg, n):
+    if n == 4:
+        return pkg.cube_model()
+    full = pkg.eight_cable_model()
+    return replace(full, frame_anchors=full.frame_anchors[:n], platform_anchors=full.platform_anchors[:n])
+
+
+def plan(pkg, cfg, steps=1, flags=0):
+    from cdpr_simulation_amd._native import lib
+
+    buf = C.create_string_buffer(256)
+    s = cfg.to_struct()
+    rc = lib().cdpr_plan_kernel(C.byref(s), steps, flags, buf, 256)
+    return rc, buf.value.decode()
+
+
+def table(pkg):
+    out = {}
+    for n in CABLES:
+        for sname, stages in STAGES.items():
+            if stages and n < 6:
+                continue  # (refused by validate_config: FK / TD need six cables)
+            for batch in BATCHES:
+                for handle in HANDLES:
+                    kw = dict(model=model_of(pkg, n), batch=batch, stages=stages)
+                    if handle == "per_robot":
+                        kw["perRobotCommands"] = True
+                    elif handle == "general":
+                        kw["velocityEpsilon"] = 0.001
+                    elif handle == "fp64":
+                        kw["precision"] = 64
+                    for steps in (1, 10):
+                        rc, name = plan(pkg, pkg.Config(**kw), steps)
+                        out[f"n{n} {sname} b{batch} {handle} k{steps}"] = name if rc == 0 else f"rc {rc}: {name}"
+    return out
+
+
+@pytest.fixture
+def clean_env(monkeypatch):
+    for k in OVERRIDES:
+        monkeypatch.delenv(k, raising=False)
+
+
+def test_auto_routing_table_is_pinned(pkg, clean_env):
+    got = table(pkg)
+    want = json.load(open(GOLDEN))
+    assert set(got) == set(want)
+    diff = {k: (want[k], got[k]) for k in got if got[k] != want[k]}
+    assert not diff, f"{len(diff)} routing decisions changed, e.g. {list(diff.items())[:5]}"
+    # the cells BASELINE.json's configs land in
+    assert got["n8 fk+td b65536 uniform k1"] == "cdpr_split_kernel<8, false>"           # config 3: the headline
+    assert got["n4 none b4096 uniform k10"] == "cdpr_pair_stream_kernel<4>"              # config 2, scheduled / fused
+    assert got["n4 none b4096 uniform k1"] == "cdpr_step_kernel_pair<4, false, false, true>"
+    assert got["n8 fk+td b524288 uniform k1"] == "cdpr_step_kernel<8, true, true, SINGLE, LOWREG>"  # config 4 on one GPU
+    assert got["n8 fk+td b65536 general k1"].startswith("cdpr_gen_lean_kernel<8>")
+    assert got["n8 fk+td b65536 fp64 k1"] == "cdpr_split_kernel_f64<8, LEAN>"
+
+
+def test_launch_flags_and_overrides(pkg, clean_env, monkeypatch):
+    c2 = pkg.Config(batch=4096)
+    assert plan(pkg, c2, 1000, SCHEDULED) == (0, "cdpr_pair_stream_kernel<4>")
+    assert plan(pkg, c2, 1, SCHEDULED) == (0, "cdpr_pair_stream_kernel<4>")  # a schedule of one step still runs the several-steps form
+    assert plan(pkg, c2, 1000, SCHEDULED | FIRST) == (0, "cdpr_step_kernel_pair<4, false, false, false>")  # world step 0: a window to fill
+    assert plan(pkg, c2, 10, NOT_STEADY) == (0, "cdpr_step_kernel_pair<4, false, false, false>")
+    c5 = pkg.Config(model=pkg.eight_cable_model(), batch=512, stages=3)
+    assert plan(pkg, c5, 64, ROLLOUT) == (0, "cdpr_step_kernel<8, true, true, ROLLOUT>")  # config 5
+    g = pkg.Config(model=pkg.eight_cable_model(), batch=16384, stages=3, velocityEpsilon=0.001)
+    assert plan(pkg, g, 1) == (0, "cdpr_gen_split_kernel<8>") and plan(pkg, g, 10) == (0, "cdpr_gen_split_kernel<8>")  # fused runs as one-step launches
+    big = pkg.Config(model=pkg.eight_cable_model(), batch=65536, stages=3, velocityEpsilon=0.001)
+    assert plan(pkg, big, 1, FIRST)[1] == "cdpr_gen_step_kernel<8, true, true, false, 11, SINGLE>"  # world step 0: the one-wave kernel
+    monkeypatch.setenv("CDPR_GEN_SPLIT", "0")  # "the one-wave kernel" (ADVICE r05): the lean kernel stays off with it
+    assert plan(pkg, big, 1)[1] == "cdpr_gen_step_kernel<8, true, true, false, 11, SINGLE>"
+    monkeypatch.setenv("CDPR_GEN_LEAN", "1")
+    assert plan(pkg, big, 1)[1].startswith("cdpr_gen_lean_kernel<8>")
+    monkeypatch.delenv("CDPR_GEN_SPLIT"), monkeypatch.delenv("CDPR_GEN_LEAN")
+    monkeypatch.setenv("CDPR_PAIR_STREAM", "0")
+    assert plan(pkg, c2, 10) == (0, "cdpr_step_kernel_pair<4, false, false, false>")
+    monkeypatch.delenv("CDPR_PAIR_STREAM")
+    monkeypatch.setenv("CDPR_MAPPING", "1")
+    assert plan(pkg, c2, 1) == (0, "cdpr_step_kernel<4, false, false, SINGLE>")
+
+
+def test_refusals_carry_their_reason(pkg, clean_env):
+    lumped = pkg.eight_cable_model()
+    lumped.leg_inertia = 0.004
+    rc, why = plan(pkg, pkg.Config(model=lumped, batch=4, precision=64))
+    assert rc == pkg._abi.ERR_UNSUPPORTED and "precision = 64" in why
+    rc, why = plan(pkg, pkg.Config(batch=4, mapping=pkg._abi.MAP_LANE_PAIR, perRobotCommands=True))
+    assert rc == pkg._abi.ERR_UNSUPPORTED and "CDPR_MAP_LANE_PAIR" in why
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    import cdpr_simulation_amd as pkg_
+
+    for k_ in OVERRIDES:
+        os.environ.pop(k_, None)
+    if "--write" in sys.argv:
+        json.dump(table(pkg_), open(GOLDEN, "w"), indent=0, sort_keys=True)
+        print("wrote", GOLDEN)
+    else:
+        print(json.dumps(table(pkg_), indent=0, sort_keys=True))
