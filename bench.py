@@ -17,6 +17,11 @@ it is one of those ranks.  The rendezvous (barrier, max of the elapsed time over
 plain socket + a shared-memory spin barrier (cdpr_simulation_amd/sharding.py): no torch, no RCCL;
 CDPR_BENCH_BACKEND=nccl|gloo opts into a torch.distributed process group instead.
 
+Secondary legs on the same line (N = 1; never substituted for `value`): `config2` (BASELINE configs[1]: 4 096 x 4-cable,
+cdpr_update_scheduled and one launch per step), `config1` (configs[0]: one robot under the sinevelocitytest publisher, the host in
+the loop on every world step, f32 and precision = 64), `fused`, `rollout` (config 5), `general_path`, `fp64`, `large_batch`
+(config 4's 524 288 robots on one GPU) - each with its own roofline object (`bound` per leg) and its own replay on the oracle.
+
 One JSON line on stdout (rank 0).  `roofline.achieved` = algorithmic bytes per launch
 (4*(39+28n) = 1052 B per state-step at n = 8) / the average launch duration
 measured with HIP events on the engine's stream; `roofline.achieved_wall` / `frac_wall` price the

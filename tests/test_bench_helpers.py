@@ -301,3 +301,24 @@ def test_bench_dry_run_reports_the_numa_node_of_every_rank(tmp_path):
     assert [p["placement"]["numa_node"] for p in out["per_rank"]] == [1, 1, 1, 1, 0, 0, 0, 0]
     assert out["placement"]["gpu_numa_nodes"] == [1, 1, 1, 1, 0, 0, 0, 0] and out["placement"]["numa_node"] == 1
     assert all(p["cpus"] == half // 4 for p in out["per_rank"])
+
+
+def test_bench_under_torch_distributed_run_uses_the_socket_rendezvous():
+    """The driver's N > 1 launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`.  The launcher is torch's, the ranks' rendezvous is not: the default backend is the
+    socket star keyed by MASTER_PORT (the agent's own store owns that TCP port, which is why the ranks meet on a Unix socket)."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("CDPR_BENCH_BACKEND", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--dry-run"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rendezvous"] == "socket" and [p["rank"] for p in out["per_rank"]] == [0, 1]
