@@ -935,6 +935,43 @@ def main():
                               "ok": bool(np.isfinite(gp).all() and dp <= PARITY_TOL["pose"] and de <= PARITY_TOL["eff"])}
             eg.device_free(d_cmd_g)
             eg.close()
+            # ... and with the cables SWITCHING between their two Pids: velocityEpsilon = 0.004 in the middle of
+            # the commands' amplitudes (0.01-0.05 m/s sines), the schedule refreshed every 10 steps - a cable crosses epsilon twice a
+            # period, each crossing leaves a window with a gap (the fit on real stamps for the next ten steps)
+            eps_s, warm_sw, periods_sw = 0.004, 120, 30
+            model_s, pose_s, command_s, _ = make_workload(pkg, Bg, n, 1235 + rank, warm_sw + periods_sw * refresh, refresh)
+            kw_s = dict(cfg_kwargs, velocityEpsilon=eps_s)
+            es = pkg.Engine(pkg.Config(batch=Bg, **kw_s), device=device)
+            es.set_platform_state(pose7=pose_s)
+            sched_s = [es.device_upload(command_s(j)) for j in range(warm_sw // refresh + periods_sw)]
+            for j in range(warm_sw // refresh):
+                es.bind_velocity_command_device(sched_s[j], Bg * n)
+                es.update(refresh)
+            es.synchronize()
+            es.profile_begin()
+            for j in range(warm_sw // refresh, warm_sw // refresh + periods_sw):
+                es.bind_velocity_command_device(sched_s[j], Bg * n)
+                es.update(refresh)
+            mss, nls = es.profile_end()
+            sw_parity = None
+            if not args.no_parity_check:
+                gs = slice(Bg - 64, Bg)
+                osim = oracle.OracleSim(pkg.Config(batch=64, **kw_s).to_struct(), oracle.DERIV_EXACT)
+                osim.set_platform_state(pose7=pose_s[gs].astype(np.float64))
+                for j in range(warm_sw // refresh + periods_sw):
+                    osim.set_velocity_command(command_s(j)[gs])
+                    osim.update(refresh)
+                gp, ge = es.platform_state()[0][gs], es.joint_states()[2][gs]
+                dp, de = float(np.abs(gp - osim.platform_state()[0]).max()), float(np.abs(ge - osim.joint_states()[2]).max())
+                osim.close()
+                held_now = float((np.abs(command_s(warm_sw // refresh + periods_sw - 1)) <= eps_s).mean())
+                sw_parity = {"robots": [Bg - 64, Bg], "steps": warm_sw + periods_sw * refresh, "max_abs_pose": dp, "max_abs_effort": de, "held_cable_share_last_period": held_now,
+                             "tolerance": {"pose": PARITY_TOL["pose"], "eff": PARITY_TOL["eff"]},
+                             "ok": bool(np.isfinite(gp).all() and dp <= PARITY_TOL["pose"] and de <= PARITY_TOL["eff"])}
+            for p_ in sched_s:
+                es.device_free(p_)
+            es.close()
+            kus_sw = mss * 1e3 / max(nls, 1)
             kus = msg * 1e3 / max(nlg, 1)
             gen_traffic = None  # HBM bytes per launch of this leg's kernel (rocprofv3 PMC, profiles/traffic.json)
             try:
@@ -952,7 +989,10 @@ def main():
                 "frac": 4 * (39 + 28 * n) * Bg / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS,  # algorithmic bytes per launch / kernel time / 8 TB/s
                 "traffic": gen_traffic,
                 "traffic_frac": (gen_traffic / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if gen_traffic else None,
-                "parity_check": gen_parity,
+                "switching": {"workload": f"velocityEpsilon = {eps_s}, per-robot sines refreshed every {refresh} steps: cables keep switching between their two Pids",
+                              "kernel_us": kus_sw, "value_per_gpu": Bg / (kus_sw * 1e-6), "steps_timed": periods_sw * refresh,
+                              "frac": 4 * (39 + 28 * n) * Bg / (kus_sw * 1e-6) / 1e9 / HBM_PEAK_GBS, "parity_check": sw_parity},
+                "parity_check": None if gen_parity is None else dict(gen_parity, ok=bool(gen_parity["ok"] and (sw_parity or {"ok": True})["ok"])),
             }
 
         # (d) the step in the reference's own precision (cdpr_config_t.precision = 64: Pid.h and Gazebo/ODE compute in double):
