@@ -6,7 +6,7 @@ loader and the function prototypes are in `_native.py`.
 import ctypes as C
 
 ABI_VERSION = 6
-MAX_CABLES = 8
+MAX_CABLES = 12
 MAX_D_BUFFER = 32
 MAX_D_DEGREE = 4
 COMMAND_VELOCITY, COMMAND_POSITION, COMMAND_FORCE = 0, 1, 2  # cdpr_update_scheduled_kind

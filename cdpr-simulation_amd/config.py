@@ -132,6 +132,18 @@ def eight_cable_model() -> Model:
     return Model(np.array(fa), np.array(pa))
 
 
+def twelve_cable_model() -> Model:
+    """Build-defined 12-cable robot (round 6: cube.yaml:21-29 is a free-length `points` list; the engine takes up to 12):
+    the eight cables of eight_cable_model plus four from the middle of the frame's vertical edges' height (z = 0.3) at the
+    mid-points of its sides to the platform's side mid-points - redundant cables in the horizontal plane, rank(J) = 6."""
+    m8 = eight_cable_model()
+    fa, pa = list(m8.frame_anchors), list(m8.platform_anchors)
+    for sx, sy in ((1, 0), (0, 1), (-1, 0), (0, -1)):
+        fa.append([0.3 * sx, 0.3 * sy, 0.3])
+        pa.append([0.03 * sx, 0.03 * sy, 0.0])
+    return Model(np.array(fa), np.array(pa))
+
+
 @dataclass
 class Config:
     model: Model = field(default_factory=cube_model)

@@ -375,6 +375,10 @@ SolveKernel pick_solver(uint32_t n, int op) {
     case 6: return pick_solver_n<6>(op);
     case 7: return pick_solver_n<7>(op);
     case 8: return pick_solver_n<8>(op);
+    case 9: return pick_solver_n<9>(op);
+    case 10: return pick_solver_n<10>(op);
+    case 11: return pick_solver_n<11>(op);
+    case 12: return pick_solver_n<12>(op);
   }
   return nullptr;
 }

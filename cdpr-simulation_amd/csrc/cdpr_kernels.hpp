@@ -34,6 +34,16 @@ using GenKernel = void (*)(const StepArgs, const GenCtl);
   }                                        \
   return nullptr
 
+// nine to twelve cables (round 6: cube.yaml's `points` list is free-length): the first-generation kernel and the MPC rollout only
+#define CDPR_PICK_CABLES12(FN, ...)        \
+  switch (n) {                             \
+    case 9: return FN<9>(__VA_ARGS__);     \
+    case 10: return FN<10>(__VA_ARGS__);   \
+    case 11: return FN<11>(__VA_ARGS__);   \
+    case 12: return FN<12>(__VA_ARGS__);   \
+  }                                        \
+  CDPR_PICK_CABLES(FN, __VA_ARGS__)
+
 // k_step.hip: first-generation kernel (cdpr_step_kernel.hpp): one step / several steps per launch, the low-register
 // build (FK on, n >= 6), the MPC rollout, the PHYS instantiations (lumped legs, joint stop)
 StepKernel pick_step_kernel(bool single, uint32_t n, bool fk, bool td);

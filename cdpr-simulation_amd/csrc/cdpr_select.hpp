@@ -156,6 +156,21 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
     return p;
   }
   const bool general = general_cfg && cfg->precision != 64;  // (a precision = 64 handle that got here runs on the fp64 kernels' own instantiations)
+  // Nine to twelve cables (round 6; cube.yaml:21-29 is a free-length list of anchor points): the first-generation lane-per-robot
+  // kernels carry them - one step or several per launch, FK and TD, trajectory record, schedules, the MPC rollout, the one-shot
+  // solvers - on uniform-mode fp32 handles with the reduced physics.  Everything else is instantiated to eight cables.
+  if (cfg->n_cables > 8u) {
+    const char* why9 = general_cfg ? "the general controller path (hold branch, cascades, long windows, cmd_limit 0)"
+                       : cfg->per_robot_commands != 0 ? "per_robot_commands"
+                       : phys_cfg ? "the lumped legs / the joint stop"
+                       : cfg->precision == 64 ? "precision = 64"
+                       : (cfg->mapping != CDPR_MAP_AUTO && cfg->mapping != CDPR_MAP_LANE_PER_ROBOT) ? "a mapping other than one lane per robot" : nullptr;
+    if (why9) {
+      p.rc = CDPR_ERR_UNSUPPORTED;
+      p.error = std::string("more than 8 cables: not together with ") + why9 + " (those kernels are instantiated to 8 cables)";
+      return p;
+    }
+  }
   p.fk = (cfg->stages & CDPR_STAGE_FK) != 0;
   p.td = (cfg->stages & CDPR_STAGE_TD) != 0;
   p.general = general;  // (precision = 64 with the hold branch: the fp64 kernel's HOLD instantiations, not the fp32 general path)
@@ -188,7 +203,7 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
     const bool split_case = !general && !p.phys && (cfg->stages & CDPR_STAGE_FK) && (cfg->stages & CDPR_STAGE_TD) && cfg->n_cables >= 6;
     if (mapping == CDPR_MAP_AUTO)
       mapping = (can_pair && !split_case && cfg->batch <= (cfg->n_cables == 4 ? 65536u : 32768u)) ? CDPR_MAP_LANE_PAIR : CDPR_MAP_LANE_PER_ROBOT;
-    if (p.fp64) mapping = CDPR_MAP_LANE_PER_ROBOT;  // one plain kernel
+    if (p.fp64 || cfg->n_cables > 8u) mapping = CDPR_MAP_LANE_PER_ROBOT;  // one plain kernel (the CDPR_MAPPING override does not reach more than 8 cables)
     // a mapping the CONFIGURATION asks for by name is served or refused; the CDPR_MAPPING environment override (A/B runs over
     // whole test suites) keeps falling back to one lane per robot where the requested mapping does not exist
     const bool can_cable = !general && !p.phys && !p.per_robot;
@@ -234,6 +249,7 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   // latency and the extra LDS round trip loses (4 096 x 4: 4.18 vs 3.99 us by rocprofv3)
   p.onestep_v2 = p.fk || cfg->batch > 32768u;
   if (const char* os = env("CDPR_ONESTEP")) p.onestep_v2 = (os[0] != '1');
+  if (cfg->n_cables > 8u) p.onestep_v2 = p.lowreg = p.persist = false;  // (more than 8 cables: the first-generation kernel)
   p.split = (p.onestep_v2 || p.per_robot) && !general && !p.phys && !p.lane_pair && !p.lane_cable && !p.lowreg && !p.persist && p.fk && p.td && cfg->n_cables >= 6;
   if (const char* sp = env("CDPR_SPLIT")) p.split = p.split && sp[0] != '0';
   {

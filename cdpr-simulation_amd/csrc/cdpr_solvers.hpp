@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void cdpr_solver_kernel(const SolveArgs a) {
   constexpr int NP = cable_pairs(N);
   __shared__ __attribute__((aligned(16))) float lds[NP * kGeomFloatsPerPair];
   const uint32_t lane = threadIdx.x;
-  if (lane < NP * kGeomFloatsPerPair) lds[lane] = a.geom[lane];
+  for (uint32_t g = lane; g < (uint32_t)(NP * kGeomFloatsPerPair); g += 64u) lds[g] = a.geom[g];  // (96 floats at n = 12)
   __syncthreads();
   const uint32_t r = blockIdx.x * 64u + lane;
   if (r >= a.batch) return;

@@ -892,6 +892,9 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   // below waits for the geometry only, the record stays in flight behind it
   CDPR_STAMP(0);
   const float gval = (lane < NP * kGeomFloatsPerPair) ? a.geom[lane] : 0.f;
+  // (more than 8 cables: the geometry table is longer than the wave - 96 floats at n = 12 - and takes a second word per lane)
+  float gval2 = 0.f;
+  if constexpr (NP * kGeomFloatsPerPair > 64) gval2 = (lane + 64u < (uint32_t)(NP * kGeomFloatsPerPair)) ? a.geom[lane + 64u] : 0.f;
 
   const uint32_t off = rr * 16u;   // byte offset of this robot inside every slot row
   const uint32_t woff = r * 16u;   // same for stores (only used when live)
@@ -936,6 +939,9 @@ __global__ __launch_bounds__(64, LOWREG ? 2 : CDPR_LPR_WAVES) void cdpr_step_ker
   if (!ROLLOUT) load_joy(vec_in + (size_t)rr * N);
 
   if (lane < NP * kGeomFloatsPerPair) lds[lane] = gval;
+  if constexpr (NP * kGeomFloatsPerPair > 64) {
+    if (lane + 64u < (uint32_t)(NP * kGeomFloatsPerPair)) lds[lane + 64u] = gval2;
+  }
   // single-wave workgroup: LDS operations of one wave execute in order, so the broadcast reads
   // below see the fill without an s_barrier (and without the vmcnt(0) a __syncthreads implies)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

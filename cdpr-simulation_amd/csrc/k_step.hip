@@ -15,8 +15,8 @@ template <int N> StepKernel phys_roll_n(bool fk, bool td) { CDPR_PICK_STAGES(N, 
 template <int N> StepKernel phys_n(bool fk, bool td, int kind) { return kind == kPhysRollout ? phys_roll_n<N>(fk, td) : phys_step_n<N>(fk, td); }
 }  // namespace
 
-StepKernel pick_step_kernel(bool single, uint32_t n, bool fk, bool td) { CDPR_PICK_CABLES(step_n, single, fk, td); }
-StepKernel pick_rollout_kernel(uint32_t n, bool fk, bool td) { CDPR_PICK_CABLES(roll_n, fk, td); }
+StepKernel pick_step_kernel(bool single, uint32_t n, bool fk, bool td) { CDPR_PICK_CABLES12(step_n, single, fk, td); }
+StepKernel pick_rollout_kernel(uint32_t n, bool fk, bool td) { CDPR_PICK_CABLES12(roll_n, fk, td); }
 StepKernel pick_phys_kernel(uint32_t n, bool fk, bool td, int kind) { CDPR_PICK_CABLES(phys_n, fk, td, kind); }
 // one-step kernels compiled for two waves per SIMD (FK on, n >= 6): see LOWREG in cdpr_step_kernel.hpp
 StepKernel pick_lowreg_kernel(uint32_t n, bool td) {

@@ -36,8 +36,9 @@
 extern "C" {
 #endif
 
-#define CDPR_ABI_VERSION 6u   /* 6 = 5 + cdpr_plan_kernel, cdpr_kernel_name (cdpr_config_t unchanged); 5 = 4 + cdpr_update_scheduled_kind, cdpr_device_pci_bus_id, cdpr_decode_observables_f64 */
-#define CDPR_MAX_CABLES 8u          /* PLG.h:20 fixes 4; the engine takes 1..8 */
+#define CDPR_ABI_VERSION 6u   /* 6 = 5 + cdpr_plan_kernel, cdpr_kernel_name, CDPR_MAX_CABLES 8 -> 12 (cdpr_config_t's anchor arrays grow); 5 = 4 + cdpr_update_scheduled_kind, cdpr_device_pci_bus_id, cdpr_decode_observables_f64 */
+#define CDPR_MAX_CABLES 12u         /* PLG.h:20 fixes 4 (kCableCount); cube.yaml:21-29 is a free-length `points` list: the engine takes 1..12
+                                      (9..12: uniform-mode fp32 handles on the lane-per-robot kernels, FK and TD included; see cdpr_create) */
 #define CDPR_MAX_D_BUFFER 32u       /* Pid: mDbufferLength                      */
 #define CDPR_MAX_D_DEGREE 4u        /* Pid: mDpolynomialDegree                  */
 #define CDPR_MAX_CASCADE 4u         /* Pid::CascadeFilter: mCascade             */

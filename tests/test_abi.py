@@ -52,7 +52,7 @@ def test_invalid_configuration_is_rejected_before_touching_the_gpu(pkg):
     from cdpr_simulation_amd._native import lib
 
     s = pkg.Config().to_struct()
-    s.n_cables = 9  # PLG.cpp:167-168: wrong joint count throws at Load
+    s.n_cables = 13  # PLG.cpp:167-168: wrong joint count throws at Load (the engine takes 1..12)
     h = C.c_void_p()
     assert lib().cdpr_create(C.byref(s), 0, C.byref(h)) == pkg._abi.ERR_INVALID
     assert b"invalid joint count" in lib().cdpr_last_error(None)

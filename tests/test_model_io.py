@@ -181,3 +181,19 @@ def test_reference_launch_file_gives_the_shipped_configuration(pkg):
     assert len(d["params"]) == 23  # PLG.h:32-54: publishPeriod, velocityEpsilon, 14 velocity-controller and 7 position-controller keys
     assert pkg.Config.from_launch_params(d["params"]).launch_params() == pkg.Config().launch_params()
     assert d["frame_pose"] == [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0] and d["sdf_file"].endswith("sdf/cube.sdf")
+
+
+def test_yaml_with_twelve_points_loads_and_is_routed(pkg):
+    """sdf/cube.yaml:21-29 is a free-length `points` list: twelve entries (round 6: CDPR_MAX_CABLES 12) load to the built-in
+    twelve-cable model, validate with FK + TD, and are routed to the first-generation lane-per-robot kernel; thirteen are refused."""
+    ref = pkg.twelve_cable_model()
+    pts = "\n".join(f"  - frame: [{a[0]}, {a[1]}, {a[2]}]\n    platform: [{b[0]}, {b[1]}, {b[2]}]" for a, b in zip(ref.frame_anchors, ref.platform_anchors))
+    text = "platform:\n  mass: 1.0\n  position:\n    xyz: [0, 0, 0.3]\n    rpy: [0, 0, 0]\npoints:\n" + pts + "\n"
+    m = pkg.load_yaml(text)
+    assert m.n_cables == 12 and np.allclose(m.frame_anchors, ref.frame_anchors) and np.allclose(m.platform_anchors, ref.platform_anchors)
+    cfg = pkg.Config(model=m, batch=1000, stages=3)
+    cfg.to_struct()
+    assert pkg.plan_kernel(cfg, 1) == "cdpr_step_kernel<12, true, true, SINGLE>" and pkg.plan_kernel(cfg, 10) == "cdpr_step_kernel<12, true, true>"
+    one_more = text + "  - frame: [0.1, 0.1, 0.6]\n    platform: [0.0, 0.0, 0.0]\n"
+    with pytest.raises(ValueError):
+        pkg.Config(model=pkg.load_yaml(one_more), batch=1).to_struct()
