@@ -84,6 +84,10 @@ struct cdpr_engine {
   float* d_gptab = nullptr;  // the two Pids' parameters as the kernel stages them in LDS (gen_pid_table)
   GenPid gpid[2]{};
   GenLayout glay{};          // rows of a Pid block: sized by the configured window length and cascade count
+  double* d_roll64 = nullptr;    // MPC rollout on a precision = 64 handle: the trajectories' state rows, their cost accumulators, the step's Joy batch
+  double* d_roll64_acc = nullptr;
+  float* d_roll64_cmd = nullptr;
+  size_t roll64_cols = 0;
   float* d_roll_rec = nullptr;   // MPC rollout on the general path: every trajectory's private copy of the records
   size_t roll_rec_cols = 0;      // columns d_roll_rec can hold
   // hipGraph cache: chains of identical steady-state launches (see run_steps)
@@ -480,6 +484,8 @@ void free_all(cdpr_engine* h) {
   if (h->d_gwtab) (void)hipFree(h->d_gwtab);
   if (h->d_gptab) (void)hipFree(h->d_gptab);
   if (h->d_roll_rec) (void)hipFree(h->d_roll_rec);
+  for (void* p64 : {(void*)h->d_roll64, (void*)h->d_roll64_acc, (void*)h->d_roll64_cmd})
+    if (p64) (void)hipFree(p64);
   if (h->d_mode) (void)hipFree(h->d_mode);
   if (h->d_target) (void)hipFree(h->d_target);
   for (int i = 0; i < 3; ++i)
@@ -2443,7 +2449,69 @@ int cdpr_get_limit_state(cdpr_handle_t h, uint32_t* cable_mask) {
 
 // Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in
 // DEVICE buffers.  Nothing is allocated, copied or synchronised here.
+// The rollout of a precision = 64 handle (uniform modes, no hold branch / joint stop): see Roll64Args (cdpr_step_kernel_f64.hpp).
+static int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d_commands, const float* d_ref, float* d_cost) {
+  const uint32_t n = h->n;
+  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
+  const size_t cols = (size_t)((traj + 63u) & ~(uint64_t)63u);
+  const uint32_t rows = (uint32_t)f64_state_rows((int)n);
+  if (h->roll64_cols < cols) {
+    HIP_TRY(h, wait_stream(h));
+    for (void** p64 : {(void**)&h->d_roll64, (void**)&h->d_roll64_acc, (void**)&h->d_roll64_cmd}) {
+      if (*p64) (void)hipFree(*p64);
+      *p64 = nullptr;
+    }
+    h->roll64_cols = 0;
+    HIP_TRY(h, hipMalloc(&h->d_roll64, (size_t)rows * cols * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_roll64_acc, cols * sizeof(double)));
+    HIP_TRY(h, hipMalloc(&h->d_roll64_cmd, cols * n * sizeof(float)));
+    h->roll64_cols = cols;
+  }
+  const bool reset = h->mode != kModeVelocity;  // JFC.cpp:113-115: the copies start from a reset velocity Pid, the handle's rows stay
+  const uint32_t blocks = (uint32_t)((traj + 255u) / 256u);
+  Roll64Args e{};
+  e.src = h->d_state64, e.dst = h->d_roll64, e.src_stride = h->stride, e.dst_stride = (uint32_t)h->roll64_cols, e.rows = rows, e.batch = h->batch,
+  e.samples = (uint32_t)samples, e.zero_from = reset ? 20u : rows;
+  hipLaunchKernelGGL(cdpr_roll64_expand_kernel, dim3(blocks), dim3(256), 0, h->stream, e);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemsetAsync(h->d_roll64_acc, 0, cols * sizeof(double), h->stream));
+  F64Args a = h->base64;
+  fill_pid64(h->cfg.velocity_pid, h->cfg.dt, a);
+  a.state = h->d_roll64;
+  a.obs = h->d_obs64;  // (nothing is published: publish_mask = 0)
+  a.dbg = nullptr;
+  a.cmd = h->d_roll64_cmd;
+  a.wtab = h->d_wtab64;
+  a.batch = (uint32_t)traj;
+  a.stride = (uint32_t)h->roll64_cols;
+  a.nsteps = 1;
+  a.publish_mask = 0;
+  a.obs_step_stride = 0;
+  F64Kernel kern = pick_f64_kernel(n, false, false);
+  int calls = reset ? 0 : h->pid_calls;
+  for (int k = 0; k < horizon; ++k) {
+    Roll64CmdArgs c{};
+    c.commands = d_commands, c.out = h->d_roll64_cmd, c.batch = h->batch, c.samples = (uint32_t)samples, c.horizon = (uint32_t)horizon, c.n = n, c.k = (uint32_t)k;
+    hipLaunchKernelGGL(cdpr_roll64_cmd_kernel, dim3((uint32_t)((traj * n + 255u) / 256u)), dim3(256), 0, h->stream, c);
+    const bool first_world = (h->step + (uint64_t)k) == 0;
+    a.flags = kFlagActualIsVelocity | (first_world ? kFlagFirstWorldStep : 0u);
+    a.pid_calls = sat_pid_calls(calls);
+    a.ring_slot = ring_slot_of(h->step + (uint64_t)k);
+    a.step0 = (int)(h->step + (uint64_t)k);
+    hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
+    calls = sat_pid_calls(calls + (first_world ? 0 : 1));
+    Roll64CostArgs q{};
+    q.state = h->d_roll64, q.ref = d_ref, q.acc = h->d_roll64_acc, q.out = (k == horizon - 1) ? d_cost : nullptr, q.stride = (uint32_t)h->roll64_cols,
+    q.batch = h->batch, q.samples = (uint32_t)samples;
+    hipLaunchKernelGGL(cdpr_roll64_cost_kernel, dim3(blocks), dim3(256), 0, h->stream, q);
+    HIP_TRY(h, hipGetLastError());
+    h->launches += 1;
+  }
+  return CDPR_OK;
+}
+
 static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float* d_commands, const float* d_ref, float* d_cost) {
+  if (h->fp64) return rollout_enqueue_f64(h, samples, horizon, d_commands, d_ref, d_cost);
   if (h->general) {
     // every trajectory steps a private copy of its robot's controller records (both Pids of every cable: the hold branch
     // switches between them from step to step): one column per trajectory in a persistent, grow-only scratch
@@ -2534,8 +2602,8 @@ static int rollout_check(cdpr_engine* h, int samples, int horizon, const void* d
     h->err = "rollout: samples, horizon >= 1 and the command buffer are required";
     return CDPR_ERR_INVALID;
   }
-  if (h->fp64) {
-    h->err = "rollout: not available with precision = 64";
+  if (h->fp64 && (h->hold64 || h->tstop64 || h->per_robot)) {
+    h->err = "rollout with precision = 64: uniform-mode handles without the hold branch / cascades / cmd_limit 0 and without the joint stop";
     return CDPR_ERR_UNSUPPORTED;
   }
   if ((uint64_t)h->batch * (uint64_t)samples > (1ull << 30)) {

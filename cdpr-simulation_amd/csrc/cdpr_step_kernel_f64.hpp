@@ -1258,6 +1258,52 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
 }
 
 // Read-out of double rows into robot-major arrays (double or float), one thread per (robot, column)
+// ---- cdpr_rollout_velocity on a precision = 64 handle (round 6), by composition: every (robot, sampled sequence) becomes a column
+// of a scratch state (expand), every step of the horizon is ONE launch of the handle's own step kernel over those columns with the
+// step's commands gathered into a Joy batch (cmd), and a third kernel adds |p(t_k+1) - p_ref|^2 to the trajectory's cost (cost).
+// No rollout kernel of its own: the rollout in double is there for checking the fp32 one, not for throughput.
+struct Roll64Args {
+  const double* src;  // the handle's state rows
+  double* dst;        // the trajectories' state rows
+  uint32_t src_stride, dst_stride, rows, batch, samples;
+  uint32_t zero_from;  // rows >= this are cleared in the copies (a Joy on jointVelocities in Position mode resets the velocity Pid,
+                       // JFC.cpp:113-115); == rows: none
+};
+static __global__ __launch_bounds__(256) void cdpr_roll64_expand_kernel(const Roll64Args a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= a.batch * a.samples) return;
+  const uint32_t b = t / a.samples;
+  for (uint32_t r = 0; r < a.rows; ++r) a.dst[(size_t)r * a.dst_stride + t] = (r >= a.zero_from) ? 0.0 : a.src[(size_t)r * a.src_stride + b];
+}
+struct Roll64CmdArgs {
+  const float* commands;  // float[B][H][S][n]
+  float* out;             // float[B * S][n]: the Joy batch of step k
+  uint32_t batch, samples, horizon, n, k;
+};
+static __global__ __launch_bounds__(256) void cdpr_roll64_cmd_kernel(const Roll64CmdArgs a) {
+  const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= a.batch * a.samples * a.n) return;
+  const uint32_t t = e / a.n, i = e - t * a.n, b = t / a.samples, s = t - b * a.samples;
+  a.out[e] = a.commands[(((size_t)b * a.horizon + a.k) * a.samples + s) * a.n + i];
+}
+struct Roll64CostArgs {
+  const double* state;  // the trajectories' state rows (rows 0..2: position)
+  const float* ref;     // float[B][3]
+  double* acc;          // double[B * S]
+  float* out;           // float[B][S], written with the last step (nullptr before)
+  uint32_t stride, batch, samples;
+};
+static __global__ __launch_bounds__(256) void cdpr_roll64_cost_kernel(const Roll64CostArgs a) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= a.batch * a.samples) return;
+  const uint32_t b = t / a.samples;
+  const double ex = a.state[t] - (double)a.ref[3 * b], ey = a.state[(size_t)a.stride + t] - (double)a.ref[3 * b + 1],
+               ez = a.state[(size_t)2 * a.stride + t] - (double)a.ref[3 * b + 2];
+  const double c = a.acc[t] + fma(ez, ez, fma(ey, ey, ex * ex));
+  a.acc[t] = c;
+  if (a.out) a.out[t] = (float)c;
+}
+
 // Several row ranges of a double row buffer -> robot-major arrays in ONE launch (cdpr_get_observables_f64: position, velocity,
 // effort, pose, twist): segment s = rows [first_row[s], + width[s]) -> out + off[s] elements, [batch][width[s]].
 struct Unpack64MultiArgs {

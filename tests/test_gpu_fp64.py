@@ -516,3 +516,40 @@ def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, ca
                 assert np.array_equal(x, y)
     print(f"fp64 role-split (build {build}) vs one-wave kernel, n = {cables}: worst difference {worst:.3e}")
     assert worst == 0.0
+
+
+@pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0"])
+def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
+    """cdpr_rollout_velocity on a precision = 64 handle (round 6; refused before): every (robot, sampled sequence) steps a private
+    copy of the robot's state through the handle's own fp64 step kernel, one launch per step of the horizon, the cost accumulated
+    in double.  Against the oracle's rollout (the cost leaves as float32: agreement to its rounding), entered from Velocity mode
+    (the Pid's history carries on), from Position mode (a Joy on jointVelocities resets the velocity Pid, JFC.cpp:113-115) and at
+    world step 0 (no force at t = 0, JFC.cpp:61-66); the handle itself is not advanced by a rollout."""
+    B, n, S, H = 20, 8, 12, 16
+    rng = np.random.default_rng(660)
+    cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, precision=64)
+    pose = np.tile(cfg.model.home_pose(), (B, 1))
+    pose[:, :3] += rng.uniform(-0.02, 0.02, (B, 3))
+    eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+    eng.set_platform_state_f64(pose7=pose), ora.set_platform_state(pose7=pose)
+    first = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+    if entered_from == "velocity":
+        for sim in (eng, ora):
+            sim.set_velocity_command(first)
+            sim.update(23)
+    elif entered_from == "position":
+        for sim in (eng, ora):
+            sim.set_position_command((0.1 * first).astype(np.float32))
+            sim.update(17)
+    cmds = (rng.uniform(-0.03, 0.03, (B, H, 1, n)) + rng.normal(0.0, 0.01, (B, H, S, n))).astype(np.float32)
+    ref = pose[:, :3].astype(np.float32)
+    before = eng.raw_state_f64()
+    cost = eng.rollout_velocity(cmds, ref)
+    ocost = ora.rollout_velocity(cmds, ref.astype(np.float64))
+    assert cost.shape == (B, S) and np.isfinite(cost).all()
+    assert np.abs(cost - ocost).max() <= 3e-7 * np.abs(ocost).max(), float(np.abs(cost - ocost).max() / np.abs(ocost).max())
+    assert (cost.argmin(axis=1) == ocost.argmin(axis=1)).all()
+    after = eng.raw_state_f64()
+    assert all(np.array_equal(x, y) for x, y in zip(before, after)) and eng.step_count == ora.step_count
+    eng.update(5), ora.update(5)  # ... and carries on as if nothing had happened
+    assert np.abs(eng.observables_f64()[3] - ora.platform_state()[0]).max() < 1e-12
