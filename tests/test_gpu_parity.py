@@ -841,7 +841,7 @@ def test_error_codes_of_the_c_abi(pkg, mapping):
     L.cdpr_destroy(None)  # harmless
     assert L.cdpr_mapping(h) in (pkg._abi.MAP_LANE_PER_ROBOT, pkg._abi.MAP_LANE_PAIR)
     with pytest.raises(ValueError):
-        pkg.Engine(pkg.Config(model=pkg.Model(np.zeros((9, 3)), np.zeros((9, 3)))), 0)
+        pkg.Engine(pkg.Config(model=pkg.Model(np.zeros((13, 3)), np.zeros((13, 3)))), 0)  # (the engine takes 1..12 cables)
     h2 = C.c_void_p()
     assert L.cdpr_create(C.byref(pkg.Config().to_struct()), 99, C.byref(h2)) == pkg._abi.ERR_INVALID  # no such device
     cfg = pkg.Config(mapping=pkg._abi.MAP_LANE_PAIR, model=pkg.Model(pkg.eight_cable_model().frame_anchors[:6], pkg.eight_cable_model().platform_anchors[:6]))
