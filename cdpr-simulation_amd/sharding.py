@@ -226,7 +226,7 @@ class SocketGroup:
 
     name = "socket"
 
-    def __init__(self, rank: int, world: int, local_world: int, timeout_s: float = 120.0):
+    def __init__(self, rank: int, world: int, local_world: int, timeout_s: float = 600.0):  # (generous: a fresh box pages the image in during the first imports)
         import socket
         import time
 
