@@ -101,6 +101,7 @@ struct cdpr_engine {
   };
   std::vector<GraphEntry> graphs;
   PlannedKernel last_kernel;  // what the last step launch ran on (cdpr_kernel_name)
+  int win64 = kWin;         // precision = 64: prior errors kept per cable (kWinLong on handles with windows of 12 .. 32 samples)
   KernelPlan plan;          // the routing cdpr_create took for this configuration (cdpr_select.hpp)
   int cus = 256;
   bool use_graphs = true;
@@ -422,7 +423,7 @@ std::vector<float4> home_state(const cdpr_engine* h) {
 }
 
 // rows of an fp64 handle's state: platform, FK estimate, one Pid's rows per cable - and, hold branch live, both Pids' records
-static size_t state64_rows(const cdpr_engine* h) { return (size_t)f64_state_rows((int)h->n) + (h->hold64 ? (size_t)f64_hold_rows((int)h->n) : 0); }
+static size_t state64_rows(const cdpr_engine* h) { return (size_t)f64_state_rows((int)h->n, h->win64) + (h->hold64 ? (size_t)f64_hold_rows((int)h->n) : 0); }
 
 // fp64 handles: home state (platform at home, FK seed at home, controller rows zero), observables before the first publish
 int upload_home64(cdpr_engine* h) {
@@ -596,6 +597,8 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
 constexpr int kCallSat = 64;
 inline int sat_pid_calls(int calls) { return calls < kCallSat ? calls : kCallSat; }
 inline int ring_slot_of(uint64_t step) { return (int)((step + 8u) % (uint64_t)kWin); }
+// ... of a ring of w errors: the first sample of a handle that runs without a Pid reset since Load is taken at world step 2
+inline int ring_slot_of(uint64_t step, int w) { return (int)((step + (uint64_t)(w - 2)) % (uint64_t)w); }
 
 // Weights of the ring position a launch starts at, copied into its arguments (see StepArgs::wrow).
 inline void set_weight_row(const cdpr_engine* h, StepArgs& a) {
@@ -795,7 +798,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   const uint32_t n = h->n;
   if (reset_pid && !h->hold64) {  // Pid::reset (Pid.cpp:100-115): zero every controller row (hold branch live: the latch reset that Pid's own rows)
     h->pid_calls = 0;
-    HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)11 * n * h->stride * sizeof(double), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)(h->win64 + 1) * n * h->stride * sizeof(double), h->stream));
   }
   F64Args a = h->base64;
   const bool pr = h->per_robot;
@@ -804,7 +807,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   a.cmd = pr ? h->d_target
              : frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0])
                    : vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
-  a.wtab = h->d_wtab64 + (vel ? 0 : kWin * (kWin + 2));
+  a.wtab = h->d_wtab64 + (vel ? 0 : h->win64 * (h->win64 + 2));
   if (pr) {  // mode, Pid call count and so the Pid per lane: the velocity Pid in the primary fields, the position Pid in alt_*
     F64Args p = h->base64;
     fill_pid64(h->cfg.position_pid, h->cfg.dt, p);
@@ -870,6 +873,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
       case KernelId::F64Hold: return pick_f64_hold_kernel(n, hold_full);
       case KernelId::F64HoldPr: return pick_f64_hold_pr_kernel(n, hold_full);
       case KernelId::F64Tstop: return pick_f64_tstop_kernel(n);
+      case KernelId::F64Long: return pick_f64_long_kernel(n);
       case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
       default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);
     }
@@ -892,7 +896,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
     if (first_world) a.flags |= kFlagFirstWorldStep;
     if (record) a.obs = record + (size_t)done * image64;
     a.pid_calls = sat_pid_calls(h->pid_calls);
-    a.ring_slot = ring_slot_of(h->step);
+    a.ring_slot = ring_slot_of(h->step, h->win64);
     a.step0 = (int)h->step;
     a.publish_mask = 0;
     for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
@@ -1531,6 +1535,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->fp64 = plan.fp64;
   h->hold64 = plan.hold64;
   h->tstop64 = plan.tstop64;
+  h->win64 = plan.long64 ? kWinLong : kWin;
   h->per_robot = plan.per_robot;
   h->phys = plan.phys;
   h->lane_pair = plan.lane_pair;
@@ -1575,7 +1580,8 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     const size_t row = (size_t)h->stride * sizeof(double);
     if ((e = hipMalloc(&h->d_state64, row * state64_rows(h))) != hipSuccess) return fail("hipMalloc(state64)", e);
     if ((e = hipMalloc(&h->d_obs64, row * f64_obs_rows((int)h->n))) != hipSuccess) return fail("hipMalloc(obs64)", e);
-    std::vector<double> g((size_t)h->n * 7), wt((size_t)2 * kWin * (kWin + 2), 0.0);
+    const int W64 = h->win64;  // ring length of this handle's fp64 kernels (10, or 31 with windows of 12 .. 32 samples)
+    std::vector<double> g((size_t)h->n * 7), wt((size_t)2 * W64 * (W64 + 2), 0.0);
     for (uint32_t i = 0; i < h->n; ++i) {
       for (int k = 0; k < 3; ++k) {
         g[(size_t)i * 7 + k] = cfg->frame_anchor[i][k];
@@ -1585,18 +1591,18 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     }
     const cdpr_pid_params_t* pids[2] = {&cfg->velocity_pid, &cfg->position_pid};
     for (int t = 0; t < 2; ++t) {  // the rotated weight tables of fill_pid, in double
-      double w[CDPR_MAX_D_BUFFER], wpad[kWin + 1];
-      for (int j = 0; j <= kWin; ++j) wpad[j] = 0.0;
-      if (derivative_weights(pids[t]->d_buffer_length, pids[t]->d_degree, w) == CDPR_OK)
-        for (uint32_t j = 0; j < pids[t]->d_buffer_length; ++j) wpad[kWin + 1 - pids[t]->d_buffer_length + j] = w[j];
-      double* tab = &wt[(size_t)t * kWin * (kWin + 2)];
-      for (int ws = 0; ws < kWin; ++ws) {
-        for (int sl = 0; sl < kWin; ++sl) {
-          int j = ((ws - sl) % kWin + kWin) % kWin;
-          if (j == 0) j = kWin;
-          tab[ws * (kWin + 2) + sl] = wpad[kWin - j];
+      double w[CDPR_MAX_D_BUFFER];
+      std::vector<double> wpad((size_t)W64 + 1, 0.0);
+      if (derivative_weights(pids[t]->d_buffer_length, pids[t]->d_degree, w) == CDPR_OK && pids[t]->d_buffer_length <= (uint32_t)W64 + 1)
+        for (uint32_t j = 0; j < pids[t]->d_buffer_length; ++j) wpad[(size_t)W64 + 1 - pids[t]->d_buffer_length + j] = w[j];
+      double* tab = &wt[(size_t)t * W64 * (W64 + 2)];
+      for (int ws = 0; ws < W64; ++ws) {
+        for (int sl = 0; sl < W64; ++sl) {
+          int j = ((ws - sl) % W64 + W64) % W64;
+          if (j == 0) j = W64;
+          tab[ws * (W64 + 2) + sl] = wpad[(size_t)W64 - j];
         }
-        tab[ws * (kWin + 2) + kWin] = wpad[kWin];
+        tab[ws * (W64 + 2) + W64] = wpad[(size_t)W64];
       }
     }
     if ((e = hipMalloc(&h->d_geom64, g.size() * sizeof(double))) != hipSuccess) return fail("hipMalloc(geom64)", e);
@@ -2454,7 +2460,7 @@ static int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const f
   const uint32_t n = h->n;
   const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
   const size_t cols = (size_t)((traj + 63u) & ~(uint64_t)63u);
-  const uint32_t rows = (uint32_t)f64_state_rows((int)n);
+  const uint32_t rows = (uint32_t)f64_state_rows((int)n, h->win64);
   if (h->roll64_cols < cols) {
     HIP_TRY(h, wait_stream(h));
     for (void** p64 : {(void**)&h->d_roll64, (void**)&h->d_roll64_acc, (void**)&h->d_roll64_cmd}) {
@@ -2487,7 +2493,7 @@ static int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const f
   a.nsteps = 1;
   a.publish_mask = 0;
   a.obs_step_stride = 0;
-  F64Kernel kern = pick_f64_kernel(n, false, false);
+  F64Kernel kern = h->plan.long64 ? pick_f64_long_kernel(n) : pick_f64_kernel(n, false, false);
   int calls = reset ? 0 : h->pid_calls;
   for (int k = 0; k < horizon; ++k) {
     Roll64CmdArgs c{};
@@ -2496,7 +2502,7 @@ static int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const f
     const bool first_world = (h->step + (uint64_t)k) == 0;
     a.flags = kFlagActualIsVelocity | (first_world ? kFlagFirstWorldStep : 0u);
     a.pid_calls = sat_pid_calls(calls);
-    a.ring_slot = ring_slot_of(h->step + (uint64_t)k);
+    a.ring_slot = ring_slot_of(h->step + (uint64_t)k, h->win64);
     a.step0 = (int)(h->step + (uint64_t)k);
     hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
     calls = sat_pid_calls(calls + (first_world ? 0 : 1));

@@ -93,6 +93,7 @@ struct KernelPlan {
   bool phys = false;       // lumped legs / joint stop: the PHYS instantiations
   bool general = false;    // fp32 general controller path (hold branch, cascades, long windows, cmd_limit 0, ...)
   bool fp64 = false, hold64 = false, tstop64 = false;
+  bool long64 = false;     // precision = 64 with derivative windows of 12 .. 32 samples: the one-wave kernel with a ring of 31
   bool lane_pair = false, lane_cable = false;
   bool lowreg = false, persist = false, onestep_v2 = false, split = false;
   bool gen_split = false, gen_lean = false, gen_hot = false;
@@ -147,10 +148,19 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   // ... and with the joint stop as the only optional physics: the TSTOP instantiations (uniform-mode handles without the hold branch)
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
   const bool tstop64 = clean64 && cfg->travel_stop != 0 && !lumped_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;
-  if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64) {
+  // ... and derivative windows of 12 .. 32 samples as the ONLY thing beyond the register-resident path (round 6): the plain one-wave
+  // fp64 kernel with a ring of 31 errors per cable (uniform-mode handles, reduced physics)
+  bool long64 = false;
+  if (cfg->precision == 64 && !windows_fit && cfg->per_robot_commands == 0 && !phys_cfg) {
+    cdpr_config_t probe = *cfg;
+    probe.velocity_pid.d_buffer_length = probe.position_pid.d_buffer_length = 11;
+    probe.velocity_pid.d_degree = probe.position_pid.d_degree = std::min(cfg->velocity_pid.d_degree, 4u);
+    long64 = fast_path_obstacle(probe).empty();  // (no hold branch, no cascades, a command clamp)
+  }
+  if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64 && !long64) {
     p.rc = CDPR_ERR_UNSUPPORTED;
-    p.error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) with windows to 11 samples and the joint stop "
-              "on uniform-mode handles without those (no lumped legs): " +
+    p.error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) with windows to 11 samples, windows to 32 "
+              "samples and the joint stop on uniform-mode handles without those (no lumped legs): " +
               (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
                            : std::string("optional physics"));
     return p;
@@ -177,6 +187,7 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   p.fp64 = cfg->precision == 64;
   p.hold64 = hold64;
   p.tstop64 = tstop64;
+  p.long64 = long64;
   p.per_robot = cfg->per_robot_commands != 0;
   p.phys = phys_cfg;
   if (hold64) {
@@ -293,7 +304,7 @@ enum class KernelId {
   // general controller path (k_gen*.hip)
   GenOne, GenMulti, GenSplit, GenLean, GenRollout,
   // precision = 64 (k_f64.hip)
-  F64, F64Pr, F64Tstop, F64Hold, F64HoldPr, F64Split, F64SplitHold,
+  F64, F64Pr, F64Tstop, F64Long, F64Hold, F64HoldPr, F64Split, F64SplitHold,
 };
 
 struct LaunchShape {
@@ -321,7 +332,7 @@ inline PlannedKernel planned_kernel(const KernelPlan& p, const LaunchShape& s) {
     const bool ring_lds = s.f64_ring_lds >= 0 ? s.f64_ring_lds != 0 : p.batch <= 32768u;
     const bool jcache = ring_lds && (s.f64_jcache >= 0 ? s.f64_jcache != 0 : p.batch <= 16384u);
     const bool lean = s.f64_split >= 0 ? s.f64_split == 2 : p.batch > 16384u;
-    const bool can_split = p.fk && p.td && s.f64_split != 0 && !p.per_robot && !p.tstop64;
+    const bool can_split = p.fk && p.td && s.f64_split != 0 && !p.per_robot && !p.tstop64 && !p.long64;
     k.f64_ring_lds = ring_lds, k.f64_jcache = jcache, k.f64_lean = lean;
     // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's several-steps ones (14.4
     // against 20.8 us per step at one robot x 8, same bits): the engine then runs a fused update as one-step launches
@@ -330,7 +341,7 @@ inline PlannedKernel planned_kernel(const KernelPlan& p, const LaunchShape& s) {
       k.block = 128;
       return k;
     }
-    k.id = p.hold64 ? (p.per_robot ? KernelId::F64HoldPr : KernelId::F64Hold) : p.tstop64 ? KernelId::F64Tstop : p.per_robot ? KernelId::F64Pr : KernelId::F64;
+    k.id = p.hold64 ? (p.per_robot ? KernelId::F64HoldPr : KernelId::F64Hold) : p.tstop64 ? KernelId::F64Tstop : p.long64 ? KernelId::F64Long : p.per_robot ? KernelId::F64Pr : KernelId::F64;
     return k;
   }
   if (p.general) {
@@ -404,6 +415,7 @@ inline std::string planned_kernel_name(const KernelPlan& p, const PlannedKernel&
     case KernelId::F64: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u%s%s>", n, k.f64_ring_lds ? ", RING_LDS" : "", k.f64_jcache ? ", JCACHE" : ""); break;
     case KernelId::F64Pr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR%s>", n, k.f64_ring_lds ? ", RING_LDS" : ""); break;
     case KernelId::F64Tstop: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, TSTOP>", n); break;
+    case KernelId::F64Long: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, W = 31>", n); break;
     case KernelId::F64Hold: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, HOLD = %d>", n, p.hold_full ? 2 : 1); break;
     case KernelId::F64HoldPr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR, HOLD = %d>", n, p.hold_full ? 2 : 1); break;
     case KernelId::F64Split: snprintf(b, sizeof b, "cdpr_split_kernel_f64<%u%s>", n, k.f64_lean ? ", LEAN" : ""); break;

@@ -80,7 +80,8 @@ struct F64Args {
   double pcoef[2][5], dcoef[2][5];
 };
 
-__host__ __device__ constexpr int f64_state_rows(int n) { return 20 + 11 * n; }
+constexpr int kWinLong = 31;  // the ring of a derivative window of 12 .. 32 samples (CDPR_MAX_D_BUFFER - 1)
+__host__ __device__ constexpr int f64_state_rows(int n, int w = kWin) { return 20 + (w + 1) * n; }
 // HOLD handles keep BOTH Pids of every cable behind those rows: per cable mLastPosition (JFC.h:45), then per Pid (0 position,
 // 1 velocity) one packed word (bits 0-31 mLastTime as a world step | 32-35 ring head | 36-39 samples in the window | 40-47 length
 // of the newest run of consecutive steps, saturating | 48 mWasLastTime; the bits of a double, moved, never computed with) |
@@ -404,8 +405,12 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
 // between the velocity and the pose half of the world step a joint at or beyond a limit that
 // still moves outward takes the impulse that stops it, cables in index order, travel_stop sweeps; the rows of the structure
 // matrix at t_k wait in private LDS columns.
-template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, int HOLD = 0, bool TSTOP = false>  // HOLD: 0 | 1 | 2 (+ cascades, cmd_limit 0)
+// W: prior errors kept per cable (the derivative ring).  kWin = 10 serves windows to 11 samples (shorter ones by zero weights);
+// W = kWinLong = 31 (round 6: Pid.h:135 allows any mDbufferLength, the engine takes 32) serves 12 .. 32 samples on the plain
+// instantiation - same code, W + 1 rows per cable instead of 11, a weight table of W rows.
+template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, int HOLD = 0, bool TSTOP = false, int W = kWin>  // HOLD: 0 | 1 | 2 (+ cascades, cmd_limit 0)
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
+  static_assert(W == kWin || (!RING_LDS && !JCACHE && !PR && !HOLD && !TSTOP), "long derivative windows: the plain instantiation");
   static_assert(!HOLD || (!RING_LDS && !JCACHE), "the hold branch: the plain instantiation (uniform modes, or PR: the mode per lane)");
   static_assert(!TSTOP || (!RING_LDS && !JCACHE && !PR && !HOLD), "the joint stop: the plain instantiation");
   __shared__ double c_js[TSTOP ? N : 1][TSTOP ? 6 : 1][64];
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   // nothing beyond two (65 536 x 8: 35.3 us at 2, 36.5 at 4, 54.8 at 8 - `profiles/r04final_fp64_timing.txt`)
   constexpr int kCableUnroll = RING_LDS ? (N < 4 ? N : 4) : (N < 2 ? N : 2);
   __shared__ double c_len[N][64], c_q[N][64], c_qd[N][64], c_f[N][64], c_des[N][64], c_ierr[N][64];
-  __shared__ double c_win[RING_LDS ? N : 1][RING_LDS ? kWin : 1][64];
+  __shared__ double c_win[RING_LDS ? N : 1][RING_LDS ? W : 1][64];
   __shared__ double c_jt[JCACHE ? N : 1][JCACHE ? 6 : 1][64];  // rows at the true pose
   __shared__ double c_je[JCACHE ? N : 1][JCACHE ? 6 : 1][64];  // rows at the FK estimate
   const uint32_t lane = threadIdx.x;
@@ -449,11 +454,11 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   // the integrals and the commands (and, RING_LDS, the derivative rings) in one batch of loads
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    if (!HOLD) c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
+    if (!HOLD) c_ierr[i][lane] = S[(size_t)(20 + (W + 1) * i + W) * st];
     c_des[i][lane] = (double)a.cmd[(size_t)r * N + i];
     if (RING_LDS) {
 #pragma unroll
-      for (int k = 0; k < kWin; ++k) c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] = S[(size_t)(20 + 11 * i + k) * st];
+      for (int k = 0; k < W; ++k) c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] = S[(size_t)(20 + (W + 1) * i + k) * st];
     }
   }
   // uniform handles: mode and call count are launch arguments; PR: this robot's own (per lane)
@@ -472,8 +477,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
     const bool force_mode = PR ? ((meta & kMetaModeMask) == kMetaForce) : ((a.flags & kFlagForceMode) != 0u);  // UpdateMode::Force (JFC.cpp:67-70): no Pid
     const bool run_pid = !first_world && !force_mode && calls != 0;  // Pid.cpp:123-126: the first call since reset returns 0
     const bool full = calls >= a.nbuf;
-    const int ring_slot = (a.ring_slot + step) % kWin;
-    const double* wt = a.wtab + ring_slot * (kWin + 2);
+    const int ring_slot = (a.ring_slot + step) % W;
+    const double* wt = a.wtab + ring_slot * (W + 2);
     double dbg_p = 0.0, dbg_i = 0.0, dbg_d = 0.0, dbg_des = 0.0;
     bool dbg_ran = false;  // (HOLD: cable 0's Pid really ran this step)
     // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
@@ -529,9 +534,9 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
         } else if (run_pid) {
           const double desired = c_des[i][lane];
           const double error = desired - (actual_is_vel ? qd : q);
-          double acc = wt[kWin] * error;
+          double acc = wt[W] * error;
 #pragma unroll
-          for (int k = 0; k < kWin; ++k) acc = fma(wt[k], RING_LDS ? c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] : S[(size_t)(20 + 11 * i + k) * st], acc);
+          for (int k = 0; k < W; ++k) acc = fma(wt[k], RING_LDS ? c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane] : S[(size_t)(20 + (W + 1) * i + k) * st], acc);
           const double p_term = kp * error;
           const double prev_ierr = c_ierr[i][lane];
           double ie = fma(a.dt, error, prev_ierr);
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           if (RING_LDS)
             c_win[RING_LDS ? i : 0][RING_LDS ? ring_slot : 0][lane] = error;
           else
-            S[(size_t)(20 + 11 * i + ring_slot) * st] = error;  // after the FIR has read the slot's old content
+            S[(size_t)(20 + (W + 1) * i + ring_slot) * st] = error;  // after the FIR has read the slot's old content
           if (i == 0) {
             dbg_p = p_term;
             dbg_i = i_raw;
@@ -805,10 +810,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   }
 #pragma clang loop unroll_count(kCableUnroll)
   for (int i = 0; i < N; ++i) {
-    if (!HOLD) S[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];  // (HOLD: the integrals live in the Pids' own rows)
+    if (!HOLD) S[(size_t)(20 + (W + 1) * i + W) * st] = c_ierr[i][lane];  // (HOLD: the integrals live in the Pids' own rows)
     if (RING_LDS) {
 #pragma unroll
-      for (int k = 0; k < kWin; ++k) S[(size_t)(20 + 11 * i + k) * st] = c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane];
+      for (int k = 0; k < W; ++k) S[(size_t)(20 + (W + 1) * i + k) * st] = c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane];
     }
   }
   if (PR) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)calls << kMetaCallShift));

@@ -460,10 +460,10 @@ def test_fp64_refuses_what_it_does_not_cover(pkg):
     lumped.travel_lower, lumped.travel_upper, lumped.travel_stop, lumped.leg_inertia = -0.01, 0.01, 2, 0.004
     stop_pr = pkg.eight_cable_model()
     stop_pr.travel_lower, stop_pr.travel_upper, stop_pr.travel_stop = -0.01, 0.01, 2
-    long_window = pkg.Config(batch=4, precision=64)
-    long_window.velocityController.dBufferLength = 16
+    long_window_hold = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)  # (long windows alone are served since round 6)
+    long_window_hold.velocityController.dBufferLength = 16
     stop_hold = pkg.Config(model=stop_pr, batch=4, precision=64, velocityEpsilon=0.01)
-    for cfg in (pkg.Config(model=lumped, batch=4, precision=64), pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), long_window, stop_hold):
+    for cfg in (pkg.Config(model=lumped, batch=4, precision=64), pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), long_window_hold, stop_hold):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(cfg, 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
@@ -518,7 +518,7 @@ def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, ca
     assert worst == 0.0
 
 
-@pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0"])
+@pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0", "velocity_long_window"])
 def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     """cdpr_rollout_velocity on a precision = 64 handle (round 6; refused before): every (robot, sampled sequence) steps a private
     copy of the robot's state through the handle's own fp64 step kernel, one launch per step of the horizon, the cost accumulated
@@ -528,12 +528,14 @@ def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     B, n, S, H = 20, 8, 12, 16
     rng = np.random.default_rng(660)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, precision=64)
+    if entered_from == "velocity_long_window":  # (a 20-sample window: the kernel with a ring of 31, its rows copied per trajectory)
+        cfg.velocityController.dBufferLength, cfg.velocityController.dDegree = 20, 3
     pose = np.tile(cfg.model.home_pose(), (B, 1))
     pose[:, :3] += rng.uniform(-0.02, 0.02, (B, 3))
     eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
     eng.set_platform_state_f64(pose7=pose), ora.set_platform_state(pose7=pose)
     first = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
-    if entered_from == "velocity":
+    if entered_from.startswith("velocity"):
         for sim in (eng, ora):
             sim.set_velocity_command(first)
             sim.update(23)
@@ -553,3 +555,51 @@ def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     assert all(np.array_equal(x, y) for x, y in zip(before, after)) and eng.step_count == ora.step_count
     eng.update(5), ora.update(5)  # ... and carries on as if nothing had happened
     assert np.abs(eng.observables_f64()[3] - ora.platform_state()[0]).max() < 1e-12
+
+
+@pytest.mark.parametrize("nbuf,degree,cables,stages", [(16, 3, 8, 3), (32, 2, 8, 3), (12, 4, 4, 0), (24, 1, 6, 1)])
+def test_fp64_long_derivative_windows(pkg, oracle, nbuf, degree, cables, stages):
+    """Derivative windows of 12 .. 32 samples with precision = 64 (round 6; Pid.h:135 allows any mDbufferLength, refused in double
+    before): the plain one-wave fp64 kernel with a ring of 31 errors per cable.  Against the oracle through the window fill (the D
+    term is 0 until nbuf samples are in, Pid.cpp:200-203), a mode change (the entered Pid is reset), several steps per launch and
+    the trajectory record; the other Pid keeps the shipped 11-sample window."""
+    from dataclasses import replace
+
+    B = 70
+    rng = np.random.default_rng(670 + nbuf)
+    full = pkg.eight_cable_model()
+    model = pkg.cube_model() if cables == 4 else replace(full, frame_anchors=full.frame_anchors[:cables], platform_anchors=full.platform_anchors[:cables])
+    cfg = pkg.Config(model=model, batch=B, stages=stages, precision=64)
+    cfg.velocityController.dBufferLength, cfg.velocityController.dDegree = nbuf, degree
+    assert pkg.plan_kernel(cfg, 1) == f"cdpr_step_kernel_f64<{cables}, W = 31>" == pkg.plan_kernel(cfg, 10)
+    pose = np.tile(model.home_pose(), (B, 1))
+    pose[:, :3] += rng.uniform(-0.02, 0.02, (B, 3))
+    eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+    eng.set_platform_state_f64(pose7=pose), ora.set_platform_state(pose7=pose)
+
+    def same(where, tol_p=1e-12, tol_e=1e-8):
+        g = eng.observables_f64()
+        dp, de = np.abs(g[3] - ora.platform_state()[0]).max(), np.abs(g[2] - ora.joint_states()[2]).max()
+        assert dp < tol_p and de < tol_e, (where, dp, de)
+
+    cmd = rng.uniform(-0.03, 0.03, (B, cables)).astype(np.float32)
+    eng.update(9), ora.update(9)
+    for sim in (eng, ora):
+        sim.set_velocity_command(cmd)
+    for k in range(nbuf + 6):  # step by step through the fill of the long window
+        eng.update(1), ora.update(1)
+        if k in (0, nbuf - 2, nbuf - 1, nbuf, nbuf + 5):
+            same(f"fill step {k}")
+    eng.update(45, 9), ora.update(45)  # several steps per launch: the ring turns more than once
+    same("fused")
+    for sim in (eng, ora):
+        sim.set_position_command((0.1 * cmd).astype(np.float32))  # the position Pid (11 samples) is entered: reset
+    eng.update(30), ora.update(30)
+    same("position mode")
+    for sim in (eng, ora):
+        sim.set_velocity_command((-cmd).astype(np.float32))  # back: the velocity Pid starts its long window again
+    rec = eng.update_record(nbuf + 8, 4)
+    ora.update(nbuf + 8)
+    same("record")
+    assert np.array_equal(rec["effort"][-1], eng.observables_f64()[2])
+    assert eng.kernel_name == f"cdpr_step_kernel_f64<{cables}, W = 31>"
