@@ -1624,6 +1624,10 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
     b.unilateral = cfg->unilateral_cables ? 1 : 0;
     b.travel_on = (cfg->travel_lower != 0.0 || cfg->travel_upper != 0.0) ? 1 : 0;
     b.travel_lo = cfg->travel_lower; b.travel_hi = cfg->travel_upper;
+    b.ph_lumped = (cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0) ? 1 : 0;
+    b.ph_c = cfg->passive_damping; b.ph_jleg = cfg->leg_inertia; b.ph_max = cfg->cable_axial_mass; b.ph_mpt = cfg->anchor_point_mass;
+    b.ph_iadd_total = cfg->anchor_inertia * (double)cfg->n_cables; b.ph_mass = cfg->mass;
+    b.gx = cfg->gravity[0]; b.gy = cfg->gravity[1]; b.gz = cfg->gravity[2];
     b.fk_lambda = cfg->fk_lambda; b.fk_tol = cfg->fk_tolerance; b.fk_iters = (int)cfg->fk_max_iterations;
     b.td_min = cfg->td_f_min; b.td_max = cfg->td_f_max; b.td_mid = 0.5 * (cfg->td_f_min + cfg->td_f_max);
   } else {
@@ -2493,7 +2497,8 @@ static int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const f
   a.nsteps = 1;
   a.publish_mask = 0;
   a.obs_step_stride = 0;
-  F64Kernel kern = h->plan.long64 ? pick_f64_long_kernel(n) : pick_f64_kernel(n, false, false);
+  F64Kernel kern = h->tstop64 ? pick_f64_tstop_kernel(n) : h->plan.long64 ? pick_f64_long_kernel(n) : pick_f64_kernel(n, false, false);
+  a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
   int calls = reset ? 0 : h->pid_calls;
   for (int k = 0; k < horizon; ++k) {
     Roll64CmdArgs c{};
@@ -2608,8 +2613,8 @@ static int rollout_check(cdpr_engine* h, int samples, int horizon, const void* d
     h->err = "rollout: samples, horizon >= 1 and the command buffer are required";
     return CDPR_ERR_INVALID;
   }
-  if (h->fp64 && (h->hold64 || h->tstop64 || h->per_robot)) {
-    h->err = "rollout with precision = 64: uniform-mode handles without the hold branch / cascades / cmd_limit 0 and without the joint stop";
+  if (h->fp64 && (h->hold64 || h->per_robot)) {
+    h->err = "rollout with precision = 64: uniform-mode handles without the hold branch / cascades / cmd_limit 0";
     return CDPR_ERR_UNSUPPORTED;
   }
   if ((uint64_t)h->batch * (uint64_t)samples > (1ull << 30)) {

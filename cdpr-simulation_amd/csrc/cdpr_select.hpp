@@ -145,9 +145,11 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   const bool clean64 = cfg->precision == 64 && windows_fit;
   const bool hold64 = clean64 && !phys_cfg && (!fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && pr_windows_differ));  // (per-robot modes too:
                                                                                                     // each Pid has its own rows and its own window)
-  // ... and with the joint stop as the only optional physics: the TSTOP instantiations (uniform-mode handles without the hold branch)
+  // ... and with the optional physics - the joint stop, the lumped legs (round 6) - on uniform-mode handles without the hold branch:
+  // the TSTOP instantiations
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
-  const bool tstop64 = clean64 && cfg->travel_stop != 0 && !lumped_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;
+  const bool tstop64 = clean64 && phys_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;  // (round 6: the lumped legs too, with or without the stop)
+  (void)lumped_cfg;
   // ... and derivative windows of 12 .. 32 samples as the ONLY thing beyond the register-resident path (round 6): the plain one-wave
   // fp64 kernel with a ring of 31 errors per cable (uniform-mode handles, reduced physics)
   bool long64 = false;
@@ -160,7 +162,7 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64 && !long64) {
     p.rc = CDPR_ERR_UNSUPPORTED;
     p.error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) with windows to 11 samples, windows to 32 "
-              "samples and the joint stop on uniform-mode handles without those (no lumped legs): " +
+              "samples, and the joint stop / the lumped legs on uniform-mode handles without those: " +
               (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
                            : std::string("optional physics"));
     return p;

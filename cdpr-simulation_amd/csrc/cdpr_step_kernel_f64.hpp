@@ -72,6 +72,11 @@ struct F64Args {
   int degree, alt_nbuf, alt_degree;
   double hold_w[2][kWin + 1];  // [position | velocity] Pid: the uniform-grid derivative weights by AGE of the sample (0: newest), in steps
   int travel_stop;             // TSTOP instantiations: sweeps of the joint stop (cdpr_config_t.travel_stop), 0 = flag only
+  // TSTOP instantiations, the lumped legs (round 6; cdpr_config_t.passive_damping ...; the fp32 kernels' integrate_lumped_velocity in
+  // double): any term non-zero, joint damping c of the passive revolutes, inertia turning with a leg, mass sliding along the cable,
+  // point mass at each platform anchor, n x the inertia each leg adds to the platform, the platform's mass, gravity
+  int ph_lumped;
+  double ph_c, ph_jleg, ph_max, ph_mpt, ph_iadd_total, ph_mass, gx, gy, gz;
   // HOLD instantiations, the rest of Pid::update (round 5): the biquad cascades on the P and the D input (Pid.cpp:27-44 over
   // Filter.h:130-165; coefficients a0 a1 a2 b1 b2 of BiQuad::SetFc(relCutoff, 1, quality)) and cmd_limit = 0 (no clamp: the Pid
   // returns its stale mCmd member, Pid.cpp:175-184); [0] the POSITION Pid, [1] the VELOCITY Pid
@@ -735,6 +740,88 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) w[c] = fma(-j[c], t, w[c]);
       }
+      bool lumped_done = false;
+      if constexpr (TSTOP) {
+        if (a.ph_lumped) {  // (wave-uniform) the lumped legs: a 6 x 6 mass matrix instead of the platform's own (see f64_lumped_twist)
+          lumped_done = true;
+          double M[6][6];
+#pragma unroll
+          for (int x = 0; x < 6; ++x)
+#pragma unroll
+            for (int y = 0; y < 6; ++y) M[x][y] = 0.0;
+          // world inertia R Ib R^T (+ the share of every leg that turns with the platform), gyroscopic torque om x (Iw om)
+          const double rr[3][3] = {{R.r00, R.r01, R.r02}, {R.r10, R.r11, R.r12}, {R.r20, R.r21, R.r22}};
+          const double ibm[3][3] = {{a.ib[0], a.ib[3], a.ib[4]}, {a.ib[3], a.ib[1], a.ib[5]}, {a.ib[4], a.ib[5], a.ib[2]}};
+          double iw[3][3];
+#pragma unroll
+          for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+              double acc = 0.0;
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) acc = fma(rr[x][c] * ibm[c][d], rr[y][d], acc);
+              iw[x][y] = acc + (x == y ? a.ph_iadd_total : 0.0);
+            }
+#pragma unroll
+          for (int x = 0; x < 3; ++x) {
+            M[x][x] = a.ph_mass;
+#pragma unroll
+            for (int y = 0; y < 3; ++y) M[3 + x][3 + y] = iw[x][y];
+          }
+          const double iom[3] = {fma(iw[0][2], om[2], fma(iw[0][1], om[1], iw[0][0] * om[0])), fma(iw[1][2], om[2], fma(iw[1][1], om[1], iw[1][0] * om[0])),
+                                 fma(iw[2][2], om[2], fma(iw[2][1], om[1], iw[2][0] * om[0]))};
+          w[3] -= fma(om[1], iom[2], -(om[2] * iom[1]));
+          w[4] -= fma(om[2], iom[0], -(om[0] * iom[2]));
+          w[5] -= fma(om[0], iom[1], -(om[1] * iom[0]));
+#pragma clang loop unroll(disable)
+          for (int i = 0; i < N; ++i) {
+            double u[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) u[c] = c_js[TSTOP ? i : 0][TSTOP ? c : 0][lane];  // the structure-matrix row [u, rb x u] at t_k
+            const double* g = c_geom + i * 7;
+            const double rb[3] = {fma(R.r02, g[5], fma(R.r01, g[4], R.r00 * g[3])), fma(R.r12, g[5], fma(R.r11, g[4], R.r10 * g[3])),
+                                  fma(R.r22, g[5], fma(R.r21, g[4], R.r20 * g[3]))};
+            const double L = g[6] - c_q[i][lane], il = 1.0 / L;
+            const double vp[3] = {v[0] + fma(om[1], rb[2], -(om[2] * rb[1])), v[1] + fma(om[2], rb[0], -(om[0] * rb[2])), v[2] + fma(om[0], rb[1], -(om[1] * rb[0]))};
+            const double along = fma(u[2], vp[2], fma(u[1], vp[1], u[0] * vp[0]));
+            const double vt[3] = {fma(-u[0], along, vp[0]), fma(-u[1], along, vp[1]), fma(-u[2], along, vp[2])};
+            const double ou[3] = {fma(om[1], u[2], -(om[2] * u[1])), fma(om[2], u[0], -(om[0] * u[2])), fma(om[0], u[1], -(om[1] * u[0]))};
+            const double uvp[3] = {fma(u[1], vp[2], -(u[2] * vp[1])), fma(u[2], vp[0], -(u[0] * vp[2])), fma(u[0], vp[1], -(u[1] * vp[0]))};
+            const double cl = -(a.ph_c * il);
+            // damper force at the anchor + the weight of the point masses there; the spherical joint's torque
+            const double fa[3] = {fma(cl, fma(2.0 * il, vt[0], -ou[0]), a.ph_mpt * a.gx), fma(cl, fma(2.0 * il, vt[1], -ou[1]), a.ph_mpt * a.gy),
+                                  fma(cl, fma(2.0 * il, vt[2], -ou[2]), a.ph_mpt * a.gz)};
+            w[0] += fa[0], w[1] += fa[1], w[2] += fa[2];
+            w[3] += fma(rb[1], fa[2], -(rb[2] * fa[1])) + a.ph_c * fma(uvp[0], il, -om[0]);
+            w[4] += fma(rb[2], fa[0], -(rb[0] * fa[2])) + a.ph_c * fma(uvp[1], il, -om[1]);
+            w[5] += fma(rb[0], fa[1], -(rb[1] * fa[0])) + a.ph_c * fma(uvp[2], il, -om[2]);
+            // apparent mass of the leg at the anchor: alpha I + beta u u^T through G = [I, -[rb]x]
+            const double mu = a.ph_jleg * il * il, alpha = mu + a.ph_mpt, beta = a.ph_max - mu;
+            const double rb2 = fma(rb[2], rb[2], fma(rb[1], rb[1], rb[0] * rb[0]));
+            const double X[3][3] = {{0.0, -rb[2], rb[1]}, {rb[2], 0.0, -rb[0]}, {-rb[1], rb[0], 0.0}};  // [rb]x
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+              M[x][x] += alpha;
+#pragma unroll
+              for (int y = 0; y < 3; ++y) {
+                M[3 + x][y] = fma(alpha, X[x][y], M[3 + x][y]);
+                M[3 + x][3 + y] = fma(alpha, ((x == y) ? rb2 : 0.0) - rb[x] * rb[y], M[3 + x][3 + y]);
+              }
+            }
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+#pragma unroll
+              for (int y = 0; y <= x; ++y) M[x][y] = fma(beta * u[x], u[y], M[x][y]);
+          }
+          double acc6[6] = {w[0], w[1], w[2], w[3], w[4], w[5]};
+          chol_solve64(M, acc6);  // (reads the lower triangle)
+          v[0] = fma(a.dt, acc6[0], v[0]), v[1] = fma(a.dt, acc6[1], v[1]), v[2] = fma(a.dt, acc6[2], v[2]);
+          om[0] = fma(a.dt, acc6[3], om[0]), om[1] = fma(a.dt, acc6[4], om[1]), om[2] = fma(a.dt, acc6[5], om[2]);
+        }
+      }
+      if (!lumped_done) {
       v[0] = fma(a.dt * w[0], a.inv_mass, v[0]);
       v[1] = fma(a.dt * w[1], a.inv_mass, v[1]);
       v[2] = fma(a.dt * w[2], a.inv_mass, v[2]);
@@ -751,6 +838,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
       om[0] = fma(a.dt, fma(R.r02, ab[2], fma(R.r01, ab[1], R.r00 * ab[0])), om[0]);
       om[1] = fma(a.dt, fma(R.r12, ab[2], fma(R.r11, ab[1], R.r10 * ab[0])), om[1]);
       om[2] = fma(a.dt, fma(R.r22, ab[2], fma(R.r21, ab[1], R.r20 * ab[0])), om[2]);
+      }  // (!lumped_done)
       if constexpr (TSTOP) {
         for (int sweep = 0; sweep < a.travel_stop; ++sweep) {
 #pragma clang loop unroll(disable)

@@ -456,14 +456,14 @@ def test_fp64_rest_of_pid_update(pkg, oracle, variant):
 
 
 def test_fp64_refuses_what_it_does_not_cover(pkg):
-    lumped = pkg.eight_cable_model()
+    lumped = pkg.eight_cable_model()  # (the lumped legs run in double since round 6 - but not together with per-robot modes)
     lumped.travel_lower, lumped.travel_upper, lumped.travel_stop, lumped.leg_inertia = -0.01, 0.01, 2, 0.004
     stop_pr = pkg.eight_cable_model()
     stop_pr.travel_lower, stop_pr.travel_upper, stop_pr.travel_stop = -0.01, 0.01, 2
     long_window_hold = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)  # (long windows alone are served since round 6)
     long_window_hold.velocityController.dBufferLength = 16
     stop_hold = pkg.Config(model=stop_pr, batch=4, precision=64, velocityEpsilon=0.01)
-    for cfg in (pkg.Config(model=lumped, batch=4, precision=64), pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), long_window_hold, stop_hold):
+    for cfg in (pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True), pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), long_window_hold, stop_hold):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(cfg, 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
@@ -518,7 +518,7 @@ def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, ca
     assert worst == 0.0
 
 
-@pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0", "velocity_long_window"])
+@pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0", "velocity_long_window", "velocity_lumped_legs"])
 def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     """cdpr_rollout_velocity on a precision = 64 handle (round 6; refused before): every (robot, sampled sequence) steps a private
     copy of the robot's state through the handle's own fp64 step kernel, one launch per step of the horizon, the cost accumulated
@@ -528,6 +528,9 @@ def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     B, n, S, H = 20, 8, 12, 16
     rng = np.random.default_rng(660)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, precision=64)
+    if entered_from == "velocity_lumped_legs":  # (the optional physics: the TSTOP instantiation steps the trajectories)
+        cfg.model.passive_damping, cfg.model.leg_inertia, cfg.model.anchor_point_mass = 0.05, 0.02, 0.01
+        cfg.model.travel_lower, cfg.model.travel_upper, cfg.model.travel_stop = -0.05, 0.05, 2
     if entered_from == "velocity_long_window":  # (a 20-sample window: the kernel with a ring of 31, its rows copied per trajectory)
         cfg.velocityController.dBufferLength, cfg.velocityController.dDegree = 20, 3
     pose = np.tile(cfg.model.home_pose(), (B, 1))
@@ -603,3 +606,40 @@ def test_fp64_long_derivative_windows(pkg, oracle, nbuf, degree, cables, stages)
     same("record")
     assert np.array_equal(rec["effort"][-1], eng.observables_f64()[2])
     assert eng.kernel_name == f"cdpr_step_kernel_f64<{cables}, W = 31>"
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0])
+@pytest.mark.parametrize("cables,stages,stop", [(8, 3, False), (4, 0, False), (7, 3, True)])
+def test_fp64_lumped_legs(pkg, oracle, cables, stages, stop, scale):
+    """The lumped legs in double (round 6; refused with precision = 64 before): passive joint damping (cube.sdf:396) and the leg
+    links' masses / inertias (cube.sdf:359-382) as a 6 x 6 mass matrix in the world step of the TSTOP instantiations - the fp32
+    kernels' integrate_lumped_velocity restated in double - at the shipped link values and 30 x exaggerated, with a full inertia
+    tensor and tilted gravity, alone and together with the joint stop; one-step and fused launches, the trajectory record."""
+    from dataclasses import replace
+
+    B = 90
+    rng = np.random.default_rng(680 + cables)
+    lumped = dict(passive_damping=0.01 * scale, leg_inertia=0.004 * scale, cable_axial_mass=0.001 * scale, anchor_point_mass=0.002 * scale,
+                  anchor_inertia=0.001 * scale)
+    eight = pkg.eight_cable_model()
+    base = pkg.cube_model() if cables == 4 else replace(eight, frame_anchors=eight.frame_anchors[:cables], platform_anchors=eight.platform_anchors[:cables])
+    model = replace(base, inertia=(0.9, 1.1, 1.0, 0.05, -0.03, 0.02), **lumped)
+    if stop:
+        model = replace(model, travel_lower=-0.004, travel_upper=0.004, travel_stop=3)
+    cfg = pkg.Config(model=model, batch=B, stages=stages, precision=64, gravity=(0.3, -0.2, -9.7))
+    assert pkg.plan_kernel(cfg, 1) == f"cdpr_step_kernel_f64<{cables}, TSTOP>"
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.003 if stop else 0.03, 0.02).astype(np.float64))
+    cmd = rng.uniform(-0.03, 0.03, (B, cables)).astype(np.float32)
+    tol = dict(TOL64, pose=1e-11, q=1e-11, twist=1e-9, qd=1e-9, eff=1e-6)
+    eng.update(20), ora.update(20)
+    eng.set_velocity_command(cmd), ora.set_velocity_command(cmd)
+    eng.update(45), ora.update(45)
+    compare64(eng, ora, "one-step launches", tol)
+    eng.update(40, 10), ora.update(40)
+    compare64(eng, ora, "fused launches", tol)
+    rec = eng.update_record(12, 4)
+    ora.update(12)
+    compare64(eng, ora, "record", tol)
+    assert np.array_equal(rec["pose"][-1], eng.observables_f64()[3])
+    if stop:
+        assert np.array_equal(eng.limit_state(), ora.limit_state())
