@@ -109,8 +109,12 @@ def test_launch_flags_and_overrides(pkg, clean_env, monkeypatch):
 def test_refusals_carry_their_reason(pkg, clean_env):
     lumped = pkg.eight_cable_model()
     lumped.leg_inertia = 0.004
-    rc, why = plan(pkg, pkg.Config(model=lumped, batch=4, precision=64))
+    assert plan(pkg, pkg.Config(model=lumped, batch=4, precision=64)) == (0, "cdpr_step_kernel_f64<8, TSTOP>")  # (in double since round 6)
+    rc, why = plan(pkg, pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True))  # ... but not with per-robot modes
     assert rc == pkg._abi.ERR_UNSUPPORTED and "precision = 64" in why
+    long_w = pkg.Config(batch=4, precision=64)
+    long_w.velocityController.dBufferLength = 20
+    assert plan(pkg, long_w, 10) == (0, "cdpr_step_kernel_f64<4, W = 31>")
     rc, why = plan(pkg, pkg.Config(batch=4, mapping=pkg._abi.MAP_LANE_PAIR, perRobotCommands=True))
     assert rc == pkg._abi.ERR_UNSUPPORTED and "CDPR_MAP_LANE_PAIR" in why
 
