@@ -316,10 +316,12 @@ def test_steady_state_stream_kernel_is_bit_identical(pkg, oracle, monkeypatch, n
             e.update_scheduled(T, refresh, d_s, d_rec, image * T, kind=kind)
             raw = e.device_download(d_rec, (T, image), dtype=np.uint8)
             rec = np.array([np.concatenate([x.ravel() for x in e.decode_observables(raw[j])]) for j in range(T)])
-            e.device_free(d_s)
         e.device_free(d_rec)
         e.update(13, 13)  # a fused launch from wherever the ring stands now (stream kernel again where it is on)
         e.update(3)
+        e.synchronize()
+        if not per_step:
+            e.device_free(d_s)  # (only now: the schedule's last batch stays latched, the updates above still read it)
         return e, rec
 
     a, rec_a = run(True, False)
