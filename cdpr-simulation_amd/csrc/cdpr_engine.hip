@@ -801,6 +801,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
     HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)(h->win64 + 1) * n * h->stride * sizeof(double), h->stream));
   }
   F64Args a = h->base64;
+  a.stamps = h->base.stamps;
   const bool pr = h->per_robot;
   const bool vel = pr || h->mode == kModeVelocity, frc = !pr && h->mode == kModeForce;
   fill_pid64(vel ? h->cfg.velocity_pid : h->cfg.position_pid, h->cfg.dt, a);

@@ -83,7 +83,34 @@ struct F64Args {
   int any_cas, any_noclamp, max_cas;
   int pcas[2], dcas[2];
   double pcoef[2][5], dcoef[2][5];
+  unsigned long long* stamps;  // diagnostic builds only (-DCDPR_STAMPS: scripts/stamp_probe_f64.py), 16 per workgroup
 };
+
+// phase boundaries of the role-split fp64 kernel (s_memrealtime, 100 MHz), lane 0 of each wave: 0.. the estimator wave's, 8.. the
+// controller wave's; never compiled into the shipped library
+#ifdef CDPR_STAMPS
+#define CDPR_F64_STAMP(i)                                                                                             \
+  do {                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  } while (0)
+#define CDPR_F64_CLOCK(i)  /* the shader clock's own counter beside the 100 MHz one: cycles per microsecond over the estimator wave */ \
+  do {                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+    if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();               \
+    __builtin_amdgcn_sched_barrier(0);                                                                                \
+  } while (0)
+#ifdef CDPR_STAMPS_WAIT  // ... with the loads before a stamp landed (vmcnt(0)): what a phase waits for memory, at the price of the overlap
+#define CDPR_F64_LANDED() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define CDPR_F64_LANDED() do { } while (0)
+#endif
+#else
+#define CDPR_F64_STAMP(i) do { } while (0)
+#define CDPR_F64_CLOCK(i) do { } while (0)
+#define CDPR_F64_LANDED() do { } while (0)
+#endif
 
 constexpr int kWinLong = 31;  // the ring of a derivative window of 12 .. 32 samples (CDPR_MAX_D_BUFFER - 1)
 __host__ __device__ constexpr int f64_state_rows(int n, int w = kWin) { return 20 + (w + 1) * n; }
@@ -316,10 +343,102 @@ __device__ __forceinline__ HoldRows64 hold_load64(const double* R, const double*
   return h;
 }
 
+// The controller tables of a HOLD kernel, in LDS, filled by the wave that reads them: w[pid][age] the uniform-grid derivative weights
+// (F64Args::hold_w), rot[pid][head][slot] the same by ring slot for every ring head, par[pid][..] the Pid's gains and limits
+// (kf kp ki kd imax imin cmax cmin w[0] imax/ki imin/ki) behind a per-lane choice of the Pid - pid 0 the POSITION Pid (alt_*), 1 the VELOCITY Pid.
+constexpr int kHoldPar = 12;
+__device__ __forceinline__ void hold_tables_fill(const F64Args& a, uint32_t lane, double (*w)[kHoldWin], double (*rot)[kHoldWin][kHoldWin], double (*par)[kHoldPar]) {
+  if (lane < 2 * kHoldWin) w[lane / kHoldWin][lane % kHoldWin] = a.hold_w[lane / kHoldWin][lane % kHoldWin];
+  if (lane == 0) {
+    par[1][0] = a.kf, par[1][1] = a.kp, par[1][2] = a.ki, par[1][3] = a.kd, par[1][4] = a.imax, par[1][5] = a.imin, par[1][6] = a.cmax, par[1][7] = a.cmin;
+    par[0][0] = a.alt_kf, par[0][1] = a.alt_kp, par[0][2] = a.alt_ki, par[0][3] = a.alt_kd, par[0][4] = a.alt_imax, par[0][5] = a.alt_imin, par[0][6] = a.alt_cmax,
+    par[0][7] = a.alt_cmin;
+    par[1][8] = a.hold_w[1][0], par[0][8] = a.hold_w[0][0];
+    par[1][9] = a.imax / a.ki, par[1][10] = a.imin / a.ki, par[0][9] = a.alt_imax / a.alt_ki, par[0][10] = a.alt_imin / a.alt_ki;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int e = (int)lane; e < 2 * kHoldWin * kHoldWin; e += 64) {
+    const int pd = e / (kHoldWin * kHoldWin), hd = (e / kHoldWin) % kHoldWin, j = e % kHoldWin;
+    const int nb = pd ? a.nbuf : a.alt_nbuf;
+    int age = hd - j;
+    age = age < 0 ? age + nb : age;
+    rot[pd][hd][j] = (hd < nb && j < nb && j != hd) ? w[pd][min(max(age, 0), kHoldWin - 1)] : 0.0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A Pid call that needs nothing but the straight line: the Pid has been called since its reset and its window, with this call's
+// sample in it, is either a uniform one (the newest run of consecutive steps covers it) or still filling (derive() returns 0) -
+// the conditions of hold_finish64's first-call and fit branches, negated.
+__device__ __forceinline__ bool hold_steady64(unsigned long long word, int now, int nbuf) {
+  const int last = (int)(uint32_t)word, count_old = (int)(word >> 36) & 15, run_old = (int)(word >> 40) & 255;
+  const bool was = ((word >> 48) & 1ull) != 0ull;
+  const int count = min(count_old + 1, nbuf);
+  const int run = (now == last + 1) ? min(run_old + 1, 255) : 1;
+  return was && !(run < nbuf && count >= nbuf);
+}
+// ... and that call: Pid::update (Pid.cpp:122-191) + JointForceCalculator's mLastPosition (JFC.cpp:68,75,87) without a branch - the
+// operations of hold_finish64 in its order (the integral's clamp by selects: i_term / ki of a clamped term is imax / ki or imin / ki,
+// par[9], par[10]; a held cable stores the mLastPosition it read), every store unconditional: a lane beyond the batch shadows the
+// last robot and writes that robot's values again.  Same bits as hold_finish64 (tests/test_gpu_fp64.py compares the two kernels).
+// In two stages so that a pass of several cables can finish with the windows (eleven of a cable's fourteen registers pairs) before the
+// gains arrive: hold_fast_fir64 - sample, ring position, the fixed filter's sum; hold_fast64 - the rest.
+struct HoldFir64 {
+  double error, dts, acc;
+  int head, count, run;
+};
+__device__ __forceinline__ HoldFir64 hold_fast_fir64(const HoldRows64& h, const double* wrot, double w0, int nbuf, double desired, double actual, int now, double dt) {
+  HoldFir64 f;
+  const int last = (int)(uint32_t)h.word, head_old = (int)(h.word >> 32) & 15, count_old = (int)(h.word >> 36) & 15, run_old = (int)(h.word >> 40) & 255;
+  f.dts = (double)(now - last) * dt;
+  f.error = desired - actual;
+  f.head = (count_old == 0) ? 0 : ((head_old + 1 >= nbuf) ? 0 : head_old + 1);
+  f.count = min(count_old + 1, nbuf);
+  f.run = (now == last + 1) ? min(run_old + 1, 255) : 1;
+  const double* const wr = wrot + f.head * kHoldWin;
+  double acc = w0 * f.error;
+#pragma unroll
+  for (int j = 0; j < kHoldWin; ++j) acc = fma(wr[j], h.y[j], acc);
+  f.acc = acc;
+  return f;
+}
+__device__ __forceinline__ double hold_fast64(double* R, double* LP, size_t st, double ierr_old, double held, const HoldFir64& f, const double* pp, int nbuf, bool hold, double q, double desired,
+                                              int now, double dt, double& p_out, double& i_out, double& d_out) {
+  const double kf = pp[0], kp = pp[1], ki = pp[2], kd = pp[3], imax = pp[4], imin = pp[5], cmax = pp[6], cmin = pp[7], ie_max = pp[9], ie_min = pp[10];
+  const double error = f.error, dts = f.dts;
+  const double p_term = kp * error;
+  double ie = fma(dts, error, ierr_old);
+  double i_term = ki * ie;
+  const double i_raw = i_term;
+  const bool hi = i_term > imax, lo = !hi && i_term < imin;  // Pid.cpp:143-152
+  i_term = hi ? imax : (lo ? imin : i_term);
+  ie = hi ? ie_max : (lo ? ie_min : ie);
+  const double derived = (f.run >= nbuf) ? f.acc / dt : 0.0;
+  const double d_term = kd * derived;
+  const double cmd = fma(kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
+  double out = fmax(fmin(cmd, cmax), cmin);                       // Pid.cpp:175-177
+  const bool sat = out != cmd;                                    // Pid.cpp:181-184
+  ie = sat ? ierr_old : ie;
+  out = sat ? fma(dts * error, ki, out) : out;
+  const unsigned long long word =
+      (unsigned long long)(uint32_t)now | (unsigned long long)f.head << 32 | (unsigned long long)f.count << 36 | (unsigned long long)f.run << 40 | 1ull << 48;
+  R[0] = __longlong_as_double((long long)word);
+  R[st] = ie;
+  R[(size_t)(2 + f.head) * st] = error;
+  R[(size_t)(2 + kHoldWin + f.head) * st] = (double)now;
+  LP[0] = hold ? held : q;
+  p_out = p_term, i_out = i_raw, d_out = d_term;
+  return out;
+}
+
 // FULL: the handle has a biquad cascade or a Pid without the command clamp (the HOLD = 2 instantiations); otherwise none of that
 // is compiled in (its uniform branches cost the others 1.3 us per step).
 template <bool FULL>
-__device__ __forceinline__ double hold_finish64(double* R, size_t st, const HoldRows64& h, const double* w_age, double desired, double actual, int now, double dt,
+__device__ __forceinline__ double hold_finish64(double* R, size_t st, const HoldRows64& h, const double* wrot, double w0, double desired, double actual, int now, double dt,
                                                 const HoldPid64& g, const F64Args& a, bool velocity_pid, bool& ran, double& p_out, double& i_out, double& d_out,
                                                 bool live = true) {
   // (the coefficients stay where they are - the argument block - behind a per-lane choice of the Pid)
@@ -346,14 +465,13 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
   const int head = (count_old == 0) ? 0 : ((head_old + 1 >= g.nbuf) ? 0 : head_old + 1);
   const int count = min(count_old + 1, g.nbuf);
   const int run = (now == last + 1) ? min(run_old + 1, 255) : 1;
-  double acc = w_age[0] * error;
+  // the uniform window's weights BY SLOT for this ring head (hold_tables_fill: the weight of the slot's age, 0 for the slot the new
+  // sample goes to and for slots beyond nbuf - round 6: one LDS read and one fma per slot where the age, its wrap, its clamp, the
+  // look-up and two selects were 13 instructions)
+  const double* const wr = wrot + head * kHoldWin;
+  double acc = w0 * error;
 #pragma unroll
-  for (int j = 0; j < kHoldWin; ++j) {
-    int age = head - j;
-    age = age < 0 ? age + g.nbuf : age;
-    const double w = w_age[min(max(age, 0), kHoldWin - 1)];
-    acc = (j < g.nbuf && j != head) ? fma(w, h.y[j], acc) : acc;
-  }
+  for (int j = 0; j < kHoldWin; ++j) acc = fma(wr[j], h.y[j], acc);
   double derived = (run >= g.nbuf) ? acc / dt : 0.0;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
   if (was && run < g.nbuf && count >= g.nbuf) {     // a full window with a gap in it: the fit on the real stamps
     double y[kHoldWin];
@@ -439,10 +557,10 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   //  a round trip more: one robot 14.4 -> 14.7 us)
   constexpr bool kGeomLds = !RING_LDS;
   __shared__ double c_geom_lds[kGeomLds ? N * 7 : 1];
-  __shared__ double c_hold_w[HOLD ? 2 : 1][kHoldWin];
+  __shared__ double c_hold_w[HOLD ? 2 : 1][kHoldWin], c_hold_rot[HOLD ? 2 : 1][HOLD ? kHoldWin : 1][kHoldWin], c_hold_par[HOLD ? 2 : 1][kHoldPar];
+  if constexpr (HOLD != 0) hold_tables_fill(a, lane, c_hold_w, c_hold_rot, c_hold_par);
   if (kGeomLds) {
     if (lane < N * 7) c_geom_lds[lane] = a.geom[lane];
-    if (HOLD && lane < 2 * kHoldWin) c_hold_w[HOLD ? lane / kHoldWin : 0][lane % kHoldWin] = a.hold_w[lane / kHoldWin][lane % kHoldWin];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -519,16 +637,15 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
             if (!hold) LP[0] = q;  // JFC.cpp:68,75,87
             if (vel_branch || pos_branch) {
               HoldPid64 g;
-              g.kf = vel_branch ? a.kf : a.alt_kf, g.kp = vel_branch ? a.kp : a.alt_kp, g.ki = vel_branch ? a.ki : a.alt_ki, g.kd = vel_branch ? a.kd : a.alt_kd;
-              g.imax = vel_branch ? a.imax : a.alt_imax, g.imin = vel_branch ? a.imin : a.alt_imin;
-              g.cmax = vel_branch ? a.cmax : a.alt_cmax, g.cmin = vel_branch ? a.cmin : a.alt_cmin;
+              const double* const pp = c_hold_par[HOLD && vel_branch ? 1 : 0];  // (LDS reads behind one per-lane address: sixteen selects before)
+              g.kf = pp[0], g.kp = pp[1], g.ki = pp[2], g.kd = pp[3], g.imax = pp[4], g.imin = pp[5], g.cmax = pp[6], g.cmin = pp[7];
               g.nbuf = vel_branch ? a.nbuf : a.alt_nbuf, g.degree = vel_branch ? a.degree : a.alt_degree;
               g.clamp = (vel_branch ? a.clamp_cmd : a.alt_clamp_cmd) != 0;
               g.pcas = vel_branch ? a.pcas[1] : a.pcas[0], g.dcas = vel_branch ? a.dcas[1] : a.dcas[0];  // (selects: a dynamic index copies the arrays to scratch)
               const double desired = vel_branch ? target : (hold ? hrows.held : target);
               bool ran = false;
               double tp = 0.0, ti = 0.0, td = 0.0;
-              force = hold_finish64<HOLD == 2>(HR, st, hrows, c_hold_w[HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, a, vel_branch, ran, tp, ti, td);
+              force = hold_finish64<HOLD == 2>(HR, st, hrows, &c_hold_rot[HOLD && vel_branch ? 1 : 0][0][0], pp[8], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, a, vel_branch, ran, tp, ti, td);
               if (i == 0 && ran) {
                 dbg_p = tp, dbg_i = ti, dbg_d = td;
                 dbg_ran = true;
@@ -564,10 +681,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
           }
           c_ierr[i][lane] = ie;
           force = out;
-          if (RING_LDS)
-            c_win[RING_LDS ? i : 0][RING_LDS ? ring_slot : 0][lane] = error;
-          else
-            S[(size_t)(20 + (W + 1) * i + ring_slot) * st] = error;  // after the FIR has read the slot's old content
+          if (RING_LDS) c_win[RING_LDS ? i : 0][RING_LDS ? ring_slot : 0][lane] = error;  // (the next steps of this launch read it there)
+          S[(size_t)(20 + (W + 1) * i + ring_slot) * st] = error;  // after the FIR has read the slot's old content; the slot, not the ring at the end
           if (i == 0) {
             dbg_p = p_term;
             dbg_i = i_raw;
@@ -899,10 +1014,6 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma clang loop unroll_count(kCableUnroll)
   for (int i = 0; i < N; ++i) {
     if (!HOLD) S[(size_t)(20 + (W + 1) * i + W) * st] = c_ierr[i][lane];  // (HOLD: the integrals live in the Pids' own rows)
-    if (RING_LDS) {
-#pragma unroll
-      for (int k = 0; k < W; ++k) S[(size_t)(20 + (W + 1) * i + k) * st] = c_win[RING_LDS ? i : 0][RING_LDS ? k : 0][lane];
-    }
   }
   if (PR) a.meta[r] = (uint8_t)((meta & kMetaModeMask) | ((uint32_t)calls << kMetaCallShift));
 }
@@ -961,6 +1072,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
   __shared__ double c_jt[LEAN ? 1 : N][LEAN ? 1 : 6][64];  // rows at the true pose (controller wave: IK stage -> world step)
   __shared__ double c_je[LEAN ? 1 : N][LEAN ? 1 : 6][64];  // rows at the FK estimate (estimator wave: closing evaluation -> tension distribution)
   __shared__ double x_est[3][64];    // estimator -> controller: residual, iterations, infeasible flag
+  __shared__ double c_park[HOLD ? 13 : 1][64];  // HOLD: the controller wave's platform state between its IK stage and the world step
 #ifndef CDPR_F64_HOLD_KU
 #define CDPR_F64_HOLD_KU N
 #endif
@@ -976,13 +1088,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   const double* const c_geom = LEAN ? c_geom_lds : a.geom;
-  __shared__ double c_hold_w[HOLD ? 2 : 1][2][kHoldWin];  // (a copy per wave: each reads what it wrote)
-  if (HOLD) {
-    if (lane < 2 * kHoldWin) c_hold_w[HOLD ? wave : 0][lane / kHoldWin][lane % kHoldWin] = a.hold_w[lane / kHoldWin][lane % kHoldWin];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
+  __shared__ double c_hold_w[HOLD ? 2 : 1][kHoldWin], c_hold_rot[HOLD ? 2 : 1][HOLD ? kHoldWin : 1][kHoldWin], c_hold_par[HOLD ? 2 : 1][kHoldPar];
   const bool live = r < a.batch;  // (no early return: both waves meet at two barriers; tail lanes shadow the last robot)
   const size_t st = a.stride;
   double* const S = a.state + (live ? r : a.batch - 1u);
@@ -992,10 +1098,14 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
   if (wave == 0) {
     // ------------------------------------------------------------------------------------------------ estimator wave
     // (measured and not kept: s_setprio 3 for this wave in the LEAN build, as cdpr_split_kernel has it: 24.1 against 23.65 us)
+    CDPR_F64_STAMP(0);
+    CDPR_F64_CLOCK(6);
     const double p[3] = {S[0 * st], S[1 * st], S[2 * st]};
     const double q4[4] = {S[3 * st], S[4 * st], S[5 * st], S[6 * st]};
     double fkp[3] = {S[13 * st], S[14 * st], S[15 * st]};
     double fkq[4] = {S[16 * st], S[17 * st], S[18 * st], S[19 * st]};
+    CDPR_F64_LANDED();
+    CDPR_F64_STAMP(1);
     {
       const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
 #pragma clang loop unroll_count(kU)
@@ -1005,6 +1115,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
         c_len[i][lane] = L;
       }
     }
+    CDPR_F64_STAMP(2);
     double fk_res = 0.0;
     int fk_it = 0, td_flag = 0;
     {
@@ -1041,13 +1152,13 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
           ++fk_it;
         }
       }
-      const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
+      if (!LEAN) {  // the closing evaluation: the residual of the estimate, its rows kept for the tension distribution
+        const Rot64 R = quat_to_rot64(fkq[0], fkq[1], fkq[2], fkq[3]);
 #pragma clang loop unroll_count(kU)
-      for (int i = 0; i < N; ++i) {
-        double L, j[6];
-        ik_row64(c_geom + i * 7, R, fkp, L, j);
-        fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
-        if (!LEAN) {
+        for (int i = 0; i < N; ++i) {
+          double L, j[6];
+          ik_row64(c_geom + i * 7, R, fkp, L, j);
+          fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
 #pragma unroll
           for (int c = 0; c < 6; ++c) c_je[LEAN ? 0 : i][LEAN ? 0 : c][lane] = j[c];
         }
@@ -1071,8 +1182,9 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       double L, j[6];
-      if (LEAN) {
+      if (LEAN) {  // ... and the closing evaluation is this pass too (round 6: the rows were evaluated twice - 480 instructions of a 7 500-instruction step)
         ik_row64(c_geom + i * 7, Rt, fkp, L, j);
+        fk_res = fmax(fk_res, fabs(c_len[i][lane] - L));
 #pragma unroll
         for (int c = 0; c < 6; ++c) jr[LEAN ? i : 0][c] = j[c];
       } else {
@@ -1086,8 +1198,27 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
       }
     }
     chol_factor64(m, invd);
+    // (pinned here: the compiler sinks the whole block - rows, matrix, factor: ~700 instructions - behind the barrier, next to its
+    //  first use; with the hold branch live the controller wave is the later one and this wave would do that work after the wait;
+    //  without it this wave is the later one, the order makes no difference and the sunk form needs fewer registers)
+    if constexpr (HOLD != 0) {
+#pragma unroll
+      for (int x = 0; x < 6; ++x) {
+        asm volatile("" : "+v"(invd[x]));
+#pragma unroll
+        for (int y = 0; y <= x; ++y) asm volatile("" : "+v"(m[x][y]));
+      }
+      if (LEAN) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+          for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(jr[LEAN ? i : 0][c]));
+      }
+    }
+    CDPR_F64_STAMP(3);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
     __builtin_amdgcn_s_barrier();        // #1: the controller wave's forces are in c_f
+    CDPR_F64_STAMP(4);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     double g[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1118,22 +1249,55 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();  // #2: tensions and estimator results are out
+    CDPR_F64_STAMP(5);
+    CDPR_F64_CLOCK(7);
     return;
   }
   // -------------------------------------------------------------------------------------------------- controller wave
+#ifndef CDPR_F64_CTL_PRIO
+#define CDPR_F64_CTL_PRIO 3
+#endif
+  // LEAN: four workgroups share a CU, every SIMD hosts the estimator wave of one and the controller wave of another, and the issue
+  // arbiter favours the OLDER wave: the fourth workgroup of a CU has the junior wave on both of its SIMDs - its controller wave, short
+  // of slots under the first workgroup's Newton stage, handed its forces over 6 us after the others' and the launch waited for that
+  // quarter of the grid (`profiles/r06_fp64_timeline.txt`: end of a workgroup by quarter of the grid 20.6 / 22.4 / 21.8 / 26.0 us).
+  // The controller wave is short and sleeps at the barriers most of the launch: at raised priority it is out of the way early, every
+  // estimator wave loses the same share, and no workgroup trails.
+  if (LEAN && CDPR_F64_CTL_PRIO) __builtin_amdgcn_s_setprio(CDPR_F64_CTL_PRIO);
+#ifndef CDPR_F64_CTL_SLEEP
+#define CDPR_F64_CTL_SLEEP 10  // (x 64 cycles; 65 536 x 8 plain, same box: 22.4 us at 10, 22.4 - 23.0 at 25, 23.0 at 0 and at 50; no difference with the hold branch)
+#endif
+  if (LEAN && CDPR_F64_CTL_SLEEP) __builtin_amdgcn_s_sleep(CDPR_F64_CTL_SLEEP);  // the estimator wave's fourteen rows ahead of this wave's fifty: its chain is the launch's
+  CDPR_F64_STAMP(8);
   double p[3] = {S[0 * st], S[1 * st], S[2 * st]};
   double q4[4] = {S[3 * st], S[4 * st], S[5 * st], S[6 * st]};
   double v[3] = {S[7 * st], S[8 * st], S[9 * st]}, om[3] = {S[10 * st], S[11 * st], S[12 * st]};
   const uint32_t rc = live ? r : a.batch - 1u;
-#pragma clang loop unroll_count(kU)
-  for (int i = 0; i < N; ++i) {
-    if (!HOLD) c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
-    c_des[i][lane] = (double)a.cmd[(size_t)rc * N + i];
-    if (!LEAN && !HOLD) {  // (HOLD: the windows live in the Pids' own rows)
+  if constexpr (HOLD != 0) {
+    float joy[N];
 #pragma unroll
-      for (int k = 0; k < kWin; ++k) c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane] = S[(size_t)(20 + 11 * i + k) * st];
+    for (int i = 0; i < N; ++i) joy[i] = a.cmd[(size_t)rc * N + i];
+    // the controller tables (this wave's: it reads what it wrote) while the platform rows and the Joy are on their way
+    hold_tables_fill(a, lane, c_hold_w, c_hold_rot, c_hold_par);
+#pragma unroll
+    for (int i = 0; i < N; ++i) c_des[i][lane] = (double)joy[i];
+  } else {
+#pragma clang loop unroll_count(kU)
+    for (int i = 0; i < N; ++i) {
+      c_ierr[i][lane] = S[(size_t)(20 + 11 * i + 10) * st];
+      c_des[i][lane] = (double)a.cmd[(size_t)rc * N + i];
+      if (!LEAN) {
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane] = S[(size_t)(20 + 11 * i + k) * st];
+      }
     }
   }
+  CDPR_F64_LANDED();
+  CDPR_F64_STAMP(9);
+  // observables of step t_k that are known before the forces (PLG.cpp:236-242, 248-280) go out as they arise: pose and twist here, joint
+  // position and velocity from the IK stage - not in the tail behind the estimator wave, where every store is on the launch's critical path
+  const bool publish = (a.publish_mask & 1ull) && live;
+  double* const O = a.obs + r;
   const bool actual_is_vel = (a.flags & kFlagActualIsVelocity) != 0u;
   const int calls = a.pid_calls;
   const bool run_pid = !first_world && !force_mode && calls != 0;  // Pid.cpp:123-126: the first call since reset returns 0
@@ -1145,56 +1309,219 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
   // ---- IK on the state at t_k and the per-cable force (PLG.cpp:222-228 -> JFC.cpp:59-96 -> Pid.cpp:122-191)
   {
     const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma clang loop unroll_count(kU)
+    auto hold_rows_of = [&](int i, bool& vb) -> double* {
+      vb = HOLD && a.hold_mode == 2 && fabs(c_des[i][lane]) > a.hold_eps;  // JFC.cpp:72
+      return S + (size_t)(f64_hold_row(N, HOLD ? i : 0, 0) + (vb ? kHoldPidRows : 0)) * st;
+    };
+    auto last_position_of = [&](int i) -> double* { return S + (size_t)(f64_state_rows(N) + (HOLD ? i : 0) * kHoldCableRows) * st; };  // mLastPosition
+    // (the stores below come behind the first requests: a store may alias a later load as far as the compiler can tell)
+    if constexpr (HOLD != 0) {
+      // ---- the hold branch live (JFC.cpp:59-96 with both Pids alive), FOUR CABLES PER PASS (round 6): their rows - the fourteen of the
+      // Pid each calls in this step, known from its command alone - are requested together, and where every lane's four cables are
+      // steady (the Pid was called one step ago or its window is still filling: no fit, no first call) they run through hold_fast64,
+      // straight-line code the scheduler interleaves.  The per-cable form before it was ~340 instructions a cable in ~25 basic blocks,
+      // each one a dependent chain: 840 issue slots a cable, 14 us of an 18 us step at one robot (`profiles/r06_fp64_timeline.txt`).
+      // A pass shorter than four cables repeats the last one: same rows in (all requests precede all stores), same values out.
+#ifndef CDPR_F64_HOLD_Q
+#define CDPR_F64_HOLD_Q 4
+#endif
+#ifndef CDPR_F64_HOLD_Q_LEAN
+#define CDPR_F64_HOLD_Q_LEAN 2  // (65 536 x 8, same box: 29.0 us at 2, 30.0 at 3, 30.6 at 4 - the longer pass takes the slots of the Newton stage next door)
+#endif
+      constexpr int kQ = LEAN ? CDPR_F64_HOLD_Q_LEAN : CDPR_F64_HOLD_Q;
+      constexpr int Q = N < kQ ? N : kQ;
+      int ci[Q];
+      bool vb[Q];
+      double *HRq[Q], *LPq[Q];
+      HoldRows64 hq[Q];
+      auto request_pass = [&](int i0) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+          ci[k] = min(i0 + k, N - 1);
+          HRq[k] = hold_rows_of(ci[k], vb[k]);
+          LPq[k] = last_position_of(ci[k]);
+          hq[k] = hold_load64(HRq[k], LPq[k], st);
+        }
+      };
+      request_pass(0);  // ... the first pass's ahead of the IK stage
+      if (publish) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          O[(size_t)c * st] = p[c];
+          O[(size_t)(7 + c) * st] = v[c];
+          O[(size_t)(10 + c) * st] = om[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) O[(size_t)(3 + c) * st] = q4[c];
+      }
+      // IK of every cable, straight-line: joint position and velocity into their LDS columns (and out as observables); the platform
+      // state then waits in LDS for the world step - its 26 registers are the passes' (two cables at a time: the first pass's rows are
+      // arriving in 28 registers a cable, and a longer straight line spilled them)
+#ifndef CDPR_F64_HOLD_IK_KU
+#define CDPR_F64_HOLD_IK_KU 4
+#endif
+#pragma clang loop unroll_count(CDPR_F64_HOLD_IK_KU)
+      for (int i = 0; i < N; ++i) {
+        double L, j[6];
+        ik_row64(c_geom + i * 7, R, p, L, j);
+        const double q = c_geom[i * 7 + 6] - L;
+        const double qd = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
+        c_q[i][lane] = q;
+        c_qd[i][lane] = qd;
+        if (publish) {
+          O[(size_t)(16 + i) * st] = q;
+          O[(size_t)(16 + N + i) * st] = qd;
+        }
+        if (!LEAN) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) c_jt[LEAN ? 0 : i][LEAN ? 0 : c][lane] = j[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) c_park[c][lane] = p[c], c_park[7 + c][lane] = v[c], c_park[10 + c][lane] = om[c];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) c_park[3 + c][lane] = q4[c];
+#pragma clang loop unroll(disable)
+      for (int i0 = 0;;) {  // (the next pass's requests at the END of a pass: asked for at its head behind `i0 > 0`, the rows would stay alive across the rare path)
+        double qq[Q], qdq[Q];
+        bool unsteady = false;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+          qq[k] = c_q[ci[k]][lane];
+          qdq[k] = c_qd[ci[k]][lane];
+          unsteady = unsteady || !hold_steady64(hq[k].word, a.step0, vb[k] ? a.nbuf : a.alt_nbuf);
+        }
+        const bool fast = HOLD == 1 && !first_world && a.hold_mode != 0 && __builtin_amdgcn_ballot_w64(unsteady) == 0ull;
+        if (__builtin_expect(fast, 1)) {  // (the other branch is the cold one: what has to be spilled is spilled there)
+          double fq[Q], des[Q], ierr_old[Q], held[Q];
+          HoldFir64 fir[Q];
+#pragma unroll
+          for (int k = 0; k < Q; ++k) {
+            const bool hold = a.hold_mode == 2 && !vb[k];
+            const double target = c_des[ci[k]][lane];
+            des[k] = vb[k] ? target : (hold ? hq[k].held : target);
+            ierr_old[k] = hq[k].ierr, held[k] = hq[k].held;
+            fir[k] = hold_fast_fir64(hq[k], &c_hold_rot[HOLD && vb[k] ? 1 : 0][0][0], c_hold_par[HOLD && vb[k] ? 1 : 0][8], vb[k] ? a.nbuf : a.alt_nbuf, des[k], vb[k] ? qdq[k] : qq[k],
+                                     a.step0, a.dt);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // (the windows are done with before the gains are fetched: see hold_fast_fir64)
+#pragma unroll
+          for (int k = 0; k < Q; ++k) {
+            const bool hold = a.hold_mode == 2 && !vb[k];
+            const double desired = des[k];
+            double tp, ti, td;
+            fq[k] = hold_fast64(HRq[k], LPq[k], st, ierr_old[k], held[k], fir[k], c_hold_par[HOLD && vb[k] ? 1 : 0], vb[k] ? a.nbuf : a.alt_nbuf, hold, qq[k], desired, a.step0, a.dt, tp, ti,
+                                td);
+            if (k == 0) {  // cable 0 is the first cable of the first pass only
+              const bool c0 = i0 == 0;
+              dbg_p = c0 ? tp : dbg_p, dbg_i = c0 ? ti : dbg_i, dbg_d = c0 ? td : dbg_d, dbg_des = c0 ? desired : dbg_des;
+              dbg_ran = dbg_ran || c0;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < Q; ++k) c_f[ci[k]][lane] = fq[k];
+        } else {
+          // any other call (first call since a reset, a window with a gap: the fit, Force mode, the first world step, cascades): a cable
+          // at a time, rolled - the form before round 6; it requests its rows again and keeps nothing of the pass alive
+#pragma clang loop unroll(disable)
+          for (int i = i0; i < (i0 + Q < N ? i0 + Q : N); ++i) {
+            bool vel_branch;
+            double* const HR = hold_rows_of(i, vel_branch);
+            double* const LP = last_position_of(i);
+            const double q = c_q[i][lane], qd = c_qd[i][lane];
+            double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
+            if (!first_world) {
+              const double target = c_des[i][lane];
+              const bool pos_branch = a.hold_mode == 1 || (a.hold_mode == 2 && !vel_branch);
+              const bool hold = a.hold_mode == 2 && !vel_branch;
+              if (!hold && live) LP[0] = q;  // JFC.cpp:68,75,87
+              if (vel_branch || pos_branch) {
+                const HoldRows64 hs = hold_load64(HR, LP, st);
+                HoldPid64 g;
+                const double* const pp = c_hold_par[HOLD && vel_branch ? 1 : 0];
+                g.kf = pp[0], g.kp = pp[1], g.ki = pp[2], g.kd = pp[3], g.imax = pp[4], g.imin = pp[5], g.cmax = pp[6], g.cmin = pp[7];
+                g.nbuf = vel_branch ? a.nbuf : a.alt_nbuf, g.degree = vel_branch ? a.degree : a.alt_degree;
+                g.clamp = (vel_branch ? a.clamp_cmd : a.alt_clamp_cmd) != 0;
+                g.pcas = vel_branch ? a.pcas[1] : a.pcas[0], g.dcas = vel_branch ? a.dcas[1] : a.dcas[0];  // (selects: a dynamic index copies the arrays to scratch)
+                const double desired = vel_branch ? target : (hold ? hs.held : target);
+                bool ran = false;
+                double tp = 0.0, ti = 0.0, td = 0.0;
+                force = hold_finish64<HOLD == 2>(HR, st, hs, &c_hold_rot[HOLD && vel_branch ? 1 : 0][0][0], pp[8], desired, vel_branch ? qd : q, a.step0, a.dt, g, a, vel_branch, ran, tp, ti, td, live);
+                if (i == 0 && ran) {
+                  dbg_p = tp, dbg_i = ti, dbg_d = td;
+                  dbg_ran = true;
+                  dbg_des = desired;
+                }
+              }
+            }
+            c_f[i][lane] = force;
+          }
+        }
+        i0 += Q;
+        if (i0 >= N) break;
+        request_pass(i0);
+      }
+    } else {
+    // The rings of a cable are requested while the cables BEFORE it are computed (LEAN, round 6): a cable's store of its ring slot may
+    // alias the next cable's loads as far as the compiler can tell, so it never moved a load across one - eight round trips in a row
+    constexpr bool kRingAhead = LEAN && !HOLD;
+#ifndef CDPR_F64_RING_KU
+#define CDPR_F64_RING_KU 2
+#endif
+    constexpr int kUc = kRingAhead ? (N < CDPR_F64_RING_KU ? N : CDPR_F64_RING_KU) : kU;  // (the requests are placed by hand: the pass no longer has to be long for them)
+    double rn0[kWin], rn1[kWin];  // kRingAhead: the rings of cable i (on entry of its pass) and of cable i + 1
+    if (kRingAhead && run_pid) {
+#pragma unroll
+      for (int k = 0; k < kWin; ++k) {
+        rn0[k] = S[(size_t)(20 + 11 * 0 + k) * st];
+        rn1[k] = S[(size_t)(20 + 11 * (N > 1 ? 1 : 0) + k) * st];
+      }
+    }
+    if (publish) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        O[(size_t)c * st] = p[c];
+        O[(size_t)(7 + c) * st] = v[c];
+        O[(size_t)(10 + c) * st] = om[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) O[(size_t)(3 + c) * st] = q4[c];
+    }
+#pragma clang loop unroll_count(kUc)
     for (int i = 0; i < N; ++i) {
-      // (HOLD: the rows of the Pid this cable calls in this step - known from the command alone - before the IK)
-      double* const LP = S + (size_t)(f64_state_rows(N) + (HOLD ? i : 0) * kHoldCableRows) * st;  // mLastPosition
-      const bool vel_branch = HOLD && a.hold_mode == 2 && fabs(c_des[i][lane]) > a.hold_eps;  // JFC.cpp:72
-      double* const HR = S + (size_t)(f64_hold_row(N, HOLD ? i : 0, 0) + (vel_branch ? kHoldPidRows : 0)) * st;
-      HoldRows64 hrows;
-      if constexpr (HOLD) hrows = hold_load64(HR, LP, st);
+      double ring[kWin];
+      if (kRingAhead && run_pid) {
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+          ring[k] = rn0[k];
+          rn0[k] = rn1[k];
+        }
+        if (i + 2 < N) {
+#pragma unroll
+          for (int k = 0; k < kWin; ++k) rn1[k] = S[(size_t)(20 + 11 * (i + 2) + k) * st];
+        }
+      }
       double L, j[6];
       ik_row64(c_geom + i * 7, R, p, L, j);
       const double q = c_geom[i * 7 + 6] - L;
       const double qd = -fma(j[5], om[2], fma(j[4], om[1], fma(j[3], om[0], fma(j[2], v[2], fma(j[1], v[1], j[0] * v[0])))));
       c_q[i][lane] = q;
       c_qd[i][lane] = qd;
+      if (publish) {
+        O[(size_t)(16 + i) * st] = q;
+        O[(size_t)(16 + N + i) * st] = qd;
+      }
       if (!LEAN) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) c_jt[LEAN ? 0 : i][LEAN ? 0 : c][lane] = j[c];
       }
       double force = (force_mode && !first_world) ? c_des[i][lane] : 0.0;
-      if constexpr (HOLD) {  // JFC.cpp:59-96 with both Pids alive
-        if (!first_world) {
-          const double target = c_des[i][lane];
-          const bool pos_branch = a.hold_mode == 1 || (a.hold_mode == 2 && !vel_branch);
-          const bool hold = a.hold_mode == 2 && !vel_branch;
-          if (!hold && live) LP[0] = q;  // JFC.cpp:68,75,87
-          if (vel_branch || pos_branch) {
-            HoldPid64 g;
-            g.kf = vel_branch ? a.kf : a.alt_kf, g.kp = vel_branch ? a.kp : a.alt_kp, g.ki = vel_branch ? a.ki : a.alt_ki, g.kd = vel_branch ? a.kd : a.alt_kd;
-            g.imax = vel_branch ? a.imax : a.alt_imax, g.imin = vel_branch ? a.imin : a.alt_imin;
-            g.cmax = vel_branch ? a.cmax : a.alt_cmax, g.cmin = vel_branch ? a.cmin : a.alt_cmin;
-            g.nbuf = vel_branch ? a.nbuf : a.alt_nbuf, g.degree = vel_branch ? a.degree : a.alt_degree;
-              g.clamp = (vel_branch ? a.clamp_cmd : a.alt_clamp_cmd) != 0;
-              g.pcas = vel_branch ? a.pcas[1] : a.pcas[0], g.dcas = vel_branch ? a.dcas[1] : a.dcas[0];  // (selects: a dynamic index copies the arrays to scratch)
-            const double desired = vel_branch ? target : (hold ? hrows.held : target);
-            bool ran = false;
-            double tp = 0.0, ti = 0.0, td = 0.0;
-            force = hold_finish64<HOLD == 2>(HR, st, hrows, c_hold_w[HOLD ? wave : 0][HOLD && vel_branch ? 1 : 0], desired, vel_branch ? qd : q, a.step0, a.dt, g, a, vel_branch, ran, tp, ti, td, live);
-            if (i == 0 && ran) {
-              dbg_p = tp, dbg_i = ti, dbg_d = td;
-              dbg_ran = true;
-              dbg_des = desired;
-            }
-          }
-        }
-      } else if (run_pid) {
+      if (run_pid) {
         const double desired = c_des[i][lane];
         const double error = desired - (actual_is_vel ? qd : q);
         double acc = wt[kWin] * error;
 #pragma unroll
-        for (int k = 0; k < kWin; ++k) acc = fma(wt[k], LEAN ? S[(size_t)(20 + 11 * i + k) * st] : c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane], acc);
+        for (int k = 0; k < kWin; ++k) acc = fma(wt[k], LEAN ? ring[k] : c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane], acc);
         const double p_term = a.kp * error;
         const double prev_ierr = c_ierr[i][lane];
         double ie = fma(a.dt, error, prev_ierr);
@@ -1215,12 +1542,13 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
           ie = prev_ierr;
           out = fma(a.dt * error, a.ki, out);
         }
-        c_ierr[i][lane] = ie;
         force = out;
-        if (LEAN) {
-          if (live) a.state[(size_t)(20 + 11 * i + ring_slot) * st + r] = error;  // after the FIR has read the slot's old content
-        } else {
-          c_win[LEAN ? 0 : i][LEAN ? 0 : ring_slot][lane] = error;
+        // after the FIR has read the slot's old content; the one slot that changed, not the ring (the LDS build wrote all ten rows of
+        // every cable back at the end of the launch until round 6: 1.4 us of stores behind the critical path at one robot); and the
+        // integral from here as well, not from the tail
+        if (live) {
+          a.state[(size_t)(20 + 11 * i + ring_slot) * st + r] = error;
+          a.state[(size_t)(20 + 11 * i + 10) * st + r] = ie;
         }
         if (i == 0) {
           dbg_p = p_term;
@@ -1230,12 +1558,42 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
       }
       c_f[i][lane] = force;
     }
+    }  // (!HOLD)
   }
+  // Experiment (CDPR_F64_EARLY_ROWS = 1; LEAN without HOLD): the rows of the world step (the structure matrix at t_k again: nothing of the IK
+  // stage is kept, the registers were the rings') rebuilt HERE, where this wave would wait for the Newton stage anyway, not behind the
+  // second barrier where all 480 instructions are the launch's critical path; they cross the barriers in registers
+#ifndef CDPR_F64_EARLY_ROWS
+#define CDPR_F64_EARLY_ROWS 0  // (measured, 65 536 x 8, same box, three runs each: 22.08 / 22.46 / 22.41 us with, 22.72 / 22.30 / 22.49 without - the slots come
+#endif                         //  out of the Newton stage next door; not kept)
+  constexpr bool kEarlyRows = LEAN && !HOLD && CDPR_F64_EARLY_ROWS;
+  double jw[kEarlyRows ? N : 1][6];
+  if (kEarlyRows) {
+    const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      double L, j[6];
+      ik_row64(c_geom + i * 7, R, p, L, j);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        jw[kEarlyRows ? i : 0][c] = j[c];
+        asm volatile("" : "+v"(jw[kEarlyRows ? i : 0][c]));  // (here, not sunk behind the barriers next to their use)
+      }
+    }
+  }
+  CDPR_F64_STAMP(10);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the forces are in LDS
   __builtin_amdgcn_s_barrier();        // #1
   __builtin_amdgcn_s_barrier();        // #2: the estimator wave has finished the tension distribution
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  CDPR_F64_STAMP(11);
+  if constexpr (HOLD != 0) {  // (the platform state waited in LDS)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = c_park[c][lane], v[c] = c_park[7 + c][lane], om[c] = c_park[10 + c][lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q4[c] = c_park[3 + c][lane];
+  }
   const double fk_res = x_est[0][lane], fk_it = x_est[1][lane];
   const uint32_t td_flag = (uint32_t)x_est[2][lane];
   uint32_t lim = 0u;
@@ -1260,34 +1618,24 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     d[4] = c_f[0][lane];
   }
   // ---- observables of step t_k (PLG.cpp:236-242, 248-280)
-  if ((a.publish_mask & 1ull) && live) {
-    double* const O = a.obs + r;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      O[(size_t)c * st] = p[c];
-      O[(size_t)(7 + c) * st] = v[c];
-      O[(size_t)(10 + c) * st] = om[c];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) O[(size_t)(3 + c) * st] = q4[c];
+  if (publish) {  // (the rest of the image left with the IK stage)
     O[13 * st] = fk_res;
     O[14 * st] = fk_it;
     O[15 * st] = (double)(td_flag | (lim << 1));
 #pragma clang loop unroll_count(kU)
-    for (int i = 0; i < N; ++i) {
-      O[(size_t)(16 + i) * st] = c_q[i][lane];
-      O[(size_t)(16 + N + i) * st] = c_qd[i][lane];
-      O[(size_t)(16 + 2 * N + i) * st] = c_f[i][lane];
-    }
+    for (int i = 0; i < N; ++i) O[(size_t)(16 + 2 * N + i) * st] = c_f[i][lane];
   }
   // ---- world step to t_{k+1}: wrench = -J^T (applied - d qdot) + m g, semi-implicit Euler
   {
     double w[6] = {a.fgx, a.fgy, a.fgz, 0.0, 0.0, 0.0};
     const Rot64 R = quat_to_rot64(q4[0], q4[1], q4[2], q4[3]);
-#pragma clang loop unroll_count(kU)
+#pragma clang loop unroll_count(kEarlyRows ? N : kU)
     for (int i = 0; i < N; ++i) {
       double L, j[6];
-      if (LEAN) {
+      if (kEarlyRows) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) j[c] = jw[kEarlyRows ? i : 0][c];
+      } else if (LEAN) {
         ik_row64(c_geom + i * 7, R, p, L, j);
       } else {
 #pragma unroll
@@ -1329,6 +1677,7 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     q4[3] = nw * inv;
   }
   // ---- store
+  CDPR_F64_STAMP(12);
   if (live) {
     double* const W = a.state + r;
 #pragma unroll
@@ -1339,15 +1688,12 @@ __global__ __launch_bounds__(128, LEAN ? 2 : 1) void cdpr_split_kernel_f64(const
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) W[(size_t)(3 + c) * st] = q4[c];
-#pragma clang loop unroll_count(kU)
-    for (int i = 0; i < N; ++i) {
-      if (!HOLD) W[(size_t)(20 + 11 * i + 10) * st] = c_ierr[i][lane];  // (HOLD: the integrals live in the Pids' own rows)
-      if (!LEAN && !HOLD) {
-#pragma unroll
-        for (int k = 0; k < kWin; ++k) W[(size_t)(20 + 11 * i + k) * st] = c_win[LEAN ? 0 : i][LEAN ? 0 : k][lane];
-      }
-    }
   }
+#ifdef CDPR_STAMPS
+  CDPR_F64_STAMP(13);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): on gfx9 the stores count too - every store of this wave acknowledged
+  CDPR_F64_STAMP(14);
+#endif
 }
 
 // Read-out of double rows into robot-major arrays (double or float), one thread per (robot, column)
