@@ -560,10 +560,21 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   const float gval = a.geom[min(lane, (uint32_t)(NP * kGeomFloatsPerPair - 1))];
   if (wave == 0) {
     const float4 p0 = load_slot(a.state, st, 0, off), p1 = load_slot(a.state, st, 1, off), p3 = load_slot(a.state, st, 3, off);
-    split_estimator_wave<N, 64, 64>(a, geo, gval, lane, live, st, off, woff, p0, p1, p3, &sm.x_force()[0][0], &sm.x_tension()[0][0], &sm.x_est()[0][0]);
+    // The general controller makes the CONTROLLER wave the longer one (its forces leave 5 us after the Newton stage has finished): it takes
+    // the raised issue priority the fast path's kernel gives the estimator wave, the estimator wave runs at the default.  65 536 x 8, same
+    // box, us per step steady / cables switching Pids: estimator raised (round 5) 14.8 / 22.3, controller raised 14.5 / 21.6, neither
+    // 15.0 / 22.2, both 15.2 / 22.3 (`profiles/r06_general_ab.txt`).
+#ifndef CDPR_GEN_EST_RAISED
+#define CDPR_GEN_EST_RAISED 0
+#endif
+#ifndef CDPR_GEN_CTL_PRIO
+#define CDPR_GEN_CTL_PRIO 3
+#endif
+    split_estimator_wave<N, 64, 64, CDPR_GEN_EST_RAISED != 0>(a, geo, gval, lane, live, st, off, woff, p0, p1, p3, &sm.x_force()[0][0], &sm.x_tension()[0][0], &sm.x_est()[0][0]);
     return;
   }
   // ---------------------------------------------------------------------------------------------------- controller wave
+  if (CDPR_GEN_CTL_PRIO) __builtin_amdgcn_s_setprio(CDPR_GEN_CTL_PRIO);
   GenLayout L;
   L.n = g.lay.n, L.nb = g.lay.nb, L.ncas = g.lay.ncas;
   GenBuf RB = gen_buffer(g.rec, g.rstride, g.rec_bytes, L);

@@ -538,14 +538,16 @@ __global__ __launch_bounds__(64, 1) void cdpr_onestep_kernel(const StepArgs a_in
 
 // The estimator wave of a role-split workgroup (cdpr_split_kernel): platform rows -> measured lengths -> Newton-Raphson FK -> [forces from the controller wave] tension distribution
 // -> tensions and estimator results back.  x_force / x_tension: v2f rows XS elements apart, x_est: float rows ES apart.
-template <int N, int XS, int ES>
+// RAISED: this wave at raised issue priority (the fast path's kernel: its chain is the launch's; the general kernels, whose controller
+// wave is the longer one, pass their own choice)
+template <int N, int XS, int ES, bool RAISED = true>
 CDPR_DEV void split_estimator_wave(const StepArgs& a, float* geo, float gval, uint32_t lane, bool live, size_t st, uint32_t off, uint32_t woff,
                                    const float4& p0, const float4& p1, const float4& p3, const v2f* x_force, v2f* x_tension, float* x_est) {
   constexpr int NP = cable_pairs(N);
 #if CDPR_SPLIT_PRIO == 1 || CDPR_SPLIT_PRIO == 4
-  __builtin_amdgcn_s_setprio(3);  // the estimator is the critical path: it wins the SIMD's issue arbitration
+  if (RAISED) __builtin_amdgcn_s_setprio(3);  // the estimator is the critical path: it wins the SIMD's issue arbitration
 #elif CDPR_SPLIT_PRIO == 3 || CDPR_SPLIT_PRIO == 5
-  __builtin_amdgcn_s_setprio(2);
+  if (RAISED) __builtin_amdgcn_s_setprio(2);
 #endif
   const float4 p4 = load_slot(a.state, st, 4, off);
   if (lane < NP * kGeomFloatsPerPair) geo[lane] = gval;
