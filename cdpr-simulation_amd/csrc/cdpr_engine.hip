@@ -4,175 +4,14 @@
 //
 // Reference paths (relative to src/cdpr_gazebo/ of balazs-bamer/cdpr-simulation):
 //   PLG.cpp = src/CdprGazeboPlugin.cpp, JFC.cpp = src/JointForceCalculator.cpp, Pid.cpp = src/Pid.cpp
-#include <hip/hip_runtime.h>
-
-#include <atomic>
-#include <chrono>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <cstdlib>
-#include <string>
-#include <vector>
-
-#include "../../include/cdpr.h"
-#include "cdpr_kernels.hpp"
-#include "cdpr_select.hpp"
-#include "cdpr_latch.hpp"
-#include "cdpr_solvers.hpp"
-
-using namespace cdpr;
+#include "cdpr_engine_internal.hpp"
 
 namespace {
-
 thread_local std::string g_create_error;
-
-enum Mode { kModeForce = 0, kModePosition = 1, kModeVelocity = 2 };  // JFC.h:35-37
-
-#define HIP_TRY(h, expr)                                                                         \
-  do {                                                                                           \
-    hipError_t e_ = (expr);                                                                      \
-    if (e_ != hipSuccess) {                                                                      \
-      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                              \
-      return CDPR_ERR_DEVICE;                                                                    \
-    }                                                                                            \
-  } while (0)
-
 }  // namespace
 
-struct cdpr_engine {
-  cdpr_config_t cfg{};
-  int device = 0;
-  hipStream_t stream = nullptr;
-  uint32_t n = 0, batch = 0, stride = 0;
-  bool fk = false, td = false, dbg = false;
-  int n_state = 0, n_obs = 0;
-  float4* d_state = nullptr;
-  float4* d_obs = nullptr;
-  float* d_dbg = nullptr;
-  float* d_geom = nullptr;  // pair-interleaved cable geometry, staged in LDS by the kernel
-  int pid_calls = 0;        // Pid::update calls since the last Pid reset (uniform over the batch)
-  bool lane_pair = false;   // two lanes per robot (cdpr_step_kernel_pair.hpp) instead of one
-  bool lane_cable = false;  // one lane per cable, 8 (or 4) lanes per robot (cdpr_step_kernel_cable.hpp)
-  bool phys = false;        // lumped-leg physics terms enabled: the PHYS instantiations of the first-generation kernels
-  bool lowreg = false;      // one-step launches use the <= 256-register build (two waves per SIMD; large batches)
-  bool gen_split = false;   // general path: one-step launches use the role-split kernel (FK + TD, n >= 6, windows <= 11, <= 2 workgroups per CU)
-  bool gen_hot = false;     // general path: robots in the deep steady state keep mLastTime / mIerr in hot rows instead of their H slots (GenHot; CDPR_GEN_HOT=0: off)
-  bool gen_lean = false;    // general path, larger batches: one-step launches use the lean role-split kernel (two waves per SIMD, the rare
-                            // controller paths by call: cdpr_general_split.hpp)
-  bool persist = false;     // one-step launches use the persistent one-wave kernel: one wave per SIMD walks over blocks of 64
-                            // robots, the next block's rows in flight under the current block's arithmetic (large batches)
-  uint32_t persist_grid = 0;  // waves of such a launch: SIMDs of the device
-  bool split = false;       // FK + TD one-step launches use cdpr_split_kernel (estimator wave + controller wave per 64 robots)
-  int sched_refresh = 0;            // cdpr_update_scheduled in progress: Joy batches per launch (StepArgs::sched_*)
-  const uint32_t* sched_ready = nullptr;
-  // cdpr_update_scheduled_kind on a per-robot handle: batch j of the schedule is latched straight from the caller's device
-  // buffers (rows d_commands + j * B * n, mask d_robot_masks + j * B or nullptr = every robot), nothing staged
-  const float* sched_rows[3] = {nullptr, nullptr, nullptr};
-  const uint8_t* sched_mask[3] = {nullptr, nullptr, nullptr};
-  uint32_t* h_fault = nullptr;      // pinned, device-mapped status word: a schedule mailbox that never delivered (kernels OR bits into it)
-  uint32_t* d_fault = nullptr;      // its device address
-  uint32_t chunk = 0;       // > 0: a step over the batch is issued as back-to-back launches over contiguous blocks of at most
-                            // this many robots (batches between one and ~5 robots per hardware lane: see cdpr_create)
-  bool onestep_v2 = true;   // one-step launches use cdpr_onestep_kernel (controller rows through LDS); CDPR_ONESTEP=1: first generation
-  // general controller path (hold branch, cascades, long windows): see cdpr_general_step.hpp
-  bool general = false;
-  float* d_rec = nullptr;    // record rows: [mLastPosition per cable][position Pid rows][velocity Pid rows], one column per robot
-  float* d_gwtab = nullptr;  // FIR weights by ring head, [pid][head][slot]
-  float* d_gptab = nullptr;  // the two Pids' parameters as the kernel stages them in LDS (gen_pid_table)
-  GenPid gpid[2]{};
-  GenLayout glay{};          // rows of a Pid block: sized by the configured window length and cascade count
-  double* d_roll64 = nullptr;    // MPC rollout on a precision = 64 handle: the trajectories' state rows, their cost accumulators, the step's Joy batch
-  double* d_roll64_acc = nullptr;
-  float* d_roll64_cmd = nullptr;
-  size_t roll64_cols = 0;
-  float* d_roll_rec = nullptr;   // MPC rollout on the general path: every trajectory's private copy of the records
-  size_t roll_rec_cols = 0;      // columns d_roll_rec can hold
-  // hipGraph cache: chains of identical steady-state launches (see run_steps)
-  struct GraphEntry {
-    void* kern;
-    const float* cmd;
-    int steps_per_launch, launches, start_slot;
-    uint32_t flags;
-    hipGraph_t graph;
-    hipGraphExec_t exec;
-  };
-  std::vector<GraphEntry> graphs;
-  PlannedKernel last_kernel;  // what the last step launch ran on (cdpr_kernel_name)
-  int win64 = kWin;         // precision = 64: prior errors kept per cable (kWinLong on handles with windows of 12 .. 32 samples)
-  KernelPlan plan;          // the routing cdpr_create took for this configuration (cdpr_select.hpp)
-  int cus = 256;
-  bool use_graphs = true;
-  bool pair_stream = true;  // cdpr_pair_stream_kernel serves the steady several-steps launches of lane-pair handles (CDPR_PAIR_STREAM=0: never; A/B and tests)
-  float* d_vel[2] = {nullptr, nullptr};  // [0] latched, [1] pending
-  float* d_pos[2] = {nullptr, nullptr};
-  float* d_frc[2] = {nullptr, nullptr};  // force commands (cdpr_set_force_command; JFC.h:92-95)
-  // zero-copy commands (cdpr_bind_*_command_device): a caller-owned device buffer takes the place of d_*[0] / d_*[1]
-  const float* ext_vel[2] = {nullptr, nullptr};
-  const float* ext_pos[2] = {nullptr, nullptr};
-  const float* ext_frc[2] = {nullptr, nullptr};
-  // per-robot command arrival (cfg.per_robot_commands): every robot has its own mode; general controller path only
-  bool per_robot = false;
-  uint8_t* d_mode = nullptr;        // uint8[B]: 1 = Position, 2 = Velocity; on the register-resident path also the robot's
-                                    // Pid call count in bits 2-7 (StepArgs::meta)
-  float* d_target = nullptr;        // per-robot handles on the register-resident path: float[B][n], every robot's ACTIVE target row
-  uint8_t* d_mask[3] = {nullptr, nullptr, nullptr};  // pending masks of the velocity / position / force command, uint8[B]
-  bool vel_masked = false, pos_masked = false, frc_masked = false;  // the pending command came with a mask
-  // Host-side Joy batches travel on their own stream (cdpr_set_*_command with a host pointer): the caller's rows go into
-  // one of two pinned staging buffers per kind and from there to the PENDING device buffer while earlier launches still
-  // run; the call returns without waiting.  kind 0 = velocity, 1 = position, 2 = force.
-  hipStream_t copy_stream = nullptr;
-  float* h_stage[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  hipEvent_t stage_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};  // the copy out of that staging buffer has completed
-  bool stage_ev_set[3][2] = {{false, false}, {false, false}, {false, false}};
-  int stage_idx[3] = {0, 0, 0};
-  hipEvent_t ready_wait[3] = {nullptr, nullptr, nullptr};  // event the compute stream has to pass before it touches the pending buffer
-  hipEvent_t free_ev[3] = {nullptr, nullptr, nullptr};     // every launch that read what is now the pending buffer has completed
-  bool free_ev_set[3] = {false, false, false};
-  bool vel_pending = false, pos_pending = false, frc_pending = false;
-  bool have_vel = false, have_pos = false, have_frc = false;  // a command of that kind has been latched since Load
-  int mode = kModePosition;
-  uint64_t step = 0;
-  double prev_publish = 0.0;
-  StepArgs base{};               // world/body/FK/TD constants, pointers; Pid fields filled per launch
-  StepArgs pid_vel{}, pid_pos{};  // only the Pid fields of these are used
-  float* d_wtab = nullptr;        // [velocity | position] rotated derivative-weight tables, kWin * (kWin + 2) floats each
-  float wtab_host[2][kWin * (kWin + 2)]{};  // the same tables on the host: one-step launches take their row by value
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  uint64_t launches = 0, launches_mark = 0;
-  // cdpr_get_observables: pinned, device-mapped host image of one published step + completion word
-  float* h_pub = nullptr;        // host pointer (hipHostMalloc)
-  uint64_t* h_pub_done = nullptr;
-  uint32_t* d_pub_arrivals = nullptr;
-  uint64_t pub_epoch = 0;
-  // MPC rollout scratch, persistent and grow-only (no hipMalloc / hipFree inside a rollout)
-  float* d_roll_ref = nullptr;   // float[B][3]
-  float* d_roll_cost = nullptr;  // float[B][samples]
-  size_t roll_cost_cap = 0;      // trajectories d_roll_cost can hold
-  uint64_t roll_pending = 0;     // trajectories of the launched, not yet fetched rollout
-  // cdpr_config_t.precision = 64: the step in double (cdpr_step_kernel_f64.hpp); its own state, observables, tables
-  bool fp64 = false;
-  bool tstop64 = false;  // ... with the joint stop modelled (travel_stop > 0; TSTOP kernels)
-  bool hold64 = false;   // ... with the position-hold branch live (velocity_epsilon >= 0): both Pids of every cable in rows behind the state (HOLD kernels)
-  double* d_state64 = nullptr;
-  double* d_obs64 = nullptr;
-  double* d_geom64 = nullptr;    // [n][7]
-  double* d_wtab64 = nullptr;    // [velocity | position] x [10][12]
-  double* d_dbg64 = nullptr;
-  void* d_unpack64 = nullptr;    // read-out scratch of the fp64 getters (bytes)
-  void* h_pub64 = nullptr;       // mapped pinned image the fp64 getters of small batches are gathered into (2 MiB)
-  size_t unpack64_cap = 0;
-  F64Args base64{};
-  float* d_unpack = nullptr;     // read-out scratch (cdpr_get_*): robot-major copy of the requested fields, grow-only
-  size_t unpack_cap = 0;
-  std::string err;
-};
 
-static hipError_t wait_stream(cdpr_engine* h);  // poll, then block (defined next to cdpr_synchronize)
-
-namespace {
+namespace cdpr_host {
 
 // ---------------------------------------------------------------------------------
 // Least-squares end-point derivative weights on a uniform grid: the closed form of
@@ -358,44 +197,6 @@ std::vector<float> geom_pairs(const cdpr_config_t& c) {
   return g;
 }
 
-using SolveKernel = void (*)(const SolveArgs);
-
-template <int N>
-SolveKernel pick_solver_n(int op) {
-  if (op == kSolveIk) return cdpr_solver_kernel<N, kSolveIk>;
-  if constexpr (N >= 6) {
-    if (op == kSolveFk) return cdpr_solver_kernel<N, kSolveFk>;
-    if (op == kSolveTd) return cdpr_solver_kernel<N, kSolveTd>;
-  }
-  return nullptr;
-}
-
-SolveKernel pick_solver(uint32_t n, int op) {
-  switch (n) {
-    case 1: return pick_solver_n<1>(op);
-    case 2: return pick_solver_n<2>(op);
-    case 3: return pick_solver_n<3>(op);
-    case 4: return pick_solver_n<4>(op);
-    case 5: return pick_solver_n<5>(op);
-    case 6: return pick_solver_n<6>(op);
-    case 7: return pick_solver_n<7>(op);
-    case 8: return pick_solver_n<8>(op);
-    case 9: return pick_solver_n<9>(op);
-    case 10: return pick_solver_n<10>(op);
-    case 11: return pick_solver_n<11>(op);
-    case 12: return pick_solver_n<12>(op);
-  }
-  return nullptr;
-}
-
-// Scratch device buffer holding caller data for the one-shot solvers.
-struct DevBuf {
-  void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
-  template <typename T> T* as() { return static_cast<T*>(p); }
-};
-
 double sim_time(uint64_t step, double dt) {
   // gazebo::common::Time keeps integer sec + nsec; Double() = sec + nsec * 1e-9 [EXT]
   const int64_t dt_ns = (int64_t)std::llround(dt * 1e9);
@@ -420,33 +221,6 @@ std::vector<float4> home_state(const cdpr_engine* h) {
     if (h->fk) s[4 * (size_t)h->stride + r] = make_float4((float)hp[3], (float)hp[4], (float)hp[5], (float)hp[6]);
   }
   return s;
-}
-
-// rows of an fp64 handle's state: platform, FK estimate, one Pid's rows per cable - and, hold branch live, both Pids' records
-static size_t state64_rows(const cdpr_engine* h) { return (size_t)f64_state_rows((int)h->n, h->win64) + (h->hold64 ? (size_t)f64_hold_rows((int)h->n) : 0); }
-
-// fp64 handles: home state (platform at home, FK seed at home, controller rows zero), observables before the first publish
-int upload_home64(cdpr_engine* h) {
-  const size_t st = h->stride;
-  std::vector<double> s(state64_rows(h) * st, 0.0), o((size_t)f64_obs_rows((int)h->n) * st, 0.0);
-  for (uint32_t r = 0; r < h->stride; ++r)
-    for (int c = 0; c < 7; ++c) {
-      s[(size_t)c * st + r] = h->cfg.home_pose[c];
-      s[(size_t)(13 + c) * st + r] = h->cfg.home_pose[c];
-      o[(size_t)c * st + r] = h->cfg.home_pose[c];
-    }
-  HIP_TRY(h, hipMemcpyAsync(h->d_state64, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(h->d_obs64, o.data(), o.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (h->d_dbg64) HIP_TRY(h, hipMemsetAsync(h->d_dbg64, 0, (size_t)h->batch * CDPR_PID_DEBUG_AXES * sizeof(double), h->stream));
-  if (h->d_mode) HIP_TRY(h, hipMemsetAsync(h->d_mode, kModePosition, h->batch, h->stream));  // PLG.cpp:153-157 (call count 0)
-  if (h->d_target) HIP_TRY(h, hipMemsetAsync(h->d_target, 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
-  for (int i = 0; i < 2; ++i) {
-    HIP_TRY(h, hipMemsetAsync(h->d_vel[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_pos[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_frc[i], 0, (size_t)h->stride * h->n * sizeof(float), h->stream));
-  }
-  HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
 }
 
 int upload_home(cdpr_engine* h) {
@@ -594,14 +368,10 @@ int stage_command(cdpr_engine* h, float* dst, const float* src, size_t count, bo
 
 // The Pid call counter only matters through calls != 0 and calls >= nbuf (<= 11 on the fast path): it saturates.  The
 // ring position does not come from it but from the world step (StepArgs::ring_slot).
-constexpr int kCallSat = 64;
-inline int sat_pid_calls(int calls) { return calls < kCallSat ? calls : kCallSat; }
-inline int ring_slot_of(uint64_t step) { return (int)((step + 8u) % (uint64_t)kWin); }
 // ... of a ring of w errors: the first sample of a handle that runs without a Pid reset since Load is taken at world step 2
-inline int ring_slot_of(uint64_t step, int w) { return (int)((step + (uint64_t)(w - 2)) % (uint64_t)w); }
 
 // Weights of the ring position a launch starts at, copied into its arguments (see StepArgs::wrow).
-inline void set_weight_row(const cdpr_engine* h, StepArgs& a) {
+void set_weight_row(const cdpr_engine* h, StepArgs& a) {
   const int slot = a.ring_slot;
   // (per-robot handles: both Pids share one window, so the velocity Pid's table serves every lane)
   memcpy(a.wrow, &h->wtab_host[(h->per_robot || h->mode == kModeVelocity) ? 0 : 1][slot * (kWin + 2)], sizeof a.wrow);
@@ -609,7 +379,7 @@ inline void set_weight_row(const cdpr_engine* h, StepArgs& a) {
 
 // The kernel a launch uses: the routing is planned_kernel's (cdpr_select.hpp: a pure function of the handle's plan and the
 // launch's shape, the same one cdpr_plan_kernel answers from without a GPU); here its answer becomes a function pointer.
-LaunchShape launch_shape(const cdpr_engine* h, int k, bool steady = false) {
+LaunchShape launch_shape(const cdpr_engine* h, int k, bool steady) {
   LaunchShape s;
   s.steps = k;
   s.first_world = h->step == 0;
@@ -641,7 +411,7 @@ StepKernel step_kernel_of(const cdpr_engine* h, const PlannedKernel& pk) {
     default: return nullptr;  // (general path and precision = 64: their own launch functions)
   }
 }
-StepKernel select_step_kernel(const cdpr_engine* h, int k, bool steady = false) { return step_kernel_of(h, planned_kernel(h->plan, launch_shape(h, k, steady))); }
+StepKernel select_step_kernel(const cdpr_engine* h, int k, bool steady) { return step_kernel_of(h, planned_kernel(h->plan, launch_shape(h, k, steady))); }
 // May a launch of k > 1 world steps with the arguments `a` (flags, pid_calls, pointers set) run on cdpr_pair_stream_kernel?
 // That kernel has no branch for anything but the steady state of a plain handle (cdpr_step_kernel_pair.hpp): every
 // condition below is one the general several-steps kernel tests per step instead (LaunchShape::steady).  CDPR_PAIR_STREAM=0: never (A/B).
@@ -780,248 +550,6 @@ int warm_first_launch(cdpr_engine* h) {
   set_weight_row(h, a);
   hipLaunchKernelGGL(select_step_kernel(h, 1), dim3(1), dim3(step_block_threads(h, 1)), 0, h->stream, a);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
-}
-
-void fill_pid64(const cdpr_pid_params_t& p, double dt, F64Args& k) {
-  k.kf = p.forward_gain; k.kp = p.p_gain; k.ki = p.i_gain; k.kd = p.d_gain;
-  k.imax = std::fabs(p.i_limit); k.imin = -std::fabs(p.i_limit);  // Pid.cpp:70-73 (abs -> fabs)
-  k.cmax = std::fabs(p.cmd_limit); k.cmin = -std::fabs(p.cmd_limit);
-  k.inv_dt = 1.0 / dt;
-  k.nbuf = (int)p.d_buffer_length;
-  k.clamp_cmd = k.cmax > k.cmin;
-}
-
-// precision = 64: the same host logic (commands are latched by run_steps before this is reached), the fp64 kernel
-int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, double* record = nullptr) {
-  const uint32_t n = h->n;
-  if (reset_pid && !h->hold64) {  // Pid::reset (Pid.cpp:100-115): zero every controller row (hold branch live: the latch reset that Pid's own rows)
-    h->pid_calls = 0;
-    HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)(h->win64 + 1) * n * h->stride * sizeof(double), h->stream));
-  }
-  F64Args a = h->base64;
-  a.stamps = h->base.stamps;
-  const bool pr = h->per_robot;
-  const bool vel = pr || h->mode == kModeVelocity, frc = !pr && h->mode == kModeForce;
-  fill_pid64(vel ? h->cfg.velocity_pid : h->cfg.position_pid, h->cfg.dt, a);
-  a.cmd = pr ? h->d_target
-             : frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0])
-                   : vel ? (h->ext_vel[0] ? h->ext_vel[0] : h->d_vel[0]) : (h->ext_pos[0] ? h->ext_pos[0] : h->d_pos[0]);
-  a.wtab = h->d_wtab64 + (vel ? 0 : h->win64 * (h->win64 + 2));
-  if (pr) {  // mode, Pid call count and so the Pid per lane: the velocity Pid in the primary fields, the position Pid in alt_*
-    F64Args p = h->base64;
-    fill_pid64(h->cfg.position_pid, h->cfg.dt, p);
-    a.alt_kf = p.kf, a.alt_kp = p.kp, a.alt_ki = p.ki, a.alt_kd = p.kd;
-    a.alt_imax = p.imax, a.alt_imin = p.imin, a.alt_cmax = p.cmax, a.alt_cmin = p.cmin, a.alt_clamp_cmd = p.clamp_cmd;
-    a.meta = h->d_mode;
-  }
-  if (h->hold64) {  // both Pids alive: the velocity Pid in the primary fields, the position Pid in alt_*
-    F64Args v = h->base64, p = h->base64;
-    fill_pid64(h->cfg.velocity_pid, h->cfg.dt, v);
-    fill_pid64(h->cfg.position_pid, h->cfg.dt, p);
-    a.kf = v.kf, a.kp = v.kp, a.ki = v.ki, a.kd = v.kd, a.imax = v.imax, a.imin = v.imin, a.cmax = v.cmax, a.cmin = v.cmin, a.nbuf = v.nbuf, a.clamp_cmd = v.clamp_cmd;
-    a.alt_kf = p.kf, a.alt_kp = p.kp, a.alt_ki = p.ki, a.alt_kd = p.kd, a.alt_imax = p.imax, a.alt_imin = p.imin, a.alt_cmax = p.cmax, a.alt_cmin = p.cmin;
-    a.alt_clamp_cmd = p.clamp_cmd, a.alt_nbuf = p.nbuf;
-    a.degree = (int)h->cfg.velocity_pid.d_degree, a.alt_degree = (int)h->cfg.position_pid.d_degree;
-    a.hold_eps = h->cfg.velocity_epsilon;
-    a.hold_mode = frc ? 0 : (vel ? 2 : 1);
-    const cdpr_pid_params_t* pids[2] = {&h->cfg.position_pid, &h->cfg.velocity_pid};
-    a.any_cas = a.max_cas = 0;
-    a.any_noclamp = (!v.clamp_cmd || !p.clamp_cmd) ? 1 : 0;
-    for (int t = 0; t < 2; ++t) {  // BiQuad::SetFc(fc, fs = 1.0, q), Filter.h:130-140, in double
-      const cdpr_filter_params_t* fl[2] = {&pids[t]->p_filter, &pids[t]->d_filter};
-      double* co[2] = {a.pcoef[t], a.dcoef[t]};
-      for (int f = 0; f < 2; ++f) {
-        for (int c = 0; c < 5; ++c) co[f][c] = 0.0;
-        if (!fl[f]->cascade) continue;
-        const double k = std::tan(M_PI * fl[f]->rel_cutoff / 1.0);
-        const double den = k * k + k / fl[f]->quality + 1.0;
-        co[f][0] = k * k / den, co[f][1] = 2.0 * co[f][0], co[f][2] = co[f][0];
-        co[f][3] = 2.0 * (k * k - 1.0) / den, co[f][4] = (k * k - k / fl[f]->quality + 1.0) / den;
-      }
-      a.pcas[t] = (int)std::min<uint32_t>(pids[t]->p_filter.cascade, (uint32_t)kHoldMaxCas);
-      a.dcas[t] = (int)std::min<uint32_t>(pids[t]->d_filter.cascade, (uint32_t)kHoldMaxCas);
-      a.max_cas = std::max(a.max_cas, std::max(a.pcas[t], a.dcas[t]));
-    }
-    a.any_cas = a.max_cas > 0 ? 1 : 0;
-    for (int t = 0; t < 2; ++t) {  // uniform-grid weights by age of the sample (derivative_weights: oldest first)
-      double w[CDPR_MAX_D_BUFFER];
-      const uint32_t nb = pids[t]->d_buffer_length;
-      if (derivative_weights(nb, pids[t]->d_degree, w) == CDPR_OK)
-        for (uint32_t age = 0; age < nb && age <= (uint32_t)kWin; ++age) a.hold_w[t][age] = w[nb - 1 - age];
-    }
-  }
-  const size_t image64 = (size_t)f64_obs_rows((int)n) * h->stride;  // doubles per observable image
-  a.obs_step_stride = record ? image64 : 0;
-  // the rings in LDS (64 KiB per wave at n = 8: two waves per CU) while the batch leaves CUs to spare
-  const int ring_env = [] { const char* v = std::getenv("CDPR_F64_RING_LDS"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
-  // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
-  const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
-  a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
-  const bool hold_full = h->plan.hold_full;  // the HOLD = 2 instantiations: cascades, cmd_limit 0
-  // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
-  const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
-  // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
-  // The routing itself: planned_kernel (cdpr_select.hpp) for a one-step and for a several-steps launch of this handle
-  LaunchShape s1 = launch_shape(h, 1), sk = launch_shape(h, 2);
-  s1.f64_ring_lds = sk.f64_ring_lds = ring_env, s1.f64_jcache = sk.f64_jcache = jc_env, s1.f64_split = sk.f64_split = sp_env;
-  const PlannedKernel pk1 = planned_kernel(h->plan, s1), pkk = planned_kernel(h->plan, sk);
-  auto f64_kernel_of = [&](const PlannedKernel& q) -> F64Kernel {
-    switch (q.id) {
-      case KernelId::F64Split: return pick_f64_split_kernel(n, q.f64_lean);
-      case KernelId::F64SplitHold: return pick_f64_split_hold_kernel(n, q.f64_lean, hold_full);
-      case KernelId::F64Hold: return pick_f64_hold_kernel(n, hold_full);
-      case KernelId::F64HoldPr: return pick_f64_hold_pr_kernel(n, hold_full);
-      case KernelId::F64Tstop: return pick_f64_tstop_kernel(n);
-      case KernelId::F64Long: return pick_f64_long_kernel(n);
-      case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
-      default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);
-    }
-  };
-  const bool split1 = pk1.id == KernelId::F64Split || pk1.id == KernelId::F64SplitHold;
-  F64Kernel split_kern = split1 ? f64_kernel_of(pk1) : nullptr;  // (per-robot handles: the one-wave kernel)
-  // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
-  // (14.4 against 20.8 us per step at one robot x 8, same bits): a fused update then runs as one-step launches
-  const bool fused_as_single = pkk.id == KernelId::F64Split || pkk.id == KernelId::F64SplitHold;
-  if (fused_as_single) per_launch = 1;
-  PlannedKernel one_wave = pkk;  // the one-wave kernel of this handle (what a several-steps launch runs, or would run)
-  if (fused_as_single) { LaunchShape so = sk; so.f64_split = 0; one_wave = planned_kernel(h->plan, so); }
-  F64Kernel kern = f64_kernel_of(one_wave);
-  int done = 0;
-  while (done < nsteps) {
-    const int k = std::min(per_launch, nsteps - done);
-    a.nsteps = k;
-    a.flags = pr ? 0u : (vel ? kFlagActualIsVelocity : (frc ? kFlagForceMode : 0u));
-    const bool first_world = (h->step == 0);
-    if (first_world) a.flags |= kFlagFirstWorldStep;
-    if (record) a.obs = record + (size_t)done * image64;
-    a.pid_calls = sat_pid_calls(h->pid_calls);
-    a.ring_slot = ring_slot_of(h->step, h->win64);
-    a.step0 = (int)h->step;
-    a.publish_mask = 0;
-    for (int j = 0; j < k; ++j) {  // PLG.cpp:236-242: strict '>' against the last published stamp
-      const double now = sim_time(h->step + (uint64_t)j, h->cfg.dt);
-      if ((now - h->prev_publish) > h->cfg.publish_period) {
-        h->prev_publish = now;
-        a.publish_mask |= (1ull << j);
-      }
-    }
-    if (k == 1 && split_kern) {
-      hipLaunchKernelGGL(split_kern, dim3((h->batch + 63u) / 64u), dim3(128), 0, h->stream, a);
-      h->last_kernel = pk1;
-    } else {
-      hipLaunchKernelGGL(kern, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
-      h->last_kernel = one_wave;
-    }
-    HIP_TRY(h, hipGetLastError());
-    ++h->launches;
-    h->step += (uint64_t)k;
-    if (!frc) h->pid_calls = sat_pid_calls(h->pid_calls + k - (first_world ? 1 : 0));  // (no Pid call in Force mode)
-    done += k;
-  }
-  if (record && h->cfg.publish_period == 0.0 && h->step > 1)  // keep cdpr_get_* consistent: latest image into the engine's own
-    HIP_TRY(h, hipMemcpyAsync(h->d_obs64, record + (size_t)(nsteps - 1) * image64, image64 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  return CDPR_OK;
-}
-
-// rows [first_row, first_row + width) of a double row buffer -> robot-major host array (double, or float when as_float)
-int fetch_rows64(cdpr_engine* h, const double* rows, uint32_t first_row, uint32_t width, void* host_out, bool as_float) {
-  if (!host_out) return CDPR_OK;
-  const size_t count = (size_t)h->batch * width, bytes = count * (as_float ? sizeof(float) : sizeof(double));
-  if (h->unpack64_cap < bytes) {
-    HIP_TRY(h, wait_stream(h));
-    if (h->d_unpack64) (void)hipFree(h->d_unpack64);
-    h->d_unpack64 = nullptr;
-    h->unpack64_cap = 0;
-    HIP_TRY(h, hipMalloc(&h->d_unpack64, bytes));
-    h->unpack64_cap = bytes;
-  }
-  Unpack64Args u{};
-  u.rows = rows;
-  u.out = h->d_unpack64;
-  u.stride = h->stride;
-  u.batch = h->batch;
-  u.width = width;
-  u.first_row = first_row;
-  u.as_float = as_float ? 1 : 0;
-  hipLaunchKernelGGL(cdpr_unpack64_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, h->stream, u);
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(host_out, h->d_unpack64, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
-}
-
-// the five observable arrays of an fp64 handle (any may be null), double or rounded to float
-// The five observable arrays of a precision = 64 handle in ONE device round trip (round 6; five unpack launches, five copies and
-// five waits before: 88 us per world step for one robot with the host in the loop): one gather launch writes them - small
-// batches straight into a mapped pinned host image, larger ones into device scratch followed by one copy each - one wait.
-int fetch_observables64(cdpr_engine* h, void* position, void* velocity, void* effort, void* pose7, void* twist6, bool as_float) {
-  const uint32_t n = h->n;
-  void* dst[5] = {position, velocity, effort, pose7, twist6};
-  const uint32_t first[5] = {16u, 16u + n, 16u + 2u * n, 0u, 7u}, width[5] = {n, n, n, 7u, 6u};
-  Unpack64MultiArgs u{};
-  u.rows = h->d_obs64;
-  u.stride = h->stride;
-  u.batch = h->batch;
-  u.as_float = as_float ? 1 : 0;
-  void* want[5];
-  uint32_t cum = 0;
-  size_t off = 0;
-  for (int i = 0; i < 5; ++i) {
-    if (!dst[i]) continue;
-    const uint32_t k = u.nseg++;
-    u.first_row[k] = first[i], u.width[k] = width[i], u.cum[k] = cum, u.off[k] = (uint32_t)off;
-    want[k] = dst[i];
-    cum += width[i];
-    off += (size_t)h->batch * width[i];
-  }
-  if (u.nseg == 0) return CDPR_OK;
-  u.total_width = cum;
-  const size_t esz = as_float ? sizeof(float) : sizeof(double), bytes = off * esz;
-  if (off >= (1ull << 32)) {  // element offsets are 32-bit
-    int rc = CDPR_OK;
-    for (int i = 0; i < 5 && rc == CDPR_OK; ++i) rc = fetch_rows64(h, h->d_obs64, first[i], width[i], dst[i], as_float);
-    return rc;
-  }
-  const bool pinned = bytes <= (2u << 20);
-  if (pinned) {
-    if (!h->h_pub64) HIP_TRY(h, hipHostMalloc(&h->h_pub64, 2u << 20, hipHostMallocMapped | hipHostMallocCoherent));
-    HIP_TRY(h, hipHostGetDevicePointer(&u.out, h->h_pub64, 0));
-  } else {
-    if (h->unpack64_cap < bytes) {
-      HIP_TRY(h, wait_stream(h));
-      if (h->d_unpack64) (void)hipFree(h->d_unpack64);
-      h->d_unpack64 = nullptr;
-      h->unpack64_cap = 0;
-      HIP_TRY(h, hipMalloc(&h->d_unpack64, bytes));
-      h->unpack64_cap = bytes;
-    }
-    u.out = h->d_unpack64;
-  }
-  hipLaunchKernelGGL(cdpr_unpack64_multi_kernel, dim3((uint32_t)(((size_t)h->batch * cum + 255) / 256)), dim3(256), 0, h->stream, u);
-  HIP_TRY(h, hipGetLastError());
-  if (!pinned)
-    for (uint32_t k = 0; k < u.nseg; ++k)
-      HIP_TRY(h, hipMemcpyAsync(want[k], static_cast<const char*>(h->d_unpack64) + (size_t)u.off[k] * esz, (size_t)h->batch * u.width[k] * esz, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, wait_stream(h));
-  if (pinned)
-    for (uint32_t k = 0; k < u.nseg; ++k) memcpy(want[k], static_cast<const char*>(h->h_pub64) + (size_t)u.off[k] * esz, (size_t)h->batch * u.width[k] * esz);
-  return CDPR_OK;
-}
-
-int set_platform_state64(cdpr_engine* h, const double* pose7, const double* twist6) {
-  const size_t st = h->stride;
-  std::vector<double> s((size_t)20 * st);
-  HIP_TRY(h, hipMemcpyAsync(s.data(), h->d_state64, s.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, wait_stream(h));
-  for (uint32_t r = 0; r < h->batch; ++r) {
-    if (pose7)
-      for (int c = 0; c < 7; ++c) s[(size_t)c * st + r] = s[(size_t)(13 + c) * st + r] = pose7[(size_t)r * 7 + c];  // the FK seed follows the spawn pose
-    if (twist6)
-      for (int c = 0; c < 6; ++c) s[(size_t)(7 + c) * st + r] = twist6[(size_t)r * 6 + c];
-  }
-  HIP_TRY(h, hipMemcpyAsync(h->d_state64, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, wait_stream(h));
   return CDPR_OK;
 }
@@ -1426,28 +954,45 @@ int fetch_platform(cdpr_engine* h, const float4* rows, float* pose7, float* twis
   return fetch_fields(h, rows, kTwistFields, twist6);
 }
 
-// image of a precision = 64 handle -> robot-major arrays, as double or rounded to float
-template <typename T>
-void decode_image64(const cdpr_engine* h, const double* o, T* position, T* velocity, T* effort, T* pose7, T* twist6) {
-  const size_t st = h->stride;
-  const uint32_t n = h->n;
-  T* dst[3] = {position, velocity, effort};
-  for (int f = 0; f < 3; ++f) {
-    if (!dst[f]) continue;
-    for (uint32_t r = 0; r < h->batch; ++r)
-      for (uint32_t i = 0; i < n; ++i) dst[f][(size_t)r * n + i] = (T)o[(size_t)(16 + f * n + i) * st + r];
-  }
-  for (uint32_t r = 0; r < h->batch; ++r) {
-    if (pose7)
-      for (int c = 0; c < 7; ++c) pose7[(size_t)r * 7 + c] = (T)o[(size_t)c * st + r];
-    if (twist6)
-      for (int c = 0; c < 6; ++c) twist6[(size_t)r * 6 + c] = (T)o[(size_t)(7 + c) * st + r];
-  }
-}
-
 inline float comp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
 
-}  // namespace
+// Wait for the handle's stream with the host in the loop in mind (update -> synchronize -> read observables, every
+// step): poll hipStreamQuery for the first kSpinUs microseconds (the blocking wait's wake-up costs 15-25 us, which is two
+// step kernels; measured by scripts/short_run_probe.py), then hand over to the blocking hipStreamSynchronize so that long
+// waits do not burn a core.  CDPR_SYNC_SPIN_US overrides (0 = always block).
+hipError_t wait_stream(cdpr_engine* h) {
+  static const long spin_us = [] {
+    const char* v = std::getenv("CDPR_SYNC_SPIN_US");
+    return v ? std::atol(v) : 2000L;
+  }();
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) return hipSuccess;
+      if (q != hipErrorNotReady) return q;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
+    }
+  }
+  return hipStreamSynchronize(h->stream);
+}
+
+// A schedule mailbox that never delivered (cdpr_update_scheduled with d_ready): the waiting kernel gave up after its poll
+// budget, raised the handle's status word and went on with whatever the schedule held - the trajectory is not what the
+// caller asked for, and every call that hands results out says so until cdpr_reset.
+int check_fault(cdpr_engine* h) {
+  if (h->h_fault && *(volatile uint32_t*)h->h_fault != 0u) {
+    h->err = "a command schedule's mailbox timed out (d_ready never became non-zero): the steps since are not the scheduled trajectory; cdpr_reset clears this";
+    return CDPR_ERR_DEVICE;
+  }
+  return CDPR_OK;
+}
+
+// every path that hands results out ends here (include/cdpr.h: after a mailbox timeout cdpr_synchronize, the getters and
+// cdpr_device_download return CDPR_ERR_DEVICE until cdpr_reset - the fp64 read-outs and the FK / TD / limit / debug getters too)
+int checked(cdpr_engine* h, int rc) { return rc != CDPR_OK ? rc : check_fault(h); }
+
+}  // namespace cdpr_host
 
 // =================================================================================
 // C-ABI
@@ -2102,21 +1647,11 @@ int cdpr_update_scheduled_kind(cdpr_handle_t h, uint32_t kind, int nsteps, int r
   return scheduled_update(h, kind, nsteps, refresh_steps, d_commands, d_ready, d_robot_masks, d_record, record_bytes);
 }
 
-int cdpr_decode_observables_f64(cdpr_handle_t h, const void* image, double* position, double* velocity, double* effort, double* pose7, double* twist6) {
-  if (!h || !image) return CDPR_ERR_INVALID;
-  if (!h->fp64) {
-    h->err = "cdpr_decode_observables_f64: the handle was not created with precision = 64";
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  decode_image64(h, static_cast<const double*>(image), position, velocity, effort, pose7, twist6);
-  return CDPR_OK;
-}
-
 int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position, float* velocity, float* effort,
                             float* pose7, float* twist6) {
   if (!h || !image) return CDPR_ERR_INVALID;
   if (h->fp64) {  // (the float getters of a precision = 64 handle round)
-    decode_image64(h, static_cast<const double*>(image), position, velocity, effort, pose7, twist6);
+    decode_image64_to_float(h, static_cast<const double*>(image), position, velocity, effort, pose7, twist6);
     return CDPR_OK;
   }
   const float4* o = static_cast<const float4*>(image);
@@ -2141,42 +1676,6 @@ int cdpr_decode_observables(cdpr_handle_t h, const void* image, float* position,
   }
   return CDPR_OK;
 }
-
-// Wait for the handle's stream with the host in the loop in mind (update -> synchronize -> read observables, every
-// step): poll hipStreamQuery for the first kSpinUs microseconds (the blocking wait's wake-up costs 15-25 us, which is two
-// step kernels; measured by scripts/short_run_probe.py), then hand over to the blocking hipStreamSynchronize so that long
-// waits do not burn a core.  CDPR_SYNC_SPIN_US overrides (0 = always block).
-static hipError_t wait_stream(cdpr_engine* h) {
-  static const long spin_us = [] {
-    const char* v = std::getenv("CDPR_SYNC_SPIN_US");
-    return v ? std::atol(v) : 2000L;
-  }();
-  if (spin_us > 0) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      const hipError_t q = hipStreamQuery(h->stream);
-      if (q == hipSuccess) return hipSuccess;
-      if (q != hipErrorNotReady) return q;
-      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
-    }
-  }
-  return hipStreamSynchronize(h->stream);
-}
-
-// A schedule mailbox that never delivered (cdpr_update_scheduled with d_ready): the waiting kernel gave up after its poll
-// budget, raised the handle's status word and went on with whatever the schedule held - the trajectory is not what the
-// caller asked for, and every call that hands results out says so until cdpr_reset.
-static int check_fault(cdpr_engine* h) {
-  if (h->h_fault && *(volatile uint32_t*)h->h_fault != 0u) {
-    h->err = "a command schedule's mailbox timed out (d_ready never became non-zero): the steps since are not the scheduled trajectory; cdpr_reset clears this";
-    return CDPR_ERR_DEVICE;
-  }
-  return CDPR_OK;
-}
-
-// every path that hands results out ends here (include/cdpr.h: after a mailbox timeout cdpr_synchronize, the getters and
-// cdpr_device_download return CDPR_ERR_DEVICE until cdpr_reset - the fp64 read-outs and the FK / TD / limit / debug getters too)
-static int checked(cdpr_engine* h, int rc) { return rc != CDPR_OK ? rc : check_fault(h); }
 
 int cdpr_synchronize(cdpr_handle_t h) {
   if (!h) return CDPR_ERR_INVALID;
@@ -2357,34 +1856,6 @@ int cdpr_get_raw_state(cdpr_handle_t h, float* pose7, float* twist6) {
   return rc != CDPR_OK ? rc : check_fault(h);
 }
 
-static int need_fp64(cdpr_engine* h, const char* what) {
-  if (h->fp64) return CDPR_OK;
-  h->err = std::string(what) + ": the handle was not created with precision = 64";
-  return CDPR_ERR_UNSUPPORTED;
-}
-
-int cdpr_get_observables_f64(cdpr_handle_t h, double* position, double* velocity, double* effort, double* pose7, double* twist6) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (int rc = need_fp64(h, "cdpr_get_observables_f64")) return rc;
-  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  return checked(h, fetch_observables64(h, position, velocity, effort, pose7, twist6, false));
-}
-
-int cdpr_get_raw_state_f64(cdpr_handle_t h, double* pose7, double* twist6) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (int rc = need_fp64(h, "cdpr_get_raw_state_f64")) return rc;
-  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  int rc = fetch_rows64(h, h->d_state64, 0, 7, pose7, false);
-  return rc != CDPR_OK ? rc : checked(h, fetch_rows64(h, h->d_state64, 7, 6, twist6, false));
-}
-
-int cdpr_set_platform_state_f64(cdpr_handle_t h, const double* pose7, const double* twist6) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (int rc = need_fp64(h, "cdpr_set_platform_state_f64")) return rc;
-  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  return set_platform_state64(h, pose7, twist6);
-}
-
 int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
   if (!h || !axes9) return CDPR_ERR_INVALID;
   if (!h->dbg) {
@@ -2403,16 +1874,6 @@ int cdpr_get_pid_debug(cdpr_handle_t h, float* axes9) {
                             h->stream));
   HIP_TRY(h, wait_stream(h));
   return check_fault(h);
-}
-
-// fp64 handles: one observable row of doubles as int32 per robot (iteration count, flags)
-static int fetch_int_row64(cdpr_engine* h, uint32_t row, int32_t* out) {
-  if (!out) return CDPR_OK;
-  std::vector<double> d(h->batch);
-  int rc = fetch_rows64(h, h->d_obs64, row, 1, d.data(), false);
-  if (rc == CDPR_OK)
-    for (uint32_t b = 0; b < h->batch; ++b) out[b] = (int32_t)d[b];
-  return rc;
 }
 
 int cdpr_get_fk_state(cdpr_handle_t h, float* pose7, float* residual, int32_t* iterations) {
@@ -2456,235 +1917,6 @@ int cdpr_get_limit_state(cdpr_handle_t h, uint32_t* cable_mask) {
   if (rc == CDPR_OK)
     for (uint32_t b = 0; b < h->batch; ++b) cable_mask[b] >>= 1;  // bit 0 is the tension-distribution flag
   return checked(h, rc);
-}
-
-// Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in
-// DEVICE buffers.  Nothing is allocated, copied or synchronised here.
-// The rollout of a precision = 64 handle (uniform modes, no hold branch / joint stop): see Roll64Args (cdpr_step_kernel_f64.hpp).
-static int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d_commands, const float* d_ref, float* d_cost) {
-  const uint32_t n = h->n;
-  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  const size_t cols = (size_t)((traj + 63u) & ~(uint64_t)63u);
-  const uint32_t rows = (uint32_t)f64_state_rows((int)n, h->win64);
-  if (h->roll64_cols < cols) {
-    HIP_TRY(h, wait_stream(h));
-    for (void** p64 : {(void**)&h->d_roll64, (void**)&h->d_roll64_acc, (void**)&h->d_roll64_cmd}) {
-      if (*p64) (void)hipFree(*p64);
-      *p64 = nullptr;
-    }
-    h->roll64_cols = 0;
-    HIP_TRY(h, hipMalloc(&h->d_roll64, (size_t)rows * cols * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&h->d_roll64_acc, cols * sizeof(double)));
-    HIP_TRY(h, hipMalloc(&h->d_roll64_cmd, cols * n * sizeof(float)));
-    h->roll64_cols = cols;
-  }
-  const bool reset = h->mode != kModeVelocity;  // JFC.cpp:113-115: the copies start from a reset velocity Pid, the handle's rows stay
-  const uint32_t blocks = (uint32_t)((traj + 255u) / 256u);
-  Roll64Args e{};
-  e.src = h->d_state64, e.dst = h->d_roll64, e.src_stride = h->stride, e.dst_stride = (uint32_t)h->roll64_cols, e.rows = rows, e.batch = h->batch,
-  e.samples = (uint32_t)samples, e.zero_from = reset ? 20u : rows;
-  hipLaunchKernelGGL(cdpr_roll64_expand_kernel, dim3(blocks), dim3(256), 0, h->stream, e);
-  HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemsetAsync(h->d_roll64_acc, 0, cols * sizeof(double), h->stream));
-  F64Args a = h->base64;
-  fill_pid64(h->cfg.velocity_pid, h->cfg.dt, a);
-  a.state = h->d_roll64;
-  a.obs = h->d_obs64;  // (nothing is published: publish_mask = 0)
-  a.dbg = nullptr;
-  a.cmd = h->d_roll64_cmd;
-  a.wtab = h->d_wtab64;
-  a.batch = (uint32_t)traj;
-  a.stride = (uint32_t)h->roll64_cols;
-  a.nsteps = 1;
-  a.publish_mask = 0;
-  a.obs_step_stride = 0;
-  F64Kernel kern = h->tstop64 ? pick_f64_tstop_kernel(n) : h->plan.long64 ? pick_f64_long_kernel(n) : pick_f64_kernel(n, false, false);
-  a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
-  int calls = reset ? 0 : h->pid_calls;
-  for (int k = 0; k < horizon; ++k) {
-    Roll64CmdArgs c{};
-    c.commands = d_commands, c.out = h->d_roll64_cmd, c.batch = h->batch, c.samples = (uint32_t)samples, c.horizon = (uint32_t)horizon, c.n = n, c.k = (uint32_t)k;
-    hipLaunchKernelGGL(cdpr_roll64_cmd_kernel, dim3((uint32_t)((traj * n + 255u) / 256u)), dim3(256), 0, h->stream, c);
-    const bool first_world = (h->step + (uint64_t)k) == 0;
-    a.flags = kFlagActualIsVelocity | (first_world ? kFlagFirstWorldStep : 0u);
-    a.pid_calls = sat_pid_calls(calls);
-    a.ring_slot = ring_slot_of(h->step + (uint64_t)k, h->win64);
-    a.step0 = (int)(h->step + (uint64_t)k);
-    hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
-    calls = sat_pid_calls(calls + (first_world ? 0 : 1));
-    Roll64CostArgs q{};
-    q.state = h->d_roll64, q.ref = d_ref, q.acc = h->d_roll64_acc, q.out = (k == horizon - 1) ? d_cost : nullptr, q.stride = (uint32_t)h->roll64_cols,
-    q.batch = h->batch, q.samples = (uint32_t)samples;
-    hipLaunchKernelGGL(cdpr_roll64_cost_kernel, dim3(blocks), dim3(256), 0, h->stream, q);
-    HIP_TRY(h, hipGetLastError());
-    h->launches += 1;
-  }
-  return CDPR_OK;
-}
-
-static int rollout_enqueue(cdpr_engine* h, int samples, int horizon, const float* d_commands, const float* d_ref, float* d_cost) {
-  if (h->fp64) return rollout_enqueue_f64(h, samples, horizon, d_commands, d_ref, d_cost);
-  if (h->general) {
-    // every trajectory steps a private copy of its robot's controller records (both Pids of every cable: the hold branch
-    // switches between them from step to step): one column per trajectory in a persistent, grow-only scratch
-    const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-    const size_t cols = (size_t)((traj + 63u) & ~(uint64_t)63u);
-    const size_t bytes = h->glay.bytes(cols);
-    if (bytes >= (1ull << 32)) {
-      h->err = "rollout on the general controller path: the trajectories' controller records pass 4 GiB; use fewer samples per call";
-      return CDPR_ERR_UNSUPPORTED;
-    }
-    if (h->roll_rec_cols < cols) {
-      HIP_TRY(h, wait_stream(h));
-      if (h->d_roll_rec) (void)hipFree(h->d_roll_rec);
-      h->d_roll_rec = nullptr;
-      h->roll_rec_cols = 0;
-      HIP_TRY(h, hipMalloc(&h->d_roll_rec, bytes));
-      h->roll_rec_cols = cols;
-    }
-    if (h->step + (uint64_t)horizon >= (1ull << 31)) {
-      h->err = "general controller path: world-step counter would pass 2^31";
-      return CDPR_ERR_UNSUPPORTED;
-    }
-    StepArgs a = h->base;
-    a.state = h->d_state;
-    a.obs = h->d_obs;
-    a.geom = h->d_geom;
-    a.batch = h->batch;
-    a.stride = h->stride;
-    a.nsteps = horizon;
-    a.publish_mask = 0;
-    copy_pid(h->pid_vel, a);  // unused
-    a.flags = (h->step == 0) ? kFlagFirstWorldStep : 0u;
-    a.roll_cmd = d_commands;
-    a.roll_ref = d_ref;
-    a.roll_cost = d_cost;
-    a.roll_samples = (uint32_t)samples;
-    GenCtl g = general_ctl(h);
-    g.src_rec = h->d_rec;
-    g.src_rstride = h->stride;
-    g.rec = h->d_roll_rec;
-    g.rstride = (uint32_t)h->roll_rec_cols;
-    g.rec_bytes = (uint32_t)h->glay.bytes(h->roll_rec_cols);
-    g.now_step = (int)h->step;
-    GenKernel kern = pick_gen_kernel(h->n, h->fk, h->td, true, h->glay.nb > 11, false);
-    hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a, g);
-    HIP_TRY(h, hipGetLastError());
-    ++h->launches;
-    return CDPR_OK;
-  }
-  StepArgs a = h->base;
-  a.state = h->d_state;
-  a.obs = h->d_obs;
-  a.cmd = nullptr;
-  a.dbg = nullptr;
-  a.geom = h->d_geom;
-  a.batch = h->batch;
-  a.stride = h->stride;
-  a.nsteps = horizon;
-  a.publish_mask = 0;
-  copy_pid(h->pid_vel, a);
-  a.flags = kFlagActualIsVelocity;
-  if (h->step == 0) a.flags |= kFlagFirstWorldStep;
-  // a Joy on jointVelocities while in Position mode resets the velocity Pid (JFC.cpp:113-115); the handle's own
-  // records stay untouched, the rollout starts from zeroed copies (per-robot handles: decided per lane from meta)
-  if (!h->per_robot && h->mode != kModeVelocity) a.flags |= kFlagRolloutResetPid;
-  a.pid_calls = (h->mode == kModeVelocity) ? sat_pid_calls(h->pid_calls) : 0;
-  a.ring_slot = ring_slot_of(h->step);
-  if (h->per_robot) {
-    copy_pid_alt(h->pid_pos, a.alt);
-    a.meta = h->d_mode;
-  }
-  a.roll_cmd = d_commands;
-  a.roll_ref = d_ref;
-  a.roll_cost = d_cost;
-  a.roll_samples = (uint32_t)samples;
-  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  LaunchShape rs = launch_shape(h, horizon);
-  rs.rollout = true;
-  StepKernel kern = step_kernel_of(h, planned_kernel(h->plan, rs));
-  hipLaunchKernelGGL(kern, dim3((uint32_t)((traj + 63u) / 64u)), dim3(64), 0, h->stream, a);
-  HIP_TRY(h, hipGetLastError());
-  ++h->launches;
-  return CDPR_OK;
-}
-
-static int rollout_check(cdpr_engine* h, int samples, int horizon, const void* d_commands) {
-  if (samples < 1 || horizon < 1 || !d_commands) {
-    h->err = "rollout: samples, horizon >= 1 and the command buffer are required";
-    return CDPR_ERR_INVALID;
-  }
-  if (h->fp64 && (h->hold64 || h->per_robot)) {
-    h->err = "rollout with precision = 64: uniform-mode handles without the hold branch / cascades / cmd_limit 0";
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  if ((uint64_t)h->batch * (uint64_t)samples > (1ull << 30)) {
-    h->err = "rollout: too many trajectories";
-    return CDPR_ERR_INVALID;
-  }
-  return set_device(h);
-}
-
-int cdpr_rollout_velocity_device(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* d_ref_position,
-                                 float* d_cost) {
-  if (!h) return CDPR_ERR_INVALID;
-  int rc = rollout_check(h, samples, horizon, d_commands);
-  if (rc != CDPR_OK) return rc;
-  if (!d_ref_position || !d_cost) {
-    h->err = "cdpr_rollout_velocity_device: d_ref_position and d_cost are required";
-    return CDPR_ERR_INVALID;
-  }
-  return rollout_enqueue(h, samples, horizon, d_commands, d_ref_position, d_cost);
-}
-
-int cdpr_rollout_velocity_launch(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* ref_position) {
-  if (!h) return CDPR_ERR_INVALID;
-  int rc = rollout_check(h, samples, horizon, d_commands);
-  if (rc != CDPR_OK) return rc;
-  if (!ref_position) {
-    h->err = "cdpr_rollout_velocity_launch: ref_position is required";
-    return CDPR_ERR_INVALID;
-  }
-  const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
-  if (!h->d_roll_ref) HIP_TRY(h, hipMalloc(&h->d_roll_ref, (size_t)h->batch * 3 * sizeof(float)));
-  if (h->roll_cost_cap < traj) {  // grow-only; the stream may still be reading the old buffer
-    HIP_TRY(h, wait_stream(h));
-    if (h->d_roll_cost) (void)hipFree(h->d_roll_cost);
-    h->d_roll_cost = nullptr;
-    h->roll_cost_cap = 0;
-    HIP_TRY(h, hipMalloc(&h->d_roll_cost, (size_t)traj * sizeof(float)));
-    h->roll_cost_cap = traj;
-  }
-  // the caller may reuse ref_position on return: a pageable source is staged before hipMemcpyAsync returns
-  HIP_TRY(h, hipMemcpyAsync(h->d_roll_ref, ref_position, (size_t)h->batch * 3 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  rc = rollout_enqueue(h, samples, horizon, d_commands, h->d_roll_ref, h->d_roll_cost);
-  if (rc == CDPR_OK) h->roll_pending = traj;
-  return rc;
-}
-
-int cdpr_rollout_velocity_fetch(cdpr_handle_t h, float* cost) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (!cost || h->roll_pending == 0) {
-    h->err = "cdpr_rollout_velocity_fetch: no rollout pending (or null cost buffer)";
-    return CDPR_ERR_INVALID;
-  }
-  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  HIP_TRY(h, hipMemcpyAsync(cost, h->d_roll_cost, (size_t)h->roll_pending * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, wait_stream(h));
-  h->roll_pending = 0;
-  return CDPR_OK;
-}
-
-int cdpr_rollout_velocity(cdpr_handle_t h, int samples, int horizon, const float* d_commands, const float* ref_position,
-                          float* cost) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (!cost) {
-    h->err = "cdpr_rollout_velocity: cost is required";
-    return CDPR_ERR_INVALID;
-  }
-  int rc = cdpr_rollout_velocity_launch(h, samples, horizon, d_commands, ref_position);
-  if (rc != CDPR_OK) return rc;
-  return cdpr_rollout_velocity_fetch(h, cost);
 }
 
 #ifdef CDPR_STAMPS
@@ -2748,129 +1980,6 @@ int cdpr_profile_end(cdpr_handle_t h, float* elapsed_ms, uint64_t* kernel_launch
   return CDPR_OK;
 }
 
-static int solver_prolog(cdpr_handle_t h, int op, const char* what, SolveKernel* k) {
-  if (!h) return CDPR_ERR_INVALID;
-  if (set_device(h) != CDPR_OK) return CDPR_ERR_DEVICE;
-  *k = pick_solver(h->n, op);
-  if (!*k) {
-    h->err = std::string(what) + " needs at least 6 cables";
-    return CDPR_ERR_UNSUPPORTED;
-  }
-  return CDPR_OK;
-}
-
-#define UP(buf, src, count, T)                                                                              \
-  do {                                                                                                       \
-    HIP_TRY(h, (buf).alloc((size_t)(count) * sizeof(T)));                                                    \
-    if (src) HIP_TRY(h, hipMemcpyAsync((buf).p, (src), (size_t)(count) * sizeof(T), hipMemcpyHostToDevice, h->stream)); \
-  } while (0)
-#define DOWN(dst, buf, count, T)                                                                             \
-  do {                                                                                                       \
-    if (dst) HIP_TRY(h, hipMemcpyAsync((dst), (buf).p, (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost, h->stream)); \
-  } while (0)
-
-int cdpr_solve_ik(cdpr_handle_t h, const float* pose7, const float* twist6, float* q, float* qdot, float* jac) {
-  SolveKernel k;
-  int rc = solver_prolog(h, kSolveIk, "cdpr_solve_ik", &k);
-  if (rc != CDPR_OK) return rc;
-  if (!pose7) {
-    h->err = "cdpr_solve_ik: pose7 is required";
-    return CDPR_ERR_INVALID;
-  }
-  const size_t B = h->batch, n = h->n;
-  DevBuf dp, dt, dq, dqd, dj;
-  UP(dp, pose7, B * 7, float);
-  UP(dt, twist6, B * 6, float);
-  UP(dq, (const float*)nullptr, B * n, float);
-  UP(dqd, (const float*)nullptr, B * n, float);
-  UP(dj, (const float*)nullptr, B * n * 6, float);
-  SolveArgs a{};
-  a.geom = h->d_geom;
-  a.batch = h->batch;
-  a.pose7 = dp.as<float>();
-  a.twist6 = twist6 ? dt.as<float>() : nullptr;
-  a.q = dq.as<float>();
-  a.qdot = dqd.as<float>();
-  a.jac = dj.as<float>();
-  hipLaunchKernelGGL(k, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
-  HIP_TRY(h, hipGetLastError());
-  DOWN(q, dq, B * n, float);
-  DOWN(qdot, dqd, B * n, float);
-  DOWN(jac, dj, B * n * 6, float);
-  HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
-}
-
-int cdpr_solve_fk(cdpr_handle_t h, const float* lengths, const float* seed7, float* pose7, float* residual, int32_t* iterations) {
-  SolveKernel k;
-  int rc = solver_prolog(h, kSolveFk, "cdpr_solve_fk", &k);
-  if (rc != CDPR_OK) return rc;
-  if (!lengths || !seed7 || !pose7) {
-    h->err = "cdpr_solve_fk: lengths, seed7 and pose7 are required";
-    return CDPR_ERR_INVALID;
-  }
-  const size_t B = h->batch, n = h->n;
-  DevBuf dl, ds, dp, dr, di;
-  UP(dl, lengths, B * n, float);
-  UP(ds, seed7, B * 7, float);
-  UP(dp, (const float*)nullptr, B * 7, float);
-  UP(dr, (const float*)nullptr, B, float);
-  UP(di, (const int32_t*)nullptr, B, int32_t);
-  SolveArgs a{};
-  a.geom = h->d_geom;
-  a.batch = h->batch;
-  a.pose7 = ds.as<float>();
-  a.lengths = dl.as<float>();
-  a.pose_out = dp.as<float>();
-  a.residual = dr.as<float>();
-  a.iters = di.as<int32_t>();
-  a.fk_lambda = h->base.fk_lambda;
-  a.fk_tol = h->base.fk_tol;
-  a.fk_iters = h->base.fk_iters > 0 ? h->base.fk_iters : 4;
-  hipLaunchKernelGGL(k, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
-  HIP_TRY(h, hipGetLastError());
-  DOWN(pose7, dp, B * 7, float);
-  DOWN(residual, dr, B, float);
-  DOWN(iterations, di, B, int32_t);
-  HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
-}
-
-int cdpr_solve_td(cdpr_handle_t h, const float* pose7, const float* wrench6, float* tension, int32_t* infeasible) {
-  SolveKernel k;
-  int rc = solver_prolog(h, kSolveTd, "cdpr_solve_td", &k);
-  if (rc != CDPR_OK) return rc;
-  if (!pose7 || !wrench6 || !tension) {
-    h->err = "cdpr_solve_td: pose7, wrench6 and tension are required";
-    return CDPR_ERR_INVALID;
-  }
-  if (!(h->cfg.td_f_max > h->cfg.td_f_min)) {
-    h->err = "cdpr_solve_td: td_f_max must exceed td_f_min";
-    return CDPR_ERR_INVALID;
-  }
-  const size_t B = h->batch, n = h->n;
-  DevBuf dp, dw, dt, df;
-  UP(dp, pose7, B * 7, float);
-  UP(dw, wrench6, B * 6, float);
-  UP(dt, (const float*)nullptr, B * n, float);
-  UP(df, (const int32_t*)nullptr, B, int32_t);
-  SolveArgs a{};
-  a.geom = h->d_geom;
-  a.batch = h->batch;
-  a.pose7 = dp.as<float>();
-  a.wrench6 = dw.as<float>();
-  a.tension = dt.as<float>();
-  a.flag = df.as<int32_t>();
-  a.td_min = h->base.td_min;
-  a.td_max = h->base.td_max;
-  a.td_mid = h->base.td_mid;
-  hipLaunchKernelGGL(k, dim3((h->batch + 63u) / 64u), dim3(64), 0, h->stream, a);
-  HIP_TRY(h, hipGetLastError());
-  DOWN(tension, dt, B * n, float);
-  DOWN(infeasible, df, B, int32_t);
-  HIP_TRY(h, wait_stream(h));
-  return CDPR_OK;
-}
 #undef UP
 #undef DOWN
 

@@ -22,7 +22,7 @@ struct LatchFastArgs {
   uint32_t new_mode;     // kMetaPosition / kMetaVelocity
 };
 
-__global__ __launch_bounds__(256) void cdpr_latch_fast_kernel(const LatchFastArgs a) {
+static __global__ __launch_bounds__(256) void cdpr_latch_fast_kernel(const LatchFastArgs a) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= a.batch) return;
   if (a.mask && !a.mask[r]) return;
@@ -39,6 +39,6 @@ __global__ __launch_bounds__(256) void cdpr_latch_fast_kernel(const LatchFastArg
 
 // cdpr_update_scheduled_kind served as a chain of launches: one thread waits for the mailbox word of the next batch in front
 // of the batch's latch (what sched_wait does inside a launch that carries the schedule itself).
-__global__ void cdpr_mailbox_wait_kernel(const uint32_t* word, uint32_t* fault) { mailbox_wait(word, fault); }
+static __global__ void cdpr_mailbox_wait_kernel(const uint32_t* word, uint32_t* fault) { mailbox_wait(word, fault); }
 
 }  // namespace cdpr

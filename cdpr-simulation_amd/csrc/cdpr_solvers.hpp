@@ -151,7 +151,7 @@ struct UnpackArgs {
   uint32_t as_int;  // bit j set: the value is converted to int32 (iteration counts, flags) before it is stored
 };
 
-__global__ __launch_bounds__(256) void cdpr_unpack_kernel(const UnpackArgs a) {
+static __global__ __launch_bounds__(256) void cdpr_unpack_kernel(const UnpackArgs a) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   if (t >= a.batch * a.width) return;
   const uint32_t r = t / a.width, j = t - r * a.width;
@@ -173,7 +173,7 @@ struct PublishArgs {
   uint8_t slot[40], comp[40];
 };
 
-__global__ __launch_bounds__(256) void cdpr_publish_kernel(const PublishArgs a) {
+static __global__ __launch_bounds__(256) void cdpr_publish_kernel(const PublishArgs a) {
   // one thread per OUTPUT element, so that a wave writes 256 contiguous bytes (the destination may be host memory behind
   // PCIe); the output is five robot-major blocks: three joint blocks of n columns, then 7 pose and 6 twist columns
   const uint32_t o = blockIdx.x * 256u + threadIdx.x;

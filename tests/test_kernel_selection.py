@@ -4,7 +4,7 @@ pure functions of the configuration, exposed without a GPU through cdpr_plan_ker
   x handle {uniform, per-robot, general (hold branch live), precision = 64} x steps per launch {1, 10}
 is pinned to the kernel name in tests/golden/kernel_selection.json (regenerate: python tests/test_kernel_selection.py --write,
 and review the diff: a changed cell is a changed routing decision).  The engine takes its kernels from the same function
-(cdpr_engine.hip: planned_kernel -> step_kernel_of), and tests/test_gpu_full_size.py checks on the GPU that the kernel a
+(cdpr_engine.hip, cdpr_engine_f64.hip: planned_kernel -> step_kernel_of), and tests/test_gpu_full_size.py checks on the GPU that the kernel a
 handle really launched (cdpr_kernel_name) is the planned one."""
 import ctypes as C
 import json
