@@ -316,7 +316,8 @@ def test_fp64_facade_runs_n_steps_as_one_launch_chain(pkg, oracle):
         assert np.array_equal(m0.effort, m1.effort) and np.array_equal(m0.position, m1.position)
 
 
-@pytest.mark.parametrize("cables,stages,B,split", [(8, 3, 130, None), (4, 0, 70, None), (8, 3, 5000, "0"), (8, 3, 17000, None), (6, 3, 100, "2")])
+@pytest.mark.parametrize("cables,stages,B,split", [(8, 3, 130, None), (4, 0, 70, None), (8, 3, 5000, "0"), (8, 3, 17000, None), (6, 3, 100, "2"), (6, 3, 75, None), (7, 3, 90, None),
+                                                  (7, 3, 100, "2")])
 def test_fp64_hold_branch(pkg, oracle, monkeypatch, cables, stages, B, split):
     """velocityEpsilon >= 0 in the reference's own precision (round 5: the HOLD instantiations of the fp64 kernel): both Pids of
     every cable alive, cables drifting into the hold branch and back (their windows sampled at non-uniform times: the
@@ -325,7 +326,9 @@ def test_fp64_hold_branch(pkg, oracle, monkeypatch, cables, stages, B, split):
     against the fp64 oracle.  The fit here runs on orthogonal polynomials, the oracle's on normal equations in centred
     time: two double formulations of an ill-conditioned step (a window with a gap), hence the effort tolerance.
     Kernels: FK + TD handles take the role-split kernel's HOLD instantiations (its LDS build to 16 384 robots, its lean build
-    beyond; CDPR_F64_SPLIT forces one or, "0", the one-wave kernel); the others the one-wave kernel's."""
+    beyond; CDPR_F64_SPLIT forces one or, "0", the one-wave kernel); the others the one-wave kernel's.  Round 6: the role-split
+    kernels step the cables in passes (4 in the LDS build, 2 in the lean one; steady cables through the straight-line path, every
+    other call through the per-cable code): 6 and 7 cables end on a short pass that repeats its last cable."""
     from test_gpu_general_matrix import hold_commands
 
     if split is not None:
