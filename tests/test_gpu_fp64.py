@@ -521,6 +521,52 @@ def test_role_split_fp64_kernel_against_the_one_wave_kernel(pkg, monkeypatch, ca
     assert worst == 0.0
 
 
+@pytest.mark.parametrize("cables,build", [(8, "1"), (8, "2"), (6, "1"), (7, "2")])
+def test_role_split_fp64_hold_controller_against_the_one_wave_kernel(pkg, monkeypatch, cables, build):
+    """The hold branch on the role-split fp64 kernels (round 6): passes of cables whose rows are requested together, steady cables
+    through the straight-line path (weights by ring slot from a rotated table, the integral's clamp by selects, unconditional stores),
+    every other call through the per-cable code - against the one-wave kernel, which has only the per-cable code: same bits through
+    window fills, held cables, cables crossing epsilon in both directions (windows with a gap: the fit), Position and Force mode,
+    saturating commands (the clamp and its back-calculation), a ragged last block."""
+    from dataclasses import replace
+    from test_gpu_general_matrix import hold_commands
+
+    B, eps = 64 * 2 + 9, 0.004
+    rng = np.random.default_rng(700 + cables)
+    full = pkg.eight_cable_model()
+    model = replace(full, frame_anchors=full.frame_anchors[:cables], platform_anchors=full.platform_anchors[:cables])
+    cfg = pkg.Config(model=model, batch=B, stages=3 | pkg._abi.STAGE_PID_DEBUG, precision=64, velocityEpsilon=eps)
+    pose = perturbed_poses(model, B, rng, 0.02, 0.05)
+    script = []
+    for j in range(6):
+        script.append(("vel", hold_commands(rng, B, cables, eps), [14, 3, 25, 12, 1, 13][j]))
+    script.append(("vel", (40.0 * hold_commands(rng, B, cables, eps)).astype(np.float32), 15))  # far beyond what the joint follows: the clamps
+    script.append(("pos", rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32), 14))
+    script.append(("frc", rng.uniform(5.0, 25.0, (B, cables)).astype(np.float32), 4))
+    script.append(("vel", hold_commands(rng, B, cables, eps), 16))
+    out = []
+    for split in ("0", build):
+        monkeypatch.setenv("CDPR_F64_SPLIT", split)
+        eng = pkg.Engine(cfg, 0)
+        eng.set_platform_state(pose7=pose)
+        eng.update(1)
+        snaps = []
+        for kind, cmd, k in script:
+            getattr(eng, {"vel": "set_velocity_command", "pos": "set_position_command", "frc": "set_force_command"}[kind])(cmd)
+            for _ in range(k):
+                eng.update(1)
+            snaps.append(eng.observables_f64() + eng.raw_state_f64() + (eng.pid_debug(),))
+        out.append((snaps, eng.kernel_name))
+        eng.close()
+    assert "split" in out[1][1] and "split" not in out[0][1], (out[0][1], out[1][1])
+    worst = 0.0
+    for a, b in zip(out[0][0], out[1][0]):
+        for x, y in zip(a, b):
+            worst = max(worst, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
+    print(f"fp64 hold controller, role-split (build {build}) vs one-wave kernel, n = {cables}: worst difference {worst:.3e}")
+    assert worst == 0.0
+
+
 @pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0", "velocity_long_window", "velocity_lumped_legs"])
 def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     """cdpr_rollout_velocity on a precision = 64 handle (round 6; refused before): every (robot, sampled sequence) steps a private
