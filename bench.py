@@ -62,7 +62,9 @@ SCHED_CHUNK = 1000  # world steps per launch on the scheduled path (small batche
 FUSED_WARM, FUSED_LAUNCHES = 3, 30  # the fused leg's own schedule: untimed / minimum timed launches of 10 steps each
 ROLLOUT_SHAPE = (512, 128, 64)  # robots per GPU, sampled sequences, horizon: one GPU's share of BASELINE config 5
 GENERAL_SHAPE = (65536, 0.001, 120, 400)  # general-path leg (the contract's size since round 5): robots, velocityEpsilon, untimed steps (past the window fill AND the 63 consecutive calls after which a robot keeps its steady state in the hot rows), timed steps
-FP64_HOLD_SHAPES = ((65536, 0.001, 200, 300), (1, 0.001, 100, 300))  # ... with the position-hold branch live (robots, velocityEpsilon, warm-up, timed steps)
+# ... with the position-hold branch live (robots, velocityEpsilon, warm-up, timed steps, every how-many-th CABLE is held; 0: none - every cable on its
+# velocity Pid, one Pid's rows per request; with held and moving cables side by side the lanes of a wave read both Pids' rows)
+FP64_HOLD_SHAPES = ((65536, 0.001, 200, 300, 3), (1, 0.001, 100, 300, 3), (65536, 0.001, 200, 300, 0))
 FP64_SHAPES = ((65536, 300, 400), (1, 100, 300))  # (robots, warm-up steps, timed steps): the warm-up also brings the clock back up after the host-side replay of the leg before
 FP64_TOL = {"pose": 1e-10, "eff": 1e-7}         # fp64 kernels against the fp64 oracle (two double implementations; tests/test_gpu_fp64.py: 1e-13 / 1e-9 over short runs)
 LARGE_BATCH_SHAPE = (524288, 100, 200)           # HBM-streaming regime on ONE GPU: robots, untimed steps, timed steps
@@ -1000,7 +1002,7 @@ def main():
         if n == 8 and args.config == 3:
             fp64_legs = []
             hold_legs = []
-            for Bf, eps_f, warm_f, steps_f in tuple((b, None, w, k) for b, w, k in FP64_SHAPES) + FP64_HOLD_SHAPES:
+            for Bf, eps_f, warm_f, steps_f, held_every in tuple((b, None, w, k, 0) for b, w, k in FP64_SHAPES) + FP64_HOLD_SHAPES:
                 Bf = min(Bf, args.batch)  # (--batch below the contract's size: the leg follows)
                 cfg_kwargs_f = cfg_kwargs if eps_f is None else dict(cfg_kwargs, velocityEpsilon=eps_f)
                 ef = pkg.Engine(pkg.Config(batch=Bf, precision=64, **cfg_kwargs_f), device=device)
@@ -1011,7 +1013,7 @@ def main():
                     # hold legs: every third CABLE (not whole robots) commanded 0 <= velocityEpsilon, so that the hold
                     # branch runs - and the two Pids of a robot diverge per cable - at every size including the one-robot leg,
                     # and the parity slice holds held cables
-                    held = (np.arange(Bf * n).reshape(Bf, n) % 3) == 0
+                    held = ((np.arange(Bf * n).reshape(Bf, n) % held_every) == 0) if held_every else np.zeros((Bf, n), dtype=bool)
                     cmd_f[held] = 0.0
                     cmd_f[~held & (np.abs(cmd_f) <= eps_f)] = 0.02  # (the others clearly above epsilon: on the velocity Pid)
                     held_share = float(held.mean())
@@ -1055,7 +1057,9 @@ def main():
                 "kernel_us_one_robot": fp64_legs[-1]["kernel_us"],
                 # the position-hold branch live (velocityEpsilon >= 0; a third of the cables commanded 0 and held by their position
                 # Pid, the others on their velocity Pid: held_cable_share) in double
-                "hold_branch": {"legs": hold_legs, "kernel_us": hold_legs[0]["kernel_us"], "kernel_us_one_robot": hold_legs[-1]["kernel_us"]},
+                # (kernel_us: the leg with a third of the cables held, as since round 5; kernel_us_none_held: every cable on its velocity Pid)
+                "hold_branch": {"legs": hold_legs, "kernel_us": hold_legs[0]["kernel_us"], "kernel_us_one_robot": hold_legs[1]["kernel_us"],
+                                "kernel_us_none_held": hold_legs[2]["kernel_us"]},
                 "parity_check": {"ok": all((l["parity_check"] or {"ok": True})["ok"] for l in fp64_legs + hold_legs)} if not args.no_parity_check else None,
             }
 

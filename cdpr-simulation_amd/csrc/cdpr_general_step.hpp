@@ -957,6 +957,7 @@ CDPR_DEV bool gen_controller(const GenCtlConst kc, const GenBuf& RB, const GenLa
                                now, t_old, kc.dt);
         else
           res = (float)(gen_fit<NBMAX>(y, t, nbuf, degree, now, t_old) / (double)kc.dt);
+        GEN_COLD_STAMP(7, __builtin_amdgcn_s_memrealtime());  // (lands in FRONT of the fit: the call is pure and sinks to its use - the item's window is assembled here)
         {  // the rest of the owner's Pid::update (Pid.cpp:154-186) by the item's lane: D term, command, clamp, anti-windup, H
           const uint32_t ix = mine ? lane : 0u;
           const float dt_i = park[ix], pre = park[64u + ix], prev = park[192u + ix];

@@ -41,6 +41,7 @@ for step in range(12):
     loop = c[:, 1] - c[:, 0]
     hasq = cold[took, 2] > 0
     fit = np.where(hasq, c[:, 3] - c[:, 2], 0.0)
+    fit_only = np.where(hasq & (cold[took, 7] > 0), c[:, 7] - c[:, 2], 0.0)  # window and stamps assembled (stamp 7 sits in front of the fit: its call is pure and sinks below the stamp's store)
     ctl = (t[took, 4] - t[took, 7])
     pre = c[:, 0] - t[took, 7]   # steady check + call entry
     e1 = c[:, 5] - t[took, 7]    # ... of which: up to the tail's first instruction behind its prologue
@@ -48,7 +49,7 @@ for step in range(12):
     post = t[took, 4] - c[:, 3]  # return + registers back + forces to LDS
     ctl_s = (t[~took, 4] - t[~took, 7])
     print(f"  step {step:2d}: {took.sum():4d}/{G} (tier 1: {(kind >= 2).sum()}) | q {np.median(qlen):5.0f} {np.percentile(qlen, 90):5.0f} {qlen.max():5d} | rot {rot.sum():4d} | "
-          f"loop {np.median(loop):5.2f} {loop.max():5.2f}  fit+finish {np.median(fit):5.2f} {fit.max():5.2f}  controller {np.median(ctl):5.2f} {ctl.max():5.2f} (entry {np.median(pre):5.2f} {pre.max():5.2f} [call {np.median(e1):4.2f}, targets {np.median(e2):4.2f}], exit {np.median(post):5.2f} {post.max():5.2f}; steady waves {np.median(ctl_s) if len(ctl_s) else 0:5.2f}) | span {span:.2f}")
+          f"loop {np.median(loop):5.2f} {loop.max():5.2f}  fit+finish {np.median(fit):5.2f} {fit.max():5.2f} (of which assembling the window and its stamps {np.median(fit_only):5.2f})  controller {np.median(ctl):5.2f} {ctl.max():5.2f} (entry {np.median(pre):5.2f} {pre.max():5.2f} [call {np.median(e1):4.2f}, targets {np.median(e2):4.2f}], exit {np.median(post):5.2f} {post.max():5.2f}; steady waves {np.median(ctl_s) if len(ctl_s) else 0:5.2f}) | span {span:.2f}")
     t0 = t[:, 0].min()
     print(f"        tier-1/2 workgroups: controller starts {np.median(t[took, 7] - t0):5.2f}, forces out {np.median(t[took, 4] - t0):5.2f} (max {(t[took, 4] - t0).max():5.2f}), "
           f"tensions back {np.median(t[took, 5] - t0):5.2f}, end {np.median(t[took, 6] - t0):5.2f} (max {(t[took, 6] - t0).max():5.2f}) | the others: "
