@@ -120,7 +120,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
       case KernelId::F64SplitHold: return pick_f64_split_hold_kernel(n, q.f64_lean, hold_full);
       case KernelId::F64Hold: return pick_f64_hold_kernel(n, hold_full);
       case KernelId::F64HoldPr: return pick_f64_hold_pr_kernel(n, hold_full);
-      case KernelId::F64Tstop: return pick_f64_tstop_kernel(n);
+      case KernelId::F64Tstop: return pick_f64_tstop_kernel(n, pr, h->hold64 ? (hold_full ? 2 : 1) : 0);
       case KernelId::F64Long: return pick_f64_long_kernel(n);
       case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
       default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);

@@ -143,12 +143,12 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   // What stays out: derivative windows beyond 11 samples.
   const bool windows_fit = cfg->velocity_pid.d_buffer_length <= (uint32_t)kSelWin + 1 && cfg->position_pid.d_buffer_length <= (uint32_t)kSelWin + 1;
   const bool clean64 = cfg->precision == 64 && windows_fit;
-  const bool hold64 = clean64 && !phys_cfg && (!fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && pr_windows_differ));  // (per-robot modes too:
+  const bool hold64 = clean64 && (!fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && pr_windows_differ));  // (per-robot modes too:
                                                                                                     // each Pid has its own rows and its own window)
   // ... and with the optional physics - the joint stop, the lumped legs (round 6) - on uniform-mode handles without the hold branch:
   // the TSTOP instantiations
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
-  const bool tstop64 = clean64 && phys_cfg && fast_path_obstacle(*cfg).empty() && cfg->per_robot_commands == 0;  // (round 6: the lumped legs too, with or without the stop)
+  const bool tstop64 = clean64 && phys_cfg;  // (round 6: the lumped legs too, with or without the stop; and together with per-robot modes and the hold branch)
   (void)lumped_cfg;
   // ... and derivative windows of 12 .. 32 samples as the ONLY thing beyond the register-resident path (round 6): the plain one-wave
   // fp64 kernel with a ring of 31 errors per cable (uniform-mode handles, reduced physics)
@@ -161,10 +161,10 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   }
   if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64 && !long64) {
     p.rc = CDPR_ERR_UNSUPPORTED;
-    p.error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) with windows to 11 samples, windows to 32 "
-              "samples, and the joint stop / the lumped legs on uniform-mode handles without those: " +
-              (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with the optional physics / different windows") : fast_path_obstacle(*cfg))
-                           : std::string("optional physics"));
+    p.error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) and the optional physics (joint stop, lumped legs) "
+              "with windows to 11 samples, and windows to 32 samples on uniform-mode handles without any of those: " +
+              (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with windows beyond 11 samples") : fast_path_obstacle(*cfg))
+                           : std::string("optional physics with windows beyond 11 samples"));
     return p;
   }
   const bool general = general_cfg && cfg->precision != 64;  // (a precision = 64 handle that got here runs on the fp64 kernels' own instantiations)
@@ -343,7 +343,7 @@ inline PlannedKernel planned_kernel(const KernelPlan& p, const LaunchShape& s) {
       k.block = 128;
       return k;
     }
-    k.id = p.hold64 ? (p.per_robot ? KernelId::F64HoldPr : KernelId::F64Hold) : p.tstop64 ? KernelId::F64Tstop : p.long64 ? KernelId::F64Long : p.per_robot ? KernelId::F64Pr : KernelId::F64;
+    k.id = p.tstop64 ? KernelId::F64Tstop : p.hold64 ? (p.per_robot ? KernelId::F64HoldPr : KernelId::F64Hold) : p.long64 ? KernelId::F64Long : p.per_robot ? KernelId::F64Pr : KernelId::F64;
     return k;
   }
   if (p.general) {
@@ -416,7 +416,12 @@ inline std::string planned_kernel_name(const KernelPlan& p, const PlannedKernel&
     case KernelId::GenLean: snprintf(b, sizeof b, "cdpr_gen_lean_kernel<%u>%s", n, p.gen_hot ? " + hot rows" : ""); break;
     case KernelId::F64: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u%s%s>", n, k.f64_ring_lds ? ", RING_LDS" : "", k.f64_jcache ? ", JCACHE" : ""); break;
     case KernelId::F64Pr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR%s>", n, k.f64_ring_lds ? ", RING_LDS" : ""); break;
-    case KernelId::F64Tstop: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, TSTOP>", n); break;
+    case KernelId::F64Tstop:
+      if (p.hold64)
+        snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %sHOLD = %d, TSTOP>", n, p.per_robot ? "PR, " : "", p.hold_full ? 2 : 1);
+      else
+        snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %sTSTOP>", n, p.per_robot ? "PR, " : "");
+      break;
     case KernelId::F64Long: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, W = 31>", n); break;
     case KernelId::F64Hold: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, HOLD = %d>", n, p.hold_full ? 2 : 1); break;
     case KernelId::F64HoldPr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR, HOLD = %d>", n, p.hold_full ? 2 : 1); break;

@@ -535,7 +535,7 @@ template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, in
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   static_assert(W == kWin || (!RING_LDS && !JCACHE && !PR && !HOLD && !TSTOP), "long derivative windows: the plain instantiation");
   static_assert(!HOLD || (!RING_LDS && !JCACHE), "the hold branch: the plain instantiation (uniform modes, or PR: the mode per lane)");
-  static_assert(!TSTOP || (!RING_LDS && !JCACHE && !PR && !HOLD), "the joint stop: the plain instantiation");
+  static_assert(!TSTOP || (!RING_LDS && !JCACHE), "the joint stop / the lumped legs: rings in memory (with or without PR and HOLD: the world step does not care who set the forces)");
   __shared__ double c_js[TSTOP ? N : 1][TSTOP ? 6 : 1][64];
   // cables per pass of the loops over the cables.  One lane's step is a dependent chain (rotate the anchor, length,
   // reciprocal square root, row, accumulate): with a single wave per SIMD a dependent fp64 instruction waits ~8 cycles for

@@ -459,17 +459,72 @@ def test_fp64_rest_of_pid_update(pkg, oracle, variant):
 
 
 def test_fp64_refuses_what_it_does_not_cover(pkg):
-    lumped = pkg.eight_cable_model()  # (the lumped legs run in double since round 6 - but not together with per-robot modes)
-    lumped.travel_lower, lumped.travel_upper, lumped.travel_stop, lumped.leg_inertia = -0.01, 0.01, 2, 0.004
-    stop_pr = pkg.eight_cable_model()
-    stop_pr.travel_lower, stop_pr.travel_upper, stop_pr.travel_stop = -0.01, 0.01, 2
-    long_window_hold = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)  # (long windows alone are served since round 6)
-    long_window_hold.velocityController.dBufferLength = 16
-    stop_hold = pkg.Config(model=stop_pr, batch=4, precision=64, velocityEpsilon=0.01)
-    for cfg in (pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True), pkg.Config(model=stop_pr, batch=4, precision=64, perRobotCommands=True), long_window_hold, stop_hold):
+    """What precision = 64 still leaves to the fp32 paths (round 6: the optional physics now compose with per-robot modes and the hold
+    branch): derivative windows beyond 11 samples together with the hold branch, with per-robot modes or with the optional physics."""
+    stop = pkg.eight_cable_model()
+    stop.travel_lower, stop.travel_upper, stop.travel_stop = -0.01, 0.01, 2
+    cases = []
+    for kw in (dict(velocityEpsilon=0.01), dict(perRobotCommands=True), dict(model=stop)):
+        cfg = pkg.Config(batch=4, precision=64, **kw)
+        cfg.velocityController.dBufferLength = cfg.positionController.dBufferLength = 16
+        cases.append(cfg)
+    for cfg in cases:
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(cfg, 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("variant", ["per_robot", "hold", "per_robot_hold", "hold_cascades"])
+def test_fp64_optional_physics_with_per_robot_modes_and_the_hold_branch(pkg, oracle, variant):
+    """The joint stop and the lumped legs in double TOGETHER with per-robot modes and / or the hold branch (round 6: refused before; the
+    TSTOP instantiations now take PR and HOLD - the world step does not care who set the forces): velocity Joys with cables at or
+    below epsilon, position and setForce commands on subsets (per-robot variants), joints running into their stops, one-step and
+    fused launches, the trajectory record - against the fp64 oracle."""
+    from dataclasses import replace
+    from test_gpu_general_matrix import hold_commands
+
+    B, cables = 140, 8
+    pr = variant.startswith("per_robot")
+    hold = "hold" in variant
+    eps = 0.004 if hold else -0.001
+    rng = np.random.default_rng(900 + len(variant))
+    model = replace(pkg.eight_cable_model(), inertia=(0.9, 1.1, 1.0, 0.05, -0.03, 0.02), passive_damping=0.05, leg_inertia=0.02, cable_axial_mass=0.005, anchor_point_mass=0.01,
+                    anchor_inertia=0.005, travel_lower=-0.004, travel_upper=0.004, travel_stop=3)
+    cfg = pkg.Config(model=model, batch=B, stages=3 | pkg._abi.STAGE_PID_DEBUG, precision=64, velocityEpsilon=eps, perRobotCommands=pr, gravity=(0.3, -0.2, -9.7))
+    if variant == "hold_cascades":
+        cfg.velocityController.pFilter.cascade, cfg.velocityController.pFilter.relCutoff = 2, 0.2
+        cfg.velocityController.dFilter.cascade, cfg.velocityController.dFilter.relCutoff = 1, 0.25
+    level = 2 if variant == "hold_cascades" else 1
+    want = f"cdpr_step_kernel_f64<8, {'PR, ' if pr else ''}{f'HOLD = {level}, ' if hold else ''}TSTOP>"
+    assert pkg.plan_kernel(cfg, 1) == want, (pkg.plan_kernel(cfg, 1), want)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.003, 0.02).astype(np.float64))
+    tol = dict(TOL64, pose=1e-11, q=1e-11, twist=1e-9, qd=1e-9, eff=1e-6)
+    eng.update(8), ora.update(8)
+    grp = np.arange(B) % 3
+    for rnd, k in enumerate([21, 34, 9, 27]):
+        v = (1.5 * hold_commands(rng, B, cables, abs(eps) if hold else 0.002)).astype(np.float32)
+        if pr:
+            p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+            f = (7.0 + rng.uniform(-0.5, 0.5, (B, cables))).astype(np.float32)
+            for e in (eng, ora):
+                e.set_velocity_command(v, mask=(grp != rnd % 3).astype(np.uint8))
+                if rnd % 2:
+                    e.set_force_command(f, mask=(grp == rnd % 3).astype(np.uint8))
+                else:
+                    e.set_position_command(p, mask=(grp == rnd % 3).astype(np.uint8))
+        else:
+            eng.set_velocity_command(v), ora.set_velocity_command(v)
+        if rnd == 1:
+            eng.update(k, 6)
+        elif rnd == 2:
+            eng.update_record(k, 3)
+        else:
+            eng.update(k)
+        ora.update(k)
+        compare64(eng, ora, f"{variant}, round {rnd}", tol)
+        assert np.array_equal(eng.limit_state(), ora.limit_state())
+    assert eng.kernel_name == want
+    assert (eng.limit_state() != 0).any()
 
 
 def test_zz_report_measured_agreement():

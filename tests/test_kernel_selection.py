@@ -110,7 +110,12 @@ def test_refusals_carry_their_reason(pkg, clean_env):
     lumped = pkg.eight_cable_model()
     lumped.leg_inertia = 0.004
     assert plan(pkg, pkg.Config(model=lumped, batch=4, precision=64)) == (0, "cdpr_step_kernel_f64<8, TSTOP>")  # (in double since round 6)
-    rc, why = plan(pkg, pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True))  # ... but not with per-robot modes
+    # ... and together with per-robot modes and the hold branch (later in round 6)
+    assert plan(pkg, pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True)) == (0, "cdpr_step_kernel_f64<8, PR, TSTOP>")
+    assert plan(pkg, pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True, velocityEpsilon=0.01)) == (0, "cdpr_step_kernel_f64<8, PR, HOLD = 1, TSTOP>")
+    long_pr = pkg.Config(batch=4, precision=64, perRobotCommands=True)  # what is left: windows beyond 11 samples with any of them
+    long_pr.velocityController.dBufferLength = long_pr.positionController.dBufferLength = 20
+    rc, why = plan(pkg, long_pr)
     assert rc == pkg._abi.ERR_UNSUPPORTED and "precision = 64" in why
     long_w = pkg.Config(batch=4, precision=64)
     long_w.velocityController.dBufferLength = 20
