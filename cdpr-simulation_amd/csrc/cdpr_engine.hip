@@ -646,6 +646,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         lf.n = h->n;
         lf.new_mode = (new_mode == kModeVelocity) ? kMetaVelocity : (new_mode == kModePosition) ? kMetaPosition : kMetaForce;
         lf.hold = h->hold64 ? 1u : 0u;
+        lf.win = (uint32_t)h->win64;
         hipLaunchKernelGGL(cdpr_latch_f64_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, lf);
         HIP_TRY(h, hipGetLastError());
         return CDPR_OK;

@@ -121,7 +121,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
       case KernelId::F64Hold: return pick_f64_hold_kernel(n, hold_full);
       case KernelId::F64HoldPr: return pick_f64_hold_pr_kernel(n, hold_full);
       case KernelId::F64Tstop: return pick_f64_tstop_kernel(n, pr, h->hold64 ? (hold_full ? 2 : 1) : 0);
-      case KernelId::F64Long: return pick_f64_long_kernel(n);
+      case KernelId::F64Long: return pick_f64_long_kernel(n, pr, h->tstop64);
       case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
       default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);
     }
@@ -388,7 +388,7 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
   a.nsteps = 1;
   a.publish_mask = 0;
   a.obs_step_stride = 0;
-  F64Kernel kern = h->tstop64 ? pick_f64_tstop_kernel(n) : h->plan.long64 ? pick_f64_long_kernel(n) : pick_f64_kernel(n, false, false);
+  F64Kernel kern = h->plan.long64 ? pick_f64_long_kernel(n, false, h->tstop64) : h->tstop64 ? pick_f64_tstop_kernel(n) : pick_f64_kernel(n, false, false);
   a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
   int calls = reset ? 0 : h->pid_calls;
   for (int k = 0; k < horizon; ++k) {

@@ -70,7 +70,7 @@ GenKernel pick_gen_split11(uint32_t n);  // k_gen_split.hip: one step per launch
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean);  // lean: nothing cached in LDS (four workgroups per CU)
 F64Kernel pick_f64_hold_pr_kernel(uint32_t n, bool full);  // HOLD on per-robot handles
 F64Kernel pick_f64_tstop_kernel(uint32_t n, bool pr = false, int hold = 0);  // joint stop / lumped legs; pr: per-robot modes, hold: 0 | 1 | 2 the HOLD level (k_f64_phys.hip)
-F64Kernel pick_f64_long_kernel(uint32_t n);  // derivative windows of 12 .. 32 samples: the plain one-wave kernel with a ring of 31  // TSTOP instantiations (the joint stop in double)
+F64Kernel pick_f64_long_kernel(uint32_t n, bool pr = false, bool tstop = false);  // windows of 12 .. 32 samples (k_f64_long.hip); pr: per-robot modes, tstop: joint stop / lumped legs
 F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean, bool full);  // ... HOLD instantiations (the position-hold branch in double)
 //  // one step per launch, two waves per 64 robots split by role (FK + TD, n >= 6)
 F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds);  // per-robot handles (mode, call count and Pid per lane)

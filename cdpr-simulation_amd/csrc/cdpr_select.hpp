@@ -148,23 +148,26 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   // ... and with the optional physics - the joint stop, the lumped legs (round 6) - on uniform-mode handles without the hold branch:
   // the TSTOP instantiations
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
-  const bool tstop64 = clean64 && phys_cfg;  // (round 6: the lumped legs too, with or without the stop; and together with per-robot modes and the hold branch)
   (void)lumped_cfg;
   // ... and derivative windows of 12 .. 32 samples as the ONLY thing beyond the register-resident path (round 6): the plain one-wave
   // fp64 kernel with a ring of 31 errors per cable (uniform-mode handles, reduced physics)
+  // (later in round 6: with per-robot modes - both Pids on one window, as on every register-resident per-robot handle - and with the
+  //  optional physics as well; not with the hold branch / cascades / cmd_limit 0: the HOLD records hold eleven samples)
   bool long64 = false;
-  if (cfg->precision == 64 && !windows_fit && cfg->per_robot_commands == 0 && !phys_cfg) {
+  if (cfg->precision == 64 && !windows_fit && !(cfg->per_robot_commands != 0 && pr_windows_differ)) {
     cdpr_config_t probe = *cfg;
     probe.velocity_pid.d_buffer_length = probe.position_pid.d_buffer_length = 11;
     probe.velocity_pid.d_degree = probe.position_pid.d_degree = std::min(cfg->velocity_pid.d_degree, 4u);
     long64 = fast_path_obstacle(probe).empty();  // (no hold branch, no cascades, a command clamp)
   }
+  const bool tstop64 = cfg->precision == 64 && phys_cfg && (windows_fit || long64);  // (round 6: the lumped legs too, with or without the stop; and together with
+                                                                                     //  per-robot modes, the hold branch, long windows)
   if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64 && !long64) {
     p.rc = CDPR_ERR_UNSUPPORTED;
     p.error = "precision = 64 covers the controller (modes, per-robot arrival, hold branch, cascades, cmd_limit 0) and the optional physics (joint stop, lumped legs) "
-              "with windows to 11 samples, and windows to 32 samples on uniform-mode handles without any of those: " +
-              (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes with windows beyond 11 samples") : fast_path_obstacle(*cfg))
-                           : std::string("optional physics with windows beyond 11 samples"));
+              "with windows to 11 samples; windows to 32 samples with per-robot modes and the optional physics, not with the hold branch / cascades / cmd_limit 0: " +
+              (general_cfg ? (fast_path_obstacle(*cfg).empty() ? std::string("per-robot modes whose two Pids fit different windows, one of them beyond 11 samples") : fast_path_obstacle(*cfg))
+                           : std::string("optional physics"));
     return p;
   }
   const bool general = general_cfg && cfg->precision != 64;  // (a precision = 64 handle that got here runs on the fp64 kernels' own instantiations)
@@ -343,7 +346,7 @@ inline PlannedKernel planned_kernel(const KernelPlan& p, const LaunchShape& s) {
       k.block = 128;
       return k;
     }
-    k.id = p.tstop64 ? KernelId::F64Tstop : p.hold64 ? (p.per_robot ? KernelId::F64HoldPr : KernelId::F64Hold) : p.long64 ? KernelId::F64Long : p.per_robot ? KernelId::F64Pr : KernelId::F64;
+    k.id = p.long64 ? KernelId::F64Long : p.tstop64 ? KernelId::F64Tstop : p.hold64 ? (p.per_robot ? KernelId::F64HoldPr : KernelId::F64Hold) : p.per_robot ? KernelId::F64Pr : KernelId::F64;
     return k;
   }
   if (p.general) {
@@ -422,7 +425,7 @@ inline std::string planned_kernel_name(const KernelPlan& p, const PlannedKernel&
       else
         snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %sTSTOP>", n, p.per_robot ? "PR, " : "");
       break;
-    case KernelId::F64Long: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, W = 31>", n); break;
+    case KernelId::F64Long: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %s%sW = 31>", n, p.per_robot ? "PR, " : "", p.tstop64 ? "TSTOP, " : ""); break;
     case KernelId::F64Hold: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, HOLD = %d>", n, p.hold_full ? 2 : 1); break;
     case KernelId::F64HoldPr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR, HOLD = %d>", n, p.hold_full ? 2 : 1); break;
     case KernelId::F64Split: snprintf(b, sizeof b, "cdpr_split_kernel_f64<%u%s>", n, k.f64_lean ? ", LEAN" : ""); break;

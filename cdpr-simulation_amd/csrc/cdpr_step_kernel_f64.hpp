@@ -533,7 +533,7 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
 // instantiation - same code, W + 1 rows per cable instead of 11, a weight table of W rows.
 template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, int HOLD = 0, bool TSTOP = false, int W = kWin>  // HOLD: 0 | 1 | 2 (+ cascades, cmd_limit 0)
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
-  static_assert(W == kWin || (!RING_LDS && !JCACHE && !PR && !HOLD && !TSTOP), "long derivative windows: the plain instantiation");
+  static_assert(W == kWin || (!RING_LDS && !JCACHE && !HOLD), "long derivative windows: rings in memory, one Pid record per cable (with or without PR and TSTOP)");
   static_assert(!HOLD || (!RING_LDS && !JCACHE), "the hold branch: the plain instantiation (uniform modes, or PR: the mode per lane)");
   static_assert(!TSTOP || (!RING_LDS && !JCACHE), "the joint stop / the lumped legs: rings in memory (with or without PR and HOLD: the world step does not care who set the forces)");
   __shared__ double c_js[TSTOP ? N : 1][TSTOP ? 6 : 1][64];
@@ -1031,6 +1031,7 @@ struct LatchF64Args {
   uint32_t batch, n;
   uint32_t new_mode;     // kMetaForce / kMetaPosition / kMetaVelocity
   uint32_t hold;         // HOLD handles: both Pids of every cable live in their own rows (f64_hold_row); entering a mode clears THAT Pid's
+  uint32_t win;          // prior errors kept per cable (kWin, or kWinLong on handles with windows of 12 .. 32 samples): the integral is row 20 + (win + 1) i + win
 };
 static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF64Args a) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
@@ -1046,7 +1047,7 @@ static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF
       for (uint32_t i = 0; i < a.n; ++i)
         for (int row = 0; row < kHoldPidRows; ++row) a.state[(size_t)(f64_hold_row((int)a.n, (int)i, pid) + row) * a.stride + r] = 0.0;
     } else {
-      for (uint32_t i = 0; i < a.n; ++i) a.state[(size_t)(20 + 11 * i + 10) * a.stride + r] = 0.0;
+      for (uint32_t i = 0; i < a.n; ++i) a.state[(size_t)(20 + (a.win + 1u) * i + a.win) * a.stride + r] = 0.0;
     }
     m = a.new_mode;  // call count 0
   }

@@ -9,10 +9,8 @@ template <int N> F64Kernel f64_n(bool ring_lds, bool jcache) {
 }
 template <int N> F64Kernel f64_hold_n(bool full) { return full ? cdpr_step_kernel_f64<N, false, false, false, 2> : cdpr_step_kernel_f64<N, false, false, false, 1>; }
 template <int N> F64Kernel f64_hold_pr_n(bool full) { return full ? cdpr_step_kernel_f64<N, false, false, true, 2> : cdpr_step_kernel_f64<N, false, false, true, 1>; }
-template <int N> F64Kernel f64_long_n() { return cdpr_step_kernel_f64<N, false, false, false, 0, false, kWinLong>; }
 }  // namespace
 F64Kernel pick_f64_hold_pr_kernel(uint32_t n, bool full) { CDPR_PICK_CABLES(f64_hold_pr_n, full); }  // ... on per-robot handles (the mode per lane)
-F64Kernel pick_f64_long_kernel(uint32_t n) { CDPR_PICK_CABLES(f64_long_n); }  // derivative windows of 12 .. 32 samples (W = kWinLong)  // the joint stop modelled (travel_stop > 0)
 F64Kernel pick_f64_hold_kernel(uint32_t n, bool full) { CDPR_PICK_CABLES(f64_hold_n, full); }  // the position-hold branch live (both Pids of every cable)
 F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }
 F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds) { CDPR_PICK_CABLES(f64_pr_n, ring_lds); }  // per-robot modes (PR)

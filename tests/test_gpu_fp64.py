@@ -459,15 +459,20 @@ def test_fp64_rest_of_pid_update(pkg, oracle, variant):
 
 
 def test_fp64_refuses_what_it_does_not_cover(pkg):
-    """What precision = 64 still leaves to the fp32 paths (round 6: the optional physics now compose with per-robot modes and the hold
-    branch): derivative windows beyond 11 samples together with the hold branch, with per-robot modes or with the optional physics."""
-    stop = pkg.eight_cable_model()
-    stop.travel_lower, stop.travel_upper, stop.travel_stop = -0.01, 0.01, 2
+    """What precision = 64 still leaves to the fp32 paths (round 6: the optional physics, per-robot modes and long windows now compose):
+    derivative windows beyond 11 samples together with the hold branch / cascades / cmd_limit 0 (their Pid records hold eleven
+    samples), or on a per-robot handle whose two Pids fit different windows (that is a HOLD handle too)."""
     cases = []
-    for kw in (dict(velocityEpsilon=0.01), dict(perRobotCommands=True), dict(model=stop)):
+    for kw in (dict(velocityEpsilon=0.01), dict(perRobotCommands=True, velocityEpsilon=0.01)):
         cfg = pkg.Config(batch=4, precision=64, **kw)
         cfg.velocityController.dBufferLength = cfg.positionController.dBufferLength = 16
         cases.append(cfg)
+    differ = pkg.Config(batch=4, precision=64, perRobotCommands=True)
+    differ.velocityController.dBufferLength = 16
+    cases.append(differ)
+    cascade = pkg.Config(batch=4, precision=64)
+    cascade.velocityController.dBufferLength, cascade.velocityController.pFilter.cascade = 16, 1
+    cases.append(cascade)
     for cfg in cases:
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(cfg, 0)
@@ -662,6 +667,52 @@ def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     assert all(np.array_equal(x, y) for x, y in zip(before, after)) and eng.step_count == ora.step_count
     eng.update(5), ora.update(5)  # ... and carries on as if nothing had happened
     assert np.abs(eng.observables_f64()[3] - ora.platform_state()[0]).max() < 1e-12
+
+
+@pytest.mark.parametrize("variant", ["per_robot", "physics", "per_robot_physics"])
+def test_fp64_long_windows_with_per_robot_modes_and_the_optional_physics(pkg, oracle, variant):
+    """Derivative windows of 12 .. 32 samples in double TOGETHER with per-robot modes (both Pids on the long window, as every
+    register-resident per-robot handle has them on one) and / or the joint stop and the lumped legs (later in round 6; refused
+    before): the W = 31 instantiations take PR and TSTOP.  Through the window fill per robot (a robot's Pid is reset when its mode
+    changes: masked commands at different times), fused launches and the record - against the fp64 oracle."""
+    from dataclasses import replace
+
+    B, cables, nbuf, degree = 100, 8, 20, 3
+    pr, phys = "per_robot" in variant, "physics" in variant
+    rng = np.random.default_rng(940 + len(variant))
+    model = pkg.eight_cable_model()
+    if phys:
+        model = replace(model, passive_damping=0.05, leg_inertia=0.02, anchor_point_mass=0.01, travel_lower=-0.004, travel_upper=0.004, travel_stop=2)
+    cfg = pkg.Config(model=model, batch=B, stages=3, precision=64, perRobotCommands=pr)
+    for c in (cfg.velocityController, cfg.positionController):
+        c.dBufferLength, c.dDegree = nbuf, degree
+    want = f"cdpr_step_kernel_f64<8, {'PR, ' if pr else ''}{'TSTOP, ' if phys else ''}W = 31>"
+    assert pkg.plan_kernel(cfg, 1) == want == pkg.plan_kernel(cfg, 10), (pkg.plan_kernel(cfg, 1), want)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.003 if phys else 0.02, 0.02).astype(np.float64))
+    tol = dict(TOL64, pose=1e-11, q=1e-11, twist=1e-9, qd=1e-9, eff=1e-6)
+    grp = np.arange(B) % 3
+    eng.update(5), ora.update(5)
+    for rnd, k in enumerate([nbuf - 3, 9, nbuf + 7, 14]):
+        v = rng.uniform(-0.04, 0.04, (B, cables)).astype(np.float32)
+        if pr:
+            p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+            for e in (eng, ora):
+                e.set_velocity_command(v, mask=(grp != rnd % 3).astype(np.uint8))   # (a robot entering Velocity mode starts its long window again)
+                e.set_position_command(p, mask=(grp == rnd % 3).astype(np.uint8))
+        else:
+            eng.set_velocity_command(v), ora.set_velocity_command(v)
+        if rnd == 1:
+            eng.update(k, 3)
+        elif rnd == 3:
+            eng.update_record(k, 7)
+        else:
+            for _ in range(k):
+                eng.update(1)
+        ora.update(k)
+        compare64(eng, ora, f"{variant}, round {rnd}", tol)
+    assert eng.kernel_name == want
+    if phys:
+        assert np.array_equal(eng.limit_state(), ora.limit_state())
 
 
 @pytest.mark.parametrize("nbuf,degree,cables,stages", [(16, 3, 8, 3), (32, 2, 8, 3), (12, 4, 4, 0), (24, 1, 6, 1)])

@@ -113,9 +113,12 @@ def test_refusals_carry_their_reason(pkg, clean_env):
     # ... and together with per-robot modes and the hold branch (later in round 6)
     assert plan(pkg, pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True)) == (0, "cdpr_step_kernel_f64<8, PR, TSTOP>")
     assert plan(pkg, pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True, velocityEpsilon=0.01)) == (0, "cdpr_step_kernel_f64<8, PR, HOLD = 1, TSTOP>")
-    long_pr = pkg.Config(batch=4, precision=64, perRobotCommands=True)  # what is left: windows beyond 11 samples with any of them
+    long_pr = pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True)  # ... and windows beyond 11 samples with both
     long_pr.velocityController.dBufferLength = long_pr.positionController.dBufferLength = 20
-    rc, why = plan(pkg, long_pr)
+    assert plan(pkg, long_pr) == (0, "cdpr_step_kernel_f64<8, PR, TSTOP, W = 31>")
+    long_hold = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)  # what is left: long windows with the hold branch
+    long_hold.velocityController.dBufferLength = 20
+    rc, why = plan(pkg, long_hold)
     assert rc == pkg._abi.ERR_UNSUPPORTED and "precision = 64" in why
     long_w = pkg.Config(batch=4, precision=64)
     long_w.velocityController.dBufferLength = 20
