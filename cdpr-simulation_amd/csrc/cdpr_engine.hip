@@ -626,7 +626,8 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
   };
   auto reset_block64 = [&](int which) -> hipError_t {  // precision = 64 with the hold branch: Pid::reset of one Pid of every cable (its rows behind the state)
     for (uint32_t i = 0; i < h->n; ++i) {
-      hipError_t e1 = hipMemsetAsync(h->d_state64 + (size_t)f64_hold_row((int)h->n, (int)i, which) * h->stride, 0, (size_t)kHoldPidRows * h->stride * sizeof(double), h->stream);
+      hipError_t e1 = hipMemsetAsync(h->d_state64 + (size_t)f64_hold_row((int)h->n, (int)i, which, h->hold_win) * h->stride, 0, (size_t)hold_pid_rows(h->hold_win) * h->stride * sizeof(double),
+                                     h->stream);
       if (e1 != hipSuccess) return e1;
     }
     return hipSuccess;
@@ -647,6 +648,7 @@ int run_steps(cdpr_engine* h, int nsteps, int per_launch, float4* record = nullp
         lf.new_mode = (new_mode == kModeVelocity) ? kMetaVelocity : (new_mode == kModePosition) ? kMetaPosition : kMetaForce;
         lf.hold = h->hold64 ? 1u : 0u;
         lf.win = (uint32_t)h->win64;
+        lf.hold_win = (uint32_t)h->hold_win;
         hipLaunchKernelGGL(cdpr_latch_f64_kernel, dim3((h->batch + 255u) / 256u), dim3(256), 0, h->stream, lf);
         HIP_TRY(h, hipGetLastError());
         return CDPR_OK;
@@ -1083,6 +1085,7 @@ int cdpr_create(const cdpr_config_t* cfg, int device, cdpr_handle_t* out) {
   h->hold64 = plan.hold64;
   h->tstop64 = plan.tstop64;
   h->win64 = plan.long64 ? kWinLong : kWin;
+  h->hold_win = plan.hold_long ? kHoldWinLong : kHoldWin;
   h->per_robot = plan.per_robot;
   h->phys = plan.phys;
   h->lane_pair = plan.lane_pair;

@@ -5,7 +5,7 @@
 namespace cdpr_host {
 
 // rows of an fp64 handle's state: platform, FK estimate, one Pid's rows per cable - and, hold branch live, both Pids' records
-size_t state64_rows(const cdpr_engine* h) { return (size_t)f64_state_rows((int)h->n, h->win64) + (h->hold64 ? (size_t)f64_hold_rows((int)h->n) : 0); }
+size_t state64_rows(const cdpr_engine* h) { return (size_t)f64_state_rows((int)h->n, h->win64) + (h->hold64 ? (size_t)f64_hold_rows((int)h->n, h->hold_win) : 0); }
 
 // fp64 handles: home state (platform at home, FK seed at home, controller rows zero), observables before the first publish
 int upload_home64(cdpr_engine* h) {
@@ -96,7 +96,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
       double w[CDPR_MAX_D_BUFFER];
       const uint32_t nb = pids[t]->d_buffer_length;
       if (derivative_weights(nb, pids[t]->d_degree, w) == CDPR_OK)
-        for (uint32_t age = 0; age < nb && age <= (uint32_t)kWin; ++age) a.hold_w[t][age] = w[nb - 1 - age];
+        for (uint32_t age = 0; age < nb && age < (uint32_t)h->hold_win; ++age) a.hold_w[t][age] = w[nb - 1 - age];
     }
   }
   const size_t image64 = (size_t)f64_obs_rows((int)n) * h->stride;  // doubles per observable image
@@ -118,9 +118,9 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
     switch (q.id) {
       case KernelId::F64Split: return pick_f64_split_kernel(n, q.f64_lean);
       case KernelId::F64SplitHold: return pick_f64_split_hold_kernel(n, q.f64_lean, hold_full);
-      case KernelId::F64Hold: return pick_f64_hold_kernel(n, hold_full);
-      case KernelId::F64HoldPr: return pick_f64_hold_pr_kernel(n, hold_full);
-      case KernelId::F64Tstop: return pick_f64_tstop_kernel(n, pr, h->hold64 ? (hold_full ? 2 : 1) : 0);
+      case KernelId::F64Hold: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, false, false) : pick_f64_hold_kernel(n, hold_full);
+      case KernelId::F64HoldPr: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, true, false) : pick_f64_hold_pr_kernel(n, hold_full);
+      case KernelId::F64Tstop: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, pr, true) : pick_f64_tstop_kernel(n, pr, h->hold64 ? (hold_full ? 2 : 1) : 0);
       case KernelId::F64Long: return pick_f64_long_kernel(n, pr, h->tstop64);
       case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
       default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);

@@ -99,6 +99,7 @@ struct cdpr_engine {
   };
   std::vector<GraphEntry> graphs;
   PlannedKernel last_kernel;  // what the last step launch ran on (cdpr_kernel_name)
+  int hold_win = kHoldWin;  // precision = 64, HOLD handles: samples a Pid record's window holds (kHoldWinLong with derivative windows of 12 .. 32 samples)
   int win64 = kWin;         // precision = 64: prior errors kept per cable (kWinLong on handles with windows of 12 .. 32 samples)
   KernelPlan plan;          // the routing cdpr_create took for this configuration (cdpr_select.hpp)
   int cus = 256;

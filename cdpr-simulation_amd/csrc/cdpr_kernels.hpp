@@ -69,6 +69,7 @@ GenKernel pick_gen_split11(uint32_t n);  // k_gen_split.hip: one step per launch
 // k_f64.hip: precision = 64
 F64Kernel pick_f64_split_kernel(uint32_t n, bool lean);  // lean: nothing cached in LDS (four workgroups per CU)
 F64Kernel pick_f64_hold_pr_kernel(uint32_t n, bool full);  // HOLD on per-robot handles
+F64Kernel pick_f64_hold_long_kernel(uint32_t n, bool pr, bool tstop);  // HOLD = 2 over Pid records of 32 samples (k_f64_hold_long.hip)
 F64Kernel pick_f64_tstop_kernel(uint32_t n, bool pr = false, int hold = 0);  // joint stop / lumped legs; pr: per-robot modes, hold: 0 | 1 | 2 the HOLD level (k_f64_phys.hip)
 F64Kernel pick_f64_long_kernel(uint32_t n, bool pr = false, bool tstop = false);  // windows of 12 .. 32 samples (k_f64_long.hip); pr: per-robot modes, tstop: joint stop / lumped legs
 F64Kernel pick_f64_split_hold_kernel(uint32_t n, bool lean, bool full);  // ... HOLD instantiations (the position-hold branch in double)

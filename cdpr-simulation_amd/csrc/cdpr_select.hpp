@@ -98,6 +98,7 @@ struct KernelPlan {
   bool lowreg = false, persist = false, onestep_v2 = false, split = false;
   bool gen_split = false, gen_lean = false, gen_hot = false;
   bool hold_full = false;  // fp64 HOLD = 2 instantiations (a cascade, or a Pid without the command clamp)
+  bool hold_long = false;  // ... over Pid records of 32 samples: the hold branch / cascades / cmd_limit 0 with derivative windows of 12 .. 32 samples
   bool pair_stream = true;
   uint32_t chunk = 0;
   int gen_nb = 0;          // general path: longest derivative window of the two Pids
@@ -143,8 +144,6 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   // What stays out: derivative windows beyond 11 samples.
   const bool windows_fit = cfg->velocity_pid.d_buffer_length <= (uint32_t)kSelWin + 1 && cfg->position_pid.d_buffer_length <= (uint32_t)kSelWin + 1;
   const bool clean64 = cfg->precision == 64 && windows_fit;
-  const bool hold64 = clean64 && (!fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && pr_windows_differ));  // (per-robot modes too:
-                                                                                                    // each Pid has its own rows and its own window)
   // ... and with the optional physics - the joint stop, the lumped legs (round 6) - on uniform-mode handles without the hold branch:
   // the TSTOP instantiations
   const bool lumped_cfg = cfg->passive_damping != 0.0 || cfg->leg_inertia != 0.0 || cfg->cable_axial_mass != 0.0 || cfg->anchor_point_mass != 0.0 || cfg->anchor_inertia != 0.0;
@@ -160,7 +159,12 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
     probe.velocity_pid.d_degree = probe.position_pid.d_degree = std::min(cfg->velocity_pid.d_degree, 4u);
     long64 = fast_path_obstacle(probe).empty();  // (no hold branch, no cascades, a command clamp)
   }
-  const bool tstop64 = cfg->precision == 64 && phys_cfg && (windows_fit || long64);  // (round 6: the lumped legs too, with or without the stop; and together with
+  // the HOLD instantiations: whatever else the register-resident path cannot represent (per-robot modes whose Pids fit different windows
+  // too: each Pid has its own rows and its own window); later in round 6 with windows of 12 .. 32 samples as well (hold_long)
+  const bool hold64 = cfg->precision == 64 && !long64 && (!fast_path_obstacle(*cfg).empty() || (cfg->per_robot_commands != 0 && pr_windows_differ));
+  const bool hold_long = hold64 && !windows_fit;
+  (void)clean64;
+  const bool tstop64 = cfg->precision == 64 && phys_cfg;  // (round 6: the lumped legs too, with or without the stop; and together with
                                                                                      //  per-robot modes, the hold branch, long windows)
   if (cfg->precision == 64 && (general_cfg || phys_cfg) && !hold64 && !tstop64 && !long64) {
     p.rc = CDPR_ERR_UNSUPPORTED;
@@ -198,7 +202,8 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
   if (hold64) {
     const bool any_cas = cfg->velocity_pid.p_filter.cascade || cfg->velocity_pid.d_filter.cascade || cfg->position_pid.p_filter.cascade || cfg->position_pid.d_filter.cascade;
     const bool any_noclamp = !(std::fabs(cfg->velocity_pid.cmd_limit) > 0.0) || !(std::fabs(cfg->position_pid.cmd_limit) > 0.0);
-    p.hold_full = any_cas || any_noclamp;
+    p.hold_full = any_cas || any_noclamp || hold_long;  // (records of 32 samples: instantiated at HOLD = 2 only)
+    p.hold_long = hold_long;
   }
   {
     // Mapping: measured on MI355X (scripts/ab_bench.py), two lanes per robot win while the batch leaves SIMDs
@@ -337,7 +342,7 @@ inline PlannedKernel planned_kernel(const KernelPlan& p, const LaunchShape& s) {
     const bool ring_lds = s.f64_ring_lds >= 0 ? s.f64_ring_lds != 0 : p.batch <= 32768u;
     const bool jcache = ring_lds && (s.f64_jcache >= 0 ? s.f64_jcache != 0 : p.batch <= 16384u);
     const bool lean = s.f64_split >= 0 ? s.f64_split == 2 : p.batch > 16384u;
-    const bool can_split = p.fk && p.td && s.f64_split != 0 && !p.per_robot && !p.tstop64 && !p.long64;
+    const bool can_split = p.fk && p.td && s.f64_split != 0 && !p.per_robot && !p.tstop64 && !p.long64 && !p.hold_long;
     k.f64_ring_lds = ring_lds, k.f64_jcache = jcache, k.f64_lean = lean;
     // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's several-steps ones (14.4
     // against 20.8 us per step at one robot x 8, same bits): the engine then runs a fused update as one-step launches
@@ -421,13 +426,13 @@ inline std::string planned_kernel_name(const KernelPlan& p, const PlannedKernel&
     case KernelId::F64Pr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR%s>", n, k.f64_ring_lds ? ", RING_LDS" : ""); break;
     case KernelId::F64Tstop:
       if (p.hold64)
-        snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %sHOLD = %d, TSTOP>", n, p.per_robot ? "PR, " : "", p.hold_full ? 2 : 1);
+        snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %sHOLD = %d, TSTOP%s>", n, p.per_robot ? "PR, " : "", p.hold_full ? 2 : 1, p.hold_long ? ", HW = 32" : "");
       else
         snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %sTSTOP>", n, p.per_robot ? "PR, " : "");
       break;
     case KernelId::F64Long: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, %s%sW = 31>", n, p.per_robot ? "PR, " : "", p.tstop64 ? "TSTOP, " : ""); break;
-    case KernelId::F64Hold: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, HOLD = %d>", n, p.hold_full ? 2 : 1); break;
-    case KernelId::F64HoldPr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR, HOLD = %d>", n, p.hold_full ? 2 : 1); break;
+    case KernelId::F64Hold: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, HOLD = %d%s>", n, p.hold_full ? 2 : 1, p.hold_long ? ", HW = 32" : ""); break;
+    case KernelId::F64HoldPr: snprintf(b, sizeof b, "cdpr_step_kernel_f64<%u, PR, HOLD = %d%s>", n, p.hold_full ? 2 : 1, p.hold_long ? ", HW = 32" : ""); break;
     case KernelId::F64Split: snprintf(b, sizeof b, "cdpr_split_kernel_f64<%u%s>", n, k.f64_lean ? ", LEAN" : ""); break;
     case KernelId::F64SplitHold: snprintf(b, sizeof b, "cdpr_split_kernel_f64<%u%s, HOLD = %d>", n, k.f64_lean ? ", LEAN" : "", p.hold_full ? 2 : 1); break;
   }

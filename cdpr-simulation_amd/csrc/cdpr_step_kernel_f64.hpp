@@ -70,7 +70,7 @@ struct F64Args {
   int step0;      // world step of the launch's first step (the Pids' stamps)
   double hold_eps;
   int degree, alt_nbuf, alt_degree;
-  double hold_w[2][kWin + 1];  // [position | velocity] Pid: the uniform-grid derivative weights by AGE of the sample (0: newest), in steps
+  double hold_w[2][32];  // [position | velocity] Pid: the uniform-grid derivative weights by AGE of the sample (0: newest), in steps (kHoldWin, or kHoldWinLong of them)
   int travel_stop;             // TSTOP instantiations: sweeps of the joint stop (cdpr_config_t.travel_stop), 0 = flag only
   // TSTOP instantiations, the lumped legs (round 6; cdpr_config_t.passive_damping ...; the fp32 kernels' integrate_lumped_velocity in
   // double): any term non-zero, joint damping c of the passive revolutes, inertia turning with a leg, mass sliding along the cable,
@@ -115,17 +115,21 @@ struct F64Args {
 constexpr int kWinLong = 31;  // the ring of a derivative window of 12 .. 32 samples (CDPR_MAX_D_BUFFER - 1)
 __host__ __device__ constexpr int f64_state_rows(int n, int w = kWin) { return 20 + (w + 1) * n; }
 // HOLD handles keep BOTH Pids of every cable behind those rows: per cable mLastPosition (JFC.h:45), then per Pid (0 position,
-// 1 velocity) one packed word (bits 0-31 mLastTime as a world step | 32-35 ring head | 36-39 samples in the window | 40-47 length
-// of the newest run of consecutive steps, saturating | 48 mWasLastTime; the bits of a double, moved, never computed with) |
+// 1 velocity) one packed word (kHwHead ... kHwWas below) |
 // mIerr | the window's values | the window's stamps (world steps, exact in a double) | mCmd | the biquads' states
-constexpr int kHoldWin = kWin + 1;
+constexpr int kHoldWin = kWin + 1;       // samples a HOLD record's window holds: 11 ...
+constexpr int kHoldWinLong = 32;         // ... or 32 on handles with derivative windows of 12 .. 32 samples (later in round 6; one-wave kernel only)
 constexpr int kHoldMaxCas = 4;                              // CDPR_MAX_CASCADE
-constexpr int kHoldCmdRow = 2 + 2 * kHoldWin;               // mCmd (read only where cmd_limit = 0 leaves it stale)
-constexpr int kHoldCasRow = kHoldCmdRow + 1;                // x1 x2 y1 y2 of the P filter's stages, then of the D filter's (Filter.h:152-165)
-constexpr int kHoldPidRows = kHoldCasRow + 8 * kHoldMaxCas;
-constexpr int kHoldCableRows = 1 + 2 * kHoldPidRows;
-__host__ __device__ constexpr int f64_hold_row(int n, int cable, int pid) { return f64_state_rows(n) + cable * kHoldCableRows + 1 + pid * kHoldPidRows; }
-__host__ __device__ constexpr int f64_hold_rows(int n) { return n * kHoldCableRows; }
+__host__ __device__ constexpr int hold_cmd_row(int hw = kHoldWin) { return 2 + 2 * hw; }             // mCmd (read only where cmd_limit = 0 leaves it stale)
+__host__ __device__ constexpr int hold_cas_row(int hw = kHoldWin) { return hold_cmd_row(hw) + 1; }   // x1 x2 y1 y2 of the P filter's stages, then of the D filter's (Filter.h:152-165)
+__host__ __device__ constexpr int hold_pid_rows(int hw = kHoldWin) { return hold_cas_row(hw) + 8 * kHoldMaxCas; }
+__host__ __device__ constexpr int hold_cable_rows(int hw = kHoldWin) { return 1 + 2 * hold_pid_rows(hw); }
+constexpr int kHoldCmdRow = hold_cmd_row(), kHoldCasRow = hold_cas_row(), kHoldPidRows = hold_pid_rows(), kHoldCableRows = hold_cable_rows();
+__host__ __device__ constexpr int f64_hold_row(int n, int cable, int pid, int hw = kHoldWin) { return f64_state_rows(n) + cable * hold_cable_rows(hw) + 1 + pid * hold_pid_rows(hw); }
+__host__ __device__ constexpr int f64_hold_rows(int n, int hw = kHoldWin) { return n * hold_cable_rows(hw); }
+// the packed word of a Pid record (the bits of a double, moved, never computed with): bits 0-31 mLastTime as a world step | 32-37 ring
+// head | 38-43 samples in the window | 44-51 length of the newest run of consecutive steps, saturating | 52 mWasLastTime
+constexpr int kHwHead = 32, kHwCount = 38, kHwRun = 44, kHwWas = 52;
 __host__ __device__ constexpr int f64_obs_rows(int n) { return 16 + 3 * n; }
 
 // 1 / sqrt(x) to double precision: v_rsq_f64 (about 26 good bits) + two Newton steps, y <- y + y e / 2 with e = 1 - x y^2
@@ -327,19 +331,22 @@ __device__ __forceinline__ double hold_cascade64(double* F, size_t st, int stage
   }
   return x;
 }
-struct HoldRows64 {
+template <int HW = kHoldWin>
+struct HoldRows64T {
   unsigned long long word;
   double ierr, held;
-  double y[kHoldWin];
+  double y[HW];
 };
+using HoldRows64 = HoldRows64T<>;
 
-__device__ __forceinline__ HoldRows64 hold_load64(const double* R, const double* LP, size_t st) {
-  HoldRows64 h;
+template <int HW = kHoldWin>
+__device__ __forceinline__ HoldRows64T<HW> hold_load64(const double* R, const double* LP, size_t st) {
+  HoldRows64T<HW> h;
   h.word = (unsigned long long)__double_as_longlong(R[0]);
   h.ierr = R[st];
   h.held = LP[0];
 #pragma unroll
-  for (int j = 0; j < kHoldWin; ++j) h.y[j] = R[(size_t)(2 + j) * st];  // (rows beyond nbuf exist and stay zero)
+  for (int j = 0; j < HW; ++j) h.y[j] = R[(size_t)(2 + j) * st];  // (rows beyond nbuf exist and stay zero)
   return h;
 }
 
@@ -347,8 +354,9 @@ __device__ __forceinline__ HoldRows64 hold_load64(const double* R, const double*
 // (F64Args::hold_w), rot[pid][head][slot] the same by ring slot for every ring head, par[pid][..] the Pid's gains and limits
 // (kf kp ki kd imax imin cmax cmin w[0] imax/ki imin/ki) behind a per-lane choice of the Pid - pid 0 the POSITION Pid (alt_*), 1 the VELOCITY Pid.
 constexpr int kHoldPar = 12;
-__device__ __forceinline__ void hold_tables_fill(const F64Args& a, uint32_t lane, double (*w)[kHoldWin], double (*rot)[kHoldWin][kHoldWin], double (*par)[kHoldPar]) {
-  if (lane < 2 * kHoldWin) w[lane / kHoldWin][lane % kHoldWin] = a.hold_w[lane / kHoldWin][lane % kHoldWin];
+template <int HW = kHoldWin>
+__device__ __forceinline__ void hold_tables_fill(const F64Args& a, uint32_t lane, double (*w)[HW], double (*rot)[HW][HW], double (*par)[kHoldPar]) {
+  if (lane < 2 * HW) w[lane / HW][lane % HW] = a.hold_w[lane / HW][lane % HW];
   if (lane == 0) {
     par[1][0] = a.kf, par[1][1] = a.kp, par[1][2] = a.ki, par[1][3] = a.kd, par[1][4] = a.imax, par[1][5] = a.imin, par[1][6] = a.cmax, par[1][7] = a.cmin;
     par[0][0] = a.alt_kf, par[0][1] = a.alt_kp, par[0][2] = a.alt_ki, par[0][3] = a.alt_kd, par[0][4] = a.alt_imax, par[0][5] = a.alt_imin, par[0][6] = a.alt_cmax,
@@ -359,12 +367,12 @@ __device__ __forceinline__ void hold_tables_fill(const F64Args& a, uint32_t lane
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int e = (int)lane; e < 2 * kHoldWin * kHoldWin; e += 64) {
-    const int pd = e / (kHoldWin * kHoldWin), hd = (e / kHoldWin) % kHoldWin, j = e % kHoldWin;
+  for (int e = (int)lane; e < 2 * HW * HW; e += 64) {
+    const int pd = e / (HW * HW), hd = (e / HW) % HW, j = e % HW;
     const int nb = pd ? a.nbuf : a.alt_nbuf;
     int age = hd - j;
     age = age < 0 ? age + nb : age;
-    rot[pd][hd][j] = (hd < nb && j < nb && j != hd) ? w[pd][min(max(age, 0), kHoldWin - 1)] : 0.0;
+    rot[pd][hd][j] = (hd < nb && j < nb && j != hd) ? w[pd][min(max(age, 0), HW - 1)] : 0.0;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -375,8 +383,8 @@ __device__ __forceinline__ void hold_tables_fill(const F64Args& a, uint32_t lane
 // sample in it, is either a uniform one (the newest run of consecutive steps covers it) or still filling (derive() returns 0) -
 // the conditions of hold_finish64's first-call and fit branches, negated.
 __device__ __forceinline__ bool hold_steady64(unsigned long long word, int now, int nbuf) {
-  const int last = (int)(uint32_t)word, count_old = (int)(word >> 36) & 15, run_old = (int)(word >> 40) & 255;
-  const bool was = ((word >> 48) & 1ull) != 0ull;
+  const int last = (int)(uint32_t)word, count_old = (int)(word >> kHwCount) & 63, run_old = (int)(word >> kHwRun) & 255;
+  const bool was = ((word >> kHwWas) & 1ull) != 0ull;
   const int count = min(count_old + 1, nbuf);
   const int run = (now == last + 1) ? min(run_old + 1, 255) : 1;
   return was && !(run < nbuf && count >= nbuf);
@@ -393,7 +401,7 @@ struct HoldFir64 {
 };
 __device__ __forceinline__ HoldFir64 hold_fast_fir64(const HoldRows64& h, const double* wrot, double w0, int nbuf, double desired, double actual, int now, double dt) {
   HoldFir64 f;
-  const int last = (int)(uint32_t)h.word, head_old = (int)(h.word >> 32) & 15, count_old = (int)(h.word >> 36) & 15, run_old = (int)(h.word >> 40) & 255;
+  const int last = (int)(uint32_t)h.word, head_old = (int)(h.word >> kHwHead) & 63, count_old = (int)(h.word >> kHwCount) & 63, run_old = (int)(h.word >> kHwRun) & 255;
   f.dts = (double)(now - last) * dt;
   f.error = desired - actual;
   f.head = (count_old == 0) ? 0 : ((head_old + 1 >= nbuf) ? 0 : head_old + 1);
@@ -425,7 +433,7 @@ __device__ __forceinline__ double hold_fast64(double* R, double* LP, size_t st, 
   ie = sat ? ierr_old : ie;
   out = sat ? fma(dts * error, ki, out) : out;
   const unsigned long long word =
-      (unsigned long long)(uint32_t)now | (unsigned long long)f.head << 32 | (unsigned long long)f.count << 36 | (unsigned long long)f.run << 40 | 1ull << 48;
+      (unsigned long long)(uint32_t)now | (unsigned long long)f.head << kHwHead | (unsigned long long)f.count << kHwCount | (unsigned long long)f.run << kHwRun | 1ull << kHwWas;
   R[0] = __longlong_as_double((long long)word);
   R[st] = ie;
   R[(size_t)(2 + f.head) * st] = error;
@@ -437,19 +445,19 @@ __device__ __forceinline__ double hold_fast64(double* R, double* LP, size_t st, 
 
 // FULL: the handle has a biquad cascade or a Pid without the command clamp (the HOLD = 2 instantiations); otherwise none of that
 // is compiled in (its uniform branches cost the others 1.3 us per step).
-template <bool FULL>
-__device__ __forceinline__ double hold_finish64(double* R, size_t st, const HoldRows64& h, const double* wrot, double w0, double desired, double actual, int now, double dt,
+template <bool FULL, int HW = kHoldWin>
+__device__ __forceinline__ double hold_finish64(double* R, size_t st, const HoldRows64T<HW>& h, const double* wrot, double w0, double desired, double actual, int now, double dt,
                                                 const HoldPid64& g, const F64Args& a, bool velocity_pid, bool& ran, double& p_out, double& i_out, double& d_out,
                                                 bool live = true) {
   // (the coefficients stay where they are - the argument block - behind a per-lane choice of the Pid)
   const double* const pc = velocity_pid ? a.pcoef[1] : a.pcoef[0];
   const double* const dc = velocity_pid ? a.dcoef[1] : a.dcoef[0];
-  const int last = (int)(uint32_t)h.word, head_old = (int)(h.word >> 32) & 15, count_old = (int)(h.word >> 36) & 15, run_old = (int)(h.word >> 40) & 255;
-  const bool was = ((h.word >> 48) & 1ull) != 0ull;  // Pid.cpp:123-126: the first call since reset returns 0 (and pushes no sample)
+  const int last = (int)(uint32_t)h.word, head_old = (int)(h.word >> kHwHead) & 63, count_old = (int)(h.word >> kHwCount) & 63, run_old = (int)(h.word >> kHwRun) & 255;
+  const bool was = ((h.word >> kHwWas) & 1ull) != 0ull;  // Pid.cpp:123-126: the first call since reset returns 0 (and pushes no sample)
   const double dts = (double)(now - last) * dt;
   const double error = desired - actual;
   double perr = error;
-  if (FULL && a.any_cas) perr = hold_cascade64(R + (size_t)kHoldCasRow * st, st, g.pcas, a.max_cas, pc, error, was && live);  // Pid.cpp:131
+  if (FULL && a.any_cas) perr = hold_cascade64(R + (size_t)hold_cas_row(HW) * st, st, g.pcas, a.max_cas, pc, error, was && live);  // Pid.cpp:131
   const double p_term = g.kp * perr;
   double ie = fma(dts, error, h.ierr);
   double i_term = g.ki * ie;
@@ -468,48 +476,48 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
   // the uniform window's weights BY SLOT for this ring head (hold_tables_fill: the weight of the slot's age, 0 for the slot the new
   // sample goes to and for slots beyond nbuf - round 6: one LDS read and one fma per slot where the age, its wrap, its clamp, the
   // look-up and two selects were 13 instructions)
-  const double* const wr = wrot + head * kHoldWin;
+  const double* const wr = wrot + head * HW;
   double acc = w0 * error;
 #pragma unroll
-  for (int j = 0; j < kHoldWin; ++j) acc = fma(wr[j], h.y[j], acc);
+  for (int j = 0; j < HW; ++j) acc = fma(wr[j], h.y[j], acc);
   double derived = (run >= g.nbuf) ? acc / dt : 0.0;  // mDbufferMissing != 0: derive() returns 0 (Pid.cpp:200-203)
   if (was && run < g.nbuf && count >= g.nbuf) {     // a full window with a gap in it: the fit on the real stamps
-    double y[kHoldWin];
-    int t[kHoldWin];
+    double y[HW];
+    int t[HW];
     int t_old = now;
-    double stamp[kHoldWin];
+    double stamp[HW];
 #pragma unroll
-    for (int j = 0; j < kHoldWin; ++j) {
-      stamp[j] = R[(size_t)(2 + kHoldWin + j) * st];
+    for (int j = 0; j < HW; ++j) {
+      stamp[j] = R[(size_t)(2 + HW + j) * st];
       asm volatile("" : "+v"(stamp[j]));  // (all eleven in flight at once: otherwise each is sunk into its own `j != head` branch, a round trip each)
     }
 #pragma unroll
-    for (int j = 0; j < kHoldWin; ++j) {
+    for (int j = 0; j < HW; ++j) {
       y[j] = (j == head) ? error : h.y[j];
       t[j] = (j == head) ? now : (int)stamp[j];
       t_old = (j < g.nbuf) ? min(t_old, t[j]) : t_old;
     }
-    derived = gen_fit<kHoldWin, double>(y, t, g.nbuf, g.degree, now, t_old) / dt;
+    derived = gen_fit<HW, double>(y, t, g.nbuf, g.degree, now, t_old) / dt;
   }
-  if (FULL && a.any_cas) derived = hold_cascade64(R + (size_t)(kHoldCasRow + 4 * kHoldMaxCas) * st, st, g.dcas, a.max_cas, dc, derived, was && live);  // Pid.cpp:157
+  if (FULL && a.any_cas) derived = hold_cascade64(R + (size_t)(hold_cas_row(HW) + 4 * kHoldMaxCas) * st, st, g.dcas, a.max_cas, dc, derived, was && live);  // Pid.cpp:157
   const double d_term = g.kd * derived;
   const double cmd = fma(g.kf, desired, p_term) + i_term + d_term;  // Pid.cpp:170
   double stale = 0.0;                                                // mCmd as the last call left it: what the Pid returns without a clamp
-  if (FULL && a.any_noclamp) stale = R[(size_t)kHoldCmdRow * st];
+  if (FULL && a.any_noclamp) stale = R[(size_t)hold_cmd_row(HW) * st];
   double out = (!FULL || g.clamp) ? fmax(fmin(cmd, g.cmax), g.cmin) : stale;  // Pid.cpp:175-177
   if (out != cmd) {                                                  // Pid.cpp:181-184
     ie = h.ierr;
     out = fma(dts * error, g.ki, out);
   }
-  const unsigned long long word = was ? ((unsigned long long)(uint32_t)now | (unsigned long long)head << 32 | (unsigned long long)count << 36 |
-                                         (unsigned long long)run << 40 | 1ull << 48)
-                                      : ((h.word & ~0xffffffffull) | (unsigned long long)(uint32_t)now | 1ull << 48);
+  const unsigned long long word = was ? ((unsigned long long)(uint32_t)now | (unsigned long long)head << kHwHead | (unsigned long long)count << kHwCount |
+                                         (unsigned long long)run << kHwRun | 1ull << kHwWas)
+                                      : ((h.word & ~0xffffffffull) | (unsigned long long)(uint32_t)now | 1ull << kHwWas);
   if (live) R[0] = __longlong_as_double((long long)word);
-  if (FULL && a.any_noclamp && live) R[(size_t)kHoldCmdRow * st] = was ? out : 0.0;  // (the first call since a reset: mCmd = 0, Pid.cpp:125)
+  if (FULL && a.any_noclamp && live) R[(size_t)hold_cmd_row(HW) * st] = was ? out : 0.0;  // (the first call since a reset: mCmd = 0, Pid.cpp:125)
   if (was && live) {
     R[st] = ie;
     R[(size_t)(2 + head) * st] = error;
-    R[(size_t)(2 + kHoldWin + head) * st] = (double)now;
+    R[(size_t)(2 + HW + head) * st] = (double)now;
   }
   ran = was, p_out = p_term, i_out = i_raw, d_out = d_term;
   return was ? out : 0.0;
@@ -531,8 +539,11 @@ __device__ __forceinline__ double hold_finish64(double* R, size_t st, const Hold
 // W: prior errors kept per cable (the derivative ring).  kWin = 10 serves windows to 11 samples (shorter ones by zero weights);
 // W = kWinLong = 31 (round 6: Pid.h:135 allows any mDbufferLength, the engine takes 32) serves 12 .. 32 samples on the plain
 // instantiation - same code, W + 1 rows per cable instead of 11, a weight table of W rows.
-template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, int HOLD = 0, bool TSTOP = false, int W = kWin>  // HOLD: 0 | 1 | 2 (+ cascades, cmd_limit 0)
+// HW: samples a HOLD record's window holds (kHoldWin; kHoldWinLong later in round 6: the hold branch / cascades / cmd_limit 0 with derivative windows
+// of 12 .. 32 samples - the same code over records of 32 samples and their 32 stamps)
+template <int N, bool RING_LDS = false, bool JCACHE = false, bool PR = false, int HOLD = 0, bool TSTOP = false, int W = kWin, int HW = kHoldWin>  // HOLD: 0 | 1 | 2 (+ cascades, cmd_limit 0)
 __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
+  static_assert(HW == kHoldWin || (HOLD != 0 && W == kWin), "long HOLD records: a HOLD instantiation (the plain ring rows stay at their short length, unused)");
   static_assert(W == kWin || (!RING_LDS && !JCACHE && !HOLD), "long derivative windows: rings in memory, one Pid record per cable (with or without PR and TSTOP)");
   static_assert(!HOLD || (!RING_LDS && !JCACHE), "the hold branch: the plain instantiation (uniform modes, or PR: the mode per lane)");
   static_assert(!TSTOP || (!RING_LDS && !JCACHE), "the joint stop / the lumped legs: rings in memory (with or without PR and HOLD: the world step does not care who set the forces)");
@@ -557,8 +568,8 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   //  a round trip more: one robot 14.4 -> 14.7 us)
   constexpr bool kGeomLds = !RING_LDS;
   __shared__ double c_geom_lds[kGeomLds ? N * 7 : 1];
-  __shared__ double c_hold_w[HOLD ? 2 : 1][kHoldWin], c_hold_rot[HOLD ? 2 : 1][HOLD ? kHoldWin : 1][kHoldWin], c_hold_par[HOLD ? 2 : 1][kHoldPar];
-  if constexpr (HOLD != 0) hold_tables_fill(a, lane, c_hold_w, c_hold_rot, c_hold_par);
+  __shared__ double c_hold_w[HOLD ? 2 : 1][HW], c_hold_rot[HOLD ? 2 : 1][HOLD ? HW : 1][HW], c_hold_par[HOLD ? 2 : 1][kHoldPar];
+  if constexpr (HOLD != 0) hold_tables_fill<HW>(a, lane, c_hold_w, c_hold_rot, c_hold_par);
   if (kGeomLds) {
     if (lane < N * 7) c_geom_lds[lane] = a.geom[lane];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -610,13 +621,13 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
 #pragma clang loop unroll_count(kCableUnroll)
       for (int i = 0; i < N; ++i) {
         // (HOLD: the rows of the Pid this cable calls in this step - known from the command alone - before the IK)
-        double* const LP = S + (size_t)(f64_state_rows(N) + (HOLD ? i : 0) * kHoldCableRows) * st;  // mLastPosition
+        double* const LP = S + (size_t)(f64_state_rows(N) + (HOLD ? i : 0) * hold_cable_rows(HW)) * st;  // mLastPosition
         // (PR: this robot's own mode - the meta byte's kMetaForce / kMetaPosition / kMetaVelocity are 0 / 1 / 2 as hold_mode's)
         const int hmode = PR ? (int)(meta & kMetaModeMask) : a.hold_mode;
         const bool vel_branch = HOLD && hmode == 2 && fabs(c_des[i][lane]) > a.hold_eps;  // JFC.cpp:72
-        double* const HR = S + (size_t)(f64_hold_row(N, HOLD ? i : 0, 0) + (vel_branch ? kHoldPidRows : 0)) * st;
-        HoldRows64 hrows;
-        if constexpr (HOLD) hrows = hold_load64(HR, LP, st);
+        double* const HR = S + (size_t)(f64_hold_row(N, HOLD ? i : 0, 0, HW) + (vel_branch ? hold_pid_rows(HW) : 0)) * st;
+        HoldRows64T<HW> hrows;
+        if constexpr (HOLD) hrows = hold_load64<HW>(HR, LP, st);
         double L, j[6];
         ik_row64(c_geom + i * 7, R, p, L, j);
         const double q = c_geom[i * 7 + 6] - L;
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
               const double desired = vel_branch ? target : (hold ? hrows.held : target);
               bool ran = false;
               double tp = 0.0, ti = 0.0, td = 0.0;
-              force = hold_finish64<HOLD == 2>(HR, st, hrows, &c_hold_rot[HOLD && vel_branch ? 1 : 0][0][0], pp[8], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, a, vel_branch, ran, tp, ti, td);
+              force = hold_finish64<HOLD == 2, HW>(HR, st, hrows, &c_hold_rot[HOLD && vel_branch ? 1 : 0][0][0], pp[8], desired, vel_branch ? qd : q, (int)(a.step0 + step), a.dt, g, a, vel_branch, ran, tp, ti, td);
               if (i == 0 && ran) {
                 dbg_p = tp, dbg_i = ti, dbg_d = td;
                 dbg_ran = true;
@@ -1031,6 +1042,7 @@ struct LatchF64Args {
   uint32_t batch, n;
   uint32_t new_mode;     // kMetaForce / kMetaPosition / kMetaVelocity
   uint32_t hold;         // HOLD handles: both Pids of every cable live in their own rows (f64_hold_row); entering a mode clears THAT Pid's
+  uint32_t hold_win;     // ... samples such a record's window holds (kHoldWin | kHoldWinLong)
   uint32_t win;          // prior errors kept per cable (kWin, or kWinLong on handles with windows of 12 .. 32 samples): the integral is row 20 + (win + 1) i + win
 };
 static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF64Args a) {
@@ -1045,7 +1057,7 @@ static __global__ __launch_bounds__(256) void cdpr_latch_f64_kernel(const LatchF
     if (a.hold) {  // Pid::reset of the Pid of the mode entered (JFC.cpp:101-103,113-115), every cable: word, integral, window, stamps
       const int pid = (a.new_mode == kMetaVelocity) ? 1 : 0;
       for (uint32_t i = 0; i < a.n; ++i)
-        for (int row = 0; row < kHoldPidRows; ++row) a.state[(size_t)(f64_hold_row((int)a.n, (int)i, pid) + row) * a.stride + r] = 0.0;
+        for (int row = 0; row < hold_pid_rows((int)a.hold_win); ++row) a.state[(size_t)(f64_hold_row((int)a.n, (int)i, pid, (int)a.hold_win) + row) * a.stride + r] = 0.0;
     } else {
       for (uint32_t i = 0; i < a.n; ++i) a.state[(size_t)(20 + (a.win + 1u) * i + a.win) * a.stride + r] = 0.0;
     }

@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cdpr-simulation_amd", "csrc")
 FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function --cuda-device-only -S"
 NOVC_UNITS = {"k_step", "k_gen_one", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32"}
-UNITS = ["k_step", "k_pr", "k_onestep", "k_pair", "k_cable", "k_f64", "k_f64_phys", "k_f64_long", "k_gen_one", "k_gen_split", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32", "cdpr_engine", "cdpr_engine_f64", "cdpr_engine_rollout", "cdpr_engine_solvers"]
+UNITS = ["k_step", "k_pr", "k_onestep", "k_pair", "k_cable", "k_f64", "k_f64_phys", "k_f64_long", "k_f64_hold_long", "k_gen_one", "k_gen_split", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32", "cdpr_engine", "cdpr_engine_f64", "cdpr_engine_rollout", "cdpr_engine_solvers"]
 
 VECTOR = re.compile(r"^(v_|ds_|buffer_|global_|scratch_|flat_)")
 HARMLESS = re.compile(r"^(v_cmp|v_cmpx|v_readlane|v_writelane|v_readfirstlane|v_nop|s_)")  # (v_writelane ignores exec)  # write no vector register / memory under exec

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cdpr-simulation_amd", "csrc")
 BASE_FLAGS = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
-UNITS = ["k_step", "k_pr", "k_onestep", "k_pair", "k_cable", "k_f64", "k_f64_phys", "k_f64_long", "k_gen_one", "k_gen_split", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32"]
+UNITS = ["k_step", "k_pr", "k_onestep", "k_pair", "k_cable", "k_f64", "k_f64_phys", "k_f64_long", "k_f64_hold_long", "k_gen_one", "k_gen_split", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32"]
 
 
 NOVC_UNITS = {"k_step", "k_gen_one", "k_gen_step", "k_gen_roll", "k_gen_step32", "k_gen_roll32"}  # (the Makefile's: built without VectorCombine)

@@ -458,25 +458,83 @@ def test_fp64_rest_of_pid_update(pkg, oracle, variant):
     compare64(eng, ora, f"{variant}, after a world reset", tol)
 
 
-def test_fp64_refuses_what_it_does_not_cover(pkg):
-    """What precision = 64 still leaves to the fp32 paths (round 6: the optional physics, per-robot modes and long windows now compose):
-    derivative windows beyond 11 samples together with the hold branch / cascades / cmd_limit 0 (their Pid records hold eleven
-    samples), or on a per-robot handle whose two Pids fit different windows (that is a HOLD handle too)."""
-    cases = []
-    for kw in (dict(velocityEpsilon=0.01), dict(perRobotCommands=True, velocityEpsilon=0.01)):
+def test_fp64_refuses_nothing_of_the_controller_any_more(pkg):
+    """Through round 6 precision = 64 refused combinations of its own features (the optional physics, per-robot modes, long windows,
+    the hold branch); the last of them - windows beyond 11 samples with the hold branch / cascades / cmd_limit 0, or on a per-robot
+    handle whose Pids fit different windows - run on HOLD records of 32 samples now.  Left to the fp32 paths: more than 8 cables,
+    the MPC rollout on per-robot / hold-branch handles (refused where it is called)."""
+    stop = pkg.eight_cable_model()
+    stop.travel_lower, stop.travel_upper, stop.travel_stop = -0.01, 0.01, 2
+    names = []
+    for kw, vel_window in ((dict(velocityEpsilon=0.01), 16), (dict(perRobotCommands=True, velocityEpsilon=0.01), 16), (dict(perRobotCommands=True), 16), (dict(model=stop, velocityEpsilon=0.01), 32)):
         cfg = pkg.Config(batch=4, precision=64, **kw)
-        cfg.velocityController.dBufferLength = cfg.positionController.dBufferLength = 16
-        cases.append(cfg)
-    differ = pkg.Config(batch=4, precision=64, perRobotCommands=True)
-    differ.velocityController.dBufferLength = 16
-    cases.append(differ)
-    cascade = pkg.Config(batch=4, precision=64)
-    cascade.velocityController.dBufferLength, cascade.velocityController.pFilter.cascade = 16, 1
-    cases.append(cascade)
-    for cfg in cases:
-        with pytest.raises(pkg.CdprError) as ei:
-            pkg.Engine(cfg, 0)
-        assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+        cfg.velocityController.dBufferLength = vel_window  # (the position Pid keeps 11 samples: on a per-robot handle that alone asks for both records)
+        eng = pkg.Engine(cfg, 0)
+        eng.update(3)
+        names.append(eng.kernel_name)
+        eng.close()
+    assert names == ["cdpr_step_kernel_f64<4, HOLD = 2, HW = 32>", "cdpr_step_kernel_f64<4, PR, HOLD = 2, HW = 32>", "cdpr_step_kernel_f64<4, PR, HOLD = 2, HW = 32>",
+                     "cdpr_step_kernel_f64<8, HOLD = 2, TSTOP, HW = 32>"], names
+    twelve = pkg.Config(model=pkg.twelve_cable_model(), batch=4, precision=64)
+    with pytest.raises(pkg.CdprError) as ei:
+        pkg.Engine(twelve, 0)
+    assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("variant", ["hold", "hold_cascades_noclamp", "per_robot_different_windows", "hold_physics"])
+def test_fp64_hold_branch_with_long_windows(pkg, oracle, variant):
+    """The hold branch, the cascades and cmd_limit = 0 with derivative windows of 12 .. 32 samples in double (later in round 6; refused
+    before): the HOLD = 2 instantiations of the one-wave kernel over Pid records of 32 samples and their 32 stamps - the fixed filter
+    by ring slot for a uniform window, the least-squares fit on the real stamps for a window with a gap, through the fill of the long
+    windows, cables crossing epsilon in both directions, mode changes (masked, on the per-robot variant, whose two Pids fit windows of
+    24 and 11 samples), fused launches and the record - against the fp64 oracle."""
+    from dataclasses import replace
+    from test_gpu_general_matrix import hold_commands
+
+    B, cables = 110, 8
+    pr = variant.startswith("per_robot")
+    eps = -0.001 if pr else 0.004
+    rng = np.random.default_rng(960 + len(variant))
+    model = pkg.eight_cable_model()
+    if variant == "hold_physics":
+        model = replace(model, passive_damping=0.05, leg_inertia=0.02, travel_lower=-0.004, travel_upper=0.004, travel_stop=2)
+    cfg = pkg.Config(model=model, batch=B, stages=3 | pkg._abi.STAGE_PID_DEBUG, precision=64, velocityEpsilon=eps, perRobotCommands=pr)
+    vc, pc = cfg.velocityController, cfg.positionController
+    vc.dBufferLength, vc.dDegree = (24, 3) if pr else (20, 2)
+    if variant == "hold":
+        pc.dBufferLength, pc.dDegree = 32, 2
+    if variant == "hold_cascades_noclamp":
+        vc.pFilter.cascade, vc.pFilter.relCutoff, vc.dFilter.cascade, vc.dFilter.relCutoff = 2, 0.2, 1, 0.25
+        pc.cmdLimit = 0.0
+    want = f"cdpr_step_kernel_f64<8, {'PR, ' if pr else ''}HOLD = 2{', TSTOP' if variant == 'hold_physics' else ''}, HW = 32>"
+    assert pkg.plan_kernel(cfg, 1) == want == pkg.plan_kernel(cfg, 7), (pkg.plan_kernel(cfg, 1), want)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.003 if variant == "hold_physics" else 0.02, 0.03).astype(np.float64))
+    tol = dict(TOL64, eff=1e-6, twist=1e-9, qd=1e-9, pose=1e-11, q=1e-11)
+    grp = np.arange(B) % 3
+    eng.update(4), ora.update(4)
+    for rnd, k in enumerate([27, 6, 41, 13, 35]):
+        v = hold_commands(rng, B, cables, abs(eps) if not pr else 0.002)
+        if pr:
+            p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+            for e in (eng, ora):
+                e.set_velocity_command(v, mask=(grp != rnd % 3).astype(np.uint8))
+                e.set_position_command(p, mask=(grp == rnd % 3).astype(np.uint8))
+        elif rnd == 3:
+            p = rng.uniform(-0.004, 0.004, (B, cables)).astype(np.float32)
+            eng.set_position_command(p), ora.set_position_command(p)  # Position mode: that Pid's (long) window starts again
+        else:
+            eng.set_velocity_command(v), ora.set_velocity_command(v)
+        if rnd == 1:
+            eng.update(k, 3)
+        elif rnd == 2:
+            eng.update_record(k, 5)
+        else:
+            for _ in range(k):
+                eng.update(1)
+        ora.update(k)
+        compare64(eng, ora, f"{variant}, round {rnd}", tol)
+        assert np.abs(eng.pid_debug() - ora.pid_debug()).max() < 1e-5, f"pid topic, round {rnd}"
+    assert eng.kernel_name == want
 
 
 @pytest.mark.parametrize("variant", ["per_robot", "hold", "per_robot_hold", "hold_cascades"])

@@ -116,9 +116,10 @@ def test_refusals_carry_their_reason(pkg, clean_env):
     long_pr = pkg.Config(model=lumped, batch=4, precision=64, perRobotCommands=True)  # ... and windows beyond 11 samples with both
     long_pr.velocityController.dBufferLength = long_pr.positionController.dBufferLength = 20
     assert plan(pkg, long_pr) == (0, "cdpr_step_kernel_f64<8, PR, TSTOP, W = 31>")
-    long_hold = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)  # what is left: long windows with the hold branch
+    long_hold = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)  # ... and long windows with the hold branch: Pid records of 32 samples
     long_hold.velocityController.dBufferLength = 20
-    rc, why = plan(pkg, long_hold)
+    assert plan(pkg, long_hold) == (0, "cdpr_step_kernel_f64<4, HOLD = 2, HW = 32>")
+    rc, why = plan(pkg, pkg.Config(model=pkg.twelve_cable_model(), batch=4, precision=64))  # what precision = 64 still refuses
     assert rc == pkg._abi.ERR_UNSUPPORTED and "precision = 64" in why
     long_w = pkg.Config(batch=4, precision=64)
     long_w.velocityController.dBufferLength = 20
