@@ -122,10 +122,11 @@ typedef struct cdpr_config {
                                        one robot / small batches; read it out with the *_f64 getters.  velocity_epsilon >= 0 (the position-hold
                                        branch, JFC.cpp:72-82: both Pids of every cable alive, derivative windows on real stamps) is served in
                                        double too (round 5), with the rest of Pid::update - biquad cascades, cmd_limit = 0 - and with
-                                       per_robot_commands (two different derivative windows included); travel_stop > 0 (the joint stop) on
-                                       uniform-mode handles without any of those.  Not with derivative windows beyond 11 samples, the joint
-                                       stop together with per_robot_commands or the hold branch, the lumped legs or rollouts (cdpr_create /
-                                       the call return CDPR_ERR_UNSUPPORTED) */
+                                       per_robot_commands (two different derivative windows included).  Round 6: the joint stop
+                                       (travel_stop > 0), the lumped legs, derivative windows to 32 samples and cdpr_rollout_velocity* in
+                                       double as well; every combination of the controller's and the physics' options is served.  Not in
+                                       double: more than 8 cables (cdpr_create), rollouts on per-robot / hold-branch handles (the call
+                                       returns CDPR_ERR_UNSUPPORTED) */
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */
