@@ -40,17 +40,10 @@ void fill_pid64(const cdpr_pid_params_t& p, double dt, F64Args& k) {
   k.clamp_cmd = k.cmax > k.cmin;
 }
 
-// precision = 64: the same host logic (commands are latched by run_steps before this is reached), the fp64 kernel
-int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, double* record) {
-  const uint32_t n = h->n;
-  if (reset_pid && !h->hold64) {  // Pid::reset (Pid.cpp:100-115): zero every controller row (hold branch live: the latch reset that Pid's own rows)
-    h->pid_calls = 0;
-    HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)(h->win64 + 1) * n * h->stride * sizeof(double), h->stream));
-  }
-  F64Args a = h->base64;
-  a.stamps = h->base.stamps;
+// The arguments of a launch that depend on the handle's mode, not on the step: the Pid(s), the command buffer, the weight table; per-robot
+// handles: both Pids and the meta row; HOLD handles: both Pids, the hold branch's parameters, the cascades' coefficients
+static void f64_mode_args(const cdpr_engine* h, bool vel, bool frc, F64Args& a) {
   const bool pr = h->per_robot;
-  const bool vel = pr || h->mode == kModeVelocity, frc = !pr && h->mode == kModeForce;
   fill_pid64(vel ? h->cfg.velocity_pid : h->cfg.position_pid, h->cfg.dt, a);
   a.cmd = pr ? h->d_target
              : frc ? (h->ext_frc[0] ? h->ext_frc[0] : h->d_frc[0])
@@ -99,6 +92,36 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
         for (uint32_t age = 0; age < nb && age < (uint32_t)h->hold_win; ++age) a.hold_w[t][age] = w[nb - 1 - age];
     }
   }
+}
+
+// the fp64 kernel a planned id stands for on this handle
+static F64Kernel f64_kernel_for(const cdpr_engine* h, const PlannedKernel& q) {
+  const uint32_t n = h->n;
+  const bool pr = h->per_robot, hold_full = h->plan.hold_full;
+  switch (q.id) {
+    case KernelId::F64Split: return pick_f64_split_kernel(n, q.f64_lean);
+    case KernelId::F64SplitHold: return pick_f64_split_hold_kernel(n, q.f64_lean, hold_full);
+    case KernelId::F64Hold: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, false, false) : pick_f64_hold_kernel(n, hold_full);
+    case KernelId::F64HoldPr: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, true, false) : pick_f64_hold_pr_kernel(n, hold_full);
+    case KernelId::F64Tstop: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, pr, true) : pick_f64_tstop_kernel(n, pr, h->hold64 ? (hold_full ? 2 : 1) : 0);
+    case KernelId::F64Long: return pick_f64_long_kernel(n, pr, h->tstop64);
+    case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
+    default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);
+  }
+}
+
+// precision = 64: the same host logic (commands are latched by run_steps before this is reached), the fp64 kernel
+int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, double* record) {
+  const uint32_t n = h->n;
+  if (reset_pid && !h->hold64) {  // Pid::reset (Pid.cpp:100-115): zero every controller row (hold branch live: the latch reset that Pid's own rows)
+    h->pid_calls = 0;
+    HIP_TRY(h, hipMemsetAsync(h->d_state64 + (size_t)20 * h->stride, 0, (size_t)(h->win64 + 1) * n * h->stride * sizeof(double), h->stream));
+  }
+  F64Args a = h->base64;
+  a.stamps = h->base.stamps;
+  const bool pr = h->per_robot;
+  const bool vel = pr || h->mode == kModeVelocity, frc = !pr && h->mode == kModeForce;
+  f64_mode_args(h, vel, frc, a);
   const size_t image64 = (size_t)f64_obs_rows((int)n) * h->stride;  // doubles per observable image
   a.obs_step_stride = record ? image64 : 0;
   // the rings in LDS (64 KiB per wave at n = 8: two waves per CU) while the batch leaves CUs to spare
@@ -106,7 +129,6 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   // ... and the structure-matrix rows too (112 KiB: one wave per CU) up to one workgroup per CU
   const int jc_env = [] { const char* v = std::getenv("CDPR_F64_JCACHE"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
-  const bool hold_full = h->plan.hold_full;  // the HOLD = 2 instantiations: cascades, cmd_limit 0
   // one step per launch on FK + TD handles up to one workgroup per CU: estimator wave + controller wave (cdpr_split_kernel_f64)
   const int sp_env = [] { const char* v = std::getenv("CDPR_F64_SPLIT"); return v ? atoi(v) : -1; }();  // (read per call: A/B in one process)
   // (CDPR_F64_SPLIT = 0 never, 1 the LDS-cached build, 2 the lean build whatever the batch)
@@ -114,18 +136,7 @@ int run_steps_f64(cdpr_engine* h, int nsteps, int per_launch, bool reset_pid, do
   LaunchShape s1 = launch_shape(h, 1), sk = launch_shape(h, 2);
   s1.f64_ring_lds = sk.f64_ring_lds = ring_env, s1.f64_jcache = sk.f64_jcache = jc_env, s1.f64_split = sk.f64_split = sp_env;
   const PlannedKernel pk1 = planned_kernel(h->plan, s1), pkk = planned_kernel(h->plan, sk);
-  auto f64_kernel_of = [&](const PlannedKernel& q) -> F64Kernel {
-    switch (q.id) {
-      case KernelId::F64Split: return pick_f64_split_kernel(n, q.f64_lean);
-      case KernelId::F64SplitHold: return pick_f64_split_hold_kernel(n, q.f64_lean, hold_full);
-      case KernelId::F64Hold: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, false, false) : pick_f64_hold_kernel(n, hold_full);
-      case KernelId::F64HoldPr: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, true, false) : pick_f64_hold_pr_kernel(n, hold_full);
-      case KernelId::F64Tstop: return h->plan.hold_long ? pick_f64_hold_long_kernel(n, pr, true) : pick_f64_tstop_kernel(n, pr, h->hold64 ? (hold_full ? 2 : 1) : 0);
-      case KernelId::F64Long: return pick_f64_long_kernel(n, pr, h->tstop64);
-      case KernelId::F64Pr: return pick_f64_pr_kernel(n, q.f64_ring_lds);
-      default: return pick_f64_kernel(n, q.f64_ring_lds, q.f64_jcache);
-    }
-  };
+  auto f64_kernel_of = [&](const PlannedKernel& q) -> F64Kernel { return f64_kernel_for(h, q); };
   const bool split1 = pk1.id == KernelId::F64Split || pk1.id == KernelId::F64SplitHold;
   F64Kernel split_kern = split1 ? f64_kernel_of(pk1) : nullptr;  // (per-robot handles: the one-wave kernel)
   // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's multi-step ones
@@ -350,12 +361,13 @@ int fetch_int_row64(cdpr_engine* h, uint32_t row, int32_t* out) {
 
 // Queue one rollout on the handle's stream: trajectories = batch * samples, reference positions and costs in
 // DEVICE buffers.  Nothing is allocated, copied or synchronised here.
-// The rollout of a precision = 64 handle (uniform modes, no hold branch / joint stop): see Roll64Args (cdpr_step_kernel_f64.hpp).
+// The rollout of a precision = 64 handle (uniform modes; with the hold branch / cascades / cmd_limit 0 since the end of round 6): see Roll64Args
+// (cdpr_step_kernel_f64.hpp).
 int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d_commands, const float* d_ref, float* d_cost) {
   const uint32_t n = h->n;
   const uint64_t traj = (uint64_t)h->batch * (uint64_t)samples;
   const size_t cols = (size_t)((traj + 63u) & ~(uint64_t)63u);
-  const uint32_t rows = (uint32_t)f64_state_rows((int)n, h->win64);
+  const uint32_t rows = (uint32_t)state64_rows(h);  // (hold branch live: both Pids' records of every cable travel with a trajectory)
   if (h->roll64_cols < cols) {
     HIP_TRY(h, wait_stream(h));
     for (void** p64 : {(void**)&h->d_roll64, (void**)&h->d_roll64_acc, (void**)&h->d_roll64_cmd}) {
@@ -372,12 +384,16 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
   const uint32_t blocks = (uint32_t)((traj + 255u) / 256u);
   Roll64Args e{};
   e.src = h->d_state64, e.dst = h->d_roll64, e.src_stride = h->stride, e.dst_stride = (uint32_t)h->roll64_cols, e.rows = rows, e.batch = h->batch,
-  e.samples = (uint32_t)samples, e.zero_from = reset ? 20u : rows;
+  e.samples = (uint32_t)samples, e.zero_from = (reset && !h->hold64) ? 20u : rows;
+  if (h->hold64 && reset) {  // ... there the velocity Pid's own record of every cable is what the Joy resets
+    e.hold_base = (uint32_t)f64_state_rows((int)n), e.hold_cable_rows = (uint32_t)hold_cable_rows(h->hold_win), e.hold_pid_rows = (uint32_t)hold_pid_rows(h->hold_win);
+    e.hold_zero_pid = 2u;  // 1 + the Pid's index
+  }
   hipLaunchKernelGGL(cdpr_roll64_expand_kernel, dim3(blocks), dim3(256), 0, h->stream, e);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->d_roll64_acc, 0, cols * sizeof(double), h->stream));
   F64Args a = h->base64;
-  fill_pid64(h->cfg.velocity_pid, h->cfg.dt, a);
+  f64_mode_args(h, true, false, a);  // Velocity mode (hold branch live: both Pids, the branch's parameters)
   a.state = h->d_roll64;
   a.obs = h->d_obs64;  // (nothing is published: publish_mask = 0)
   a.dbg = nullptr;
@@ -388,7 +404,9 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
   a.nsteps = 1;
   a.publish_mask = 0;
   a.obs_step_stride = 0;
-  F64Kernel kern = h->plan.long64 ? pick_f64_long_kernel(n, false, h->tstop64) : h->tstop64 ? pick_f64_tstop_kernel(n) : pick_f64_kernel(n, false, false);
+  LaunchShape shape = launch_shape(h, 2);  // the handle's one-wave kernel, rings in memory
+  shape.f64_split = 0, shape.f64_ring_lds = 0, shape.f64_jcache = 0;
+  F64Kernel kern = f64_kernel_for(h, planned_kernel(h->plan, shape));
   a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
   int calls = reset ? 0 : h->pid_calls;
   for (int k = 0; k < horizon; ++k) {

@@ -1720,12 +1720,21 @@ struct Roll64Args {
   uint32_t src_stride, dst_stride, rows, batch, samples;
   uint32_t zero_from;  // rows >= this are cleared in the copies (a Joy on jointVelocities in Position mode resets the velocity Pid,
                        // JFC.cpp:113-115); == rows: none
+  // HOLD handles: that Pid has a record of its own per cable (f64_hold_row) - hold_zero_pid = 1 + the Pid whose records are cleared, 0: none
+  uint32_t hold_base, hold_cable_rows, hold_pid_rows, hold_zero_pid;
 };
 static __global__ __launch_bounds__(256) void cdpr_roll64_expand_kernel(const Roll64Args a) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   if (t >= a.batch * a.samples) return;
   const uint32_t b = t / a.samples;
-  for (uint32_t r = 0; r < a.rows; ++r) a.dst[(size_t)r * a.dst_stride + t] = (r >= a.zero_from) ? 0.0 : a.src[(size_t)r * a.src_stride + b];
+  for (uint32_t r = 0; r < a.rows; ++r) {
+    bool zero = r >= a.zero_from;
+    if (a.hold_zero_pid && r >= a.hold_base) {
+      const uint32_t in_cable = (r - a.hold_base) % a.hold_cable_rows, first = 1u + (a.hold_zero_pid - 1u) * a.hold_pid_rows;
+      zero = zero || (in_cable >= first && in_cable < first + a.hold_pid_rows);
+    }
+    a.dst[(size_t)r * a.dst_stride + t] = zero ? 0.0 : a.src[(size_t)r * a.src_stride + b];
+  }
 }
 struct Roll64CmdArgs {
   const float* commands;  // float[B][H][S][n]

@@ -462,7 +462,7 @@ def test_fp64_refuses_nothing_of_the_controller_any_more(pkg):
     """Through round 6 precision = 64 refused combinations of its own features (the optional physics, per-robot modes, long windows,
     the hold branch); the last of them - windows beyond 11 samples with the hold branch / cascades / cmd_limit 0, or on a per-robot
     handle whose Pids fit different windows - run on HOLD records of 32 samples now.  Left to the fp32 paths: more than 8 cables,
-    the MPC rollout on per-robot / hold-branch handles (refused where it is called)."""
+    the MPC rollout on per-robot handles (refused where it is called)."""
     stop = pkg.eight_cable_model()
     stop.travel_lower, stop.travel_upper, stop.travel_stop = -0.01, 0.01, 2
     names = []
@@ -685,13 +685,16 @@ def test_role_split_fp64_hold_controller_against_the_one_wave_kernel(pkg, monkey
     assert worst == 0.0
 
 
-@pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0", "velocity_long_window", "velocity_lumped_legs"])
+@pytest.mark.parametrize("entered_from", ["velocity", "position", "world_step_0", "velocity_long_window", "velocity_lumped_legs", "velocity_hold_branch", "position_hold_branch",
+                                          "velocity_hold_branch_long_window_cascades"])
 def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     """cdpr_rollout_velocity on a precision = 64 handle (round 6; refused before): every (robot, sampled sequence) steps a private
     copy of the robot's state through the handle's own fp64 step kernel, one launch per step of the horizon, the cost accumulated
     in double.  Against the oracle's rollout (the cost leaves as float32: agreement to its rounding), entered from Velocity mode
     (the Pid's history carries on), from Position mode (a Joy on jointVelocities resets the velocity Pid, JFC.cpp:113-115) and at
-    world step 0 (no force at t = 0, JFC.cpp:61-66); the handle itself is not advanced by a rollout."""
+    world step 0 (no force at t = 0, JFC.cpp:61-66); the handle itself is not advanced by a rollout.  End of round 6: with the hold
+    branch live as well (the trajectories carry both Pids' records; from Position mode the velocity Pid's records are the ones cleared),
+    also over records of 32 samples with a cascade."""
     B, n, S, H = 20, 8, 12, 16
     rng = np.random.default_rng(660)
     cfg = pkg.Config(model=pkg.eight_cable_model(), batch=B, stages=3, precision=64)
@@ -700,6 +703,11 @@ def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
         cfg.model.travel_lower, cfg.model.travel_upper, cfg.model.travel_stop = -0.05, 0.05, 2
     if entered_from == "velocity_long_window":  # (a 20-sample window: the kernel with a ring of 31, its rows copied per trajectory)
         cfg.velocityController.dBufferLength, cfg.velocityController.dDegree = 20, 3
+    if "hold_branch" in entered_from:  # (end of round 6: both Pids' records of every cable travel with a trajectory; sampled commands cross epsilon)
+        cfg.velocityEpsilon = 0.012
+    if entered_from.endswith("long_window_cascades"):
+        cfg.velocityController.dBufferLength, cfg.velocityController.dDegree = 18, 2
+        cfg.velocityController.pFilter.cascade, cfg.velocityController.pFilter.relCutoff = 1, 0.2
     pose = np.tile(cfg.model.home_pose(), (B, 1))
     pose[:, :3] += rng.uniform(-0.02, 0.02, (B, 3))
     eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
@@ -709,7 +717,7 @@ def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
         for sim in (eng, ora):
             sim.set_velocity_command(first)
             sim.update(23)
-    elif entered_from == "position":
+    elif entered_from.startswith("position"):
         for sim in (eng, ora):
             sim.set_position_command((0.1 * first).astype(np.float32))
             sim.update(17)
