@@ -259,7 +259,7 @@ void free_all(cdpr_engine* h) {
   if (h->d_gwtab) (void)hipFree(h->d_gwtab);
   if (h->d_gptab) (void)hipFree(h->d_gptab);
   if (h->d_roll_rec) (void)hipFree(h->d_roll_rec);
-  for (void* p64 : {(void*)h->d_roll64, (void*)h->d_roll64_acc, (void*)h->d_roll64_cmd})
+  for (void* p64 : {(void*)h->d_roll64, (void*)h->d_roll64_acc, (void*)h->d_roll64_cmd, (void*)h->d_roll64_meta})
     if (p64) (void)hipFree(p64);
   if (h->d_mode) (void)hipFree(h->d_mode);
   if (h->d_target) (void)hipFree(h->d_target);

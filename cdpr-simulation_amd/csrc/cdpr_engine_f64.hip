@@ -370,7 +370,7 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
   const uint32_t rows = (uint32_t)state64_rows(h);  // (hold branch live: both Pids' records of every cable travel with a trajectory)
   if (h->roll64_cols < cols) {
     HIP_TRY(h, wait_stream(h));
-    for (void** p64 : {(void**)&h->d_roll64, (void**)&h->d_roll64_acc, (void**)&h->d_roll64_cmd}) {
+    for (void** p64 : {(void**)&h->d_roll64, (void**)&h->d_roll64_acc, (void**)&h->d_roll64_cmd, (void**)&h->d_roll64_meta}) {
       if (*p64) (void)hipFree(*p64);
       *p64 = nullptr;
     }
@@ -378,9 +378,11 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
     HIP_TRY(h, hipMalloc(&h->d_roll64, (size_t)rows * cols * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->d_roll64_acc, cols * sizeof(double)));
     HIP_TRY(h, hipMalloc(&h->d_roll64_cmd, cols * n * sizeof(float)));
+    if (h->per_robot) HIP_TRY(h, hipMalloc(&h->d_roll64_meta, cols));
     h->roll64_cols = cols;
   }
-  const bool reset = h->mode != kModeVelocity;  // JFC.cpp:113-115: the copies start from a reset velocity Pid, the handle's rows stay
+  const bool pr = h->per_robot;
+  const bool reset = pr || h->mode != kModeVelocity;  // JFC.cpp:113-115: the copies start from a reset velocity Pid, the handle's rows stay (per-robot handles: per robot, from its meta byte)
   const uint32_t blocks = (uint32_t)((traj + 255u) / 256u);
   Roll64Args e{};
   e.src = h->d_state64, e.dst = h->d_roll64, e.src_stride = h->stride, e.dst_stride = (uint32_t)h->roll64_cols, e.rows = rows, e.batch = h->batch,
@@ -389,6 +391,7 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
     e.hold_base = (uint32_t)f64_state_rows((int)n), e.hold_cable_rows = (uint32_t)hold_cable_rows(h->hold_win), e.hold_pid_rows = (uint32_t)hold_pid_rows(h->hold_win);
     e.hold_zero_pid = 2u;  // 1 + the Pid's index
   }
+  if (pr) e.meta_src = h->d_mode, e.meta_dst = h->d_roll64_meta;
   hipLaunchKernelGGL(cdpr_roll64_expand_kernel, dim3(blocks), dim3(256), 0, h->stream, e);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemsetAsync(h->d_roll64_acc, 0, cols * sizeof(double), h->stream));
@@ -397,7 +400,8 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
   a.state = h->d_roll64;
   a.obs = h->d_obs64;  // (nothing is published: publish_mask = 0)
   a.dbg = nullptr;
-  a.cmd = h->d_roll64_cmd;
+  a.cmd = h->d_roll64_cmd;  // (per-robot handles: the trajectory's ACTIVE target row)
+  if (pr) a.meta = h->d_roll64_meta;
   a.wtab = h->d_wtab64;
   a.batch = (uint32_t)traj;
   a.stride = (uint32_t)h->roll64_cols;
@@ -408,13 +412,13 @@ int rollout_enqueue_f64(cdpr_engine* h, int samples, int horizon, const float* d
   shape.f64_split = 0, shape.f64_ring_lds = 0, shape.f64_jcache = 0;
   F64Kernel kern = f64_kernel_for(h, planned_kernel(h->plan, shape));
   a.travel_stop = h->tstop64 ? (int)h->cfg.travel_stop : 0;
-  int calls = reset ? 0 : h->pid_calls;
+  int calls = reset ? 0 : h->pid_calls;  // (uniform handles; per-robot handles count in the meta bytes)
   for (int k = 0; k < horizon; ++k) {
     Roll64CmdArgs c{};
     c.commands = d_commands, c.out = h->d_roll64_cmd, c.batch = h->batch, c.samples = (uint32_t)samples, c.horizon = (uint32_t)horizon, c.n = n, c.k = (uint32_t)k;
     hipLaunchKernelGGL(cdpr_roll64_cmd_kernel, dim3((uint32_t)((traj * n + 255u) / 256u)), dim3(256), 0, h->stream, c);
     const bool first_world = (h->step + (uint64_t)k) == 0;
-    a.flags = kFlagActualIsVelocity | (first_world ? kFlagFirstWorldStep : 0u);
+    a.flags = (pr ? 0u : kFlagActualIsVelocity) | (first_world ? kFlagFirstWorldStep : 0u);
     a.pid_calls = sat_pid_calls(calls);
     a.ring_slot = ring_slot_of(h->step + (uint64_t)k, h->win64);
     a.step0 = (int)(h->step + (uint64_t)k);

@@ -85,6 +85,7 @@ struct cdpr_engine {
   double* d_roll64 = nullptr;    // MPC rollout on a precision = 64 handle: the trajectories' state rows, their cost accumulators, the step's Joy batch
   double* d_roll64_acc = nullptr;
   float* d_roll64_cmd = nullptr;
+  uint8_t* d_roll64_meta = nullptr;  // ... per-robot handles: every trajectory's mode / Pid call count byte
   size_t roll64_cols = 0;
   float* d_roll_rec = nullptr;   // MPC rollout on the general path: every trajectory's private copy of the records
   size_t roll_rec_cols = 0;      // columns d_roll_rec can hold

@@ -96,10 +96,6 @@ static int rollout_check(cdpr_engine* h, int samples, int horizon, const void* d
     h->err = "rollout: samples, horizon >= 1 and the command buffer are required";
     return CDPR_ERR_INVALID;
   }
-  if (h->fp64 && h->per_robot) {
-    h->err = "rollout with precision = 64: uniform-mode handles (per_robot_commands: on the fp32 paths)";
-    return CDPR_ERR_UNSUPPORTED;
-  }
   if ((uint64_t)h->batch * (uint64_t)samples > (1ull << 30)) {
     h->err = "rollout: too many trajectories";
     return CDPR_ERR_INVALID;

@@ -1722,14 +1722,24 @@ struct Roll64Args {
                        // JFC.cpp:113-115); == rows: none
   // HOLD handles: that Pid has a record of its own per cable (f64_hold_row) - hold_zero_pid = 1 + the Pid whose records are cleared, 0: none
   uint32_t hold_base, hold_cable_rows, hold_pid_rows, hold_zero_pid;
+  // per-robot handles: the robot's mode / call-count byte decides (a robot that is not in Velocity mode enters it: its - velocity - Pid
+  // is reset, its count 0); every trajectory gets its own byte
+  const uint8_t* meta_src;
+  uint8_t* meta_dst;
 };
 static __global__ __launch_bounds__(256) void cdpr_roll64_expand_kernel(const Roll64Args a) {
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   if (t >= a.batch * a.samples) return;
   const uint32_t b = t / a.samples;
+  bool resets = true;  // (uniform handles: zero_from / hold_zero_pid already say whether the Joy resets the Pid)
+  if (a.meta_src) {
+    const uint32_t m = a.meta_src[b];
+    resets = (m & kMetaModeMask) != kMetaVelocity;
+    a.meta_dst[t] = (uint8_t)(resets ? kMetaVelocity : m);
+  }
   for (uint32_t r = 0; r < a.rows; ++r) {
-    bool zero = r >= a.zero_from;
-    if (a.hold_zero_pid && r >= a.hold_base) {
+    bool zero = resets && r >= a.zero_from;
+    if (resets && a.hold_zero_pid && r >= a.hold_base) {
       const uint32_t in_cable = (r - a.hold_base) % a.hold_cable_rows, first = 1u + (a.hold_zero_pid - 1u) * a.hold_pid_rows;
       zero = zero || (in_cable >= first && in_cable < first + a.hold_pid_rows);
     }

@@ -125,8 +125,7 @@ typedef struct cdpr_config {
                                        per_robot_commands (two different derivative windows included).  Round 6: the joint stop
                                        (travel_stop > 0), the lumped legs, derivative windows to 32 samples and cdpr_rollout_velocity* in
                                        double as well; every combination of the controller's and the physics' options is served.  Not in
-                                       double: more than 8 cables (cdpr_create), rollouts on per-robot handles (the call returns
-                                       CDPR_ERR_UNSUPPORTED) */
+                                       double: more than 8 cables (cdpr_create returns CDPR_ERR_UNSUPPORTED) */
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */

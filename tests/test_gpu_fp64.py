@@ -462,7 +462,7 @@ def test_fp64_refuses_nothing_of_the_controller_any_more(pkg):
     """Through round 6 precision = 64 refused combinations of its own features (the optional physics, per-robot modes, long windows,
     the hold branch); the last of them - windows beyond 11 samples with the hold branch / cascades / cmd_limit 0, or on a per-robot
     handle whose Pids fit different windows - run on HOLD records of 32 samples now.  Left to the fp32 paths: more than 8 cables,
-    the MPC rollout on per-robot handles (refused where it is called)."""
+    nothing but that (the MPC rollout runs in double on every handle kind too)."""
     stop = pkg.eight_cable_model()
     stop.travel_lower, stop.travel_upper, stop.travel_stop = -0.01, 0.01, 2
     names = []
@@ -733,6 +733,44 @@ def test_fp64_rollout_against_the_oracle(pkg, oracle, entered_from):
     assert all(np.array_equal(x, y) for x, y in zip(before, after)) and eng.step_count == ora.step_count
     eng.update(5), ora.update(5)  # ... and carries on as if nothing had happened
     assert np.abs(eng.observables_f64()[3] - ora.platform_state()[0]).max() < 1e-12
+
+
+@pytest.mark.parametrize("variant", ["per_robot", "per_robot_hold_branch"])
+def test_fp64_rollout_on_per_robot_handles(pkg, oracle, variant):
+    """cdpr_rollout_velocity in double on per-robot handles (end of round 6; the fp32 paths had it): robots in different modes and
+    with Pids reset at different times - a robot that is not in Velocity mode enters it with the rollout's first Joy (its Pid reset,
+    its call count 0), the others carry their windows on; every trajectory has its own mode / call-count byte.  Against the oracle
+    (B independent JointForceCalculator sets); the handle's own state and modes are left alone."""
+    from test_gpu_general_matrix import hold_commands
+
+    B, n, S, H = 90, 8, 5, 14
+    hold = variant.endswith("hold_branch")
+    eps = 0.004 if hold else -0.001
+    rng = np.random.default_rng(980 + len(variant))
+    model = pkg.eight_cable_model()
+    cfg = pkg.Config(model=model, batch=B, stages=3, precision=64, perRobotCommands=True, velocityEpsilon=eps)
+    eng, ora = pair64(pkg, oracle, cfg, perturbed_poses(model, B, rng, 0.02, 0.03).astype(np.float64))
+    grp = rng.integers(0, 3, B)
+    v = hold_commands(rng, B, n, eps) if hold else rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+    p = rng.uniform(-0.003, 0.003, (B, n)).astype(np.float32)
+    f = (7.0 + rng.uniform(-0.5, 0.5, (B, n))).astype(np.float32)
+    for e in (eng, ora):
+        e.update(6)
+        e.set_velocity_command(v, mask=(grp >= 1).astype(np.uint8))   # group 0 stays in Position mode
+    eng.update(17), ora.update(17)
+    for e in (eng, ora):
+        e.set_force_command(f, mask=(grp == 2).astype(np.uint8))      # group 2: Force mode; group 1 keeps its velocity Pid's window
+    eng.update(9), ora.update(9)
+    cmds = (rng.uniform(-0.03, 0.03, (B, H, 1, n)) + rng.normal(0.0, 0.01, (B, H, S, n))).astype(np.float32)
+    ref = (eng.observables_f64()[3][:, :3] + np.array([0.0, 0.0, 0.01])).astype(np.float32)
+    before = eng.raw_state_f64()
+    cost, ocost = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref.astype(np.float64))
+    assert cost.shape == (B, S) and np.isfinite(cost).all()
+    assert np.abs(cost - ocost).max() <= 3e-7 * np.abs(ocost).max(), float(np.abs(cost - ocost).max() / np.abs(ocost).max())
+    after = eng.raw_state_f64()
+    assert all(np.array_equal(x, y) for x, y in zip(before, after)) and eng.step_count == ora.step_count
+    eng.update(8), ora.update(8)  # modes and Pids of the handle as they were: Position / Velocity / Force groups carry on
+    compare64(eng, ora, f"{variant}: after the rollout", dict(TOL64, eff=2e-7, twist=1e-10, qd=1e-10, pose=1e-12, q=1e-12))
 
 
 @pytest.mark.parametrize("variant", ["per_robot", "physics", "per_robot_physics"])
