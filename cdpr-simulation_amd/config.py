@@ -159,7 +159,7 @@ class Config:
     fkMaxIterations: int = 4
     fkLambda: float = 1e-9
     fkTolerance: float = 0.0
-    precision: int = 32  # 64: the step in the reference's own precision (fp64 kernels: every option of the controller and the physics, up to 8 cables; Engine.observables_f64)
+    precision: int = 32  # 64: the step in the reference's own precision (fp64 kernels: every option of the controller and the physics; Engine.observables_f64)
     perRobotCommands: bool = False  # every robot has its own mode / Pid history: a Joy may reach some robots only ([NEW]: B plugin instances)
     tdFMin: float | None = None  # default: model.f_min
     tdFMax: float | None = None

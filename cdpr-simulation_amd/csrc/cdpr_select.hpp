@@ -182,7 +182,6 @@ inline KernelPlan plan_kernels(const cdpr_config_t& c, int cus = 256, EnvFn env 
     const char* why9 = general_cfg ? "the general controller path (hold branch, cascades, long windows, cmd_limit 0)"
                        : cfg->per_robot_commands != 0 ? "per_robot_commands"
                        : phys_cfg ? "the lumped legs / the joint stop"
-                       : cfg->precision == 64 ? "precision = 64"
                        : (cfg->mapping != CDPR_MAP_AUTO && cfg->mapping != CDPR_MAP_LANE_PER_ROBOT) ? "a mapping other than one lane per robot" : nullptr;
     if (why9) {
       p.rc = CDPR_ERR_UNSUPPORTED;
@@ -339,10 +338,10 @@ inline PlannedKernel planned_kernel(const KernelPlan& p, const LaunchShape& s) {
   PlannedKernel k;
   const int steps = s.scheduled ? std::max(s.steps, 2) : s.steps;  // a launch over a schedule runs on the several-steps kernel even for one step
   if (p.fp64) {
-    const bool ring_lds = s.f64_ring_lds >= 0 ? s.f64_ring_lds != 0 : p.batch <= 32768u;
+    const bool ring_lds = p.n <= 8u && (s.f64_ring_lds >= 0 ? s.f64_ring_lds != 0 : p.batch <= 32768u);  // (nine to twelve cables: the plain one-wave kernel, rings in memory)
     const bool jcache = ring_lds && (s.f64_jcache >= 0 ? s.f64_jcache != 0 : p.batch <= 16384u);
     const bool lean = s.f64_split >= 0 ? s.f64_split == 2 : p.batch > 16384u;
-    const bool can_split = p.fk && p.td && s.f64_split != 0 && !p.per_robot && !p.tstop64 && !p.long64 && !p.hold_long;
+    const bool can_split = p.fk && p.td && p.n <= 8u && s.f64_split != 0 && !p.per_robot && !p.tstop64 && !p.long64 && !p.hold_long;
     k.f64_ring_lds = ring_lds, k.f64_jcache = jcache, k.f64_lean = lean;
     // up to one workgroup per CU the role-split kernel's one-step launches beat the one-wave kernel's several-steps ones (14.4
     // against 20.8 us per step at one robot x 8, same bits): the engine then runs a fused update as one-step launches

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(64) void cdpr_step_kernel_f64(const F64Args a) {
   __shared__ double c_hold_w[HOLD ? 2 : 1][HW], c_hold_rot[HOLD ? 2 : 1][HOLD ? HW : 1][HW], c_hold_par[HOLD ? 2 : 1][kHoldPar];
   if constexpr (HOLD != 0) hold_tables_fill<HW>(a, lane, c_hold_w, c_hold_rot, c_hold_par);
   if (kGeomLds) {
-    if (lane < N * 7) c_geom_lds[lane] = a.geom[lane];
+    for (int g = (int)lane; g < N * 7; g += 64) c_geom_lds[g] = a.geom[g];  // (84 doubles at twelve cables)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -12,7 +12,14 @@ template <int N> F64Kernel f64_hold_pr_n(bool full) { return full ? cdpr_step_ke
 }  // namespace
 F64Kernel pick_f64_hold_pr_kernel(uint32_t n, bool full) { CDPR_PICK_CABLES(f64_hold_pr_n, full); }  // ... on per-robot handles (the mode per lane)
 F64Kernel pick_f64_hold_kernel(uint32_t n, bool full) { CDPR_PICK_CABLES(f64_hold_n, full); }  // the position-hold branch live (both Pids of every cable)
-F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES(f64_n, ring_lds, jcache); }
+// nine to twelve cables (end of round 6): the plain one-wave kernel, rings in memory (the LDS variants' columns do not fit)
+template <int N> F64Kernel f64_n12(bool ring_lds, bool jcache) {
+  if constexpr (N > 8)
+    return cdpr_step_kernel_f64<N, false>;
+  else
+    return f64_n<N>(ring_lds, jcache);
+}
+F64Kernel pick_f64_kernel(uint32_t n, bool ring_lds, bool jcache) { CDPR_PICK_CABLES12(f64_n12, ring_lds, jcache); }
 F64Kernel pick_f64_pr_kernel(uint32_t n, bool ring_lds) { CDPR_PICK_CABLES(f64_pr_n, ring_lds); }  // per-robot modes (PR)
 template <int H> F64Kernel f64_split_hold(uint32_t n, bool lean) {
   if (lean) {

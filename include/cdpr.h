@@ -124,8 +124,8 @@ typedef struct cdpr_config {
                                        double too (round 5), with the rest of Pid::update - biquad cascades, cmd_limit = 0 - and with
                                        per_robot_commands (two different derivative windows included).  Round 6: the joint stop
                                        (travel_stop > 0), the lumped legs, derivative windows to 32 samples and cdpr_rollout_velocity* in
-                                       double as well; every combination of the controller's and the physics' options is served.  Not in
-                                       double: more than 8 cables (cdpr_create returns CDPR_ERR_UNSUPPORTED) */
+                                       double as well; every combination of the controller's and the physics' options is served, nine to
+                                       twelve cables where the fp32 kernels serve them */
 
   cdpr_pid_params_t velocity_pid;   /* PLG.cpp:102-120 */
   cdpr_pid_params_t position_pid;   /* PLG.cpp:123-134 (forward gain and filters are forced to 0 by the facade) */

@@ -461,8 +461,8 @@ def test_fp64_rest_of_pid_update(pkg, oracle, variant):
 def test_fp64_refuses_nothing_of_the_controller_any_more(pkg):
     """Through round 6 precision = 64 refused combinations of its own features (the optional physics, per-robot modes, long windows,
     the hold branch); the last of them - windows beyond 11 samples with the hold branch / cascades / cmd_limit 0, or on a per-robot
-    handle whose Pids fit different windows - run on HOLD records of 32 samples now.  Left to the fp32 paths: more than 8 cables,
-    nothing but that (the MPC rollout runs in double on every handle kind too)."""
+    handle whose Pids fit different windows - run on HOLD records of 32 samples now; the MPC rollout runs in double on every handle kind;
+    nine to twelve cables are served where the fp32 kernels serve them (uniform-mode handles on the register-resident path)."""
     stop = pkg.eight_cable_model()
     stop.travel_lower, stop.travel_upper, stop.travel_stop = -0.01, 0.01, 2
     names = []
@@ -475,8 +475,8 @@ def test_fp64_refuses_nothing_of_the_controller_any_more(pkg):
         eng.close()
     assert names == ["cdpr_step_kernel_f64<4, HOLD = 2, HW = 32>", "cdpr_step_kernel_f64<4, PR, HOLD = 2, HW = 32>", "cdpr_step_kernel_f64<4, PR, HOLD = 2, HW = 32>",
                      "cdpr_step_kernel_f64<8, HOLD = 2, TSTOP, HW = 32>"], names
-    twelve = pkg.Config(model=pkg.twelve_cable_model(), batch=4, precision=64)
-    with pytest.raises(pkg.CdprError) as ei:
+    twelve = pkg.Config(model=pkg.twelve_cable_model(), batch=4, precision=64, velocityEpsilon=0.01)  # (nine to twelve cables: uniform-mode handles on the
+    with pytest.raises(pkg.CdprError) as ei:                                                           #  register-resident path, in double as in float)
         pkg.Engine(twelve, 0)
     assert ei.value.code == pkg._abi.ERR_UNSUPPORTED
 

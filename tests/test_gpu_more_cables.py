@@ -106,11 +106,52 @@ def test_rollout_and_solvers_at_twelve_cables(pkg, oracle):
         assert int(flag[r]) == oflag and np.abs(t[r] - ot).max() < 5e-3
 
 
+@pytest.mark.parametrize("n", [9, 12])
+def test_more_than_eight_cables_in_double(pkg, oracle, n):
+    """Nine to twelve cables with precision = 64 (end of round 6): the plain one-wave fp64 kernel - uniform modes, FK and TD, one step
+    and several per launch, the trajectory record, a mode change, the rollout - against the fp64 oracle at the double tolerances."""
+    B = 70
+    rng = np.random.default_rng(930 + n)
+    cfg = pkg.Config(model=model_of(pkg, n), batch=B, stages=3, precision=64)
+    assert pkg.plan_kernel(cfg, 1) == f"cdpr_step_kernel_f64<{n}>" == pkg.plan_kernel(cfg, 10)
+    pose = perturbed_poses(cfg.model, B, rng, dp=0.02, dr=0.05).astype(np.float64)
+    eng, ora = pkg.Engine(cfg, 0), oracle.OracleSim(cfg.to_struct(), oracle.DERIV_EXACT)
+    eng.set_platform_state_f64(pose7=pose), ora.set_platform_state(pose7=pose)
+
+    def same(where):
+        g = eng.observables_f64()
+        dp, de = np.abs(g[3] - ora.platform_state()[0]).max(), np.abs(g[2] - ora.joint_states()[2]).max()
+        dq = np.abs(g[0] - ora.joint_states()[0]).max()
+        assert dp < 1e-12 and dq < 1e-12 and de < 1e-8, (where, dp, dq, de)
+
+    v = rng.uniform(-0.03, 0.03, (B, n)).astype(np.float32)
+    eng.update(7), ora.update(7)
+    eng.set_velocity_command(v), ora.set_velocity_command(v)
+    for _ in range(15):
+        eng.update(1)
+    ora.update(15)
+    same("one-step launches")
+    eng.update(30, 10), ora.update(30)
+    same("fused launches")
+    eng.set_position_command((0.1 * v).astype(np.float32)), ora.set_position_command((0.1 * v).astype(np.float32))
+    rec = eng.update_record(18, 6)
+    ora.update(18)
+    same("position mode, record")
+    assert np.array_equal(rec["effort"][-1], eng.observables_f64()[2])
+    S, H = 6, 12
+    cmds = (rng.uniform(-0.03, 0.03, (B, H, 1, n)) + rng.normal(0.0, 0.01, (B, H, S, n))).astype(np.float32)
+    ref = pose[:, :3].astype(np.float32)
+    cost, ocost = eng.rollout_velocity(cmds, ref), ora.rollout_velocity(cmds, ref.astype(np.float64))
+    assert np.abs(cost - ocost).max() <= 3e-7 * np.abs(ocost).max()
+    assert eng.kernel_name == f"cdpr_step_kernel_f64<{n}>"
+    eng.close()
+
+
 def test_what_stays_at_eight_cables_is_refused_by_name(pkg):
     m = pkg.twelve_cable_model()
     lumped = replace(m, leg_inertia=0.004)
     for kw, word in ((dict(perRobotCommands=True), "per_robot_commands"), (dict(velocityEpsilon=0.001), "general controller path"),
-                     (dict(precision=64), "precision = 64"), (dict(mapping=pkg._abi.MAP_LANE_PER_CABLE), "mapping")):
+                     (dict(precision=64, perRobotCommands=True), "per_robot_commands"), (dict(mapping=pkg._abi.MAP_LANE_PER_CABLE), "mapping")):
         with pytest.raises(pkg.CdprError) as ei:
             pkg.Engine(pkg.Config(model=m, batch=4, **kw), 0)
         assert ei.value.code == pkg._abi.ERR_UNSUPPORTED and word in str(ei.value), kw

@@ -119,8 +119,9 @@ def test_refusals_carry_their_reason(pkg, clean_env):
     long_hold = pkg.Config(batch=4, precision=64, velocityEpsilon=0.01)  # ... and long windows with the hold branch: Pid records of 32 samples
     long_hold.velocityController.dBufferLength = 20
     assert plan(pkg, long_hold) == (0, "cdpr_step_kernel_f64<4, HOLD = 2, HW = 32>")
-    rc, why = plan(pkg, pkg.Config(model=pkg.twelve_cable_model(), batch=4, precision=64))  # what precision = 64 still refuses
-    assert rc == pkg._abi.ERR_UNSUPPORTED and "precision = 64" in why
+    assert plan(pkg, pkg.Config(model=pkg.twelve_cable_model(), batch=4, precision=64)) == (0, "cdpr_step_kernel_f64<12>")  # (end of round 6)
+    rc, why = plan(pkg, pkg.Config(model=pkg.twelve_cable_model(), batch=4, precision=64, velocityEpsilon=0.01))  # beyond 8 cables: as in float
+    assert rc == pkg._abi.ERR_UNSUPPORTED and "more than 8 cables" in why
     long_w = pkg.Config(batch=4, precision=64)
     long_w.velocityController.dBufferLength = 20
     assert plan(pkg, long_w, 10) == (0, "cdpr_step_kernel_f64<4, W = 31>")
