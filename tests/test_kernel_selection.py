@@ -129,6 +129,34 @@ def test_refusals_carry_their_reason(pkg, clean_env):
     assert rc == pkg._abi.ERR_UNSUPPORTED and "CDPR_MAP_LANE_PAIR" in why
 
 
+def test_precision_64_accepts_what_precision_32_accepts(pkg, clean_env):
+    """End of round 6: no configuration that cdpr_create takes at precision = 32 is refused at precision = 64 - cable counts 4 / 8 / 12,
+    the optional physics, per-robot modes, the hold branch, long windows, cascades, mappings, stages (384 combinations, planned
+    without a GPU)."""
+    from dataclasses import replace
+
+    models = [pkg.cube_model(), pkg.eight_cable_model(), pkg.twelve_cable_model(),
+              replace(pkg.eight_cable_model(), travel_lower=-0.01, travel_upper=0.01, travel_stop=2, leg_inertia=0.004)]
+    checked = served = 0
+    for m in models:
+        for pr in (False, True):
+            for eps in (-1.0, 0.004):
+                for nbuf in (11, 20):
+                    for cas in (0, 1):
+                        for mapping in (pkg._abi.MAP_AUTO, pkg._abi.MAP_LANE_PAIR, pkg._abi.MAP_LANE_PER_ROBOT):
+                            for stages in (0, 3):
+                                def cfg(prec):
+                                    c = pkg.Config(model=m, batch=64, stages=stages if m.n_cables >= 6 else 0, precision=prec, perRobotCommands=pr, velocityEpsilon=eps, mapping=mapping)
+                                    c.velocityController.dBufferLength, c.velocityController.dDegree, c.velocityController.pFilter.cascade = nbuf, 2, cas
+                                    return c
+                                rc32, _ = plan(pkg, cfg(32))
+                                rc64, why = plan(pkg, cfg(64))
+                                checked += 1
+                                served += rc32 == 0
+                                assert rc32 != 0 or rc64 == 0, (m.n_cables, pr, eps, nbuf, cas, mapping, stages, why)
+    assert checked == 384 and served > 200
+
+
 if __name__ == "__main__":
     sys.path.insert(0, ROOT)
     import cdpr_simulation_amd as pkg_
