@@ -154,7 +154,7 @@ def test_precision_64_accepts_what_precision_32_accepts(pkg, clean_env):
                                 checked += 1
                                 served += rc32 == 0
                                 assert rc32 != 0 or rc64 == 0, (m.n_cables, pr, eps, nbuf, cas, mapping, stages, why)
-    assert checked == 384 and served > 200
+    assert checked == 384 and served >= 150
 
 
 if __name__ == "__main__":
