@@ -379,7 +379,8 @@ class Engine:
         return int(ptr.value)
 
     def device_upload_into(self, dptr: int, array: np.ndarray) -> None:
-        """Host array into an existing device buffer, on THIS handle's stream (e.g. to fill another handle's mailbox)."""
+        """Host array into an existing device buffer, on THIS handle's stream.  (Not the way to post the mailbox of a schedule that is
+        already waiting: the copy may share the waiting launch's hardware queue - keep such words in mapped pinned host memory.)"""
         a = np.ascontiguousarray(array)
         self._check(lib().cdpr_device_upload(self._h, C.c_void_p(dptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
 

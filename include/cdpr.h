@@ -273,7 +273,9 @@ int cdpr_decode_observables_f64(cdpr_handle_t h, const void *image, double *posi
  * small for a launch per step to pay (a 4 096 x 4-cable step is 1.4 us of work behind 3-4 us of launch).
  * d_commands: DEVICE buffer float[ceil(nsteps / refresh_steps)][B][n], batch j is latched at world step first + j *
  * refresh_steps.  d_ready: optional DEVICE-visible mailbox uint32[batches]: batch j is taken only once d_ready[j] != 0 (a
- * host or a producer kernel that fills the schedule while the work runs; pinned host memory mapped to the device works);
+ * host or a producer kernel that fills the schedule while the work runs.  A HOST producer should keep the words in pinned host memory
+ * mapped to the device and post them by plain stores: a copy enqueued on another stream can be placed on the hardware queue of the
+ * launch that is waiting for it and then never completes);
  * NULL = the whole schedule is there.  The wait is bounded (~2^23 polls, a few seconds): a mailbox that never delivers
  * does not hang the GPU - the handle's status word is raised instead and cdpr_synchronize and the getters return
  * CDPR_ERR_DEVICE until cdpr_reset.  d_record: as cdpr_update_record (every step's observable image kept; needs

@@ -55,3 +55,25 @@ def oracle():
 
     _oracle.build()
     return _oracle
+
+
+def mapped_words(n):
+    """uint32[n] in pinned host memory mapped to the device (fine-grained): (numpy view, device pointer, free).  What a HOST producer
+    posts a schedule's mailbox through (include/cdpr.h: cdpr_update_scheduled, d_ready): plain stores, no GPU queue in between - a copy
+    enqueued on a stream can land on the hardware queue of the launch that is waiting for it and never complete."""
+    import ctypes as C
+
+    import numpy as np
+
+    try:
+        hip = C.CDLL("libamdhip64.so")
+    except OSError:
+        hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+    host, dev = C.c_void_p(), C.c_void_p()
+    rc = hip.hipHostMalloc(C.byref(host), C.c_size_t(4 * n), C.c_uint(0x2 | 0x40000000))  # hipHostMallocMapped | hipHostMallocCoherent
+    assert rc == 0, rc
+    rc = hip.hipHostGetDevicePointer(C.byref(dev), host, C.c_uint(0))
+    assert rc == 0, rc
+    words = np.ctypeslib.as_array(C.cast(host, C.POINTER(C.c_uint32)), shape=(n,))
+    words[:] = 0
+    return words, int(dev.value), lambda: hip.hipHostFree(host)

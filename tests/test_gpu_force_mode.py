@@ -333,20 +333,21 @@ def test_scheduled_update_waits_for_its_mailbox(pkg):
     cfg = pkg.Config(batch=B)
     sched = rng.uniform(-0.03, 0.03, (T // refresh, B, 4)).astype(np.float32)
     out = []
+    from conftest import mapped_words
+
     for use_mailbox in (False, True):
-        eng, other = pkg.Engine(cfg, 0), pkg.Engine(pkg.Config(batch=1), 0)
+        eng = pkg.Engine(cfg, 0)
         eng.update(20)
         d_sched = eng.device_upload(sched)
-        ready = np.zeros(T // refresh, np.uint32)
+        ready, d_ready, free_ready = mapped_words(T // refresh)  # pinned host memory mapped to the device: the host posts by plain stores
         ready[0] = 1
-        d_ready = eng.device_upload(ready)
         eng.update_scheduled(T, refresh, d_sched, d_ready=d_ready if use_mailbox else 0)
         if use_mailbox:
-            for j in range(1, T // refresh):  # release batch by batch from another stream while the launch polls
+            for j in range(1, T // refresh):  # release batch by batch while the launch polls
                 ready[j] = 1
-                other.device_upload_into(d_ready, ready)
         eng.synchronize()
         out.append(eng.platform_state() + eng.joint_states())
-        eng.close(), other.close()
+        eng.close()
+        free_ready()
     for x, y in zip(*out):
         assert np.array_equal(x, y)
