@@ -1047,6 +1047,7 @@ def main():
                                                                      "velocity_epsilon": eps_f, "held_cable_share": held_share, "parity_check": fpar})
             secondary["fp64"] = {
                 "workload": f"precision = 64 (the reference's own arithmetic): {n}-cable robots, every stage, one launch per step, one held Joy",
+                "note": "the part runs chip-wide fp64 at a shader clock of 1.65-1.85 GHz (2.4 GHz at <= 4 096 robots): s_memtime against s_memrealtime inside the kernel, profiles/r06_fp64_timeline.txt",
                 "dtype": "f64",
                 "unit": "state-steps/s",
                 "bound": leg_bound("chain"),
