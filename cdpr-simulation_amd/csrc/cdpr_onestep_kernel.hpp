@@ -544,6 +544,9 @@ template <int N, int XS, int ES, bool RAISED = true>
 CDPR_DEV void split_estimator_wave(const StepArgs& a, float* geo, float gval, uint32_t lane, bool live, size_t st, uint32_t off, uint32_t woff,
                                    const float4& p0, const float4& p1, const float4& p3, const v2f* x_force, v2f* x_tension, float* x_est) {
   constexpr int NP = cable_pairs(N);
+#if defined(CDPR_STAMPS) && defined(CDPR_STAMPS_CLOCK)  // the shader clock over this wave: s_memtime ticks between entry and stamp 3, into slot 7
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime();
+#endif
 #if CDPR_SPLIT_PRIO == 1 || CDPR_SPLIT_PRIO == 4
   if (RAISED) __builtin_amdgcn_s_setprio(3);  // the estimator is the critical path: it wins the SIMD's issue arbitration
 #elif CDPR_SPLIT_PRIO == 3 || CDPR_SPLIT_PRIO == 5
@@ -645,6 +648,9 @@ CDPR_DEV void split_estimator_wave(const StepArgs& a, float* geo, float gval, ui
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_s_waitcnt(0xC07F);
   CDPR_SPLIT_STAMP(3);
+#if defined(CDPR_STAMPS) && defined(CDPR_STAMPS_CLOCK)
+  if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
   __builtin_amdgcn_s_barrier();  // #2: tensions and estimator results are out
 }
 
