@@ -89,14 +89,19 @@ elif case in ("general", "general65k", "general_sw", "general65k_sw"):
     else:
         eng.update(reps * 10)  # (long enough that the 62 launches before the hot rows take over weigh little in the per-kernel averages)
     eng.synchronize()
-elif case in ("fp64", "fp64hold", "fp64hold1"):
+elif case in ("fp64", "fp64hold", "fp64hold1", "fp64hold3"):
     # precision = 64 at the contract's size: the role-split kernel's lean build; fp64hold: with the hold branch live (its HOLD
-    # instantiation), one held Joy with a share of the cables at or below epsilon; fp64hold1: one robot (the LDS build)
+    # instantiation), one held Joy with a share of the cables at or below epsilon; fp64hold1: one robot (the LDS build); fp64hold3: every third cable held (bench.py's hold leg)
     B = 1 if case.endswith("1") else 65536
     model, pose, command, _ = bench.make_workload(pkg, B, 8, 1235, 4000)
     extra = {"velocityEpsilon": 0.001} if "hold" in case else {}
     eng = pkg.Engine(pkg.Config(model=model, batch=B, stages=3, precision=64, **extra), 0)
-    eng.set_platform_state(pose7=pose); eng.set_velocity_command(command(0)); eng.update(100); eng.synchronize()
+    cmd = command(0).copy()
+    if case == "fp64hold3":  # bench.py's hold leg: every third CABLE commanded 0 and held by its position Pid, the others on their velocity Pid
+        held = (np.arange(B * 8).reshape(B, 8) % 3) == 0
+        cmd[held] = 0.0
+        cmd[~held & (np.abs(cmd) <= 0.001)] = 0.02
+    eng.set_platform_state(pose7=pose); eng.set_velocity_command(cmd); eng.update(100); eng.synchronize()
     eng.update(reps * 5); eng.synchronize()
 else:
     raise SystemExit(f"unknown case {case}")
