@@ -594,8 +594,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   float target[N];
   lean_load_targets<N>(g, rr, mode, target);
   sm.mode_row[lane] = mode;
-  sm.tgt[0][lane] = make_float4(target[0], (1 < N) ? target[1 < N ? 1 : 0] : 0.f, (2 < N) ? target[2 < N ? 2 : 0] : 0.f, (3 < N) ? target[3 < N ? 3 : 0] : 0.f);
-  if (N > 4) sm.tgt[1][lane] = make_float4(target[4 < N ? 4 : 0], (5 < N) ? target[5 < N ? 5 : 0] : 0.f, (6 < N) ? target[6 < N ? 6 : 0] : 0.f, (7 < N) ? target[7 < N ? 7 : 0] : 0.f);
+  // (the Joy targets go to sm.tgt behind gen_hot_restore, round 6: until then those 2 KiB take the integrals' dword rows of a wave that is not all fresh)
   float* const dumpf = &sm.dump[0].x;
   *((lane < NP * kGeomFloatsPerPair) ? geo + lane : dumpf + lane) = gval;
 #pragma unroll
@@ -621,6 +620,7 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   }
   GenHot hot{false, false, false, 0u, 0};  // hot rows (GenHot): this kernel starts and keeps them
   bool hot_skip = false;
+  float* hot_rows = nullptr;  // the integrals' dword rows of a wave that is not all fresh, by DMA (in sm.tgt until gen_hot_restore has read them)
   {
     float keep = (s.px + s.qy) + (s.vy + s.wz);
 #pragma unroll
@@ -629,7 +629,16 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
 #pragma unroll
     for (int i = 0; i < N; ++i) holds = holds || (mode == 2 && sel[i] == 0);
     hot = gen_hot_begin<N>(hot_on, hot_step1, hot_mask, sel, mode, now, hot_skip);
-    gen_stage_records<N, NBMAX>(RB, L, col, sel, &sm.stage[0][0][0], &sm.hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull, hot_skip);
+    // 0: as in round 5 (a wave that is not all fresh requests every lane's H slots and reads the integrals from memory behind the wait for
+    // the DMA); 1: the integrals' dword rows ride the DMA (no gain by itself: 22.1 against 21.9 us); 2: ... and the fresh lanes of such a
+    // wave request no H slot (cables switching Pids, same box: 21.45 against 21.8 us by HIP events, 19.5 against 20.3 us and 92.1 against
+    // 96.1 MB per launch by rocprofv3: `profiles/r06_general_ab.txt`, `r06d_general65k_sw_*`)
+#ifndef CDPR_HOT_ROWS_BY_DMA
+#define CDPR_HOT_ROWS_BY_DMA 2
+#endif
+    static_assert(sizeof(sm.tgt) >= sizeof(float) * 64 * N, "the integrals' dword rows fit the target rows");
+    hot_rows = (CDPR_HOT_ROWS_BY_DMA && hot.on && !hot_skip && __builtin_amdgcn_ballot_w64(hot.has) != 0ull) ? &sm.tgt[0][0].x : nullptr;  // (wave-uniform)
+    gen_stage_records<N, NBMAX>(RB, L, col, sel, &sm.stage[0][0][0], &sm.hold_slots[0][0], keep, __builtin_amdgcn_ballot_w64(holds) != 0ull, hot_skip, hot_rows, CDPR_HOT_ROWS_BY_DMA == 2 && hot.fresh);
   }
 
   // ---- IK on the state at t_k; the structure matrix stays alive for the world step (the inlined controller branch leaves room)
@@ -664,7 +673,11 @@ __global__ __launch_bounds__(128, 2) void cdpr_gen_lean_kernel(const StepArgs a,
   cc.stamps = nullptr;
 #endif
 #endif
-  gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, sel, &sm.stage[0][0][0]);
+  gen_hot_restore<N, NBMAX>(cc, RB, L, lane, live, col, hot, sel, &sm.stage[0][0][0], hot_rows);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (every lane has read its integrals before a lane's targets go over them)
+  __builtin_amdgcn_wave_barrier();
+  sm.tgt[0][lane] = make_float4(target[0], (1 < N) ? target[1 < N ? 1 : 0] : 0.f, (2 < N) ? target[2 < N ? 2 : 0] : 0.f, (3 < N) ? target[3 < N ? 3 : 0] : 0.f);
+  if (N > 4) sm.tgt[1][lane] = make_float4(target[4 < N ? 4 : 0], (5 < N) ? target[5 < N ? 5 : 0] : 0.f, (6 < N) ? target[6 < N ? 6 : 0] : 0.f, (7 < N) ? target[7 < N ? 7 : 0] : 0.f);
   // tier 0 and - for waves without a gap call - tier 1 of the general controller inline (gen_controller<STEADY_ONLY>); what it
   // does not serve goes to the tail.
   // Two `if`s in sequence on the same wave-uniform decision, the second through a scalar the compiler cannot see through.  As ONE

@@ -426,7 +426,7 @@ CDPR_DEV GenHot gen_hot_begin(bool on, uint32_t step1, uint32_t mask, const int 
 // eight H slots go back to memory as they stand and its word is cleared.
 template <int N, int NBMAX>
 CDPR_DEV void gen_hot_restore(const GenCtlConst kc, const GenBuf& RB, const GenLayout L, uint32_t lane, bool live, uint32_t col, const GenHot hot, const int (&sel)[N],
-                              float4* cab) {
+                              float4* cab, const float* ierr_rows = nullptr) {  // ierr_rows: the integrals came with the DMA (gen_stage_records)
   constexpr int NV = gen_nv(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
   if (__builtin_amdgcn_ballot_w64(hot.has) == 0ull) return;  // (wave-uniform)
@@ -448,7 +448,7 @@ CDPR_DEV void gen_hot_restore(const GenCtlConst kc, const GenBuf& RB, const GenL
   // a wave with robots that are not fresh (rare): the integrals from memory, the staged H slots patched where they are this Pid's;
   // a robot that is not fresh leaves the state: H slots back to memory, word cleared
 #pragma unroll
-  for (int i = 0; i < N; ++i) ierr[i] = __uint_as_float(RB.loadc(2 + i, col * 4u));
+  for (int i = 0; i < N; ++i) ierr[i] = ierr_rows ? ierr_rows[i * 64 + lane] : __uint_as_float(RB.loadc(2 + i, col * 4u));
   const bool leaves = hot.has && !hot.fresh;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -1267,7 +1267,10 @@ CDPR_DEV float uni(float v) { return __uint_as_float(__builtin_amdgcn_readfirstl
 // operation at the first use of an ordinary load's result while an LDS-DMA is pending).
 template <int N, int NBMAX>
 CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t col, const int (&sel)[N], float4* cab, float4* hold_slots, float keep, bool need_hold,
-                                bool skip_h = false) {  // skip_h (wave-uniform): every lane's H slots come from its hot rows (gen_hot_restore)
+                                bool skip_h = false, float* ierr_rows = nullptr, bool lane_fresh = false) {  // skip_h (wave-uniform): every lane's H slots come from its hot rows (gen_hot_restore)
+  // ierr_rows (wave-uniform, round 6): a wave that holds robots with a hot word but is not all fresh - the integrals' dword rows ride the
+  // DMA too, into N rows of 64 dwords of their own (gen_hot_restore read them from memory behind the wait for this DMA: a second round
+  // trip in every such wave, and with cables switching Pids nearly every wave holds a robot without a word)
   constexpr int NV = gen_nv(NBMAX);
   constexpr int kCab = (NV + 1) * 64;
   constexpr int LP = (N + 3) / 4;
@@ -1283,10 +1286,14 @@ CDPR_DEV void gen_stage_records(const GenBuf& RB, const GenLayout L, uint32_t co
     const int sa = L.block_a(0, i);
 #pragma unroll
     for (int s4 = 0; s4 < NV; ++s4) RB.slot_to_lds(sa + min(s4, L.nv() - 1), va, cab + i * kCab + s4 * 64);  // (slots past nv: a copy, weight 0)
-    if (!skip_h)
-      RB.slot_to_lds(sa + L.nv(), va, cab + i * kCab + NV * 64);
-    else
+    if (!skip_h) {
+      // (ierr_rows: a fresh lane of such a wave takes its H slots from its hot rows like the lanes of an all-fresh wave - its request is
+      //  sent out of the descriptor's range and moves nothing; gen_hot_restore writes the slot in LDS)
+      RB.slot_to_lds(sa + L.nv(), (ierr_rows && lane_fresh) ? 0xFFFFFFFFu : va, cab + i * kCab + NV * 64);
+      if (ierr_rows) RB.rowc_to_lds(2 + i, col * 4u, ierr_rows + i * 64);
+    } else {
       RB.rowc_to_lds(2 + i, col * 4u, cab + i * kCab + NV * 64);  // (the cable's integral, a dword per lane: gen_hot_restore)
+    }
   }
 }
 
